@@ -1,0 +1,121 @@
+"""EEG<->fMRI bridge on the MI355X HIP path.
+
+``EEGfMRIBridgeFusionNet`` / ``BridgeFeatureDataset`` mirror the reference's
+``bridge_utils.py:22-152`` (names, signatures, return conventions, state_dict).
+``EEGfMRIContrastiveBridge`` is the north-star extension (SURVEY.md §8 a-X2):
+the same two projection heads, L2-normalised, scored with a batch-pairwise
+cosine-similarity matrix against all-gathered global negatives and trained with
+a symmetric InfoNCE loss.  The reference trains a 2-class CE classifier and has
+no similarity matrix, so that part's parity is unpinned by the reference.
+"""
+from __future__ import annotations
+
+import logging
+import math
+
+import torch
+import torch.nn as nn
+from torch.utils.data import Dataset
+
+from . import ops
+from .enhanced_models_v4 import LearnedFusionModule
+
+logger = logging.getLogger(__name__)
+
+
+def _proj_head(in_dim, out_dim, dropout):
+    return nn.Sequential(nn.Linear(in_dim, out_dim), nn.LayerNorm(out_dim),
+                         nn.GELU(), nn.Dropout(dropout))
+
+
+class EEGfMRIBridgeFusionNet(nn.Module):
+    """eeg (B,128) + fmri (B,64) -> logits (B,2) [, fused, fusion_w, attn_w]."""
+
+    def __init__(self, eeg_dim=128, fmri_dim=64, bridge_dim=128,
+                 num_classes=2, num_heads=4, dropout=0.3):
+        super().__init__()
+        self.bridge_dim = bridge_dim
+        self.eeg_proj = _proj_head(eeg_dim, bridge_dim, dropout)
+        self.fmri_proj = _proj_head(fmri_dim, bridge_dim, dropout)
+        self.cross_attn = nn.MultiheadAttention(bridge_dim, num_heads=num_heads,
+                                                dropout=dropout, batch_first=True)
+        self.fusion = LearnedFusionModule(num_modalities=2, hidden_dim=bridge_dim,
+                                          use_temperature=True)
+        self.classifier = nn.Sequential(
+            nn.Linear(bridge_dim, bridge_dim // 2), nn.LayerNorm(bridge_dim // 2),
+            nn.ReLU(), nn.Dropout(dropout), nn.Linear(bridge_dim // 2, num_classes))
+        self.num_heads = num_heads
+        self.drop_p = dropout
+
+    def forward(self, eeg_feats, fmri_feats, return_features=False, return_weights=False):
+        logits, fused, fusion_w, attn_w = ops.bridge_forward(self, eeg_feats, fmri_feats)
+        out = [logits]
+        if return_features:
+            out.append(fused)
+        if return_weights:
+            out += [fusion_w, attn_w]
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def get_fusion_weights(self):
+        with torch.no_grad():
+            temp = self.fusion.temperature
+            w = torch.softmax(self.fusion.fusion_logits / temp, dim=0)
+            return {"eeg_weight": w[0].item(), "fmri_weight": w[1].item(),
+                    "temperature": temp.item()}
+
+
+class EEGfMRIContrastiveBridge(nn.Module):
+    """Contrastive projection bridge (extension; SURVEY.md §8 a-X2).
+
+    ``bridge`` carries the reference-compatible parameters (its ``eeg_proj`` and
+    ``fmri_proj`` are the trained heads); ``logit_scale`` = ln(1/tau) is the one
+    extra learnable scalar (CLIP convention, tau0 = 0.07).
+    """
+
+    def __init__(self, eeg_dim=128, fmri_dim=64, bridge_dim=128, dropout=0.3,
+                 init_tau: float = 0.07):
+        super().__init__()
+        self.bridge = EEGfMRIBridgeFusionNet(eeg_dim, fmri_dim, bridge_dim, dropout=dropout)
+        self.logit_scale = nn.Parameter(torch.tensor(math.log(1.0 / init_tau)))
+
+    def embed(self, eeg_feats, fmri_feats):
+        """L2-normalised (ze, zf), each (B, bridge_dim) fp32."""
+        return ops.contrastive_embed(self.bridge, eeg_feats, fmri_feats, self.training)
+
+    def forward(self, eeg_feats, fmri_feats, group=None):
+        """-> (loss, top1_eeg_to_fmri, top1_fmri_to_eeg).  With a process
+        ``group`` the columns are the all-gathered global batch."""
+        ze, zf = self.embed(eeg_feats, fmri_feats)
+        return ops.clip_loss(ze, zf, self.logit_scale, group)
+
+
+class BridgeFeatureDataset(Dataset):
+    """Aligns dict-of-tensor EEG/fMRI features and labels on ``int(subject)``."""
+
+    def __init__(self, eeg_features, fmri_features, labels, subject_list):
+        eeg = {int(k): v for k, v in eeg_features.items()}
+        fmri = {int(k): v for k, v in fmri_features.items()}
+        lab = {int(k): v for k, v in labels.items()}
+        self.samples = [
+            {"eeg": eeg[s], "fmri": fmri[s], "label": lab[s], "subject": s}
+            for s in (int(x) for x in sorted(subject_list))
+            if s in eeg and s in fmri and s in lab]
+        if not self.samples:
+            logger.error("!!! NO SAMPLES ALIGNED !!! Check subject IDs in EEG and fMRI feature dicts.")
+        else:
+            logger.info("BridgeFeatureDataset: %d aligned samples found.", len(self.samples))
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, idx):
+        s = self.samples[idx]
+        return s["eeg"], s["fmri"], s["label"], s["subject"]
+
+
+def collate_bridge(batch):
+    """(``_test_bridge.py:755-760``) stack features, long labels, subject list."""
+    eeg = torch.stack([b[0] for b in batch])
+    fmri = torch.stack([b[1] for b in batch])
+    labels = torch.tensor([b[2] for b in batch], dtype=torch.long)
+    return eeg, fmri, labels, [b[3] for b in batch]

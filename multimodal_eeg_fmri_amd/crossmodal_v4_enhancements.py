@@ -1,0 +1,224 @@
+"""V4-Lite EEG path + training utilities on the MI355X HIP path.
+
+Class surface of the reference's ``EEG_CODE/crossmodal_v4_enhancements.py``:
+the duplicated encoder family (:29-271, re-exported from
+``enhanced_models_v4``), DropPath :639-658, LabelSmoothingCrossEntropy
+:665-677, EnhancedConnEncoder :684-739, HybridFusionModule :746-810,
+LiteERPEncoder/LitePowerEncoder :817-877, EnhancedTriModalFusionNetV4Lite
+:880-948, CosineAnnealingWarmup :1084-1112, EarlyStopping :1115-1143,
+get_lite_fusion_weights :1146-1152.  Leaf ``torch.nn`` modules are parameter
+containers (identical ``state_dict``); arithmetic is in the HIP library.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .enhanced_models_v4 import (  # noqa: F401  (reference keeps copies here)
+    EnhancedERPEncoder, EnhancedPowerEncoder, LearnedFusionModule,
+    PositionalEncoding, TemporalTransformerBlock)
+
+
+# ----------------------------------------------------------------- utilities
+def drop_path(x: torch.Tensor, drop_prob: float = 0.0, training: bool = False) -> torch.Tensor:
+    """Per-sample stochastic depth; identity in eval / p == 0."""
+    if drop_prob == 0.0 or not training:
+        return x
+    return ops.drop_path(x, drop_prob)
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training)
+
+
+class LabelSmoothingCrossEntropy(nn.Module):
+    """(1-s)*NLL + s*mean(-logp), averaged over the batch."""
+
+    def __init__(self, smoothing: float = 0.1):
+        super().__init__()
+        self.smoothing = smoothing
+        self.confidence = 1.0 - smoothing
+
+    def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        return ops.smoothed_cross_entropy(pred, target, self.smoothing)
+
+
+class CosineAnnealingWarmup:
+    """Linear warm-up for ``warmup_epochs`` then cosine decay to ``min_lr``."""
+
+    def __init__(self, optimizer, warmup_epochs: int, total_epochs: int,
+                 min_lr: float = 1e-6, base_lr: float = None):
+        self.optimizer = optimizer
+        self.warmup_epochs = warmup_epochs
+        self.total_epochs = total_epochs
+        self.min_lr = min_lr
+        self.base_lr = base_lr or optimizer.param_groups[0]["lr"]
+        self.current_epoch = 0
+
+    def _lr_at(self, epoch: int) -> float:
+        if epoch <= self.warmup_epochs:
+            return self.base_lr * (epoch / self.warmup_epochs)
+        frac = (epoch - self.warmup_epochs) / (self.total_epochs - self.warmup_epochs)
+        return self.min_lr + 0.5 * (self.base_lr - self.min_lr) * (1 + math.cos(math.pi * frac))
+
+    def step(self) -> float:
+        self.current_epoch += 1
+        lr = self._lr_at(self.current_epoch)
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        return lr
+
+    def get_lr(self) -> float:
+        return self.optimizer.param_groups[0]["lr"]
+
+
+class EarlyStopping:
+    """Stop after ``patience`` calls without a > ``min_delta`` improvement."""
+
+    def __init__(self, patience: int = 10, min_delta: float = 0.001, mode: str = "max"):
+        self.patience, self.min_delta, self.mode = patience, min_delta, mode
+        self.counter = 0
+        self.best_score = None
+        self.should_stop = False
+
+    def __call__(self, score) -> bool:
+        if self.best_score is None:
+            self.best_score = score
+            return False
+        better = (score > self.best_score + self.min_delta) if self.mode == "max" \
+            else (score < self.best_score - self.min_delta)
+        if better:
+            self.best_score, self.counter = score, 0
+        else:
+            self.counter += 1
+            self.should_stop = self.should_stop or self.counter >= self.patience
+        return self.should_stop
+
+
+def get_lite_fusion_weights(model):
+    if hasattr(model, "get_fusion_weights"):
+        return model.get_fusion_weights()
+    return getattr(model, "_fusion_weights", None)
+
+
+# ----------------------------------------------------------------- encoders
+class EnhancedConnEncoder(nn.Module):
+    """conn -> 256 -> 128 (Linear-BN-GELU) -> sigmoid feature gate -> hidden."""
+
+    def __init__(self, conn_features: int, hidden_dim: int = 96, dropout: float = 0.4):
+        super().__init__()
+
+        def block(i, o):
+            return nn.Sequential(nn.Linear(i, o), nn.BatchNorm1d(o), nn.GELU(), nn.Dropout(dropout))
+        self.proj1 = block(conn_features, 256)
+        self.proj2 = block(256, 128)
+        self.attention = nn.Sequential(nn.Linear(128, 64), nn.Tanh(),
+                                       nn.Linear(64, 128), nn.Sigmoid())
+        self.output = block(128, hidden_dim)
+        self.drop_p = dropout
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() > 2:
+            x = x.reshape(x.size(0), -1)
+        return ops.conn_encoder_forward(self, x)
+
+
+class HybridFusionModule(nn.Module):
+    """softmax-gated ERP/PW mix, boosted CONN, Linear(2H->H)-BN-GELU."""
+
+    def __init__(self, hidden_dim: int, dropout: float = 0.3, conn_boost: float = 1.2):
+        super().__init__()
+        self.conn_boost = conn_boost
+        self.erp_pw_gate = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.GELU(),
+                                         nn.Dropout(dropout), nn.Linear(hidden_dim, 2),
+                                         nn.Softmax(dim=-1))
+        self.late_fusion = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim),
+                                         nn.BatchNorm1d(hidden_dim), nn.GELU(), nn.Dropout(dropout))
+        self.final_gate = nn.Parameter(torch.tensor([0.6, 0.4]))
+        self.drop_p = dropout
+
+    def forward(self, erp_feat, pw_feat, conn_feat, return_weights: bool = False):
+        fused, gate = ops.hybrid_fusion_forward(self, erp_feat, pw_feat, conn_feat)
+        if not return_weights:
+            return fused
+        final = torch.softmax(self.final_gate.detach(), dim=0)
+        g = gate.detach().mean(dim=0)
+        weights = {"erp_weight": g[0].item() * final[0].item(),
+                   "pw_weight": g[1].item() * final[0].item(),
+                   "conn_weight": final[1].item() * self.conn_boost}
+        return fused, weights
+
+
+class _LiteEncoder(nn.Module):
+    def __init__(self, in_channels, mid, k1, k2, hidden_dim, dropout):
+        super().__init__()
+        self.conv_layers = nn.Sequential(
+            nn.Conv1d(in_channels, mid, kernel_size=k1, padding=k1 // 2), nn.BatchNorm1d(mid),
+            nn.GELU(), nn.Dropout(dropout), nn.MaxPool1d(2),
+            nn.Conv1d(mid, hidden_dim, kernel_size=k2, padding=k2 // 2), nn.BatchNorm1d(hidden_dim),
+            nn.GELU(), nn.Dropout(dropout), nn.AdaptiveAvgPool1d(1))
+        self.output = nn.Sequential(nn.Flatten(), nn.Linear(hidden_dim, hidden_dim),
+                                    nn.GELU(), nn.Dropout(dropout))
+        self.drop_p = dropout
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.lite_encoder_forward(self, x)
+
+
+class LiteERPEncoder(_LiteEncoder):
+    def __init__(self, in_channels: int, hidden_dim: int = 96, dropout: float = 0.4):
+        super().__init__(in_channels, 48, 7, 5, hidden_dim, dropout)
+
+
+class LitePowerEncoder(_LiteEncoder):
+    def __init__(self, in_channels: int, hidden_dim: int = 96, dropout: float = 0.4):
+        super().__init__(in_channels, 64, 5, 3, hidden_dim, dropout)
+
+
+class EnhancedTriModalFusionNetV4Lite(nn.Module):
+    """Lite tri-modal classifier used by ``run_training_lite``."""
+
+    def __init__(self, erp_channels: int, pw_channels: int, conn_features: int,
+                 hidden_dim: int = 96, num_classes: int = 2, dropout: float = 0.4,
+                 conn_boost: float = 1.3):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.erp_encoder = LiteERPEncoder(erp_channels, hidden_dim, dropout)
+        self.pw_encoder = LitePowerEncoder(pw_channels, hidden_dim, dropout)
+        self.conn_encoder = EnhancedConnEncoder(conn_features, hidden_dim, dropout)
+        self.fusion = HybridFusionModule(hidden_dim, dropout, conn_boost)
+        self.classifier = nn.Sequential(
+            nn.Linear(hidden_dim, hidden_dim // 2), nn.BatchNorm1d(hidden_dim // 2),
+            nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden_dim // 2, num_classes))
+        self.drop_p = dropout
+        self._fusion_weights = None
+
+    def forward(self, erp, pw, conn, return_fusion_weights: bool = False,
+                return_fused_feats: bool = False):
+        e = self.erp_encoder(erp)
+        p = self.pw_encoder(pw)
+        c = self.conn_encoder(conn)
+        weights = None
+        if return_fusion_weights:
+            fused, weights = self.fusion(e, p, c, return_weights=True)
+            self._fusion_weights = weights
+        else:
+            fused = self.fusion(e, p, c)
+        logits = ops.bn_classifier_forward(self.classifier, fused, self.drop_p, self.training)
+        out = [logits]
+        if return_fusion_weights:
+            out.append(weights)
+        if return_fused_feats:
+            out.append(fused)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def get_fusion_weights(self):
+        return self._fusion_weights
