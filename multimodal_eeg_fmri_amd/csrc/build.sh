@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Builds libmmeeg_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+out="$here/../libmmeeg_hip.so"
+mkdir -p "$here/build"
+objs=()
+pids=()
+for src in "$here"/*.hip; do
+  obj="$here/build/$(basename "${src%.hip}").o"
+  objs+=("$obj")
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$here/common.h" -nt "$obj" ]]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function \
+        -I"$here" -I"$here/../../include" -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "built $out"

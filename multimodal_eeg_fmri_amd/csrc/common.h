@@ -1,0 +1,88 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// wave = 64 lanes; MFMA operands bf16, accumulation fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define MM_OK 0
+#define MM_ERR_ARG (-1)
+#define MM_ERR_LAUNCH (-2)
+#define MM_ERR_UNSUPPORTED (-3)
+
+// activation codes shared with include/mmeeg_hip.h
+#define MM_ACT_NONE 0
+#define MM_ACT_GELU 1
+#define MM_ACT_RELU 2
+#define MM_ACT_TANH 3
+#define MM_ACT_SIGMOID 4
+
+int mm_fail(int code, const char* fmt, ...);      // records mm_last_error()
+int mm_check_launch(const char* what);            // hipGetLastError -> code
+
+#define MM_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return mm_fail(MM_ERR_ARG, __VA_ARGS__);   \
+    } while (0)
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case MM_ACT_GELU: return gelu_erf(v);
+        case MM_ACT_RELU: return v > 0.f ? v : 0.f;
+        case MM_ACT_TANH: return tanhf(v);
+        case MM_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        default: return v;
+    }
+}
+// derivative w.r.t. the pre-activation z, given z
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case MM_ACT_GELU: return gelu_erf_grad(z);
+        case MM_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case MM_ACT_TANH: { float t = tanhf(z); return 1.f - t * t; }
+        case MM_ACT_SIGMOID: { float s = 1.0f / (1.0f + __expf(-z)); return s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.
+// Same function in forward and backward, so no mask tensor is stored.
+__device__ __forceinline__ uint32_t mm_hash(uint32_t seed, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + seed;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
+    return mm_hash(seed, idx) >= thresh ? inv_keep : 0.f;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,331 @@
+// 1-D implicit-GEMM family on bf16 MFMA (fp32 accumulate), channels-last.
+//
+//   forward : Y[b,t,n]  = sum_{tap,c} X[b, t+tap-pad, c] * W[n, tap, c]
+//   (a Linear layer is the taps == 1 case; data-gradient is the same kernel
+//    run on dY with the flipped/transposed weight image)
+//   wgrad   : dW[n,tap,c] = sum_{b,t} dY[b,t,n] * X[b, t+tap-pad, c]
+//
+// Layouts: X [B][T][Cin] bf16 (Cin % 16 == 0), W [Cout][taps][Cin] bf16,
+// Y [B][T/pool][Cout].  One workgroup = 256 threads = 4 waves computes a
+// BM x BN output tile of ONE batch item: the (BM + taps - 1) x KC halo tile of
+// X is staged once per Cin-chunk into LDS and every tap reads it at a row
+// offset (the im2col matrix is never materialised); W for the chunk sits
+// beside it.  Rows are padded by 16 B so the 16-lane groups of ds_read_b128
+// hit 16 distinct 16-B slots (row stride = odd multiple of 16 B).
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 32;        // Cin chunk staged per step
+constexpr int KPAD = 8;       // +16 B per LDS row
+
+struct EpiArgs {
+    const float* scale;       // [N] multiply (nullptr = 1)
+    const float* shift;       // [N] add (bias / folded BN shift) (nullptr = 0)
+    const float* residual;    // [M][N] fp32 added after activation (nullptr)
+    const float* pe;          // [>=T][N] fp32 positional table added per t (nullptr)
+    float* stats;             // [2][N] sum / sum-of-squares of v (atomics) (nullptr)
+    float* out_f32;           // [M/pool][N]
+    bf16* out_bf16;           // [M/pool][N]
+    bf16* out_pre;            // [M][N] pre-activation copy (nullptr)
+    int act;
+    int pool;                 // 1 or 2 (max over adjacent t pairs, after act)
+    uint32_t drop_thresh;     // 0 = no dropout
+    uint32_t drop_seed;
+    float drop_inv_keep;
+};
+
+struct ConvArgs {
+    const bf16* x;
+    const bf16* w;
+    int B, T, Cin, Cout, taps, pad;
+    EpiArgs e;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv1d_fwd_kernel(ConvArgs a) {
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tilesT = (a.T + BM - 1) / BM;
+    const int b = blockIdx.x / tilesT;
+    const int t0 = (blockIdx.x % tilesT) * BM;
+    const int n0 = blockIdx.y * BN;
+    const int kc = a.Cin < KC ? a.Cin : KC;       // 16 or 32
+    const int AS = kc + KPAD;                     // LDS row stride (elements)
+    const int arows = BM + a.taps - 1;
+    bf16* As = reinterpret_cast<bf16*>(smem);
+    bf16* Ws = As + arows * AS;
+    const int segs = kc / 8;                      // 16-B segments per row
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bf16* xb = a.x + (size_t)b * a.T * a.Cin;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += kc) {
+        // ---- stage halo tile of X
+        for (int s = tid; s < arows * segs; s += 256) {
+            const int r = s / segs, sg = s - r * segs;
+            const int t = t0 - a.pad + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t >= 0 && t < a.T)
+                v = *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c0 + sg * 8);
+            *reinterpret_cast<uint4*>(As + r * AS + sg * 8) = v;
+        }
+        // ---- stage W[n0..n0+BN)[taps][c0..c0+kc)
+        const int wrows = BN * a.taps;
+        for (int s = tid; s < wrows * segs; s += 256) {
+            const int r = s / segs, sg = s - r * segs;      // r = n_local*taps + tap
+            const int n = n0 + r / a.taps;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (n < a.Cout)
+                v = *reinterpret_cast<const uint4*>(a.w + ((size_t)n0 * a.taps + r) * a.Cin + c0 + sg * 8);
+            *reinterpret_cast<uint4*>(Ws + r * AS + sg * 8) = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < a.taps; ++tap) {
+            for (int ks = 0; ks < kc; ks += 16) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 32 + lr + tap;
+                    af[i] = *reinterpret_cast<const bf16x8*>(As + row * AS + ks + lh * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = (wn * TN + j) * 32 + lr;
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(Ws + (nl * a.taps + tap) * AS + ks + lh * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const EpiArgs& e = a.e;
+    float* sstat = reinterpret_cast<float*>(smem);      // [2][BN] (LDS reuse; synced above)
+    if (e.stats) {
+        for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
+        __syncthreads();
+    }
+    const int N = a.Cout;
+    const int To = a.T / e.pool;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lr;
+        const bool nok = n < N;
+        const float sc = (e.scale && nok) ? e.scale[n] : 1.f;
+        const float sh = (e.shift && nok) ? e.shift[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rp = 0; rp < 16; rp += 2) {
+                float v[2];
+                int tt[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = rp + q;
+                    const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int t = t0 + ml;
+                    tt[q] = t;
+                    float val = acc[i][j][r] * sc + sh;
+                    const bool ok = nok && t < a.T;
+                    if (ok) {
+                        s1 += val; s2 += val * val;
+                        const size_t idx = ((size_t)b * a.T + t) * N + n;
+                        if (e.out_pre) e.out_pre[idx] = (bf16)val;
+                        val = apply_act(val, e.act);
+                        if (e.drop_thresh) val *= dropout_scale(e.drop_seed, (uint32_t)idx, e.drop_thresh, e.drop_inv_keep);
+                        if (e.residual) val += e.residual[idx];
+                        if (e.pe) val += e.pe[(size_t)t * N + n];
+                    }
+                    v[q] = val;
+                }
+                if (!nok) continue;
+                if (e.pool == 2) {
+                    if (tt[0] + 1 < a.T) {
+                        const float m = fmaxf(v[0], v[1]);
+                        const size_t o = ((size_t)b * To + (tt[0] >> 1)) * N + n;
+                        if (e.out_f32) e.out_f32[o] = m;
+                        if (e.out_bf16) e.out_bf16[o] = (bf16)m;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (tt[q] < a.T) {
+                            const size_t o = ((size_t)b * a.T + tt[q]) * N + n;
+                            if (e.out_f32) e.out_f32[o] = v[q];
+                            if (e.out_bf16) e.out_bf16[o] = (bf16)v[q];
+                        }
+                }
+            }
+        }
+        if (e.stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                const int nl = (wn * TN + j) * 32 + lr;
+                atomicAdd(&sstat[nl], s1);
+                atomicAdd(&sstat[BN + nl], s2);
+            }
+        }
+    }
+    if (e.stats) {
+        __syncthreads();
+        for (int i = tid; i < BN; i += 256)
+            if (n0 + i < N) {
+                atomicAdd(&e.stats[n0 + i], sstat[i]);
+                atomicAdd(&e.stats[N + n0 + i], sstat[BN + i]);
+            }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_fwd(const ConvArgs& a, hipStream_t st) {
+    const int kc = a.Cin < KC ? a.Cin : KC;
+    const size_t lds = (size_t)(BM + a.taps - 1 + BN * a.taps) * (kc + KPAD) * sizeof(bf16);
+    const size_t need = lds > 2 * BN * sizeof(float) ? lds : 2 * BN * sizeof(float);
+    if (need > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_fwd: LDS %zu B > 160 KiB", need);
+    auto kern = conv1d_fwd_kernel<BM, BN, WM, WN>;
+    if (need > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+    dim3 grid(a.B * ceil_div(a.T, BM), ceil_div(a.Cout, BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), need, st, a);
+    return mm_check_launch("conv1d_fwd");
+}
+
+// ------------------------------------------------------------------ packers
+// (B, C, T) fp32  ->  (B, T, Cp) bf16, channels zero-padded to Cp
+__global__ void pack_nct_kernel(const float* __restrict__ x, bf16* __restrict__ y, int C, int T, int Cp) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 256 threads: 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        tile[i][tx] = (c < C && t < T) ? x[((size_t)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < Cp) y[((size_t)b * T + t) * Cp + c] = (bf16)tile[tx][i];
+    }
+}
+
+// (B, T, Cp) (bf16 grads) -> (B, C, T) fp32  (input-gradient un-pack)
+__global__ void unpack_ntc_kernel(const bf16* __restrict__ g, float* __restrict__ dx, int C, int T, int Cp) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        tile[i][tx] = (t < T && c < Cp) ? (float)g[((size_t)b * T + t) * Cp + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        if (c < C && t < T) dx[((size_t)b * C + c) * T + t] = tile[tx][i];
+    }
+}
+
+// conv weight (Cout, Cin, k) fp32 -> forward image [Cout][k][Cinp] bf16 and
+// data-gradient image [Cinp16][k (flipped)][Coutp] bf16 (Coutp = Cout padded to 16)
+__global__ void prep_weight_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wd,
+                                   int Cout, int Cin, int k, int Cinp, int Coutp) {
+    const int total_f = Cout * k * Cinp;
+    const int CinRows = Cinp;
+    const int total_d = wd ? CinRows * k * Coutp : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_f + total_d; i += gridDim.x * blockDim.x) {
+        if (i < total_f) {
+            const int c = i % Cinp, tap = (i / Cinp) % k, n = i / (Cinp * k);
+            wf[i] = (bf16)(c < Cin ? w[((size_t)n * Cin + c) * k + tap] : 0.f);
+        } else {
+            const int d = i - total_f;
+            const int n = d % Coutp, tap = (d / Coutp) % k, c = d / (Coutp * k);
+            const float v = (c < Cin && n < Cout) ? w[((size_t)n * Cin + c) * k + (k - 1 - tap)] : 0.f;
+            wd[d] = (bf16)v;
+        }
+    }
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI (declared in include/mmeeg_hip.h)
+// ============================================================================
+extern "C" {
+
+int mm_pack_nct_bf16(const float* x, void* y, int B, int C, int T, int Cp, hipStream_t st) {
+    MM_REQUIRE(x && y && B > 0 && C > 0 && T > 0 && Cp >= C && Cp % 16 == 0, "pack_nct: bad args");
+    dim3 grid(ceil_div(T, 32), ceil_div(Cp, 32), B);
+    hipLaunchKernelGGL(pack_nct_kernel, grid, dim3(256), 0, st, x, (bf16*)y, C, T, Cp);
+    return mm_check_launch("pack_nct");
+}
+
+int mm_unpack_ntc_f32(const void* g, float* dx, int B, int C, int T, int Cp, hipStream_t st) {
+    MM_REQUIRE(g && dx && B > 0 && C > 0 && T > 0 && Cp >= C, "unpack_ntc: bad args");
+    dim3 grid(ceil_div(T, 32), ceil_div(Cp, 32), B);
+    hipLaunchKernelGGL(unpack_ntc_kernel, grid, dim3(256), 0, st, (const bf16*)g, dx, C, T, Cp);
+    return mm_check_launch("unpack_ntc");
+}
+
+int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int k,
+                        int Cinp, int Coutp, hipStream_t st) {
+    MM_REQUIRE(w && w_fwd && Cinp % 16 == 0 && Cinp >= Cin && (!w_dgrad || (Coutp % 16 == 0 && Coutp >= Cout)),
+               "prep_conv_weight: bad args");
+    const int total = Cout * k * Cinp + (w_dgrad ? Cinp * k * Coutp : 0);
+    hipLaunchKernelGGL(prep_weight_kernel, dim3(ceil_div(total, 256) < 1024 ? ceil_div(total, 256) : 1024), dim3(256),
+                       0, st, w, (bf16*)w_fwd, (bf16*)w_dgrad, Cout, Cin, k, Cinp, Coutp);
+    return mm_check_launch("prep_conv_weight");
+}
+
+// Generic forward implicit GEMM.  See include/mmeeg_hip.h for the contract.
+int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
+                  const float* scale, const float* shift, int act, const float* residual, const float* pe,
+                  int pool, float* stats, float* out_f32, void* out_bf16, void* out_pre,
+                  float drop_p, uint32_t drop_seed, hipStream_t st) {
+    MM_REQUIRE(x && w, "conv1d_fwd: null operand");
+    MM_REQUIRE(B > 0 && T > 0 && Cout > 0 && taps >= 1 && taps <= 9 && pad >= 0 && pad < taps, "conv1d_fwd: bad dims");
+    MM_REQUIRE(Cin % 16 == 0 && (Cin <= 32 ? (Cin == 16 || Cin == 32) : Cin % 32 == 0), "conv1d_fwd: Cin=%d must be 16 or a multiple of 32", Cin);
+    MM_REQUIRE(pool == 1 || (pool == 2 && T % 2 == 0), "conv1d_fwd: pool=%d T=%d", pool, T);
+    MM_REQUIRE(out_f32 || out_bf16 || out_pre, "conv1d_fwd: no output");
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1d_fwd: drop_p");
+    ConvArgs a;
+    a.x = (const bf16*)x; a.w = (const bf16*)w;
+    a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.taps = taps; a.pad = pad;
+    a.e.scale = scale; a.e.shift = shift; a.e.residual = residual; a.e.pe = pe; a.e.stats = stats;
+    a.e.out_f32 = out_f32; a.e.out_bf16 = (bf16*)out_bf16; a.e.out_pre = (bf16*)out_pre;
+    a.e.act = act; a.e.pool = pool;
+    a.e.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    a.e.drop_seed = drop_seed;
+    a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    const long tiles128 = (long)B * ceil_div(T, 128);
+    if (Cout <= 64) {
+        if (tiles128 >= 256 || T < 64) return launch_fwd<128, 64, 4, 1>(a, st);
+        return launch_fwd<64, 64, 2, 2>(a, st);
+    }
+    if (tiles128 * ceil_div(Cout, 128) >= 256 || T < 64) return launch_fwd<128, 128, 2, 2>(a, st);
+    return launch_fwd<64, 128, 2, 2>(a, st);
+}
+
+}  // extern "C"
