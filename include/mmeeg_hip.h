@@ -1,0 +1,120 @@
+/*
+ * mmeeg_hip.h — C ABI of libmmeeg_hip.so, the MI355X (gfx950) kernel library
+ * behind multimodal_eeg_fmri_amd.
+ *
+ * The reference (bacon205/Multimodal_eeg_fmri) has no FFI / operator plug-in
+ * interface: its only boundary is the Python nn.Module surface, whose leaf
+ * arithmetic is torch.nn (ATen).  Each entry point below therefore cites the
+ * reference call site(s) whose arithmetic it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Contract (all entry points)
+ *   - plain pointers and sizes only; device pointers are BORROWED (no
+ *     allocation, free or host sync inside the library; workspaces come in);
+ *   - asynchronous on `stream`; safe to capture in a hipGraph;
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure,
+ *     -3 unsupported shape); mm_last_error() gives the thread-local message;
+ *   - `void*` tensors are bf16, `float*` fp32; channels-last layouts:
+ *     1-D activations [B][T][C], tokens [M][D], volumes [B][D][H][W][C];
+ *   - activation codes: 0 none, 1 GELU(erf), 2 ReLU, 3 tanh, 4 sigmoid;
+ *   - dropout: keep iff hash(seed, element index) >= p * 2^32, scaled 1/(1-p);
+ *     the backward entry points recompute the same mask from (p, seed).
+ */
+#ifndef MMEEG_HIP_H
+#define MMEEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+const char* mm_last_error(void);
+int mm_abi_version(void);
+
+/* ---- layout packers --------------------------------------------------------
+ * (B,C,T) fp32 -> (B,T,Cp) bf16, zero-padded channels.  Replaces the implicit
+ * NCT layout of every nn.Conv1d input (enhanced_models_v4.py:129, 211-223). */
+int mm_pack_nct_bf16(const float* x, void* y, int B, int C, int T, int Cp, hipStream_t stream);
+/* inverse for the input gradient: (B,T,Cp) bf16 -> (B,C,T) fp32 */
+int mm_unpack_ntc_f32(const void* g, float* dx, int B, int C, int T, int Cp, hipStream_t stream);
+/* weight (Cout,Cin,k) fp32 -> forward image [Cout][k][Cinp] bf16 and (optional)
+ * data-gradient image [Cinp][k flipped][Coutp] bf16 */
+int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, int Cin, int k,
+                        int Cinp, int Coutp, hipStream_t stream);
+
+/* ---- 1-D implicit GEMM (bf16 MFMA, fp32 accumulate) -----------------------
+ * Y[b,t,n] = epilogue( sum_{tap,c} X[b,t+tap-pad,c] * W[n,tap,c] )
+ * epilogue: v = acc*scale[n] + shift[n]; stats[0][n]+=v, stats[1][n]+=v*v;
+ *           out_pre = v; v = act(v); v *= dropout; v += residual; v += pe[t][n];
+ *           max over t pairs if pool == 2; store fp32 and/or bf16.
+ * Replaces nn.Conv1d (+ folded eval BatchNorm1d + GELU + MaxPool1d)
+ * (enhanced_models_v4.py:128-144, 210-234; crossmodal_v4_enhancements.py:822-877)
+ * and, with taps == 1, every nn.Linear / MHA projection on the path
+ * (enhanced_models_v4.py:71-81, 164; bridge_utils.py:34-66). */
+int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
+                  const float* scale, const float* shift, int act, const float* residual,
+                  const float* pe, int pool, float* stats, float* out_f32, void* out_bf16,
+                  void* out_pre, float drop_p, uint32_t drop_seed, hipStream_t stream);
+/* dW[n][c][tap] (fp32, strides sn/sc/stap in elements) += sum_{b,t} dY[b,t,n]*X[b,t+tap-pad,c];
+ * optional dbias[n] += sum dY.  Replaces the weight/bias gradients autograd
+ * derives for the layers above (loss.backward(), run_training_lite.py:486). */
+int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin,
+                    int Cout, int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap,
+                    hipStream_t stream);
+
+/* ---- BatchNorm / activation / pool ----------------------------------------
+ * mode 0 (train): stats{sum,sumsq}/count -> out4 = {scale, shift, mean, rstd},
+ * running stats updated (momentum, unbiased var);  mode 1 (eval): fold running
+ * stats (+conv bias).  nn.BatchNorm1d/3d (enhanced_models_v4.py:130,135,141). */
+int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, float* run_mean,
+                   float* run_var, const float* conv_bias, float* out4, int N, float count,
+                   float momentum, float eps, int mode, hipStream_t stream);
+/* y fp32 [R][S][N] -> act(y*scale+shift) [-> maxpool2 over S] [-> dropout] [+pe[s][n]]
+ * (BN -> GELU -> MaxPool1d -> Dropout -> PositionalEncoding add,
+ *  enhanced_models_v4.py:130-143, 49-54) */
+int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe,
+                  void* out_bf16, float* out_f32, int R, int S, int N, int act, int pool,
+                  int drop_first, float drop_p, uint32_t seed, hipStream_t stream);
+int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16,
+                         const float* dout_f32, float* sums_out, int R, int S, int N, int act,
+                         int pool, int drop_first, float drop_p, uint32_t seed, hipStream_t stream);
+int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16,
+                        const float* dout_f32, const float* sums, void* dy, int R, int S, int N,
+                        int act, int pool, int drop_first, float drop_p, uint32_t seed, int train,
+                        hipStream_t stream);
+
+/* ---- LayerNorm (nn.LayerNorm, enhanced_models_v4.py:80-81; bridge_utils.py:36,42,62) */
+int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16,
+                     float* out_f32, float* stat, int M, int D, float eps, hipStream_t stream);
+int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stat,
+                     const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                     float* dbeta, int M, int D, hipStream_t stream);
+
+/* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
+ * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,
+ * lse [B][H][L] fp32.  The head-averaged weights the reference computes and
+ * discards (:99) are not produced. */
+int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim,
+                float scale, hipStream_t stream);
+int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                float* delta_ws, int B, int L, int H, int head_dim, float scale, hipStream_t stream);
+
+/* ---- small reductions / elementwise --------------------------------------- */
+int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, hipStream_t stream);
+/* AdaptiveAvgPool1d(1)+Flatten (enhanced_models_v4.py:162-163) on fp32 tokens */
+int mm_meanpool_fwd(const float* x, float* out_f32, void* out_bf16, int B, int L, int D, hipStream_t stream);
+int mm_meanpool_bwd(const float* g, float* dx, int B, int L, int D, hipStream_t stream);
+int mm_cast_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
+int mm_cast_f32(const void* x, float* y, int64_t n, hipStream_t stream);
+/* out = bf16( g * dropout_mask * act'(z) ) */
+int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out, int64_t n, int act,
+               float drop_p, uint32_t seed, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMEEG_HIP_H */

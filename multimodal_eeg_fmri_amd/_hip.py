@@ -8,56 +8,52 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Dict, List
+import re
+from typing import Dict
 
 import torch
 
 _LIB_NAME = "libmmeeg_hip.so"
 _lib = None
 
-# signature codes: p = device/host pointer, i = int, f = float, u = uint32, l = int64
-# (the trailing hipStream_t is implicit for every entry except those in _NO_STREAM)
-_SIGS: Dict[str, str] = {
-    "mm_pack_nct_bf16": "ppiiii",
-    "mm_unpack_ntc_f32": "ppiiii",
-    "mm_prep_conv_weight": "pppiiiii",
-    "mm_conv1d_fwd": "ppiiiiiippippippppfu",
-    "mm_conv1d_wgrad": "pppiiiiiip",
-    "mm_bn_finalize": "pppppppiffi",
-    "mm_bn_act_fwd": "pppppppiiiiiifui",
-    "mm_bn_act_bwd_reduce": "pppppppiiiiiifui",
-    "mm_bn_act_bwd_apply": "ppppppppiiiiiifuii",
-    "mm_layernorm_fwd": "ppppppiif",
-    "mm_layernorm_bwd": "ppppppppppii",
-    "mm_attn_fwd": "pppiiiif",
-    "mm_attn_bwd": "ppppppiiiif",
-    "mm_colsum": "pppii",
-    "mm_meanpool_fwd": "ppiii",
-    "mm_meanpool_bwd": "ppiii",
-    "mm_act_bwd": "ppppiiifu",
-    "mm_small_linear_fwd": "pppppiiiiifu",
-    "mm_cast_bf16": "ppl",
-    "mm_cast_f32": "ppl",
-    "mm_add_pe": "ppppiiifu",
-    "mm_conv3d_direct_fwd": "pppppiiiiii",
-    "mm_conv3d_direct_wgrad": "ppppiiiii",
-    "mm_conv3d_fwd": "pppiiiiiippp",
-    "mm_conv3d_wgrad": "pppiiiiiip",
-    "mm_pool3d_bn_act_fwd": "ppppppppiiiiiiifui",
-    "mm_pool3d_bn_act_bwd_reduce": "pppppppiiiiiiifui",
-    "mm_pool3d_bn_act_bwd_apply": "ppppppppiiiiiiifuii",
-    "mm_prep_conv3d_weight": "pppiiii",
-    "mm_proj_head_fwd": "ppppppppiiifu",
-    "mm_proj_head_bwd": "pppppppppppiiifu",
-    "mm_clip_loss": "pppppppppiiifi",
-    "mm_bridge_fwd": "ppppppppi",
-    "mm_adamw_clip": "ppppppplffffffi",
-    "mm_sumsq": "ppl",
-    "mm_scale_inplace": "ppl",
-}
-_NO_STREAM: List[str] = []
+# Signatures are parsed from include/mmeeg_hip.h (single source of truth):
+# pointer -> c_void_p, int -> c_int, float -> c_float, uint32_t -> c_uint32,
+# int64_t -> c_int64; the trailing hipStream_t is supplied by call().
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float,
        "u": ctypes.c_uint32, "l": ctypes.c_int64}
+_SIGS: Dict[str, str] = {}
+
+
+def header_path() -> str:
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.join(os.path.dirname(here), "include", "mmeeg_hip.h")
+
+
+def parse_header(path: str = None) -> Dict[str, str]:
+    """{'mm_name': 'ppii...'} for every ``int mm_*(..., hipStream_t stream);``."""
+    text = open(path or header_path()).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\bint\s+(mm_\w+)\s*\(([^)]*)\)\s*;", text):
+        name, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+        if not args or "hipStream_t" not in args[-1]:
+            continue
+        code = ""
+        for a in args[:-1]:
+            if "*" in a:
+                code += "p"
+            elif a.startswith("int64_t"):
+                code += "l"
+            elif a.startswith("uint32_t"):
+                code += "u"
+            elif a.startswith("float"):
+                code += "f"
+            elif a.startswith("int"):
+                code += "i"
+            else:
+                raise ValueError(f"{name}: cannot map argument '{a}'")
+        sigs[name] = code
+    return sigs
 
 
 class HipLibraryError(RuntimeError):
@@ -81,12 +77,14 @@ def load():
     lib = ctypes.CDLL(path)
     lib.mm_last_error.restype = ctypes.c_char_p
     lib.mm_abi_version.restype = ctypes.c_int
+    _SIGS.update(parse_header())
+    missing = [n for n in _SIGS if not hasattr(lib, n)]
+    if missing:
+        raise HipLibraryError(f"{path} is stale: missing symbols {missing}; rebuild it")
     for name, sig in _SIGS.items():
-        fn = getattr(lib, name, None)
-        if fn is None:
-            continue                      # checked by tests/test_abi.py against the header
+        fn = getattr(lib, name)
         fn.restype = ctypes.c_int
-        fn.argtypes = [_CT[c] for c in sig] + ([] if name in _NO_STREAM else [ctypes.c_void_p])
+        fn.argtypes = [_CT[c] for c in sig] + [ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -112,8 +110,7 @@ def call(name: str, *args):
     if len(args) != len(sig):
         raise HipLibraryError(f"{name}: expected {len(sig)} args, got {len(args)}")
     conv = [(_ptr(a) if c == "p" else a) for a, c in zip(args, sig)]
-    if name not in _NO_STREAM:
-        conv.append(torch.cuda.current_stream().cuda_stream)
+    conv.append(torch.cuda.current_stream().cuda_stream)
     rc = fn(*conv)
     if rc != 0:
         raise HipLibraryError(f"{name} failed ({rc}): {lib.mm_last_error().decode()}")

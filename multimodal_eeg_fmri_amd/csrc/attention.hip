@@ -1,0 +1,365 @@
+// Multi-head self-attention for head_dim 32 on bf16 MFMA, fp32 softmax.
+//
+// qkv : [B][L][3E] bf16 (nn.MultiheadAttention packed in_proj order q|k|v, head
+//       h owns columns h*32 .. h*32+31 of each E-wide third),  E = H*32
+// out : [B][L][E]  bf16   (heads concatenated, ready for out_proj)
+// lse : [B][H][L]  fp32   log-sum-exp of the scaled scores (for backward)
+//
+// One workgroup = 4 waves = 128 queries of one (b, h); each wave owns 32
+// queries.  Keys/values of the (b, h) pair are staged in LDS in chunks of KCH
+// keys: K row-major [key][32] (+16 B pad), V transposed [d][key] with the key
+// order inside each 16-key group permuted so that the P^T accumulator tile of
+// the first MFMA is directly the B operand of the second (no lane movement):
+//     S^T[key][q] = K_tile . Q^T          (A = K rows, B = Q^T from registers)
+//     O^T[d][q]  += V^T[d][key] . P^T     (A = V^T rows, B = exp(S^T) as bf16)
+// Each lane therefore owns one query column: the row max / row sum are 16
+// in-register values plus one exchange with lane^32.
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 32;
+constexpr int KCH = 256;                 // keys staged per chunk
+constexpr int KS = DH + 8;               // K row stride (elements): 80 B
+constexpr int VS = KCH + 8;              // V^T row stride (elements)
+
+__device__ __forceinline__ int vperm(int key) {       // swap bits 2 and 3 of the key index
+    return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                       float* __restrict__ lse, int L, int H, float scale_log2) {
+    __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
+    __shared__ __attribute__((aligned(16))) bf16 Vt[DH * VS];
+    const int E = H * DH, E3 = 3 * E;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    const bf16* base = qkv + (size_t)b * L * E3 + h * DH;
+
+    // Q^T fragments (B operand): lane holds Q[q][16s + 8*lh .. +8]
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (q < L) qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * E3 + 16 * s + 8 * lh);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)0.f;
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < L; k0 += KCH) {
+        const int kn = min(KCH, L - k0);
+        const int kn32 = (kn + 31) & ~31;
+        __syncthreads();
+        // stage K rows and V^T (zero-padded to a multiple of 32 keys)
+        for (int s = tid; s < kn32 * 4; s += 256) {
+            const int key = s >> 2, sg = s & 3;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (key < kn) {
+                const bf16* row = base + (size_t)(k0 + key) * E3;
+                kv = *reinterpret_cast<const uint4*>(row + E + sg * 8);
+                vv = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
+            }
+            *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kv;
+            const bf16* ve = reinterpret_cast<const bf16*>(&vv);
+            const int pos = vperm(key);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Vt[(sg * 8 + j) * VS + pos] = ve[j];
+        }
+        __syncthreads();
+        for (int kt = 0; kt < kn32; kt += 32) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt + lr) * KS + 16 * s + 8 * lh);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+            }
+            // scaled scores in log2 units; mask padded keys
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                sacc[r] = key < kn ? sacc[r] * scale_log2 : -INFINITY;
+                mx = fmaxf(mx, sacc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f(m_run - m_new);      // m_run = -inf first time -> 0
+            float ps = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(sacc[r] - m_new);
+                ps += p;
+                pf[r >> 3][r & 7] = (bf16)p;
+            }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + lr * VS + kt + 16 * s + 8 * lh);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o, 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q < L) {
+        bf16* orow = out + ((size_t)b * L + q) * E + h * DH;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                       // rows d = 8g + 4*lh + {0..3}
+            bf16x4 v = {(bf16)(o[4 * g] * inv), (bf16)(o[4 * g + 1] * inv), (bf16)(o[4 * g + 2] * inv), (bf16)(o[4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * lh) = v;
+        }
+        if (lse && lh == 0) lse[((size_t)b * H + h) * L + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Backward.  P = exp(scale*S - lse), dS = P o (dP - delta), delta = rowsum(dO o O)
+//   dQ = scale * dS K      dK = scale * dS^T Q      dV = P^T dO
+// Two passes, no atomics (bit-reproducible):
+//   dq kernel : one WG = 128 queries, sweeps all keys (K, V, K^T in LDS);
+//               also writes delta[b][h][q] for the second pass.
+//   dkv kernel: one WG = 128 keys (K, V fragments in registers), sweeps all
+//               queries (Q, dO, Q^T, dO^T, lse, delta in LDS).
+// In both, the first product is oriented so that its accumulator tile is the
+// B operand of the following products (rows = reduction index).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                          bf16* __restrict__ dqkv, float* __restrict__ delta,
+                                                          int L, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * KS];
+    __shared__ __attribute__((aligned(16))) bf16 Kt[DH * VS];
+    const int E = H * DH, E3 = 3 * E;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int q = blockIdx.x * 128 + wave * 32 + lr;
+    const bool qok = q < L;
+    const bf16* base = qkv + (size_t)b * L * E3 + h * DH;
+    const float scale_log2 = scale * 1.4426950408889634f;
+
+    bf16x8 qf[2], dof[2];
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { qf[s][j] = (bf16)0.f; dof[s][j] = (bf16)0.f; }
+        if (qok) {
+            qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * E3 + 16 * s + 8 * lh);
+            const size_t oi = ((size_t)b * L + q) * E + h * DH + 16 * s + 8 * lh;
+            dof[s] = *reinterpret_cast<const bf16x8*>(dout + oi);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(out + oi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)of[j];
+        }
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const float lse2 = qok ? lse[((size_t)b * H + h) * L + q] * 1.4426950408889634f : 0.f;
+    if (qok && lh == 0) delta[((size_t)b * H + h) * L + q] = dl;
+
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+
+    for (int k0 = 0; k0 < L; k0 += KCH) {
+        const int kn = min(KCH, L - k0);
+        const int kn32 = (kn + 31) & ~31;
+        __syncthreads();
+        for (int s = tid; s < kn32 * 4; s += 256) {
+            const int key = s >> 2, sg = s & 3;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (key < kn) {
+                const bf16* row = base + (size_t)(k0 + key) * E3;
+                kv = *reinterpret_cast<const uint4*>(row + E + sg * 8);
+                vv = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
+            }
+            *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kv;
+            *reinterpret_cast<uint4*>(Vs + key * KS + sg * 8) = vv;
+            const bf16* ke = reinterpret_cast<const bf16*>(&kv);
+            const int pos = vperm(key);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Kt[(sg * 8 + j) * VS + pos] = ke[j];
+        }
+        __syncthreads();
+        for (int kt = 0; kt < kn32; kt += 32) {
+            f32x16 sacc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt + lr) * KS + 16 * s + 8 * lh);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt + lr) * KS + 16 * s + 8 * lh);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
+            }
+            bf16x8 dsf[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float p = key < kn ? exp2f(sacc[r] * scale_log2 - lse2) : 0.f;
+                dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] - dl));
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(Kt + lr * VS + kt + 16 * s + 8 * lh);
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[s], dq, 0, 0, 0);
+            }
+        }
+    }
+    if (qok) {
+        bf16* drow = dqkv + ((size_t)b * L + q) * E3 + h * DH;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v = {(bf16)(dq[4 * g] * scale), (bf16)(dq[4 * g + 1] * scale), (bf16)(dq[4 * g + 2] * scale), (bf16)(dq[4 * g + 3] * scale)};
+            *reinterpret_cast<bf16x4*>(drow + 8 * g + 4 * lh) = v;
+        }
+    }
+}
+
+constexpr int QCH = 128;                 // queries staged per chunk in the dK/dV pass
+constexpr int QS = QCH + 8;              // transposed row stride
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16* __restrict__ dqkv, int L, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16 Qs[QCH * KS];
+    __shared__ __attribute__((aligned(16))) bf16 Ds[QCH * KS];
+    __shared__ __attribute__((aligned(16))) bf16 Qt[DH * QS];
+    __shared__ __attribute__((aligned(16))) bf16 Dt[DH * QS];
+    __shared__ float Ls[QCH], Dl[QCH];
+    const int E = H * DH, E3 = 3 * E;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int key = blockIdx.x * 128 + wave * 32 + lr;
+    const bool kok = key < L;
+    const bf16* base = qkv + (size_t)b * L * E3 + h * DH;
+    const float scale_log2 = scale * 1.4426950408889634f;
+
+    // K^T / V^T fragments as B operands: lane holds K[key][16s + 8*lh .. +8]
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kf[s][j] = (bf16)0.f; vf[s][j] = (bf16)0.f; }
+        if (kok) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * E3 + E + 16 * s + 8 * lh);
+            vf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * E3 + 2 * E + 16 * s + 8 * lh);
+        }
+    }
+    f32x16 dk, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+
+    for (int q0 = 0; q0 < L; q0 += QCH) {
+        const int qn = min(QCH, L - q0);
+        const int qn32 = (qn + 31) & ~31;
+        __syncthreads();
+        for (int s = tid; s < qn32 * 4; s += 256) {
+            const int qi = s >> 2, sg = s & 3;
+            uint4 qv = make_uint4(0, 0, 0, 0), dv4 = make_uint4(0, 0, 0, 0);
+            if (qi < qn) {
+                qv = *reinterpret_cast<const uint4*>(base + (size_t)(q0 + qi) * E3 + sg * 8);
+                dv4 = *reinterpret_cast<const uint4*>(dout + ((size_t)b * L + q0 + qi) * E + h * DH + sg * 8);
+            }
+            *reinterpret_cast<uint4*>(Qs + qi * KS + sg * 8) = qv;
+            *reinterpret_cast<uint4*>(Ds + qi * KS + sg * 8) = dv4;
+            const bf16* qe = reinterpret_cast<const bf16*>(&qv);
+            const bf16* de = reinterpret_cast<const bf16*>(&dv4);
+            const int pos = vperm(qi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                Qt[(sg * 8 + j) * QS + pos] = qe[j];
+                Dt[(sg * 8 + j) * QS + pos] = de[j];
+            }
+        }
+        for (int i = tid; i < qn32; i += 256) {
+            const bool ok = i < qn;
+            Ls[i] = ok ? lse[((size_t)b * H + h) * L + q0 + i] * 1.4426950408889634f : INFINITY;
+            Dl[i] = ok ? delta[((size_t)b * H + h) * L + q0 + i] : 0.f;
+        }
+        __syncthreads();
+        for (int qt = 0; qt < qn32; qt += 32) {
+            // S[q][key] and dP[q][key]: rows = q (registers), column = this lane's key
+            f32x16 sacc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt + lr) * KS + 16 * s + 8 * lh);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sacc, 0, 0, 0);
+                const bf16x8 da = *reinterpret_cast<const bf16x8*>(Ds + (qt + lr) * KS + 16 * s + 8 * lh);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dp, 0, 0, 0);
+            }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float p = kok ? exp2f(sacc[r] * scale_log2 - Ls[qi]) : 0.f;
+                pf[r >> 3][r & 7] = (bf16)p;
+                dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] - Dl[qi]));
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 dta = *reinterpret_cast<const bf16x8*>(Dt + lr * QS + qt + 16 * s + 8 * lh);
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dta, pf[s], dv, 0, 0, 0);
+                const bf16x8 qta = *reinterpret_cast<const bf16x8*>(Qt + lr * QS + qt + 16 * s + 8 * lh);
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsf[s], dk, 0, 0, 0);
+            }
+        }
+    }
+    if (kok) {
+        bf16* krow = dqkv + ((size_t)b * L + key) * E3 + E + h * DH;
+        bf16* vrow = krow + E;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 a = {(bf16)(dk[4 * g] * scale), (bf16)(dk[4 * g + 1] * scale), (bf16)(dk[4 * g + 2] * scale), (bf16)(dk[4 * g + 3] * scale)};
+            bf16x4 c = {(bf16)dv[4 * g], (bf16)dv[4 * g + 1], (bf16)dv[4 * g + 2], (bf16)dv[4 * g + 3]};
+            *reinterpret_cast<bf16x4*>(krow + 8 * g + 4 * lh) = a;
+            *reinterpret_cast<bf16x4*>(vrow + 8 * g + 4 * lh) = c;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, float scale,
+                hipStream_t st) {
+    MM_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0, "attn_fwd: null/invalid");
+    MM_REQUIRE(head_dim == DH, "attn_fwd: head_dim=%d (kernel is specialised for 32)", head_dim);
+    dim3 grid(ceil_div(L, 128), H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
+                       scale * 1.4426950408889634f);
+    return mm_check_launch("attn_fwd");
+}
+
+int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
+                int B, int L, int H, int head_dim, float scale, hipStream_t st) {
+    MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
+    MM_REQUIRE(head_dim == DH, "attn_bwd: head_dim=%d (kernel is specialised for 32)", head_dim);
+    dim3 grid(ceil_div(L, 128), H, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)out,
+                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale);
+    int rc = mm_check_launch("attn_bwd_dq");
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
+                       delta_ws, (bf16*)dqkv, L, H, scale);
+    return mm_check_launch("attn_bwd_dkv");
+}
+
+}  // extern "C"

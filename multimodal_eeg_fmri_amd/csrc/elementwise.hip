@@ -1,0 +1,517 @@
+// HBM-bound row/channel kernels: BatchNorm finalize + BN/act/pool apply (fwd,
+// bwd), LayerNorm (fwd, bwd), mean-pool, column sums, casts.  All statistics,
+// normalisation and activation math is fp32; bf16 only at rest.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// BatchNorm finalize.  mode 0 (train): stats = {sum, sumsq} over `count`
+// samples -> mean / rstd, scale = g*rstd, shift = b - mean*scale, and the
+// running-stat update (momentum, unbiased variance) of nn.BatchNorm*d.
+// mode 1 (eval): fold running stats (+ optional conv bias) into scale/shift.
+// ---------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* stats, const float* gamma, const float* beta,
+                                   float* run_mean, float* run_var, const float* conv_bias,
+                                   float* out /* [4][N]: scale, shift, mean, rstd */, int N,
+                                   float count, float momentum, float eps, int mode) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float mean, var;
+    if (mode == 0) {
+        mean = stats[n] / count;
+        var = fmaxf(stats[N + n] / count - mean * mean, 0.f);
+        run_mean[n] = (1.f - momentum) * run_mean[n] + momentum * mean;
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        run_var[n] = (1.f - momentum) * run_var[n] + momentum * unb;
+    } else {
+        mean = run_mean[n];
+        var = run_var[n];
+    }
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[n] * rstd;
+    const float cb = (mode == 1 && conv_bias) ? conv_bias[n] : 0.f;
+    out[n] = sc;
+    out[N + n] = beta[n] + (cb - mean) * sc;
+    out[2 * N + n] = mean;
+    out[3 * N + n] = rstd;
+}
+
+// ---------------------------------------------------------------------------
+// y (fp32 [R][S][N], S = pooled axis length) -> act(y*scale+shift) -> pool ->
+// dropout -> (+pe) -> bf16 / fp32.   R = batch, S = T (1-D).  pool in {1,2}.
+// drop_first: dropout before the pool (Lite encoders) or after it (ERP conv2).
+// ---------------------------------------------------------------------------
+struct BnActArgs {
+    const float* y; const float* scale; const float* shift; const float* pe;
+    bf16* out_bf16; float* out_f32;
+    int R, S, N, act, pool, drop_first;
+    uint32_t thresh, seed; float inv_keep;
+};
+
+__device__ __forceinline__ float bnact_one(const BnActArgs& a, float y, float sc, float sh, uint32_t idx, bool drop_here) {
+    float v = apply_act(y * sc + sh, a.act);
+    if (drop_here && a.thresh) v *= dropout_scale(a.seed, idx, a.thresh, a.inv_keep);
+    return v;
+}
+
+__global__ void bn_act_fwd_kernel(BnActArgs a) {
+    const int So = a.S / a.pool;
+    const int nv = a.N / 4;
+    const size_t total = (size_t)a.R * So * nv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n4 = (int)(i % nv) * 4;
+        const size_t rs = i / nv;                    // r * So + so
+        const int so = (int)(rs % So);
+        const size_t r = rs / So;
+        const float4 sc = *reinterpret_cast<const float4*>(a.scale + n4);
+        const float4 sh = *reinterpret_cast<const float4*>(a.shift + n4);
+        float o[4];
+        const size_t in0 = (r * a.S + (size_t)so * a.pool) * a.N + n4;
+        const float4 y0 = *reinterpret_cast<const float4*>(a.y + in0);
+        const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float y0s[4] = {y0.x, y0.y, y0.z, y0.w};
+        const size_t oidx = (r * So + so) * a.N + n4;
+        if (a.pool == 2) {
+            const float4 y1 = *reinterpret_cast<const float4*>(a.y + in0 + a.N);
+            const float y1s[4] = {y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v0 = bnact_one(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), a.drop_first);
+                const float v1 = bnact_one(a, y1s[q], scs[q], shs[q], (uint32_t)(in0 + a.N + q), a.drop_first);
+                float m = fmaxf(v0, v1);
+                if (!a.drop_first && a.thresh) m *= dropout_scale(a.seed, (uint32_t)(oidx + q), a.thresh, a.inv_keep);
+                o[q] = m;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = bnact_one(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), true);
+        }
+        if (a.pe) {
+            const float4 p = *reinterpret_cast<const float4*>(a.pe + (size_t)so * a.N + n4);
+            o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
+        }
+        if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + oidx) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.out_bf16) {
+            bf16x4 b = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+            *reinterpret_cast<bf16x4*>(a.out_bf16 + oidx) = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward of the above.  dz = dOut routed through dropout/pool/act'.
+//   reduce : sums[0][n] += dz, sums[1][n] += dz * xhat          (train BN)
+//   apply  : dy = scale * (dz - sums0/M - xhat * sums1/M)   (train)
+//            dy = scale * dz                                 (frozen stats)
+// ---------------------------------------------------------------------------
+struct BnBwdArgs {
+    const float* y; const float* scale; const float* shift; const float* mean; const float* rstd;
+    const bf16* dout_bf16; const float* dout_f32; const float* sums;
+    float* sums_out; bf16* dy;
+    int R, S, N, act, pool, drop_first, train;
+    uint32_t thresh, seed; float inv_keep, inv_count;
+};
+
+// computes dz for the (up to) two inputs of one pooled output element
+__device__ __forceinline__ void bn_dz_pair(const BnBwdArgs& a, float y0, float y1, float sc, float sh, float g,
+                                           uint32_t i0, uint32_t i1, uint32_t io, float& dz0, float& dz1) {
+    const float z0 = y0 * sc + sh;
+    if (a.pool == 1) {
+        float m = a.thresh ? dropout_scale(a.seed, i0, a.thresh, a.inv_keep) : 1.f;
+        dz0 = g * m * act_grad(z0, a.act);
+        dz1 = 0.f;
+        return;
+    }
+    const float z1 = y1 * sc + sh;
+    float a0 = apply_act(z0, a.act), a1 = apply_act(z1, a.act);
+    float m0 = 1.f, m1 = 1.f;
+    if (a.thresh) {
+        if (a.drop_first) {
+            m0 = dropout_scale(a.seed, i0, a.thresh, a.inv_keep);
+            m1 = dropout_scale(a.seed, i1, a.thresh, a.inv_keep);
+            a0 *= m0; a1 *= m1;
+        } else {
+            g *= dropout_scale(a.seed, io, a.thresh, a.inv_keep);
+        }
+    }
+    const bool first = a0 >= a1;                       // ties -> first (torch max_pool)
+    dz0 = first ? g * m0 * act_grad(z0, a.act) : 0.f;
+    dz1 = first ? 0.f : g * m1 * act_grad(z1, a.act);
+}
+
+template <bool APPLY>
+__global__ void bn_act_bwd_kernel(BnBwdArgs a) {
+    // block = 256 threads = (N/4 channel-vectors) x rows; grid-stride over pooled rows
+    const int nv = a.N / 4;
+    const int So = a.S / a.pool;
+    const int rows_per_blk = 256 / nv > 0 ? 256 / nv : 1;
+    const int vi = threadIdx.x % nv, ri = threadIdx.x / nv;
+    const bool active = ri < rows_per_blk;
+    const int n4 = vi * 4;
+    const size_t nrows = (size_t)a.R * So;
+    float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    float scs[4], shs[4], mus[4], rss[4], c0[4], c1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        scs[q] = a.scale[n4 + q]; shs[q] = a.shift[n4 + q];
+        mus[q] = a.mean ? a.mean[n4 + q] : 0.f; rss[q] = a.rstd ? a.rstd[n4 + q] : 1.f;
+        c0[q] = (APPLY && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;
+        c1[q] = (APPLY && a.train) ? a.sums[a.N + n4 + q] * a.inv_count : 0.f;
+    }
+    if (active)
+        for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
+            const size_t r = row / So;
+            const int so = (int)(row % So);
+            const size_t in0 = (r * a.S + (size_t)so * a.pool) * a.N + n4;
+            const size_t oidx = row * a.N + n4;
+            float g[4];
+            if (a.dout_f32) {
+                const float4 t = *reinterpret_cast<const float4*>(a.dout_f32 + oidx);
+                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+            } else {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(a.dout_bf16 + oidx);
+                g[0] = (float)t[0]; g[1] = (float)t[1]; g[2] = (float)t[2]; g[3] = (float)t[3];
+            }
+            const float4 y0 = *reinterpret_cast<const float4*>(a.y + in0);
+            float4 y1 = y0;
+            if (a.pool == 2) y1 = *reinterpret_cast<const float4*>(a.y + in0 + a.N);
+            const float y0s[4] = {y0.x, y0.y, y0.z, y0.w}, y1s[4] = {y1.x, y1.y, y1.z, y1.w};
+            float d0[4], d1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bn_dz_pair(a, y0s[q], y1s[q], scs[q], shs[q], g[q], (uint32_t)(in0 + q),
+                           (uint32_t)(in0 + a.N + q), (uint32_t)(oidx + q), d0[q], d1[q]);
+                const float xh0 = (y0s[q] - mus[q]) * rss[q], xh1 = (y1s[q] - mus[q]) * rss[q];
+                if (APPLY) {
+                    if (a.train) {
+                        d0[q] = scs[q] * (d0[q] - c0[q] - xh0 * c1[q]);
+                        d1[q] = scs[q] * (d1[q] - c0[q] - xh1 * c1[q]);
+                    } else {
+                        d0[q] *= scs[q]; d1[q] *= scs[q];
+                    }
+                } else {
+                    s0[q] += d0[q] + d1[q];
+                    s1[q] += d0[q] * xh0 + d1[q] * xh1;
+                }
+            }
+            if (APPLY) {
+                bf16x4 b0 = {(bf16)d0[0], (bf16)d0[1], (bf16)d0[2], (bf16)d0[3]};
+                *reinterpret_cast<bf16x4*>(a.dy + in0) = b0;
+                if (a.pool == 2) {
+                    bf16x4 b1 = {(bf16)d1[0], (bf16)d1[1], (bf16)d1[2], (bf16)d1[3]};
+                    *reinterpret_cast<bf16x4*>(a.dy + in0 + a.N) = b1;
+                }
+            }
+        }
+    if (!APPLY) {
+        __shared__ float red[2][1024];                 // N <= 1024
+        for (int i = threadIdx.x; i < 2 * a.N; i += 256) (&red[0][0])[(i / a.N) * 1024 + i % a.N] = 0.f;
+        __syncthreads();
+        if (active)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                atomicAdd(&red[0][n4 + q], s0[q]);
+                atomicAdd(&red[1][n4 + q], s1[q]);
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.N; i += 256) {
+            atomicAdd(&a.sums_out[i], red[0][i]);
+            atomicAdd(&a.sums_out[a.N + i], red[1][i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over the last dim (D % 64 == 0, D <= 1024): one wave per row.
+// ---------------------------------------------------------------------------
+template <int VPL>   // values per lane = D / 64
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                     bf16* __restrict__ out_bf16, float* __restrict__ out_f32,
+                                     float* __restrict__ stat /* [M][2] mean,rstd */, int M, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    constexpr int D = VPL * 64;
+    float v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i] = x[(size_t)row * D + i * 64 + lane]; s += v[i]; }
+    const float mean = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        const float o = (v[i] - mean) * rstd * g[c] + b[c];
+        if (out_bf16) out_bf16[(size_t)row * D + c] = (bf16)o;
+        if (out_f32) out_f32[(size_t)row * D + c] = o;
+    }
+    if (stat && lane == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
+}
+
+// dx = dres + rstd * (gh - mean(gh) - xhat * mean(gh * xhat)),  gh = dy * gamma
+// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy       (block partial + atomics)
+// optional second output: bf16(dx * dropout_mask) for the next GEMM operand.
+template <int VPL>
+__global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+                                     const float* __restrict__ x, const float* __restrict__ stat,
+                                     const float* __restrict__ g, const float* __restrict__ dres,
+                                     float* __restrict__ dx, bf16* __restrict__ dx_bf16,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                     int rows_per_wave) {
+    constexpr int D = VPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    float ag[VPL], ab[VPL], gam[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gam[i] = g[i * 64 + lane]; }
+    const int row0 = (blockIdx.x * wpb + wave) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int row = row0 + rr;
+        if (row >= M) break;
+        const float mean = stat[2 * row], rstd = stat[2 * row + 1];
+        float dyv[VPL], xh[VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const size_t idx = (size_t)row * D + i * 64 + lane;
+            dyv[i] = dy_bf16 ? (float)dy_bf16[idx] : dy_f32[idx];
+            xh[i] = (x[idx] - mean) * rstd;
+            const float gh = dyv[i] * gam[i];
+            s1 += gh; s2 += gh * xh[i];
+            ag[i] += dyv[i] * xh[i]; ab[i] += dyv[i];
+        }
+        s1 = wave_sum(s1) * (1.f / D);
+        s2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const size_t idx = (size_t)row * D + i * 64 + lane;
+            float o = rstd * (dyv[i] * gam[i] - s1 - xh[i] * s2);
+            if (dres) o += dres[idx];
+            if (dx) dx[idx] = o;
+            if (dx_bf16) dx_bf16[idx] = (bf16)o;
+        }
+    }
+    __shared__ float red[2][1024];
+    for (int i = threadIdx.x; i < 2 * 1024; i += blockDim.x) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        atomicAdd(&red[0][i * 64 + lane], ag[i]);
+        atomicAdd(&red[1][i * 64 + lane], ab[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        if (dgamma) atomicAdd(&dgamma[i], red[0][i]);
+        if (dbeta) atomicAdd(&dbeta[i], red[1][i]);
+    }
+}
+
+// column sums of a bf16/fp32 [M][N] matrix into fp32 [N] (atomics; bias grads)
+__global__ void colsum_kernel(const bf16* __restrict__ a_bf16, const float* __restrict__ a_f32,
+                              float* __restrict__ out, int M, int N, int rows_per_blk) {
+    const int m0 = blockIdx.x * rows_per_blk;
+    const int m1 = min(M, m0 + rows_per_blk);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int m = m0; m < m1; ++m) s += a_bf16 ? (float)a_bf16[(size_t)m * N + n] : a_f32[(size_t)m * N + n];
+        atomicAdd(&out[n], s);
+    }
+}
+
+// mean over L of fp32 [B][L][D] -> [B][D] fp32 + bf16
+__global__ void meanpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out_f32,
+                                    bf16* __restrict__ out_bf16, int L, int D) {
+    const int b = blockIdx.x;
+    const int d = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6, parts = blockDim.x >> 6;
+    __shared__ float red[4][64];
+    float s = 0.f;
+    if (d < D)
+        for (int l = part; l < L; l += parts) s += x[((size_t)b * L + l) * D + d];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && d < D) {
+        float t = 0.f;
+        for (int p = 0; p < parts; ++p) t += red[p][threadIdx.x & 63];
+        t /= (float)L;
+        if (out_f32) out_f32[(size_t)b * D + d] = t;
+        if (out_bf16) out_bf16[(size_t)b * D + d] = (bf16)t;
+    }
+}
+
+// dx[b,l,d] = g[b,d] / L  (fp32)
+__global__ void meanpool_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int B, int L, int D) {
+    const size_t total = (size_t)B * L * D;
+    const float inv = 1.f / (float)L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const size_t b = i / ((size_t)L * D);
+        dx[i] = g[b * D + d] * inv;
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (bf16)x[i];
+}
+__global__ void cast_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+
+// dz = g * dropout_mask * act'(z): elementwise gradient through act+dropout
+__global__ void act_bwd_kernel(const float* __restrict__ g_f32, const bf16* __restrict__ g_bf16,
+                               const bf16* __restrict__ z, bf16* __restrict__ out, size_t n, int act,
+                               uint32_t thresh, uint32_t seed, float inv_keep) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float g = g_f32 ? g_f32[i] : (float)g_bf16[i];
+        if (thresh) g *= dropout_scale(seed, (uint32_t)i, thresh, inv_keep);
+        if (z) g *= act_grad((float)z[i], act);
+        out[i] = (bf16)g;
+    }
+}
+
+inline int grid_for(size_t n, int block = 256, int cap = 4096) {
+    size_t g = (n + block - 1) / block;
+    return (int)(g < (size_t)cap ? (g ? g : 1) : cap);
+}
+inline uint32_t thresh_of(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+
+}  // namespace
+
+extern "C" {
+
+int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                   const float* conv_bias, float* out4, int N, float count, float momentum, float eps, int mode,
+                   hipStream_t st) {
+    MM_REQUIRE(gamma && beta && run_mean && run_var && out4 && N > 0, "bn_finalize: null/invalid");
+    MM_REQUIRE(mode == 1 || (stats && count >= 1.f), "bn_finalize: train mode needs stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(N, 128)), dim3(128), 0, st, stats, gamma, beta, run_mean,
+                       run_var, conv_bias, out4, N, count, momentum, eps, mode);
+    return mm_check_launch("bn_finalize");
+}
+
+int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe, void* out_bf16,
+                  float* out_f32, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
+                  uint32_t seed, hipStream_t st) {
+    MM_REQUIRE(y && scale && shift && (out_bf16 || out_f32), "bn_act_fwd: null");
+    MM_REQUIRE(N % 4 == 0 && (pool == 1 || (pool == 2 && S % 2 == 0)), "bn_act_fwd: N%%4, pool");
+    BnActArgs a{y, scale, shift, pe, (bf16*)out_bf16, out_f32, R, S, N, act, pool, drop_first,
+                thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
+    const size_t total = (size_t)R * (S / pool) * (N / 4);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, a);
+    return mm_check_launch("bn_act_fwd");
+}
+
+static int bn_bwd_common(bool apply, const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
+                         const float* sums_in, float* sums_out, void* dy, int R, int S, int N, int act, int pool,
+                         int drop_first, float drop_p, uint32_t seed, int train, hipStream_t st) {
+    MM_REQUIRE(y && out4 && (dout_bf16 || dout_f32), "bn_act_bwd: null");
+    MM_REQUIRE(N % 4 == 0 && N <= 1024 && (N / 4) <= 256, "bn_act_bwd: N");
+    BnBwdArgs a;
+    a.y = y; a.scale = out4; a.shift = out4 + N; a.mean = out4 + 2 * N; a.rstd = out4 + 3 * N;
+    a.dout_bf16 = (const bf16*)dout_bf16; a.dout_f32 = dout_f32; a.sums = sums_in; a.sums_out = sums_out;
+    a.dy = (bf16*)dy; a.R = R; a.S = S; a.N = N; a.act = act; a.pool = pool; a.drop_first = drop_first;
+    a.train = train; a.thresh = thresh_of(drop_p); a.seed = seed;
+    a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.inv_count = 1.f / ((float)R * (float)S);
+    const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
+    const size_t rows = (size_t)R * (S / pool);
+    int grid = (int)((rows + rpb - 1) / rpb);
+    if (grid > 1024) grid = 1024;
+    if (apply) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    return mm_check_launch("bn_act_bwd");
+}
+
+int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
+                         float* sums_out, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
+                         uint32_t seed, hipStream_t st) {
+    MM_REQUIRE(sums_out, "bn_act_bwd_reduce: null sums");
+    return bn_bwd_common(false, y, out4, dout_bf16, dout_f32, nullptr, sums_out, nullptr, R, S, N, act, pool,
+                         drop_first, drop_p, seed, 1, st);
+}
+
+int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
+                        const float* sums, void* dy, int R, int S, int N, int act, int pool, int drop_first,
+                        float drop_p, uint32_t seed, int train, hipStream_t st) {
+    MM_REQUIRE(dy && (!train || sums), "bn_act_bwd_apply: null");
+    return bn_bwd_common(true, y, out4, dout_bf16, dout_f32, sums, nullptr, dy, R, S, N, act, pool, drop_first,
+                         drop_p, seed, train, st);
+}
+
+#define LN_DISPATCH(D, CALL)                                   \
+    switch ((D) / 64) {                                        \
+        case 1: { constexpr int V = 1; CALL; } break;          \
+        case 2: { constexpr int V = 2; CALL; } break;          \
+        case 4: { constexpr int V = 4; CALL; } break;          \
+        case 8: { constexpr int V = 8; CALL; } break;          \
+        case 16: { constexpr int V = 16; CALL; } break;        \
+        default: return mm_fail(MM_ERR_UNSUPPORTED, "layernorm: D=%d (need 64,128,256,512,1024)", (D)); \
+    }
+
+int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16, float* out_f32,
+                     float* stat, int M, int D, float eps, hipStream_t st) {
+    MM_REQUIRE(x && gamma && beta && (out_bf16 || out_f32) && M > 0, "layernorm_fwd: null");
+    const dim3 grid(ceil_div(M, 4)), block(256);
+    LN_DISPATCH(D, hipLaunchKernelGGL(layernorm_fwd_kernel<V>, grid, block, 0, st, x, gamma, beta, (bf16*)out_bf16,
+                                      out_f32, stat, M, eps));
+    return mm_check_launch("layernorm_fwd");
+}
+
+int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stat, const float* gamma,
+                     const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int M, int D,
+                     hipStream_t st) {
+    MM_REQUIRE((dy_bf16 || dy_f32) && x && stat && gamma && (dx || dx_bf16), "layernorm_bwd: null");
+    const int rpw = M >= 8192 ? 8 : (M >= 1024 ? 2 : 1);
+    const dim3 grid(ceil_div(M, 4 * rpw)), block(256);
+    LN_DISPATCH(D, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, 0, st, (const bf16*)dy_bf16, dy_f32, x,
+                                      stat, gamma, dres, dx, (bf16*)dx_bf16, dgamma, dbeta, M, rpw));
+    return mm_check_launch("layernorm_bwd");
+}
+
+int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, hipStream_t st) {
+    MM_REQUIRE((a_bf16 || a_f32) && out && M > 0 && N > 0, "colsum: null");
+    const int rpb = M >= 4096 ? 64 : 16;
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(M, rpb)), dim3(N >= 256 ? 256 : (N >= 128 ? 128 : 64)), 0, st,
+                       (const bf16*)a_bf16, a_f32, out, M, N, rpb);
+    return mm_check_launch("colsum");
+}
+
+int mm_meanpool_fwd(const float* x, float* out_f32, void* out_bf16, int B, int L, int D, hipStream_t st) {
+    MM_REQUIRE(x && (out_f32 || out_bf16) && B > 0 && L > 0 && D > 0, "meanpool_fwd: null");
+    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, ceil_div(D, 64)), dim3(256), 0, st, x, out_f32, (bf16*)out_bf16, L, D);
+    return mm_check_launch("meanpool_fwd");
+}
+
+int mm_meanpool_bwd(const float* g, float* dx, int B, int L, int D, hipStream_t st) {
+    MM_REQUIRE(g && dx, "meanpool_bwd: null");
+    hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(grid_for((size_t)B * L * D)), dim3(256), 0, st, g, dx, B, L, D);
+    return mm_check_launch("meanpool_bwd");
+}
+
+int mm_cast_bf16(const float* x, void* y, int64_t n, hipStream_t st) {
+    MM_REQUIRE(x && y && n > 0, "cast_bf16: null");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, x, (bf16*)y, (size_t)n);
+    return mm_check_launch("cast_bf16");
+}
+
+int mm_cast_f32(const void* x, float* y, int64_t n, hipStream_t st) {
+    MM_REQUIRE(x && y && n > 0, "cast_f32: null");
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, (const bf16*)x, y, (size_t)n);
+    return mm_check_launch("cast_f32");
+}
+
+int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out, int64_t n, int act, float drop_p,
+               uint32_t seed, hipStream_t st) {
+    MM_REQUIRE((g_f32 || g_bf16) && out && n > 0, "act_bwd: null");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, g_f32, (const bf16*)g_bf16,
+                       (const bf16*)z, (bf16*)out, (size_t)n, act, thresh_of(drop_p), seed,
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    return mm_check_launch("act_bwd");
+}
+
+}  // extern "C"

@@ -268,6 +268,116 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, bf16* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// weight gradient:  dW[n][tap][c] += sum_{t in chunk} dY[b,t,n] * X[b,t+tap-pad,c]
+// MFMA view: D[i=n][j=c] = sum_k A[i][k] B[k][j] with k = t, so both operands
+// are k-strided in memory.  The dY tile [64 t][64 n] and the X halo tile
+// [64+taps-1][64 c] are staged row-major and read with ds_read_b64_tr_b16
+// (hardware transpose): each 16-lane group fetches a 4(t) x 16(col) block and
+// every lane receives its column's 4 consecutive t values.  Row stride 192 B
+// (== 192 mod 256) puts the 4 rows x 64 B a half-wave touches on 64 distinct
+// banks.  Partial sums leave the workgroup as fp32 atomics straight into the
+// parameter-gradient tensor (arbitrary element strides sn/sc/stap).
+// ---------------------------------------------------------------------------
+constexpr int WG_MK = 64;          // t rows per LDS tile
+constexpr int WG_LD = 96;          // LDS row stride in elements (192 B)
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int row0, int col0, int lane) {
+    // rows row0 + 8*(lane>>5) + {0..7}, column col0 + (lane & 31)
+    const int li = lane & 15, g = lane >> 4;
+    const bf16* p = tile + (row0 + 8 * (g >> 1) + (li >> 2)) * WG_LD + col0 + (g & 1) * 16 + 4 * (li & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * WG_LD));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = lo; u.s[1] = hi;
+    return u.v;
+}
+
+struct WgradArgs {
+    const bf16* dy; const bf16* x; float* dw; float* dbias;
+    int B, T, Cin, Cout, pad, Cin_real, rows_per_wg;
+    long sn, sc, stap;
+};
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 Ys[WG_MK * WG_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Xs[(WG_MK + TAPS - 1) * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int chunksT = (a.T + a.rows_per_wg - 1) / a.rows_per_wg;
+    const int b = blockIdx.x / chunksT;
+    const int tbeg = (blockIdx.x % chunksT) * a.rows_per_wg;
+    const int tend = min(a.T, tbeg + a.rows_per_wg);
+    const int n0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
+    const bf16* dyb = a.dy + (size_t)b * a.T * a.Cout;
+    const bf16* xb = a.x + (size_t)b * a.T * a.Cin;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+    float bsum = 0.f;
+
+    for (int t0 = tbeg; t0 < tend; t0 += WG_MK) {
+        __syncthreads();
+        for (int s = tid; s < WG_MK * 8; s += 256) {               // dY tile: 64 rows x 8 segs
+            const int r = s >> 3, sg = s & 7;
+            const int t = t0 + r, n = n0 + sg * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t < tend && n < a.Cout) v = *reinterpret_cast<const uint4*>(dyb + (size_t)t * a.Cout + n);
+            *reinterpret_cast<uint4*>(Ys + r * WG_LD + sg * 8) = v;
+        }
+        for (int s = tid; s < (WG_MK + TAPS - 1) * 8; s += 256) {  // X halo tile
+            const int r = s >> 3, sg = s & 7;
+            const int t = t0 - a.pad + r, c = c0 + sg * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t >= 0 && t < a.T && c < a.Cin) v = *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c);
+            *reinterpret_cast<uint4*>(Xs + r * WG_LD + sg * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < WG_MK; kk += 16) {
+            const bf16x8 af = tr_frag(Ys, kk, wn * 32, lane);
+            if (a.dbias && blockIdx.z == 0 && wc == 0)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += (float)af[j];
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+                const bf16x8 bfr = tr_frag(Xs, kk + tp, wc * 32, lane);
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tp], 0, 0, 0);
+            }
+        }
+    }
+    // D[i = n][j = c]: lane owns column c, rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (c < a.Cin_real) {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < a.Cout) atomicAdd(a.dw + n * a.sn + c * a.sc + tp * a.stap, acc[tp][r]);
+            }
+    }
+    if (a.dbias && blockIdx.z == 0 && wc == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int n = n0 + wn * 32 + (lane & 31);
+        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + n, bsum);
+    }
+}
+
+template <int TAPS>
+int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+    const int chunksT = ceil_div(a.T, a.rows_per_wg);
+    dim3 grid(a.B * chunksT, ceil_div(a.Cout, 64), ceil_div(a.Cin, 64));
+    hipLaunchKernelGGL(conv1d_wgrad_kernel<TAPS>, grid, dim3(256), 0, st, a);
+    return mm_check_launch("conv1d_wgrad");
+}
+
 }  // namespace
 
 // ============================================================================
@@ -326,6 +436,31 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     }
     if (tiles128 * ceil_div(Cout, 128) >= 256 || T < 64) return launch_fwd<128, 128, 2, 2>(a, st);
     return launch_fwd<64, 128, 2, 2>(a, st);
+}
+
+int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin, int Cout,
+                    int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap, hipStream_t st) {
+    MM_REQUIRE(dy && x && dw && B > 0 && T > 0, "conv1d_wgrad: null/invalid");
+    MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "conv1d_wgrad: Cin=%d Cout=%d must be multiples of 8", Cin, Cout);
+    MM_REQUIRE(Cin_real > 0 && Cin_real <= Cin, "conv1d_wgrad: Cin_real");
+    WgradArgs a;
+    a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
+    a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.pad = pad; a.Cin_real = Cin_real;
+    a.sn = sn; a.sc = sc; a.stap = stap;
+    // aim for ~512 workgroups: split each batch item's T into chunks of whole 64-row tiles
+    const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
+    const int tilesT = ceil_div(T, WG_MK);
+    int want_chunks = ceil_div(512, tiles * B);
+    if (want_chunks < 1) want_chunks = 1;
+    if (want_chunks > tilesT) want_chunks = tilesT;
+    a.rows_per_wg = ceil_div(tilesT, want_chunks) * WG_MK;
+    switch (taps) {
+        case 1: return launch_wgrad<1>(a, st);
+        case 3: return launch_wgrad<3>(a, st);
+        case 5: return launch_wgrad<5>(a, st);
+        case 7: return launch_wgrad<7>(a, st);
+        default: return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_wgrad: taps=%d (1,3,5,7)", taps);
+    }
 }
 
 }  // extern "C"

@@ -1,7 +1,326 @@
-"""placeholder - replaced by the HIP-backed ops below in this commit series."""
+"""Host-side composition of the HIP kernels (``libmmeeg_hip.so``) into the
+reference's layers.  PyTorch is used for device memory, streams and autograd
+bookkeeping only; every FLOP of the path runs in the C-ABI kernels.
+
+Conventions
+-----------
+* activations between kernels are channels-last: EEG ``(B, T, C)``, tokens
+  ``(B, L, d)``; GEMM operands are bf16, the transformer residual stream, all
+  statistics and all parameter gradients are fp32;
+* a Linear layer is the ``taps == 1`` case of the 1-D implicit GEMM;
+* dropout masks are a counter hash of (seed, element index) recomputed in the
+  backward kernels, never stored.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _hip
+
+ACT = {"none": 0, "gelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
+_BF = torch.bfloat16
+_F32 = torch.float32
 
 
-def __getattr__(name):
-    def _missing(*a, **k):
-        raise NotImplementedError(f"ops.{name} not built yet")
-    return _missing
+# --------------------------------------------------------------------- helpers
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _hip.HipLibraryError(
+                "multimodal_eeg_fmri_amd runs on the MI355X HIP path only: got a CPU tensor "
+                "(no CPU / eager-PyTorch fallback is provided)")
+    _hip.load()
+
+
+def cpad(c: int) -> int:
+    """channel count as the MFMA K-chunking wants it: 16, 32 or a multiple of 32."""
+    c16 = max(16, (c + 15) // 16 * 16)
+    return c16 if c16 <= 32 else (c16 + 31) // 32 * 32
+
+
+def _empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _zeros(shape, like, dtype=_F32):
+    return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+_seed_state = {"base": 0x1234567, "step": 0}
+
+
+def set_dropout_seed(seed: int):
+    _seed_state["base"] = int(seed) & 0x7FFFFFFF
+    _seed_state["step"] = 0
+
+
+def _next_seed() -> int:
+    _seed_state["step"] += 1
+    return (_seed_state["base"] * 2654435761 + _seed_state["step"] * 40503) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------ weight images
+class _WeightCache:
+    """bf16 MFMA images of fp32 parameters, rebuilt when the parameter changes.
+
+    forward image  ``wf [Cout][k][Cinp]``; data-gradient image
+    ``wd [Cinp][k flipped][Coutp]`` (``mm_prep_conv_weight``)."""
+
+    def __init__(self):
+        self._gen = 0
+        self._store: Dict[int, tuple] = {}
+
+    def invalidate(self):
+        self._gen += 1
+
+    def get(self, w: torch.Tensor, need_dgrad: bool):
+        key = id(w)
+        ver = (w.data_ptr(), w._version, self._gen)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver and (hit[2] is not None or not need_dgrad):
+            return hit[1], hit[2], hit[3], hit[4]
+        wd3 = w.detach()
+        if wd3.dim() == 2:
+            wd3 = wd3.unsqueeze(-1)
+        if wd3.dim() == 5:
+            wd3 = wd3.reshape(wd3.shape[0], wd3.shape[1], -1)
+        wd3 = wd3.contiguous()
+        cout, cin, k = wd3.shape
+        cinp, coutp = cpad(cin), cpad(cout)
+        wf = _empty((cout, k, cinp), _BF, w)
+        wd = _empty((cinp, k, coutp), _BF, w) if need_dgrad else None
+        _hip.call("mm_prep_conv_weight", wd3, wf, wd, cout, cin, k, cinp, coutp if need_dgrad else 0)
+        self._store[key] = (ver, wf, wd, cinp, coutp)
+        return wf, wd, cinp, coutp
+
+
+weights = _WeightCache()
+
+
+def weights_changed():
+    """call after parameters were updated outside torch's version counter
+    (the fused AdamW kernel writes through raw pointers)."""
+    weights.invalidate()
+
+
+# ----------------------------------------------------------- kernel wrappers
+def pack_nct(x: torch.Tensor) -> torch.Tensor:
+    """(B, C, T) fp32 -> (B, T, Cp) bf16 channels-last, zero-padded channels."""
+    B, C, T = x.shape
+    cp = cpad(C)
+    y = _empty((B, T, cp), _BF, x)
+    _hip.call("mm_pack_nct_bf16", x.contiguous(), y, B, C, T, cp)
+    return y
+
+
+def igemm(x: torch.Tensor, wf: torch.Tensor, taps: int, pad: int, cout: int, *,
+          scale=None, shift=None, act="none", residual=None, pe=None, pool=1, stats=None,
+          out_f32=False, out_bf16=True, out_pre=False, drop_p=0.0, seed=0):
+    """x (B, T, Cin) bf16 -> dict(out_f32, out_bf16, out_pre) of (B, T/pool, cout)."""
+    B, T, cin = x.shape
+    res = {}
+    of = _empty((B, T // pool, cout), _F32, x) if out_f32 else None
+    ob = _empty((B, T // pool, cout), _BF, x) if out_bf16 else None
+    op = _empty((B, T, cout), _BF, x) if out_pre else None
+    _hip.call("mm_conv1d_fwd", x, wf, B, T, cin, cout, taps, pad, scale, shift, ACT[act], residual, pe,
+              pool, stats, of, ob, op, float(drop_p), int(seed))
+    res["f32"], res["bf16"], res["pre"] = of, ob, op
+    return res
+
+
+def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, *, act="none", residual=None,
+                out_f32=False, out_bf16=True, out_pre=False, drop_p=0.0, seed=0, need_dgrad=False):
+    """(M, K) bf16 @ weight(N, K)^T + bias with a fused epilogue (taps == 1)."""
+    M, K = x2d.shape
+    wf, _, cinp, _ = weights.get(weight, need_dgrad)
+    if cinp != K:
+        raise _hip.HipLibraryError(f"linear: activation width {K} != padded weight width {cinp}")
+    r = igemm(x2d.view(1, M, K), wf, 1, 0, weight.shape[0], shift=bias, act=act,
+              residual=residual, out_f32=out_f32, out_bf16=out_bf16, out_pre=out_pre,
+              drop_p=drop_p, seed=seed)
+    return {k: (v.view(-1, v.shape[-1]) if v is not None else None) for k, v in r.items()}
+
+
+def bn_fold_eval(bn, conv_bias) -> torch.Tensor:
+    """[4][N] = scale, shift (conv bias folded), mean, rstd from running stats."""
+    n = bn.num_features
+    out4 = _empty((4, n), _F32, bn.weight)
+    _hip.call("mm_bn_finalize", None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+              conv_bias, out4, n, 1.0, 0.0, float(bn.eps), 1)
+    return out4
+
+
+def bn_finalize_train(bn, stats, count) -> torch.Tensor:
+    n = bn.num_features
+    out4 = _empty((4, n), _F32, bn.weight)
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    _hip.call("mm_bn_finalize", stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+              None, out4, n, float(count), mom, float(bn.eps), 0)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return out4
+
+
+def layernorm(x2d: torch.Tensor, ln, want_stat: bool):
+    M, D = x2d.shape
+    out = _empty((M, D), _BF, x2d)
+    stat = _empty((M, 2), _F32, x2d) if want_stat else None
+    _hip.call("mm_layernorm_fwd", x2d, ln.weight, ln.bias, out, None, stat, M, D, float(ln.eps))
+    return out, stat
+
+
+def attention(qkv: torch.Tensor, nhead: int, want_lse: bool):
+    B, L, E3 = qkv.shape
+    E = E3 // 3
+    dh = E // nhead
+    out = _empty((B, L, E), _BF, qkv)
+    lse = _empty((B, nhead, L), _F32, qkv) if want_lse else None
+    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh))
+    return out, lse
+
+
+# ------------------------------------------------------------------- stages
+def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=False, drop_p=0.0,
+                drop_first=True, pe=None, want_f32=False, want_bf16=True, need_dgrad=False):
+    """Conv1d -> BatchNorm1d -> act [-> MaxPool(2)] [-> Dropout] on (B, T, Cp) bf16.
+
+    eval : one kernel (BN folded into the GEMM epilogue).
+    train: GEMM (+bias, per-channel sum/sumsq) -> finalize -> BN/act/pool apply.
+    Returns (out dict, saved-for-backward dict or None)."""
+    k = conv.kernel_size[0]
+    pad = conv.padding[0]
+    cout = conv.out_channels
+    wf, _, cinp, _ = weights.get(conv.weight, need_dgrad)
+    assert xb.shape[2] == cinp, (xb.shape, cinp)
+    B, T, _ = xb.shape
+    if not training:
+        out4 = bn_fold_eval(bn, conv.bias)
+        r = igemm(xb, wf, k, pad, cout, scale=out4[0], shift=out4[1], act=act, pe=pe, pool=pool,
+                  out_f32=want_f32, out_bf16=want_bf16)
+        return r, None
+    stats = _zeros((2, cout), xb)
+    y = igemm(xb, wf, k, pad, cout, shift=conv.bias, stats=stats, out_f32=True, out_bf16=False)["f32"]
+    out4 = bn_finalize_train(bn, stats, B * T)
+    seed = _next_seed() if drop_p > 0 else 0
+    of = _empty((B, T // pool, cout), _F32, xb) if want_f32 else None
+    ob = _empty((B, T // pool, cout), _BF, xb) if want_bf16 else None
+    _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, B, T, cout, ACT[act], pool,
+              1 if drop_first else 0, float(drop_p), seed)
+    saved = dict(xb=xb, y=y, out4=out4, act=act, pool=pool, drop_p=drop_p, seed=seed,
+                 drop_first=drop_first, conv=conv, bn=bn)
+    return {"f32": of, "bf16": ob, "pre": None}, saved
+
+
+def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False):
+    """x fp32 (B, L, d) -> fp32 (B, L, d); returns (out, saved)."""
+    B, L, D = x.shape
+    M = B * L
+    p = blk.dropout.p if training else 0.0
+    x2 = x.view(M, D)
+    h1, st1 = layernorm(x2, blk.norm1, training)
+    qkv = linear_rows(h1, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias,
+                      need_dgrad=need_dgrad)["bf16"]
+    o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, training)
+    s1 = _next_seed() if p > 0 else 0
+    x1 = linear_rows(o.view(M, D), blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias,
+                     residual=x2, out_f32=True, out_bf16=False, drop_p=p, seed=s1,
+                     need_dgrad=need_dgrad)["f32"]
+    h2, st2 = layernorm(x1, blk.norm2, training)
+    s2 = _next_seed() if p > 0 else 0
+    f1 = linear_rows(h2, blk.linear1.weight, blk.linear1.bias, act=blk._act, out_pre=training,
+                     drop_p=p, seed=s2, need_dgrad=need_dgrad)
+    s3 = _next_seed() if p > 0 else 0
+    x2o = linear_rows(f1["bf16"], blk.linear2.weight, blk.linear2.bias, residual=x1, out_f32=True,
+                      out_bf16=False, drop_p=p, seed=s3, need_dgrad=need_dgrad)["f32"]
+    saved = None
+    if training:
+        saved = dict(x=x2, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2,
+                     z=f1["pre"], g=f1["bf16"], p=p, seeds=(s1, s2, s3), B=B, L=L, blk=blk)
+    return x2o.view(B, L, D), saved
+
+
+def pooled_head_fwd(x: torch.Tensor, lin, *, act="gelu", training=False, drop_p=0.0,
+                    need_dgrad=False):
+    """mean over L of fp32 (B, L, d) -> Linear -> act [-> dropout]: fp32 (B, out)."""
+    B, L, D = x.shape
+    pooled = _empty((B, D), _BF, x)
+    _hip.call("mm_meanpool_fwd", x, None, pooled, B, L, D)
+    seed = _next_seed() if (training and drop_p > 0) else 0
+    r = linear_rows(pooled, lin.weight, lin.bias, act=act, out_f32=True, out_bf16=False,
+                    out_pre=training, drop_p=drop_p if training else 0.0, seed=seed,
+                    need_dgrad=need_dgrad)
+    saved = dict(pooled=pooled, z=r["pre"], seed=seed, drop_p=drop_p, B=B, L=L, D=D, lin=lin,
+                 act=act) if training else None
+    return r["f32"], saved
+
+
+def pe_table(pos_encoder, L: int) -> torch.Tensor:
+    """(L, d) fp32 view of the sinusoid buffer (max_len, 1, d)."""
+    pe = pos_encoder.pe
+    if L > pe.shape[0]:
+        raise ValueError(f"sequence length {L} exceeds PositionalEncoding max_len {pe.shape[0]}")
+    return pe[:L, 0, :].contiguous()
+
+
+# ------------------------------------------------------------ EEG encoders
+def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool):
+    """EnhancedERPEncoder forward; returns (features fp32 (B, H), saved list)."""
+    cl = m.conv_layers
+    p = m.drop_p if training else 0.0
+    xb = pack_nct(x)
+    saved = []
+    r, s = conv_bn_act(xb, cl[0], cl[1], training=training, drop_p=p, need_dgrad=need_dgrad)
+    saved.append(s)
+    r, s = conv_bn_act(r["bf16"], cl[4], cl[5], pool=2, training=training, drop_p=p,
+                       drop_first=False, need_dgrad=need_dgrad)
+    saved.append(s)
+    L = r["bf16"].shape[1]
+    r, s = conv_bn_act(r["bf16"], cl[9], cl[10], training=training, drop_p=p,
+                       pe=pe_table(m.pos_encoder, L), want_f32=True, want_bf16=False,
+                       need_dgrad=need_dgrad)
+    saved.append(s)
+    h = r["f32"]
+    blocks = []
+    for blk in m.transformer_layers:
+        h, s = transformer_block_fwd(h, blk, training, need_dgrad)
+        blocks.append(s)
+    out, s = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad)
+    return out, dict(convs=saved, blocks=blocks, head=s, x_shape=tuple(x.shape), tokens=h)
+
+
+def erp_encoder_forward(m, x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    if m.training or (torch.is_grad_enabled() and x.requires_grad):
+        from .autograd import ErpEncoderFn
+        return ErpEncoderFn.run(m, x)
+    with torch.no_grad():
+        return _erp_forward_impl(m, x.float(), False, False)[0]
+
+
+def add_positional(x, pe, drop_p, training):
+    """PositionalEncoding.forward on the fp32 stream (reference quirk kept:
+    a (B, 1, d) input is read as (seq, batch=1, d))."""
+    _need_gpu(x)
+    if x.dim() == 3 and x.size(1) != 1:
+        B, L, D = x.shape
+        tab = pe[:L, 0, :].contiguous()
+    else:
+        L, B, D = x.shape[0], 1, x.shape[-1]
+        tab = pe[:L, 0, :].contiguous()
+        x = x.reshape(1, L, D)
+    out = torch.empty_like(x, dtype=_F32)
+    seed = _next_seed() if (training and drop_p > 0) else 0
+    _hip.call("mm_add_pe", x.float().contiguous(), tab, out, None, B, L, D, float(drop_p if training else 0.0), seed)
+    return out if x.shape == out.shape else out.view_as(x)
+
+
+def transformer_block(x, blk, training):
+    _need_gpu(x)
+    if training or (torch.is_grad_enabled() and x.requires_grad):
+        from .autograd import TransformerBlockFn
+        return TransformerBlockFn.run(blk, x)
+    with torch.no_grad():
+        return transformer_block_fwd(x.float().contiguous(), blk, False)[0]

@@ -78,3 +78,142 @@ def test_conv1d_fwd_epilogue_bn_gelu_pool_stats():
     torch.testing.assert_close(out.float().cpu(), want, rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(stats[0].cpu(), z.sum(dim=(0, 2)), rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(stats[1].cpu(), (z * z).sum(dim=(0, 2)), rtol=1e-3, atol=1e-2)
+
+
+def _attn_ref(qkv, H):
+    B, L, E3 = qkv.shape
+    E = E3 // 3
+    dh = E // H
+    q, k, v = (t.view(B, L, H, dh).transpose(1, 2) for t in qkv.split(E, dim=2))
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B, L, E)
+    return o, torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 512, 4), (3, 125, 4), (1, 300, 2), (2, 32, 1)])
+def test_attention_fwd_bwd(B, L, H):
+    hip = _hip()
+    g = torch.Generator().manual_seed(L)
+    E = H * 32
+    qkv = _bf(torch.randn(B, L, 3 * E, generator=g))
+    do = _bf(torch.randn(B, L, E, generator=g))
+    qg = qkv.cuda().to(torch.bfloat16)
+    out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, L, device="cuda")
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32))
+    qr = qkv.clone().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, H)
+    torch.testing.assert_close(out.float().cpu(), o_ref.detach(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse.cpu(), lse_ref.detach(), rtol=1e-3, atol=1e-3)
+    o_ref.backward(do)
+    dqkv = torch.empty_like(qg)
+    delta = torch.empty(B, H, L, device="cuda")
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32))
+    got, want = dqkv.float().cpu(), qr.grad
+    assert ((got - want).norm() / want.norm()).item() < 2e-2
+    torch.testing.assert_close(got, want, rtol=5e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("B,C,T,Cout,k", [(2, 64, 256, 64, 7), (3, 64, 200, 128, 5), (2, 128, 128, 128, 3),
+                                          (4, 8, 256, 64, 7), (1, 128, 1000, 384, 1), (2, 512, 64, 128, 1)])
+def test_conv1d_wgrad_matches_autograd(B, C, T, Cout, k):
+    hip = _hip()
+    g = torch.Generator().manual_seed(C + T + k)
+    x = _bf(torch.randn(B, C, T, generator=g))
+    dy = _bf(torch.randn(B, Cout, T, generator=g))
+    w = torch.zeros(Cout, C, k, requires_grad=True)
+    bias = torch.zeros(Cout, requires_grad=True)
+    F.conv1d(x, w, bias, padding=k // 2).backward(dy)
+    cp = _cpad(C)
+    xg = torch.empty(B, T, cp, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_pack_nct_bf16", x.cuda(), xg, B, C, T, cp)
+    dyg = dy.transpose(1, 2).contiguous().cuda().to(torch.bfloat16)
+    dw = torch.zeros(Cout, C, k, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
+
+
+def test_conv1d_dgrad_via_forward_kernel():
+    """data gradient = forward kernel on dY with the flipped/transposed image"""
+    hip = _hip()
+    g = torch.Generator().manual_seed(77)
+    B, C, T, Cout, k = 2, 64, 128, 128, 5
+    x = torch.randn(B, C, T, generator=g, requires_grad=True)
+    w = _bf(torch.randn(Cout, C, k, generator=g) / 10)
+    dy = _bf(torch.randn(B, Cout, T, generator=g))
+    F.conv1d(x, w, None, padding=k // 2).backward(dy)
+    _, wd = _prep_w(hip, w, C, Cout)
+    dyg = dy.transpose(1, 2).contiguous().cuda().to(torch.bfloat16)
+    dx = torch.empty(B, T, C, device="cuda")
+    hip.call("mm_conv1d_fwd", dyg, wd, B, T, Cout, C, k, k - 1 - k // 2, None, None, 0, None, None, 1,
+             None, dx, None, None, 0.0, 0)
+    torch.testing.assert_close(dx.cpu().transpose(1, 2), x.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,D", [(1000, 128), (37, 64), (64, 512)])
+def test_layernorm_fwd_bwd(M, D):
+    hip = _hip()
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, D, generator=g) * 2 + 0.5
+    gam = 0.5 + torch.rand(D, generator=g)
+    bet = torch.randn(D, generator=g)
+    dy = _bf(torch.randn(M, D, generator=g))
+    dres = torch.randn(M, D, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    y.backward(dy)
+    out = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    stat = torch.empty(M, 2, device="cuda")
+    hip.call("mm_layernorm_fwd", x.cuda(), gam.cuda(), bet.cuda(), out, None, stat, M, D, 1e-5)
+    torch.testing.assert_close(out.float().cpu(), y.detach(), rtol=1e-2, atol=1e-2)
+    dx = torch.empty(M, D, device="cuda")
+    dg = torch.zeros(D, device="cuda")
+    db = torch.zeros(D, device="cuda")
+    hip.call("mm_layernorm_bwd", dy.cuda().to(torch.bfloat16), None, x.cuda(), stat, gam.cuda(), dres.cuda(), dx, None,
+             dg, db, M, D)
+    torch.testing.assert_close(dx.cpu(), xr.grad + dres, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("pool", [1, 2])
+@pytest.mark.parametrize("N", [128, 48])
+def test_bn_act_pool_train_fwd_bwd(pool, N):
+    hip = _hip()
+    g = torch.Generator().manual_seed(N + pool)
+    R, S = 3, 64
+    y = torch.randn(R, S, N, generator=g) * 1.5 + 0.3
+    gam = 0.5 + torch.rand(N, generator=g)
+    bet = torch.randn(N, generator=g) * 0.2
+    rm, rv = torch.zeros(N), torch.ones(N)
+    yr, gr, br = y.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    z = F.batch_norm(yr.permute(0, 2, 1), rm.clone(), rv.clone(), gr, br, training=True, momentum=0.1, eps=1e-5)
+    a = F.gelu(z)
+    if pool == 2:
+        a = F.max_pool1d(a, 2)
+    a = a.permute(0, 2, 1)
+    dout = _bf(torch.randn(R, S // pool, N, generator=g))
+    a.backward(dout)
+    yg = y.cuda()
+    stats = torch.stack([y.sum(dim=(0, 1)), (y * y).sum(dim=(0, 1))]).cuda()
+    rmg, rvg = rm.cuda(), rv.cuda()
+    out4 = torch.empty(4, N, device="cuda")
+    hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), rmg, rvg, None, out4, N, float(R * S), 0.1, 1e-5, 0)
+    rm_ref, rv_ref = torch.zeros(N), torch.ones(N)
+    F.batch_norm(y.permute(0, 2, 1), rm_ref, rv_ref, gam, bet, training=True, momentum=0.1, eps=1e-5)
+    torch.testing.assert_close(rmg.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rvg.cpu(), rv_ref, rtol=1e-4, atol=1e-5)
+    ob = torch.empty(R, S // pool, N, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_bn_act_fwd", yg, out4[0], out4[1], None, ob, None, R, S, N, 1, pool, 1, 0.0, 0)
+    torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
+    sums = torch.zeros(2, N, device="cuda")
+    dg = dout.cuda().to(torch.bfloat16)
+    hip.call("mm_bn_act_bwd_reduce", yg, out4, dg, None, sums, R, S, N, 1, pool, 1, 0.0, 0)
+    torch.testing.assert_close(sums[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(sums[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+    dy = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy, R, S, N, 1, pool, 1, 0.0, 0, 1)
+    torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
