@@ -1,0 +1,217 @@
+"""Backward passes of the HIP path, exposed to torch.autograd as a handful of
+coarse ``Function``s (one per encoder / block / head) so the tape stays short.
+
+Parameter gradients are produced by the kernels as fp32 atomics.  When a
+parameter carries a gradient *sink* (``param._mm_grad``, a view into the
+trainer's flat gradient bucket) the kernels accumulate straight into it and
+autograd receives ``None``; otherwise a fresh tensor is returned to autograd.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _hip
+from . import ops
+from .ops import ACT, _BF, _F32, _empty, _zeros
+
+
+# ------------------------------------------------------------ gradient sinks
+class GradBag:
+    """collects parameter gradients of one backward call."""
+
+    def __init__(self):
+        self.fresh: Dict[int, torch.Tensor] = {}
+
+    def target(self, p: torch.Tensor) -> Optional[torch.Tensor]:
+        """fp32 buffer (PyTorch layout of ``p``) the kernels accumulate into."""
+        if p is None or not p.requires_grad:
+            return None
+        sink = getattr(p, "_mm_grad", None)
+        if sink is not None:
+            return sink
+        t = self.fresh.get(id(p))
+        if t is None:
+            t = torch.zeros_like(p, dtype=_F32, memory_format=torch.contiguous_format)
+            self.fresh[id(p)] = t
+        return t
+
+    def result(self, p: torch.Tensor) -> Optional[torch.Tensor]:
+        return self.fresh.get(id(p))
+
+
+def _mask_cast(g_f32=None, g_bf16=None, z=None, act="none", drop_p=0.0, seed=0):
+    """bf16( g * dropout_mask * act'(z) )"""
+    src = g_f32 if g_f32 is not None else g_bf16
+    out = _empty(src.shape, _BF, src)
+    _hip.call("mm_act_bwd", g_f32, g_bf16, z, out, src.numel(), ACT[act], float(drop_p), int(seed))
+    return out
+
+
+def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *, need_dx=True,
+               dx_f32=False):
+    """dy (M, N) bf16, x (M, Kp) bf16 -> dx (M, Kp); accumulates dW, db."""
+    M, N = dy.shape
+    Kp = x.shape[1]
+    K = weight.shape[1]
+    dw = bag.target(weight)
+    db = bag.target(bias)
+    if dw is not None:
+        _hip.call("mm_conv1d_wgrad", dy, x, dw, db, 1, M, Kp, N, 1, 0, K, K, 1, 0)
+    elif db is not None:
+        _hip.call("mm_colsum", dy, None, db, M, N)
+    if not need_dx:
+        return None
+    _, wd, cinp, coutp = ops.weights.get(weight, True)
+    if coutp != N:
+        raise _hip.HipLibraryError(f"linear_bwd: dY width {N} != padded out width {coutp}")
+    r = ops.igemm(dy.view(1, M, N), wd, 1, 0, cinp, out_f32=dx_f32, out_bf16=not dx_f32)
+    return (r["f32"] if dx_f32 else r["bf16"]).view(M, cinp)
+
+
+def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_dx=True):
+    """backward of ops.conv_bn_act (train mode). returns dx (B, T, Cinp) bf16."""
+    conv, bn = s["conv"], s["bn"]
+    y, out4, xb = s["y"], s["out4"], s["xb"]
+    B, T, N = y.shape
+    sums = _zeros((2, N), y)
+    args = (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]))
+    _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
+    dy = _empty((B, T, N), _BF, y)
+    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sums, dy, *args, 1)
+    gb, gg = bag.target(bn.bias), bag.target(bn.weight)
+    if gb is not None:
+        gb.add_(sums[0])
+    if gg is not None:
+        gg.add_(sums[1])
+    k, pad = conv.kernel_size[0], conv.padding[0]
+    cin = conv.in_channels
+    dw = bag.target(conv.weight)
+    if dw is not None:
+        _hip.call("mm_conv1d_wgrad", dy, xb, dw, bag.target(conv.bias), B, T, xb.shape[2], N, k, pad, cin,
+                  cin * k, k, 1)
+    if not need_dx:
+        return None
+    _, wd, cinp, coutp = ops.weights.get(conv.weight, True)
+    assert coutp == N
+    return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"]
+
+
+def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor) -> torch.Tensor:
+    """dx2 fp32 (M, D) -> dx0 fp32 (M, D)"""
+    blk = s["blk"]
+    p = s["p"]
+    s1, s2, s3 = s["seeds"]
+    B, L = s["B"], s["L"]
+    M, D = dx2.shape
+    at = blk.self_attn
+    # FFN second linear:  x2 = x1 + drop(g W2^T + b2)
+    dy2 = _mask_cast(g_f32=dx2, drop_p=p, seed=s3)
+    dg = linear_bwd(bag, dy2, s["g"], blk.linear2.weight, blk.linear2.bias)
+    # g = drop(act(z))
+    dz = _mask_cast(g_bf16=dg, z=s["z"], act=blk._act, drop_p=p, seed=s2)
+    dh2 = linear_bwd(bag, dz, s["h2"], blk.linear1.weight, blk.linear1.bias)
+    dx1 = _empty((M, D), _F32, dx2)
+    _hip.call("mm_layernorm_bwd", dh2, None, s["x1"], s["st2"], blk.norm2.weight, dx2, dx1, None,
+              bag.target(blk.norm2.weight), bag.target(blk.norm2.bias), M, D)
+    # attention output projection:  x1 = x0 + drop(o Wo^T + bo)
+    dyo = _mask_cast(g_f32=dx1, drop_p=p, seed=s1)
+    do = linear_bwd(bag, dyo, s["o"].view(M, D), at.out_proj.weight, at.out_proj.bias)
+    dqkv = _empty((B, L, 3 * D), _BF, dx2)
+    delta = _empty((B, blk.nhead, L), _F32, dx2)
+    dh = D // blk.nhead
+    _hip.call("mm_attn_bwd", s["qkv"], s["o"], do, s["lse"], dqkv, delta, B, L, blk.nhead, dh, float(dh) ** -0.5)
+    dh1 = linear_bwd(bag, dqkv.view(M, 3 * D), s["h1"], at.in_proj_weight, at.in_proj_bias)
+    dx0 = _empty((M, D), _F32, dx2)
+    _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, None,
+              bag.target(blk.norm1.weight), bag.target(blk.norm1.bias), M, D)
+    return dx0
+
+
+def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor) -> torch.Tensor:
+    """dout fp32 (B, H) -> d tokens fp32 (B, L, D)"""
+    lin = s["lin"]
+    dz = _mask_cast(g_f32=dout.contiguous(), z=s["z"], act=s["act"], drop_p=s["drop_p"], seed=s["seed"])
+    dpool = linear_bwd(bag, dz, s["pooled"], lin.weight, lin.bias, dx_f32=True)
+    B, L, D = s["B"], s["L"], s["D"]
+    dx = _empty((B, L, D), _F32, dout)
+    _hip.call("mm_meanpool_bwd", dpool, dx, B, L, D)
+    return dx
+
+
+def _module_params(m) -> List[torch.nn.Parameter]:
+    return [p for p in m.parameters()]
+
+
+class _ModuleFn(torch.autograd.Function):
+    """shared plumbing: forward(ctx, module, x, *params) with params passed only
+    so that autograd tracks them."""
+
+    @staticmethod
+    def _finish(ctx, bag, params, dx):
+        return (None, dx) + tuple(bag.result(p) for p in params)
+
+
+class ErpEncoderFn(_ModuleFn):
+    @staticmethod
+    def run(m, x):
+        return ErpEncoderFn.apply(m, x, *_module_params(m))
+
+    @staticmethod
+    def forward(ctx, m, x, *params):
+        training = m.training
+        out, saved = ops._erp_forward_impl(m, x.float(), training, True) if training else \
+            _frozen_forward(m, x)
+        ctx.m, ctx.saved, ctx.params = m, saved, params
+        ctx.need_dx = x.requires_grad
+        ctx.frozen = not training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.frozen:
+            raise NotImplementedError(
+                "backward through an eval-mode EnhancedERPEncoder (frozen BatchNorm) is not built yet; "
+                "call .train() or wrap the forward in torch.no_grad()")
+        m, sv = ctx.m, ctx.saved
+        bag = GradBag()
+        d = pooled_head_bwd(bag, sv["head"], dout)
+        B, L, D = d.shape
+        d = d.view(B * L, D)
+        for s in reversed(sv["blocks"]):
+            d = transformer_block_bwd(bag, s, d)
+        c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
+        g = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D))
+        g = conv_bn_act_bwd(bag, c2, dout_bf16=g)
+        g = conv_bn_act_bwd(bag, c1, dout_bf16=g, need_dx=ctx.need_dx)
+        dx = None
+        if ctx.need_dx:
+            Bx, C, T = sv["x_shape"]
+            dx = _empty((Bx, C, T), _F32, dout)
+            _hip.call("mm_unpack_ntc_f32", g, dx, Bx, C, T, g.shape[2])
+        return _ModuleFn._finish(ctx, bag, ctx.params, dx)
+
+
+def _frozen_forward(m, x):
+    return ops._erp_forward_impl(m, x.float(), False, False)[0], None
+
+
+class TransformerBlockFn(_ModuleFn):
+    @staticmethod
+    def run(blk, x):
+        return TransformerBlockFn.apply(blk, x, *_module_params(blk))
+
+    @staticmethod
+    def forward(ctx, blk, x, *params):
+        xf = x.float().contiguous()
+        out, saved = ops.transformer_block_fwd(xf, blk, blk.training, True, save=True)
+        ctx.blk, ctx.saved, ctx.params = blk, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        bag = GradBag()
+        B, L, D = dout.shape
+        dx = transformer_block_bwd(bag, ctx.saved, dout.contiguous().view(B * L, D).float())
+        return _ModuleFn._finish(ctx, bag, ctx.params, dx.view(B, L, D))

@@ -214,29 +214,32 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
     return {"f32": of, "bf16": ob, "pre": None}, saved
 
 
-def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False):
-    """x fp32 (B, L, d) -> fp32 (B, L, d); returns (out, saved)."""
+def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False,
+                          save: Optional[bool] = None):
+    """x fp32 (B, L, d) -> fp32 (B, L, d); returns (out, saved).  ``training``
+    switches dropout on; ``save`` (default = training) keeps what backward needs."""
     B, L, D = x.shape
     M = B * L
+    save = training if save is None else save
     p = blk.dropout.p if training else 0.0
     x2 = x.view(M, D)
-    h1, st1 = layernorm(x2, blk.norm1, training)
+    h1, st1 = layernorm(x2, blk.norm1, save)
     qkv = linear_rows(h1, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias,
                       need_dgrad=need_dgrad)["bf16"]
-    o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, training)
+    o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save)
     s1 = _next_seed() if p > 0 else 0
     x1 = linear_rows(o.view(M, D), blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias,
                      residual=x2, out_f32=True, out_bf16=False, drop_p=p, seed=s1,
                      need_dgrad=need_dgrad)["f32"]
-    h2, st2 = layernorm(x1, blk.norm2, training)
+    h2, st2 = layernorm(x1, blk.norm2, save)
     s2 = _next_seed() if p > 0 else 0
-    f1 = linear_rows(h2, blk.linear1.weight, blk.linear1.bias, act=blk._act, out_pre=training,
+    f1 = linear_rows(h2, blk.linear1.weight, blk.linear1.bias, act=blk._act, out_pre=save,
                      drop_p=p, seed=s2, need_dgrad=need_dgrad)
     s3 = _next_seed() if p > 0 else 0
     x2o = linear_rows(f1["bf16"], blk.linear2.weight, blk.linear2.bias, residual=x1, out_f32=True,
                       out_bf16=False, drop_p=p, seed=s3, need_dgrad=need_dgrad)["f32"]
     saved = None
-    if training:
+    if save:
         saved = dict(x=x2, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2,
                      z=f1["pre"], g=f1["bf16"], p=p, seeds=(s1, s2, s3), B=B, L=L, blk=blk)
     return x2o.view(B, L, D), saved

@@ -40,3 +40,50 @@ def test_a3_erp_encoder_eval_vs_golden(golden, tag):
     c = cos_min(y, want)
     assert c >= 1 - COS_TOL, f"cosine {c}"
     assert rel_err(y, want) < 2e-2
+
+
+def _grad_check(name, got, want, rel_tol):
+    e = rel_err(got, want)
+    assert e < rel_tol, f"{name}: rel err {e:.3e}"
+
+
+def test_a3_erp_encoder_train_grads_vs_golden(golden):
+    """train-mode (batch-stat BN, dropout 0) forward, input grad and every
+    parameter grad against the reference's autograd (golden (vii)).
+    Tolerance: every GEMM operand (activations AND back-propagated gradients) is
+    rounded to bf16, so errors compound with depth: 5e-2 relative L2 on parameter
+    gradients, 8e-2 on the input gradient (deepest, ~20 roundings)."""
+    fx = golden("a3_erp_train_grads.npz")
+    m = build(E.EnhancedERPEncoder, int(fx["seed"]), 8, 128, 2, 4, 0.0).train().cuda()
+    x = seeded_randn(int(fx["x_seed"]), 8, 8, 256).cuda().requires_grad_(True)
+    gy = seeded_randn(int(fx["gy_seed"]), 8, 128).cuda()
+    y = m(x)
+    y.backward(gy)
+    want = torch.as_tensor(fx["out"])
+    assert cos_min(y.detach().cpu(), want) >= 1 - COS_TOL
+    _grad_check("dx", x.grad.cpu(), torch.as_tensor(fx["dx"]), 8e-2)
+    # (1) gradient norms pinned by the reference golden
+    params = dict(m.named_parameters())
+    for n, gn in zip((str(n) for n in fx["gnames"]), fx["gnorms"]):
+        g = params[n].grad
+        assert g is not None, n
+        if gn < 1e-4:      # conv biases feed BatchNorm: true gradient ~0 (rounding noise only)
+            continue
+        assert abs(g.double().norm().item() - gn) <= 5e-2 * gn, (n, g.double().norm().item(), gn)
+    # (2) full tensors against the CPU oracle (itself pinned to the same golden on CPU)
+    mo = build(E.EnhancedERPEncoder, int(fx["seed"]), 8, 128, 2, 4, 0.0).train()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in mo.state_dict().items()}
+    xo = seeded_randn(int(fx["x_seed"]), 8, 8, 256).requires_grad_(True)
+    RF.erp_encoder(sd, xo, train=True).backward(gy.cpu())
+    bad = []
+    for n, p in params.items():
+        want_g = sd[n].grad
+        if want_g.norm() < 1e-4:
+            continue
+        e = rel_err(p.grad.cpu(), want_g)
+        if e > 5e-2:
+            bad.append((n, e))
+    assert not bad, bad
+    # BatchNorm running statistics after one training step
+    m_ref_cks = fx["cks_after"]
+    np.testing.assert_allclose(checksum(m.cpu()), m_ref_cks, rtol=2e-3, atol=2e-3)
