@@ -114,6 +114,29 @@ int mm_cast_f32(const void* x, float* y, int64_t n, hipStream_t stream);
 int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out, int64_t n, int act,
                float drop_p, uint32_t seed, hipStream_t stream);
 
+/* ---- 3-D voxel convolution, k=3 pad=1 (north-star extension: the reference has
+ * no volume code, SURVEY.md section 0; semantics = torch.nn.Conv3d / BatchNorm3d /
+ * MaxPool3d(2)).  Volumes are channels-last [B][D][H][W][C] bf16. */
+/* (B,1,D,H,W) fp32 -> [B][D][H][W][Cp] bf16, channel 0 = voxel value, rest 0 */
+int mm_pack_volume_bf16(const float* x, void* y, int64_t nvox, int Cp, hipStream_t stream);
+/* Y = X (*) W + shift; W image [Cout][27][Cin] (mm_prep_conv_weight with k=27);
+ * optional stats[2][Cout] (sum, sumsq) for training BatchNorm.  LDS-staged
+ * (TD+2)x10x10 halo block -> 27 tap-shifted A fragments -> bf16 MFMA. */
+int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int Cin, int Cout,
+                  const float* shift, float* stats, float* out_f32, void* out_bf16, hipStream_t stream);
+int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W,
+                    int Cin, int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap,
+                    hipStream_t stream);
+/* y fp32 [B][D][H][W][N] -> act(BN(y)) -> MaxPool3d(2) -> dropout -> bf16 [B][D/2][H/2][W/2][N] */
+int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, int B, int D, int H, int W,
+                         int N, int act, float drop_p, uint32_t seed, hipStream_t stream);
+int mm_pool3d_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, float* sums_out,
+                                int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
+                                hipStream_t stream);
+int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* sums,
+                               void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
+                               uint32_t seed, int train, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,3 +215,61 @@ class TransformerBlockFn(_ModuleFn):
         B, L, D = dout.shape
         dx = transformer_block_bwd(bag, ctx.saved, dout.contiguous().view(B * L, D).float())
         return _ModuleFn._finish(ctx, bag, ctx.params, dx.view(B, L, D))
+
+
+def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
+    """backward of ops.conv3d_bn_act (train). dout: bf16 pooled volume, or fp32
+    (B, V, N) for the un-pooled last stage.  returns dx bf16 (B,D,H,W,Cinp)."""
+    conv, bn = s["conv"], s["bn"]
+    y, out4, xv = s["y"], s["out4"], s["xv"]
+    B, D, H, W, N = y.shape
+    sums = _zeros((2, N), y)
+    dy = _empty((B, D, H, W, N), _BF, y)
+    gelu = ACT["gelu"]
+    if s["pool"]:
+        _hip.call("mm_pool3d_bn_act_bwd_reduce", y, out4, dout, sums, B, D, H, W, N, gelu, float(s["drop_p"]), int(s["seed"]))
+        _hip.call("mm_pool3d_bn_act_bwd_apply", y, out4, dout, sums, dy, B, D, H, W, N, gelu, float(s["drop_p"]),
+                  int(s["seed"]), 1)
+    else:
+        args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]))
+        _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
+        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, *args, 1)
+    gb, gg = bag.target(bn.bias), bag.target(bn.weight)
+    if gb is not None:
+        gb.add_(sums[0])
+    if gg is not None:
+        gg.add_(sums[1])
+    cin = conv.in_channels
+    dw = bag.target(conv.weight)
+    if dw is not None:
+        _hip.call("mm_conv3d_wgrad", dy, xv, dw, bag.target(conv.bias), B, D, H, W, xv.shape[4], N, cin,
+                  cin * 27, 27, 1)
+    if not need_dx:
+        return None
+    _, wd, cinp, coutp = ops.weights.get(conv.weight, True)
+    assert coutp == N
+    dx = _empty((B, D, H, W, cinp), _BF, y)
+    _hip.call("mm_conv3d_fwd", dy, wd, B, D, H, W, N, cinp, None, None, None, dx)
+    return dx
+
+
+class VolumeEncoderFn(_ModuleFn):
+    @staticmethod
+    def run(m, x):
+        return VolumeEncoderFn.apply(m, x, *_module_params(m))
+
+    @staticmethod
+    def forward(ctx, m, x, *params):
+        out, saved = ops._vol_forward_impl(m, x.float(), True, True)
+        ctx.saved, ctx.params = saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sv = ctx.saved
+        bag = GradBag()
+        d = pooled_head_bwd(bag, sv["head"], dout)            # fp32 (B, V, N)
+        g = conv3d_bn_act_bwd(bag, sv["convs"][2], d)
+        g = conv3d_bn_act_bwd(bag, sv["convs"][1], g)
+        conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=False)
+        return _ModuleFn._finish(ctx, bag, ctx.params, None)

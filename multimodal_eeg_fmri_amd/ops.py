@@ -327,3 +327,67 @@ def transformer_block(x, blk, training):
         return TransformerBlockFn.run(blk, x)
     with torch.no_grad():
         return transformer_block_fwd(x.float().contiguous(), blk, False)[0]
+
+
+# --------------------------------------------------------- 3-D voxel encoder
+def pack_volume(x: torch.Tensor) -> torch.Tensor:
+    """(B, 1, D, H, W) fp32 -> (B, D, H, W, 16) bf16 (channel 0 = voxel)."""
+    B, C, D, H, W = x.shape
+    if C != 1:
+        raise _hip.HipLibraryError("fMRIVolumeEncoder3D: single-channel volumes only")
+    y = _empty((B, D, H, W, 16), _BF, x)
+    _hip.call("mm_pack_volume_bf16", x.contiguous(), y, B * D * H * W, 16)
+    return y
+
+
+def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, drop_p: float,
+                  need_dgrad: bool):
+    """Conv3d(k3,p1) -> BatchNorm3d -> GELU [-> MaxPool3d(2)] [-> Dropout] on
+    channels-last bf16 volumes.  Returns (out, saved)."""
+    B, D, H, W, cinp = xv.shape
+    cout = conv.out_channels
+    wf, _, cp, _ = weights.get(conv.weight, need_dgrad)
+    assert cp == cinp, (cp, cinp)
+    y = _empty((B, D, H, W, cout), _F32, xv)
+    if training:
+        stats = _zeros((2, cout), xv)
+        _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, stats, y, None)
+        out4 = bn_finalize_train(bn, stats, B * D * H * W)
+    else:
+        _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, None, None, y, None)
+        out4 = bn_fold_eval(bn, conv.bias)
+    seed = _next_seed() if (training and drop_p > 0) else 0
+    p = drop_p if training else 0.0
+    if pool:
+        out = _empty((B, D // 2, H // 2, W // 2, cout), _BF, xv)
+        _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, B, D, H, W, cout, ACT["gelu"], float(p), seed)
+    else:
+        out = _empty((B, D * H * W, cout), _F32, xv)
+        _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], None, None, out, B, D * H * W, cout,
+                  ACT["gelu"], 1, 1, float(p), seed)
+    saved = dict(xv=xv, y=y, out4=out4, pool=pool, drop_p=p, seed=seed, conv=conv, bn=bn) if training else None
+    return out, saved
+
+
+def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool):
+    cl = m.conv_layers
+    p = m.drop_p
+    xv = pack_volume(x)
+    saved = []
+    h, s = conv3d_bn_act(xv, cl[0], cl[1], pool=True, training=training, drop_p=p, need_dgrad=need_dgrad)
+    saved.append(s)
+    h, s = conv3d_bn_act(h, cl[5], cl[6], pool=True, training=training, drop_p=p, need_dgrad=need_dgrad)
+    saved.append(s)
+    h, s = conv3d_bn_act(h, cl[10], cl[11], pool=False, training=training, drop_p=p, need_dgrad=need_dgrad)
+    saved.append(s)
+    out, hs = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad)
+    return out, dict(convs=saved, head=hs)
+
+
+def volume_encoder_forward(m, x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    if m.training:
+        from .autograd import VolumeEncoderFn
+        return VolumeEncoderFn.run(m, x)
+    with torch.no_grad():
+        return _vol_forward_impl(m, x.float(), False, False)[0]

@@ -217,3 +217,69 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     dy = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
     hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy, R, S, N, 1, pool, 1, 0.0, 0, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
+
+
+def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
+    return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(2, 32, 64, 8, 8, 8), (1, 64, 128, 4, 8, 8), (2, 16, 32, 8, 16, 8),
+                                              (1, 32, 64, 6, 8, 12)])
+def test_conv3d_fwd_wgrad_dgrad(B, Cin, Cout, D, H, W):
+    hip = _hip()
+    g = torch.Generator().manual_seed(Cin + Cout + D)
+    x = _bf(torch.randn(B, Cin, D, H, W, generator=g)).requires_grad_(True)
+    w = _bf(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin)).requires_grad_(True)
+    bias = torch.randn(Cout, generator=g).requires_grad_(True)
+    dy = _bf(torch.randn(B, Cout, D, H, W, generator=g))
+    y = F.conv3d(x, w, bias, padding=1)
+    y.backward(dy)
+    wf, wd = _prep_w(hip, w.detach().reshape(Cout, Cin, 27), Cin, Cout)
+    xg = _vol_cl(x.detach())
+    out = torch.empty(B, D, H, W, Cout, device="cuda")
+    stats = torch.zeros(2, Cout, device="cuda")
+    hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, bias.detach().cuda(), stats, out, None)
+    want = y.detach().permute(0, 2, 3, 4, 1)
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(stats[0].cpu(), want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(stats[1].cpu(), (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1e-2)
+    dyg = _vol_cl(dy)
+    dw = torch.zeros(Cout, Cin, 27, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+    hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1)
+    torch.testing.assert_close(dw.cpu().view_as(w), w.grad, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
+    dx = torch.empty(B, D, H, W, Cin, device="cuda")
+    hip.call("mm_conv3d_fwd", dyg, wd, B, D, H, W, Cout, Cin, None, None, dx, None)
+    torch.testing.assert_close(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1), rtol=1e-3, atol=2e-3)
+
+
+def test_pool3d_bn_act_train_fwd_bwd():
+    hip = _hip()
+    g = torch.Generator().manual_seed(9)
+    B, D, H, W, N = 2, 4, 8, 4, 32
+    y = torch.randn(B, D, H, W, N, generator=g) * 1.5 + 0.3
+    gam = 0.5 + torch.rand(N, generator=g)
+    bet = torch.randn(N, generator=g) * 0.2
+    yr, gr, br = y.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    z = F.batch_norm(yr.permute(0, 4, 1, 2, 3), None, None, gr, br, training=True, eps=1e-5)
+    a = F.max_pool3d(F.gelu(z), 2).permute(0, 2, 3, 4, 1)
+    dout = _bf(torch.randn(a.shape, generator=g))
+    a.backward(dout)
+    yg = y.cuda()
+    flat = y.reshape(-1, N)
+    stats = torch.stack([flat.sum(0), (flat * flat).sum(0)]).cuda()
+    out4 = torch.empty(4, N, device="cuda")
+    hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"),
+             None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0)
+    ob = torch.empty(B, D // 2, H // 2, W // 2, N, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob, B, D, H, W, N, 1, 0.0, 0)
+    torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
+    sums = torch.zeros(2, N, device="cuda")
+    dg = dout.cuda().to(torch.bfloat16)
+    hip.call("mm_pool3d_bn_act_bwd_reduce", yg, out4, dg, sums, B, D, H, W, N, 1, 0.0, 0)
+    torch.testing.assert_close(sums[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(sums[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+    dy = torch.empty(B, D, H, W, N, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_pool3d_bn_act_bwd_apply", yg, out4, dg, sums, dy, B, D, H, W, N, 1, 0.0, 0, 1)
+    torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)

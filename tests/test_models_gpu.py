@@ -87,3 +87,60 @@ def test_a3_erp_encoder_train_grads_vs_golden(golden):
     # BatchNorm running statistics after one training step
     m_ref_cks = fx["cks_after"]
     np.testing.assert_allclose(checksum(m.cpu()), m_ref_cks, rtol=2e-3, atol=2e-3)
+
+
+import multimodal_eeg_fmri_amd.fmri_utils as Fm
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 16, 16, 16), (2, 1, 32, 32, 32), (1, 1, 16, 16, 24)])
+def test_volume_encoder_eval_vs_oracle(shape):
+    """a-X1 (extension, parity unpinned by the reference): HIP path vs the CPU
+    restatement (== torch.nn.Conv3d semantics). cos >= 1 - 1e-4."""
+    m = build(Fm.fMRIVolumeEncoder3D, 31).eval()
+    x = seeded_randn(131, *shape)
+    with torch.no_grad():
+        want = RF.volume_encoder3d(m.state_dict(), x)
+        got = m.cuda()(x.cuda()).cpu()
+    assert got.shape == want.shape
+    assert cos_min(got, want) >= 1 - COS_TOL, cos_min(got, want)
+    assert rel_err(got, want) < 2e-2
+
+
+def _oracle_grads(fn, m, *inputs, gy, emulate):
+    from oracle.bf16_emulation import bf16_operands
+    import contextlib
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    with (bf16_operands() if emulate else contextlib.nullcontext()):
+        out = fn(sd, *inputs, train=True)
+        out.backward(gy)
+    return out.detach(), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+def _worst(named_params, want, skip_below=1e-4):
+    worst = ("", 0.0)
+    for n, p in named_params:
+        if n not in want or want[n].norm() < skip_below:
+            continue
+        e = rel_err(p.grad.cpu(), want[n])
+        if e > worst[1]:
+            worst = (n, e)
+    return worst
+
+
+def test_volume_encoder_train_grads_vs_oracle():
+    """Tolerances: <= 5e-2 rel-L2 per tensor against the oracle run with bf16-rounded
+    GEMM operands (what the MFMA path computes), <= 2e-1 against pure fp32 (bf16
+    rounding flips 2x2x2 max-pool argmaxes, which moves whole gradient entries)."""
+    m = build(Fm.fMRIVolumeEncoder3D, 32, dropout=0.0).train()
+    x = seeded_randn(132, 4, 1, 16, 16, 16)
+    gy = seeded_randn(133, 4, 64)
+    out32, g32 = _oracle_grads(RF.volume_encoder3d, m, x, gy=gy, emulate=False)
+    _, g16 = _oracle_grads(RF.volume_encoder3d, m, x, gy=gy, emulate=True)
+    mg = m.cuda()
+    y = mg(x.cuda())
+    y.backward(gy.cuda())
+    assert cos_min(y.detach().cpu(), out32) >= 1 - COS_TOL
+    w16 = _worst(mg.named_parameters(), g16)
+    w32 = _worst(mg.named_parameters(), g32)
+    assert w16[1] <= 5e-2, ("vs bf16-operand oracle", w16)
+    assert w32[1] <= 2e-1, ("vs fp32 oracle", w32)
