@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star hot path: one data-parallel contrastive training
+step (EEG temporal encoder + fMRI voxel encoder + projection bridge + InfoNCE,
+forward + backward + clip + AdamW) per "step", 32 (EEG-epoch, fMRI-volume)
+pairs per GPU of synthetic 64-ch x 1024-sample EEG and 32^3-voxel fMRI
+(BASELINE.json configs[1]; configs[2] at --gpus 8).
+
+Prints ONE JSON line (rank 0).  `value` = pairs/sec of the whole job, inputs
+resident in HBM.  `roofline` is for the layer-2 3-D conv implicit-GEMM kernel,
+timed live with HIP events on the launch stream inside the timed steps.
+`cpu_baseline` = the CPU oracle (fp32 torch restatement of the same step) on the
+host cores, rank 0 at N=1 only, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0          # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PAIRS_PER_GPU = 32
+EEG_CH, EEG_T, VOL = 64, 1024, (32, 32, 32)
+
+
+def cpu_baseline(pairs: int, steps: int = 2):
+    """oracle/ training step on the host (checker code, reported baseline only)."""
+    import torch.nn.functional as F
+    from oracle import ref_functional as RF
+    import multimodal_eeg_fmri_amd.enhanced_models_v4 as E
+    import multimodal_eeg_fmri_amd.fmri_utils as Fm
+    import multimodal_eeg_fmri_amd.bridge_utils as Bu
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    mods = {"e.": E.EnhancedERPEncoder(EEG_CH, 128, 2, 4, 0.0), "f.": Fm.fMRIVolumeEncoder3D(1, 64, dropout=0.0),
+            "h.": Bu.EEGfMRIContrastiveBridge(dropout=0.0)}
+    sd = {}
+    for pre, m in mods.items():
+        for k, v in m.state_dict().items():
+            sd[pre + k] = v.detach().clone().requires_grad_(v.is_floating_point())
+    leaves = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(leaves, lr=1e-4, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    eeg = torch.randn(pairs, EEG_CH, EEG_T, generator=g)
+    vol = torch.randn(pairs, 1, *VOL, generator=g)
+
+    def step():
+        opt.zero_grad()
+        fe = RF.erp_encoder(sd, eeg, "e.", train=True)
+        ff = RF.volume_encoder3d(sd, vol, "f.", train=True)
+        ze, zf = RF.contrastive_head(sd, fe, ff, "h.bridge.")
+        loss = RF.clip_loss(ze, zf, ze, zf, sd["h.logit_scale"].exp())[0]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in leaves if p.grad is not None], 1.0)
+        opt.step()
+    step()                                    # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed + 1 warm-up full training steps of {pairs} pairs "
+                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = dist.group.WORLD
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from multimodal_eeg_fmri_amd import ops
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    tr = BridgeTrainer(eeg_channels=EEG_CH, dropout=args.dropout, group=group).train()
+    eeg, fmri = synthetic_pairs(PAIRS_PER_GPU, EEG_CH, EEG_T, VOL, seed=1234 + rank)
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(eeg, fmri)
+    ops.kernel_timer.reset("conv3d_fwd_c32")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.train_step(eeg, fmri)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cuda")
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    kt = ops.kernel_timer.mean_ms("conv3d_fwd_c32")
+    ev = tr.evaluate(eeg, fmri)
+    if rank != 0:
+        return
+    global_batch = PAIRS_PER_GPU * world
+    # layer-2 conv3d forward: M = 32 * 16^3, N = 64, K = 27 * 32
+    flops = 2.0 * PAIRS_PER_GPU * 16 ** 3 * 64 * 27 * 32
+    achieved = flops / (kt * 1e-3) / 1e12 if kt else None
+    line = {
+        "metric": "pairs_per_sec_per_node", "value": global_batch * args.steps / dt, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "C2 bridge train step: 64ch x 1024 EEG (EnhancedERPEncoder) + 32^3 fMRI "
+                               "(3-D conv encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW",
+                   "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": global_batch, "parallelism": f"dp{world}",
+                   "dropout": args.dropout, "mfma_operands": "bf16", "accumulate": "fp32"},
+        "top1_retrieval_acc": {"eeg_to_fmri": ev["top1_e2f"].item(), "fmri_to_eeg": ev["top1_f2e"].item(),
+                               "chance": 1.0 / global_batch, "note": "on the training batch after the timed steps"},
+        "final_loss": out["loss"].item(),
+        "roofline": {"kernel": "conv3d_fwd_kernel (layer 2: 32->64 ch @16^3, implicit GEMM M=131072 N=64 K=864)",
+                     "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (achieved / PEAK_BF16_MFMA_TFLOPS) if achieved else None,
+                     "flops_per_launch": flops, "avg_launch_ms": kt, "traffic": None},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(PAIRS_PER_GPU)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

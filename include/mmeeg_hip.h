@@ -137,6 +137,42 @@ int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* do
                                void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
                                uint32_t seed, int train, hipStream_t stream);
 
+/* ---- small fp32 row kernels (projection bridge, tabular fMRI/conn MLPs) ------
+ * y = dropout(act(x W^T + b)), optional pre-activation copy.  nn.Linear on
+ * (B, K) feature rows: bridge_utils.py:34-45,60-66; fmri_utils.py:26-35,44-53;
+ * crossmodal_v4_enhancements.py:695-723. */
+int mm_small_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* pre, int B,
+                        int K, int N, int act, float drop_p, uint32_t seed, hipStream_t stream);
+/* dx = dy W ; dW += dy^T x ; db += colsum(dy)   (dy already through act') */
+int mm_small_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db,
+                        int B, int K, int N, hipStream_t stream);
+int mm_act_f32(const float* z, float* y, int64_t n, int act, float drop_p, uint32_t seed, hipStream_t stream);
+int mm_act_bwd_f32(const float* g, const float* z, float* out, int64_t n, int act, float drop_p,
+                   uint32_t seed, hipStream_t stream);
+/* stats[0][n] = sum_b x, stats[1][n] = sum_b x^2 (BatchNorm1d over (B, N)) */
+int mm_colstats(const float* x, float* stats, int B, int N, hipStream_t stream);
+/* F.normalize(h, dim=1): z = h / max(||h||, 1e-12)  (extension a-X2) */
+int mm_l2norm_fwd(const float* h, float* z, float* nrm, int B, int N, int ldz, hipStream_t stream);
+int mm_l2norm_bwd(const float* dz, const float* z, const float* nrm, float* dh, int B, int N, int ldz,
+                  hipStream_t stream);
+/* batch-pairwise cosine-similarity matrix + symmetric InfoNCE.  Embeddings are
+ * packed rows [ze (N) | zf (N)]: z_local [B][2N] = this rank's pairs, z_all
+ * [Bg][2N] = the all-gathered global batch, local rows at [row0, row0+B).
+ * scal4 += {loss, top1 e->f, top1 f->e, dloss/dlogit_scale}; dz_all [Bg][2N] +=
+ * gradients w.r.t. the GLOBAL embeddings (reduce-scatter-sum across ranks).
+ * Extension a-X2: the reference trains a CE classifier (_test_bridge.py:858). */
+int mm_clip_loss(const float* z_local, const float* z_all, const float* logit_scale, float* scal4,
+                 float* dz_all, int B, int Bg, int N, int row0, hipStream_t stream);
+
+/* ---- optimizer: clip_grad_norm_(max_norm) + AdamW.step() on one flat bucket
+ * (run_training_lite.py:487-488; _test_bridge.py:784-786).  state (device, 8 floats):
+ * [0] step count, [1] sum of squared grads (mm_sumsq adds into it), [2] lr,
+ * [3] clip coefficient of the last step, [4] grad norm of the last step. */
+int mm_sumsq(const float* g, float* state, int64_t n, hipStream_t stream);
+int mm_adamw_clip(float* p, const float* g, float* m, float* v, float* state, int64_t n, float beta1,
+                  float beta2, float eps, float weight_decay, float max_norm, float grad_scale,
+                  hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,3 +273,85 @@ class VolumeEncoderFn(_ModuleFn):
         g = conv3d_bn_act_bwd(bag, sv["convs"][1], g)
         conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=False)
         return _ModuleFn._finish(ctx, bag, ctx.params, None)
+
+
+# ------------------------------------------------ projection bridge / loss
+def proj_head_bwd(bag: GradBag, s: dict, da: torch.Tensor, need_dx=True):
+    lin, ln = s["seq"][0], s["seq"][1]
+    B, N = da.shape
+    K = lin.weight.shape[1]
+    dhn = _empty((B, N), _F32, da)
+    _hip.call("mm_act_bwd_f32", da, s["hn"], dhn, B * N, ACT["gelu"], float(s["p"]), int(s["seed"]))
+    dz1 = _empty((B, N), _F32, da)
+    _hip.call("mm_layernorm_bwd", None, dhn, s["z1"], s["stat"], ln.weight, None, dz1, None,
+              bag.target(ln.weight), bag.target(ln.bias), B, N)
+    dx = _empty((B, K), _F32, da) if need_dx else None
+    _hip.call("mm_small_linear_bwd", dz1, s["x"], lin.weight, dx, bag.target(lin.weight), bag.target(lin.bias), B, K, N)
+    return dx
+
+
+class ContrastiveEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def run(bridge, eeg, fmri):
+        ps = list(bridge.eeg_proj.parameters()) + list(bridge.fmri_proj.parameters())
+        return ContrastiveEmbedFn.apply(bridge, eeg, fmri, *ps)
+
+    @staticmethod
+    def forward(ctx, bridge, eeg, fmri, *params):
+        z, saved = ops.contrastive_embed_impl(bridge, eeg, fmri, bridge.training)
+        ctx.saved, ctx.params = saved, params
+        ctx.need = (eeg.requires_grad, fmri.requires_grad)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        s = ctx.saved
+        B, N = s["B"], s["N"]
+        dz = dz.contiguous()
+        bag = GradBag()
+        da_e = _empty((B, N), _F32, dz)
+        da_f = _empty((B, N), _F32, dz)
+        _hip.call("mm_l2norm_bwd", dz.data_ptr(), s["z"].data_ptr(), s["nrm"][0], da_e, B, N, 2 * N)
+        _hip.call("mm_l2norm_bwd", dz.data_ptr() + 4 * N, s["z"].data_ptr() + 4 * N, s["nrm"][1], da_f, B, N, 2 * N)
+        dxe = proj_head_bwd(bag, s["e"], da_e, ctx.need[0])
+        dxf = proj_head_bwd(bag, s["f"], da_f, ctx.need[1])
+        return (None, dxe, dxf) + tuple(bag.result(p) for p in ctx.params)
+
+
+class ClipLossFn(torch.autograd.Function):
+    """z (B, 2N) packed local embeddings -> (loss, acc_e2f, acc_f2e).  With a
+    process group the columns are the all-gathered global batch and the column
+    gradients travel back by reduce-scatter (sum)."""
+
+    @staticmethod
+    def forward(ctx, z, logit_scale, group):
+        import torch.distributed as dist
+        z = z.contiguous()
+        B, N2 = z.shape
+        N = N2 // 2
+        world = dist.get_world_size(group) if group is not None else 1
+        rank = dist.get_rank(group) if group is not None else 0
+        if world > 1:
+            z_all = _empty((world * B, N2), _F32, z)
+            dist.all_gather_into_tensor(z_all, z, group=group)
+        else:
+            z_all = z
+        need_grad = z.requires_grad or logit_scale.requires_grad
+        scal = _zeros((4,), z)
+        dz_all = _zeros((world * B, N2), z) if need_grad else None
+        ls = logit_scale.detach().reshape(1).float().contiguous()
+        _hip.call("mm_clip_loss", z, z_all, ls, scal, dz_all, B, world * B, N, rank * B)
+        if need_grad:
+            if world > 1:
+                dz = _empty((B, N2), _F32, z)
+                dist.reduce_scatter_tensor(dz, dz_all, op=dist.ReduceOp.SUM, group=group)
+            else:
+                dz = dz_all
+            ctx.save_for_backward(dz, scal)
+        ctx.mark_non_differentiable(*(()))
+        return scal[0].clone(), scal[1].clone(), scal[2].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss, g_a, g_b):
+        dz, scal = ctx.saved_tensors
+        return dz * g_loss, (scal[3] * g_loss).reshape(()), None

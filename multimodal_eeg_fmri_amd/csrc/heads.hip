@@ -1,0 +1,338 @@
+// Small fp32 row kernels for the projection bridge and the tabular models:
+// dense layer (fwd/bwd), elementwise act, L2-normalise, column statistics, and
+// the fused batch-pairwise cosine-similarity / symmetric InfoNCE loss with its
+// gradients.  Batches here are tens of rows: these kernels are latency-bound,
+// kept in fp32 end-to-end (they sit right before the parity-checked outputs)
+// and use wave-level shuffles for every row reduction.
+#include "common.h"
+
+namespace {
+
+// y[b][n] = dropout(act(x[b][:] . W[n][:] + bias[n])); one wave per (b, 64 outputs)
+__global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                        const float* __restrict__ bias, float* __restrict__ y,
+                                        float* __restrict__ pre, int B, int K, int N, int act,
+                                        uint32_t thresh, uint32_t seed, float inv_keep) {
+    extern __shared__ float xs[];                   // one input row
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) xs[k] = x[(size_t)b * K + k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int n = blockIdx.y * nw + wave; n < N; n += gridDim.y * nw) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += xs[k] * W[(size_t)n * K + k];
+        s = wave_sum(s);
+        if (lane == 0) {
+            s += bias ? bias[n] : 0.f;
+            const size_t idx = (size_t)b * N + n;
+            if (pre) pre[idx] = s;
+            s = apply_act(s, act);
+            if (thresh) s *= dropout_scale(seed, (uint32_t)idx, thresh, inv_keep);
+            y[idx] = s;
+        }
+    }
+}
+
+// dx[b][k] = sum_n dy[b][n] W[n][k]           (grid.x = B, threads over k)
+__global__ void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                       float* __restrict__ dx, int B, int K, int N) {
+    extern __shared__ float ds[];
+    const int b = blockIdx.x;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) ds[n] = dy[(size_t)b * N + n];
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += ds[n] * W[(size_t)n * K + k];
+        dx[(size_t)b * K + k] = s;
+    }
+}
+
+// dW[n][k] += sum_b dy[b][n] x[b][k];  db[n] += sum_b dy[b][n]   (unique owner per element)
+__global__ void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                       float* __restrict__ dW, float* __restrict__ db, int B, int K, int N) {
+    const int n = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dy[(size_t)b * N + n] * x[(size_t)b * K + k];
+        dW[(size_t)n * K + k] += s;
+    }
+    if (db && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dy[(size_t)b * N + n];
+        db[n] += s;
+    }
+}
+
+__global__ void act_f32_kernel(const float* __restrict__ z, float* __restrict__ y, size_t n, int act,
+                               uint32_t thresh, uint32_t seed, float inv_keep) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = apply_act(z[i], act);
+        if (thresh) v *= dropout_scale(seed, (uint32_t)i, thresh, inv_keep);
+        y[i] = v;
+    }
+}
+__global__ void act_bwd_f32_kernel(const float* __restrict__ g, const float* __restrict__ z, float* __restrict__ out,
+                                   size_t n, int act, uint32_t thresh, uint32_t seed, float inv_keep) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = g[i];
+        if (thresh) v *= dropout_scale(seed, (uint32_t)i, thresh, inv_keep);
+        if (z) v *= act_grad(z[i], act);
+        out[i] = v;
+    }
+}
+
+// column sum / sum-of-squares of fp32 [B][N]  (BatchNorm1d over a (B, N) batch)
+__global__ void colstats_kernel(const float* __restrict__ x, float* __restrict__ stats, int B, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f, q = 0.f;
+    for (int b = 0; b < B; ++b) { const float v = x[(size_t)b * N + n]; s += v; q += v * v; }
+    stats[n] = s; stats[N + n] = q;
+}
+
+// z = h / max(||h||, eps); one wave per row
+__global__ void l2norm_fwd_kernel(const float* __restrict__ h, float* __restrict__ z, float* __restrict__ nrm, int B, int N, int ldz) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float q = 0.f;
+    for (int n = lane; n < N; n += 64) { const float v = h[(size_t)row * N + n]; q += v * v; }
+    const float nr = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    for (int n = lane; n < N; n += 64) z[(size_t)row * ldz + n] = h[(size_t)row * N + n] / nr;
+    if (lane == 0) nrm[row] = nr;
+}
+// dh = (dz - z (z . dz)) / ||h||
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ nrm,
+                                  float* __restrict__ dh, int B, int N, int ldz) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float d = 0.f;
+    for (int n = lane; n < N; n += 64) d += dz[(size_t)row * ldz + n] * z[(size_t)row * ldz + n];
+    d = wave_sum(d);
+    const float inv = 1.f / nrm[row];
+    for (int n = lane; n < N; n += 64)
+        dh[(size_t)row * N + n] = (dz[(size_t)row * ldz + n] - z[(size_t)row * ldz + n] * d) * inv;
+}
+
+// ---------------------------------------------------------------------------
+// symmetric InfoNCE over local rows [row0, row0+B) vs Bg global columns.
+//   S_ef[i][j] = s * ze_i . zf_all_j     S_fe[i][j] = s * zf_i . ze_all_j
+//   loss = 0.5 * (CE(S_ef, row0+i) + CE(S_fe, row0+i)) averaged over the B rows
+// One workgroup per local row i.  Outputs:
+//   scal[0] += loss_i/B, scal[1] += top1(e->f)/B, scal[2] += top1(f->e)/B,
+//   scal[3] += d loss / d logit_scale
+//   dze_all[Bg][N], dzf_all[Bg][N] += gradients w.r.t. the GLOBAL embeddings
+//   (row role at row0+i, column role at every j); the host reduce-scatters them.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict__ z_loc, const float* __restrict__ z_all,
+                                                        const float* __restrict__ logit_scale, float* __restrict__ scal,
+                                                        float* __restrict__ dz_all, int B, int Bg, int N, int row0) {
+    // packed rows: [ze (N) | zf (N)], leading dimension 2N
+    const int LD = 2 * N;
+    const float* ze = z_loc;
+    const float* zf = z_loc + N;
+    const float* ze_all = z_all;
+    const float* zf_all = z_all + N;
+    float* dze_all = dz_all;
+    float* dzf_all = dz_all ? dz_all + N : nullptr;
+    extern __shared__ float sm[];
+    float* qe = sm;                 // ze_i [N]
+    float* qf = qe + N;             // zf_i [N]
+    float* Gef = qf + N;            // [Bg]
+    float* Gfe = Gef + Bg;          // [Bg]
+    float* red = Gfe + Bg;          // [8 * 4]
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float s = __expf(logit_scale[0]);
+    for (int n = tid; n < N; n += 256) { qe[n] = ze[(size_t)i * LD + n]; qf[n] = zf[(size_t)i * LD + n]; }
+    __syncthreads();
+    // raw cosines
+    float mxe = -INFINITY, mxf = -INFINITY;
+    for (int j = tid; j < Bg; j += 256) {
+        float a = 0.f, c = 0.f;
+        for (int n = 0; n < N; ++n) { a += qe[n] * zf_all[(size_t)j * LD + n]; c += qf[n] * ze_all[(size_t)j * LD + n]; }
+        Gef[j] = a; Gfe[j] = c;
+        mxe = fmaxf(mxe, a); mxf = fmaxf(mxf, c);
+    }
+    mxe = wave_max(mxe); mxf = wave_max(mxf);
+    if (lane == 0) { red[wave] = mxe; red[4 + wave] = mxf; }
+    __syncthreads();
+    mxe = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mxf = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    __syncthreads();
+    float se = 0.f, sf = 0.f;
+    for (int j = tid; j < Bg; j += 256) { se += __expf(s * (Gef[j] - mxe)); sf += __expf(s * (Gfe[j] - mxf)); }
+    se = wave_sum(se); sf = wave_sum(sf);
+    if (lane == 0) { red[wave] = se; red[4 + wave] = sf; }
+    __syncthreads();
+    se = red[0] + red[1] + red[2] + red[3];
+    sf = red[4] + red[5] + red[6] + red[7];
+    const int tgt = row0 + i;
+    const float ce = Gef[tgt], cf = Gfe[tgt];
+    const float invB = 1.f / (float)B;
+    if (tid == 0) {
+        const float le = -(s * (ce - mxe) - __logf(se)), lf = -(s * (cf - mxf) - __logf(sf));
+        atomicAdd(&scal[0], 0.5f * (le + lf) * invB);
+        atomicAdd(&scal[1], (ce >= mxe ? 1.f : 0.f) * invB);
+        atomicAdd(&scal[2], (cf >= mxf ? 1.f : 0.f) * invB);
+    }
+    __syncthreads();
+    // G = 0.5/B * (softmax - onehot); d/ds accumulates G * cos
+    float dsc = 0.f;
+    for (int j = tid; j < Bg; j += 256) {
+        const float ce_j = Gef[j], cf_j = Gfe[j];
+        float ge = __expf(s * (ce_j - mxe)) / se, gf = __expf(s * (cf_j - mxf)) / sf;
+        if (j == tgt) { ge -= 1.f; gf -= 1.f; }
+        ge *= 0.5f * invB; gf *= 0.5f * invB;
+        dsc += ge * ce_j + gf * cf_j;
+        Gef[j] = ge; Gfe[j] = gf;
+    }
+    dsc = wave_sum(dsc);
+    if (lane == 0) atomicAdd(&scal[3], dsc * s);      // d/d logit_scale = s * d/ds
+    __syncthreads();
+    if (!dze_all) return;
+    // row-role gradients:  dze_i += s * sum_j Gef[j] zf_all_j ; dzf_i += s * sum_j Gfe[j] ze_all_j
+    for (int n = tid; n < N; n += 256) {
+        float a = 0.f, c = 0.f;
+        for (int j = 0; j < Bg; ++j) { a += Gef[j] * zf_all[(size_t)j * LD + n]; c += Gfe[j] * ze_all[(size_t)j * LD + n]; }
+        atomicAdd(&dze_all[(size_t)tgt * LD + n], s * a);
+        atomicAdd(&dzf_all[(size_t)tgt * LD + n], s * c);
+    }
+    // column-role gradients: dzf_all_j += s * Gef[j] ze_i ; dze_all_j += s * Gfe[j] zf_i
+    for (int idx = tid; idx < Bg * N; idx += 256) {
+        const int j = idx / N, n = idx - j * N;
+        atomicAdd(&dzf_all[(size_t)j * LD + n], s * Gef[j] * qe[n]);
+        atomicAdd(&dze_all[(size_t)j * LD + n], s * Gfe[j] * qf[n]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused AdamW (decoupled weight decay) + global-norm clip on a flat fp32 bucket.
+// state[0] = step counter (float, incremented on device so the launch can live
+// in a hipGraph), state[1] = sum of squared gradients (filled by sumsq_kernel),
+// state[2] = learning rate (host-updatable), state[3] = last clip coefficient.
+// ---------------------------------------------------------------------------
+__global__ void sumsq_kernel(const float* __restrict__ g, float* __restrict__ state, size_t n) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += g[i] * g[i];
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&state[1], red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, const float* __restrict__ state, size_t n, float beta1,
+                             float beta2, float eps, float wd, float max_norm, float grad_scale) {
+    const float step = state[0] + 1.f;
+    const float lr = state[2];
+    const float gn = sqrtf(state[1]) * grad_scale;
+    const float clip = (max_norm > 0.f) ? fminf(1.f, max_norm / (gn + 1e-6f)) : 1.f;
+    const float gs = grad_scale * clip;
+    const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gs;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+__global__ void adamw_finish_kernel(float* __restrict__ state, float max_norm, float grad_scale) {
+    const float gn = sqrtf(state[1]) * grad_scale;
+    state[3] = (max_norm > 0.f) ? fminf(1.f, max_norm / (gn + 1e-6f)) : 1.f;
+    state[4] = gn;
+    state[0] += 1.f;
+    state[1] = 0.f;
+}
+
+inline uint32_t thresh_h(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+inline int grid_h(size_t n, int cap = 2048) { size_t g = (n + 255) / 256; return (int)(g < (size_t)cap ? (g ? g : 1) : cap); }
+
+}  // namespace
+
+extern "C" {
+
+int mm_small_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* pre, int B, int K, int N,
+                        int act, float drop_p, uint32_t seed, hipStream_t st) {
+    MM_REQUIRE(x && W && y && B > 0 && K > 0 && N > 0, "small_linear_fwd: null/invalid");
+    MM_REQUIRE((size_t)K * 4 <= 64 * 1024, "small_linear_fwd: K=%d too large", K);
+    const int gy = ceil_div(N, 4) < 64 ? ceil_div(N, 4) : 64;
+    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(B, gy), dim3(256), K * sizeof(float), st, x, W, bias, y, pre, B,
+                       K, N, act, thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    return mm_check_launch("small_linear_fwd");
+}
+
+int mm_small_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int B, int K,
+                        int N, hipStream_t st) {
+    MM_REQUIRE(dy && x && W && B > 0 && K > 0 && N > 0, "small_linear_bwd: null/invalid");
+    MM_REQUIRE((size_t)N * 4 <= 64 * 1024, "small_linear_bwd: N=%d too large", N);
+    if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3(B), dim3(256), N * sizeof(float), st, dy, W, dx, B, K, N);
+    if (dW) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(N), dim3(128), 0, st, dy, x, dW, db, B, K, N);
+    return mm_check_launch("small_linear_bwd");
+}
+
+int mm_act_f32(const float* z, float* y, int64_t n, int act, float drop_p, uint32_t seed, hipStream_t st) {
+    MM_REQUIRE(z && y && n > 0, "act_f32: null");
+    hipLaunchKernelGGL(act_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, z, y, (size_t)n, act, thresh_h(drop_p),
+                       seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    return mm_check_launch("act_f32");
+}
+
+int mm_act_bwd_f32(const float* g, const float* z, float* out, int64_t n, int act, float drop_p, uint32_t seed,
+                   hipStream_t st) {
+    MM_REQUIRE(g && out && n > 0, "act_bwd_f32: null");
+    hipLaunchKernelGGL(act_bwd_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, g, z, out, (size_t)n, act,
+                       thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    return mm_check_launch("act_bwd_f32");
+}
+
+int mm_colstats(const float* x, float* stats, int B, int N, hipStream_t st) {
+    MM_REQUIRE(x && stats && B > 0 && N > 0, "colstats: null");
+    hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, st, x, stats, B, N);
+    return mm_check_launch("colstats");
+}
+
+int mm_l2norm_fwd(const float* h, float* z, float* nrm, int B, int N, int ldz, hipStream_t st) {
+    MM_REQUIRE(h && z && nrm && B > 0 && N > 0 && ldz >= N, "l2norm_fwd: null");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, h, z, nrm, B, N, ldz);
+    return mm_check_launch("l2norm_fwd");
+}
+
+int mm_l2norm_bwd(const float* dz, const float* z, const float* nrm, float* dh, int B, int N, int ldz, hipStream_t st) {
+    MM_REQUIRE(dz && z && nrm && dh && B > 0 && N > 0 && ldz >= N, "l2norm_bwd: null");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, dz, z, nrm, dh, B, N, ldz);
+    return mm_check_launch("l2norm_bwd");
+}
+
+int mm_clip_loss(const float* z_local, const float* z_all, const float* logit_scale, float* scal4, float* dz_all,
+                 int B, int Bg, int N, int row0, hipStream_t st) {
+    MM_REQUIRE(z_local && z_all && logit_scale && scal4, "clip_loss: null");
+    MM_REQUIRE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg && N > 0, "clip_loss: B=%d Bg=%d row0=%d", B, Bg, row0);
+    const size_t lds = (size_t)(2 * N + 2 * Bg + 32) * sizeof(float);
+    MM_REQUIRE(lds <= 64 * 1024, "clip_loss: N/Bg too large for LDS");
+    hipLaunchKernelGGL(clip_loss_kernel, dim3(B), dim3(256), lds, st, z_local, z_all, logit_scale, scal4, dz_all, B,
+                       Bg, N, row0);
+    return mm_check_launch("clip_loss");
+}
+
+int mm_sumsq(const float* g, float* state, int64_t n, hipStream_t st) {
+    MM_REQUIRE(g && state && n > 0, "sumsq: null");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_h((size_t)n, 1024)), dim3(256), 0, st, g, state, (size_t)n);
+    return mm_check_launch("sumsq");
+}
+
+int mm_adamw_clip(float* p, const float* g, float* m, float* v, float* state, int64_t n, float beta1, float beta2,
+                  float eps, float weight_decay, float max_norm, float grad_scale, hipStream_t st) {
+    MM_REQUIRE(p && g && m && v && state && n > 0, "adamw_clip: null");
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, p, g, m, v, state, (size_t)n, beta1,
+                       beta2, eps, weight_decay, max_norm, grad_scale);
+    hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(1), 0, st, state, max_norm, grad_scale);
+    return mm_check_launch("adamw_clip");
+}
+
+}  // extern "C"

@@ -62,6 +62,36 @@ def _next_seed() -> int:
     return (_seed_state["base"] * 2654435761 + _seed_state["step"] * 40503) & 0xFFFFFFFF
 
 
+class _KernelTimer:
+    """optional HIP-event bracket around named kernel launches on the current
+    stream (bench.py uses it for the roofline line; off by default)."""
+
+    def __init__(self):
+        self._ev = {}
+
+    def reset(self, name):
+        self._ev[name] = []
+
+    def bracket(self, name):
+        lst = self._ev.get(name)
+        if lst is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lst.append((a, b))
+        a.record()
+        return b
+
+    def mean_ms(self, name):
+        lst = self._ev.get(name) or []
+        if not lst:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in lst) / len(lst)
+
+
+kernel_timer = _KernelTimer()
+
+
 # ------------------------------------------------------------ weight images
 class _WeightCache:
     """bf16 MFMA images of fp32 parameters, rebuilt when the parameter changes.
@@ -351,7 +381,10 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     y = _empty((B, D, H, W, cout), _F32, xv)
     if training:
         stats = _zeros((2, cout), xv)
+        end = kernel_timer.bracket(f"conv3d_fwd_c{cinp}")
         _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, stats, y, None)
+        if end is not None:
+            end.record()
         out4 = bn_finalize_train(bn, stats, B * D * H * W)
     else:
         _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, None, None, y, None)
@@ -391,3 +424,59 @@ def volume_encoder_forward(m, x: torch.Tensor) -> torch.Tensor:
         return VolumeEncoderFn.run(m, x)
     with torch.no_grad():
         return _vol_forward_impl(m, x.float(), False, False)[0]
+
+
+# ------------------------------------------------- projection bridge (fp32)
+def small_linear(x: torch.Tensor, lin, *, act="none", drop_p=0.0, seed=0, want_pre=False):
+    """fp32 (B, K) -> (B, N): dropout(act(x W^T + b)); optional pre-activation."""
+    B, K = x.shape
+    N = lin.weight.shape[0]
+    y = _empty((B, N), _F32, x)
+    pre = _empty((B, N), _F32, x) if want_pre else None
+    _hip.call("mm_small_linear_fwd", x, lin.weight, lin.bias, y, pre, B, K, N, ACT[act], float(drop_p), int(seed))
+    return y, pre
+
+
+def proj_head_fwd(seq, x: torch.Tensor, training: bool, drop_p: float):
+    """Linear -> LayerNorm -> GELU -> Dropout (bridge_utils.py:34-45) in fp32."""
+    lin, ln = seq[0], seq[1]
+    B = x.shape[0]
+    N = lin.weight.shape[0]
+    z1, _ = small_linear(x, lin)
+    hn = _empty((B, N), _F32, x)
+    stat = _empty((B, 2), _F32, x)
+    _hip.call("mm_layernorm_fwd", z1, ln.weight, ln.bias, None, hn, stat, B, N, float(ln.eps))
+    p = drop_p if training else 0.0
+    seed = _next_seed() if p > 0 else 0
+    a = _empty((B, N), _F32, x)
+    _hip.call("mm_act_f32", hn, a, B * N, ACT["gelu"], float(p), seed)
+    return a, dict(x=x, z1=z1, hn=hn, stat=stat, p=p, seed=seed, seq=seq)
+
+
+def contrastive_embed_impl(bridge, eeg: torch.Tensor, fmri: torch.Tensor, training: bool):
+    """-> packed L2-normalised embeddings z (B, 2N) = [ze | zf], saved."""
+    B = eeg.shape[0]
+    N = bridge.bridge_dim
+    ae, se = proj_head_fwd(bridge.eeg_proj, eeg.float().contiguous(), training, bridge.drop_p)
+    af, sf = proj_head_fwd(bridge.fmri_proj, fmri.float().contiguous(), training, bridge.drop_p)
+    z = _empty((B, 2 * N), _F32, eeg)
+    nrm = _empty((2, B), _F32, eeg)
+    _hip.call("mm_l2norm_fwd", ae, z.data_ptr(), nrm[0], B, N, 2 * N)
+    _hip.call("mm_l2norm_fwd", af, z.data_ptr() + 4 * N, nrm[1], B, N, 2 * N)
+    return z, dict(e=se, f=sf, z=z, nrm=nrm, B=B, N=N)
+
+
+def contrastive_embed(bridge, eeg, fmri, training):
+    _need_gpu(eeg, fmri)
+    from .autograd import ContrastiveEmbedFn
+    z = ContrastiveEmbedFn.run(bridge, eeg, fmri)
+    N = bridge.bridge_dim
+    return z[:, :N], z[:, N:]
+
+
+def clip_loss(ze, zf, logit_scale, group=None):
+    """symmetric InfoNCE over the (all-gathered) batch -> (loss, top1 e->f, top1 f->e)."""
+    _need_gpu(ze)
+    from .autograd import ClipLossFn
+    z = ze._base if (ze._base is not None and ze._base is zf._base) else torch.cat([ze, zf], dim=1)
+    return ClipLossFn.apply(z, logit_scale, group)
