@@ -65,6 +65,10 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
 int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin,
                     int Cout, int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap,
                     hipStream_t stream);
+/* dw[n][c][tap] += ws[n][tap][c]: conv weight gradients are accumulated by the
+ * wgrad kernels in a channel-contiguous workspace (contiguous fp32 atomics run
+ * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */
+int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, hipStream_t stream);
 
 /* ---- BatchNorm / activation / pool ----------------------------------------
  * mode 0 (train): stats{sum,sumsq}/count -> out4 = {scale, shift, mean, rstd},

@@ -89,8 +89,14 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     cin = conv.in_channels
     dw = bag.target(conv.weight)
     if dw is not None:
-        _hip.call("mm_conv1d_wgrad", dy, xb, dw, bag.target(conv.bias), B, T, xb.shape[2], N, k, pad, cin,
-                  cin * k, k, 1)
+        cinp_x = xb.shape[2]
+        if k == 1:
+            _hip.call("mm_conv1d_wgrad", dy, xb, dw, bag.target(conv.bias), B, T, cinp_x, N, 1, 0, cin, cin, 1, 0)
+        else:
+            ws = _zeros((N, k, cinp_x), y)                     # channel-contiguous atomics
+            _hip.call("mm_conv1d_wgrad", dy, xb, ws, bag.target(conv.bias), B, T, cinp_x, N, k, pad, cinp_x,
+                      k * cinp_x, 1, cinp_x)
+            _hip.call("mm_wgrad_scatter", ws, dw, N, cin, k, cinp_x)
     if not need_dx:
         return None
     _, wd, cinp, coutp = ops.weights.get(conv.weight, True)
@@ -242,8 +248,11 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
     cin = conv.in_channels
     dw = bag.target(conv.weight)
     if dw is not None:
-        _hip.call("mm_conv3d_wgrad", dy, xv, dw, bag.target(conv.bias), B, D, H, W, xv.shape[4], N, cin,
-                  cin * 27, 27, 1)
+        cinp_x = xv.shape[4]
+        ws = _zeros((N, 27, cinp_x), y)                        # channel-contiguous atomics
+        _hip.call("mm_conv3d_wgrad", dy, xv, ws, bag.target(conv.bias), B, D, H, W, cinp_x, N, cinp_x,
+                  27 * cinp_x, 1, cinp_x)
+        _hip.call("mm_wgrad_scatter", ws, dw, N, cin, 27, cinp_x)
     if not need_dx:
         return None
     _, wd, cinp, coutp = ops.weights.get(conv.weight, True)

@@ -9,7 +9,7 @@ pids=()
 for src in "$here"/*.hip; do
   obj="$here/build/$(basename "${src%.hip}").o"
   objs+=("$obj")
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$here/common.h" -nt "$obj" ]]; then
+  if [[ ! -f "$obj" ]] || ! [[ "$src" -ot "$obj" ]] || ! [[ "$here/common.h" -ot "$obj" ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function \
         -I"$here" -I"$here/../../include" -c "$src" -o "$obj" &
     pids+=($!)

@@ -457,7 +457,7 @@ int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
     a.sn = sn; a.sc = sc; a.stap = stap;
     const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
     const int par = ceil_div(Cout, 64) * 3 * ceil_div(Cin, 64);
-    int chunks = ceil_div(768, par);
+    int chunks = ceil_div(384, par);
     if (chunks > tiles_total) chunks = tiles_total;
     if (chunks < 1) chunks = 1;
     a.tiles_per_wg = ceil_div(tiles_total, chunks);

@@ -370,6 +370,18 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// dw[n][c][tap] += ws[n][tap][c]   (contiguous-atomics workspace -> PyTorch layout)
+__global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps,
+                                     int Cinp) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int c = (int)((i / taps) % Cin);
+        const int n = (int)(i / ((size_t)taps * Cin));
+        dw[i] += ws[((size_t)n * taps + tap) * Cinp + c];
+    }
+}
+
 template <int TAPS>
 int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int chunksT = ceil_div(a.T, a.rows_per_wg);
@@ -447,10 +459,10 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
     a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
     a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.pad = pad; a.Cin_real = Cin_real;
     a.sn = sn; a.sc = sc; a.stap = stap;
-    // aim for ~512 workgroups: split each batch item's T into chunks of whole 64-row tiles
+    // aim for ~384 workgroups: split each batch item's T into chunks of whole 64-row tiles
     const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
     const int tilesT = ceil_div(T, WG_MK);
-    int want_chunks = ceil_div(512, tiles * B);
+    int want_chunks = ceil_div(384, tiles * B);
     if (want_chunks < 1) want_chunks = 1;
     if (want_chunks > tilesT) want_chunks = tilesT;
     a.rows_per_wg = ceil_div(tilesT, want_chunks) * WG_MK;
@@ -461,6 +473,15 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
         case 7: return launch_wgrad<7>(a, st);
         default: return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_wgrad: taps=%d (1,3,5,7)", taps);
     }
+}
+
+int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, hipStream_t st) {
+    MM_REQUIRE(ws && dw && Cout > 0 && Cin > 0 && taps > 0 && Cinp >= Cin, "wgrad_scatter: bad args");
+    const size_t total = (size_t)Cout * Cin * taps;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(grid), dim3(256), 0, st, ws, dw, Cout, Cin, taps, Cinp);
+    return mm_check_launch("wgrad_scatter");
 }
 
 }  // extern "C"
