@@ -141,6 +141,19 @@ int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* do
                                void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
                                uint32_t seed, int train, hipStream_t stream);
 
+/* Fused first voxel layer Conv3d(1->32,k3,p1)+BatchNorm3d+GELU+MaxPool3d(2)[+Dropout]
+ * on fp32 [B][D][H][W] volumes; the 32x larger pre-BN tensor is recomputed, never
+ * stored.  mode 0: stats[2][32] += {sum, sumsq} of conv+bias; mode 1: forward
+ * (out bf16 [B][D/2][H/2][W/2][32]); mode 2: stats += {sum dz, sum dz*xhat};
+ * mode 3: dw_tapmajor[27][32] += x^T dy, dbias += sum dy.  wimg = bf16 [32][32]
+ * (n, tap) from mm_prep_conv_weight(w as (32,27,1)). */
+int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, const float* out4,
+                 const void* dout, const float* sums, float* stats, void* out, float* dw_tapmajor,
+                 float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
+                 hipStream_t stream);
+/* dst[c][r] += src[r][c] */
+int mm_transpose_add(const float* src, float* dst, int R, int C, hipStream_t stream);
+
 /* ---- small fp32 row kernels (projection bridge, tabular fMRI/conn MLPs) ------
  * y = dropout(act(x W^T + b)), optional pre-activation copy.  nn.Linear on
  * (B, K) feature rows: bridge_utils.py:34-45,60-66; fmri_utils.py:26-35,44-53;

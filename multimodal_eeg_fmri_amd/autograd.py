@@ -262,6 +262,26 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
     return dx
 
 
+def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
+    """backward of ops.conv3d_l1_bn_act (no input gradient: the volume is data)."""
+    conv, bn, x = s["conv"], s["bn"], s["x"]
+    B, _, D, H, W = x.shape
+    sums = _zeros((2, 32), x)
+    _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
+              B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]))
+    ws = _zeros((27, 32), x)
+    _hip.call("mm_conv3d_l1", 3, x, s["wimg"], conv.bias, s["out4"], dout, sums, None, None, ws,
+              bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]))
+    gb, gg = bag.target(bn.bias), bag.target(bn.weight)
+    if gb is not None:
+        gb.add_(sums[0])
+    if gg is not None:
+        gg.add_(sums[1])
+    dw = bag.target(conv.weight)
+    if dw is not None:
+        _hip.call("mm_transpose_add", ws, dw, 27, 32)
+
+
 class VolumeEncoderFn(_ModuleFn):
     @staticmethod
     def run(m, x):
@@ -280,7 +300,10 @@ class VolumeEncoderFn(_ModuleFn):
         d = pooled_head_bwd(bag, sv["head"], dout)            # fp32 (B, V, N)
         g = conv3d_bn_act_bwd(bag, sv["convs"][2], d)
         g = conv3d_bn_act_bwd(bag, sv["convs"][1], g)
-        conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=False)
+        if sv["convs"][0].get("l1"):
+            conv3d_l1_bwd(bag, sv["convs"][0], g)
+        else:
+            conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=False)
         return _ModuleFn._finish(ctx, bag, ctx.params, None)
 
 

@@ -1,0 +1,290 @@
+// First layer of the 3-D voxel encoder: Conv3d(1 -> 32, k3, p1) + BatchNorm3d +
+// GELU + MaxPool3d(2) [+ Dropout] on single-channel fp32 volumes, fused.
+//
+// With Cin = 1 the GEMM K is just the 27 taps, so the layer is HBM/VALU-bound,
+// not MFMA-bound.  The pre-BN activation (32x the input, 134 MB fp32 at the C2
+// config) is never written: every pass recomputes the convolution from the
+// 4 MB input (8 bf16 MFMAs per 128 voxels) and keeps only per-channel sums:
+//   mode 0  stats        : sum / sumsq of y = conv + bias           (train fwd 1)
+//   mode 1  apply        : BN -> GELU -> 2x2x2 max -> dropout -> bf16 (fwd 2 / eval)
+//   mode 2  bwd reduce   : S1 = sum dz, S2 = sum dz*xhat
+//   mode 3  bwd apply    : dy = BN'(dz) for every voxel, dW[tap][n] += x^T dy,
+//                          dbias += sum dy     (second MFMA: the dy accumulator
+//                          tile is the B operand, the im2col gather the A operand)
+// One wave owns a 2 x 8 x 8 block of conv outputs (= 1 x 4 x 4 pooled voxels) x
+// 32 channels: all 8 members of every pooling window sit in the same lane.
+// GELU is evaluated once per window when max(z) >= 0 (GELU is monotone on
+// [-0.7518, inf) and negative left of 0, so the window max is GELU(max z));
+// otherwise on all 8 members.  Both branches are exact.
+#include "common.h"
+
+namespace {
+
+constexpr int HP = 36;                 // halo row pitch (34 used)
+constexpr int HROWS1 = 4 * 10;         // (2+2) depth x (8+2) height rows
+constexpr int HSZ = HROWS1 * HP;
+
+struct L1Args {
+    const float* x;        // [B][D][H][W]
+    const bf16* wimg;      // [32][32] (n, tap; taps 27..31 zero)
+    const float* bias;     // [32] or nullptr (eval: folded into out4 shift)
+    const float* out4;     // [4][32] scale, shift, mean, rstd  (modes 1-3)
+    const bf16* dout;      // [B][D/2][H/2][W/2][32]            (modes 2-3)
+    const float* sums;     // [2][32]                           (mode 3)
+    float* stats;          // mode 0: [2][32];  mode 2: sums_out
+    bf16* out;             // mode 1
+    float* dw;             // mode 3: [27][32] (tap-major, channel-contiguous atomics)
+    float* dbias;          // mode 3
+    int B, D, H, W, train;
+    uint32_t thresh, seed; float inv_keep, inv_count;
+};
+
+__device__ __forceinline__ int tap_off(int tap) {          // halo offset of tap (0..26), pads -> 0
+    if (tap >= 27) return 0;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    return kd * 10 * HP + kh * HP + kw;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned short halo[HSZ];
+    __shared__ float red[4][32];
+    __shared__ float wred[27][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tw = (a.W + 31) / 32, th = (a.H + 7) / 8, td = a.D / 2;
+    const int ntiles = a.B * td * th * tw;
+    const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
+
+    // B fragments of the forward product: W[n = lr][k = 16s + 8lh + j]
+    bf16x8 wf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(a.wimg + lr * 32 + 16 * s + 8 * lh);
+    // gather offsets for the forward A fragments (row = voxel, k = tap)
+    int foff[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) foff[s][j] = tap_off(16 * s + 8 * lh + j);
+    const float bias = a.bias ? a.bias[lr] : 0.f;
+    float sc = 1.f, sh = 0.f, mu = 0.f, rs = 1.f, c0 = 0.f, c1 = 0.f;
+    if (MODE >= 1) {
+        sc = a.out4[lr]; sh = a.out4[32 + lr]; mu = a.out4[64 + lr]; rs = a.out4[96 + lr];
+        if (MODE == 3 && a.train) { c0 = a.sums[lr] * a.inv_count; c1 = a.sums[32 + lr] * a.inv_count; }
+    }
+    float acc1 = 0.f, acc2 = 0.f;          // per-lane channel sums (modes 0, 2) / dbias (mode 3)
+    f32x16 dwacc;                          // mode 3: D[tap][n]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+    const int my_tap_off = tap_off(lr);    // mode 3: A row = tap lr
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int q = tile;
+        const int w0 = (q % tw) * 32; q /= tw;
+        const int h0 = (q % th) * 8; q /= th;
+        const int d0 = (q % td) * 2; q /= td;
+        const int b = q;
+        __syncthreads();
+        for (int i = tid; i < HROWS1 * 34; i += 256) {
+            const int hw = i % 34, hr = i / 34;
+            const int hd = hr / 10, hh = hr % 10;
+            const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+            float v = 0.f;
+            if (d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
+                v = a.x[(((size_t)b * a.D + d) * a.H + h) * a.W + w];
+            const bf16 hv = (bf16)v;
+            halo[hr * HP + hw] = *reinterpret_cast<const unsigned short*>(&hv);
+        }
+        __syncthreads();
+        const int wbase = 8 * wave;                         // this wave's w-block inside the tile
+        // ---- conv: acc[i] (rows m = 32 i + ..., voxel = (m>>6, (m>>3)&7, m&7))
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const int m = 32 * i + lr;
+            const int vb = ((m >> 6) * 10 + ((m >> 3) & 7)) * HP + (m & 7) + wbase;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                union { unsigned short u[8]; bf16x8 v; } fr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fr.u[j] = halo[vb + foff[s][j]];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, wf[s], acc[i], 0, 0, 0);
+            }
+        }
+        // lane owns channel n = lr; register r of tile i is voxel
+        //   dz = i >> 1, hy = 4 (i & 1) + (r >> 2), wx = (r & 3) + 4 lh
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = d0 + (i >> 1), h = h0 + 4 * (i & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
+                    if (d < a.D && h < a.H && w < a.W) {
+                        const float y = acc[i][r] + bias;
+                        acc1 += y; acc2 += y * y;
+                    }
+                }
+            continue;
+        }
+        // ---- pooled windows: (ip, ra, rb) -> regs {r0, r0+1, r0+4, r0+5} of tiles ip and ip+2
+        bf16x8 dyf[4][2];                                   // mode 3: dy fragments per tile / k-step
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const int r0 = 8 * ra + 2 * rb;
+                    const int oh = (h0 >> 1) + 2 * ip + ra, ow = (w0 >> 1) + 4 * wave + rb + 2 * lh, od = d0 >> 1;
+                    const bool ok = oh < Ho && ow < Wo;
+                    float y[8], z[8];
+                    float zmax = -INFINITY;
+                    int jmax = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {           // j = (dd << 2) | (hh << 1) | ww
+                        const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                        y[j] = acc[ti][r] + bias;
+                        z[j] = y[j] * sc + sh;
+                        if (z[j] > zmax) { zmax = z[j]; jmax = j; }
+                    }
+                    float best;
+                    if (zmax >= 0.f) {
+                        best = gelu_erf(zmax);
+                    } else {
+                        best = -INFINITY;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float g = gelu_erf(z[j]);
+                            if (g > best) { best = g; jmax = j; }
+                        }
+                    }
+                    const size_t oidx = ((((size_t)b * Do + od) * Ho + oh) * Wo + ow) * 32 + lr;
+                    if (MODE == 1) {
+                        if (ok) {
+                            if (a.thresh) best *= dropout_scale(a.seed, (uint32_t)oidx, a.thresh, a.inv_keep);
+                            a.out[oidx] = (bf16)best;
+                        }
+                    } else {
+                        float g = ok ? (float)a.dout[oidx] : 0.f;
+                        if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)oidx, a.thresh, a.inv_keep);
+                        float zs = z[0], ys = y[0];
+#pragma unroll
+                        for (int j = 1; j < 8; ++j)
+                            if (j == jmax) { zs = z[j]; ys = y[j]; }
+                        const float dzs = g * gelu_erf_grad(zs);
+                        if (MODE == 2) {
+                            acc1 += dzs;
+                            acc2 += dzs * (ys - mu) * rs;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                                const float dzj = (j == jmax) ? dzs : 0.f;
+                                float dy = a.train ? sc * (dzj - c0 - (y[j] - mu) * rs * c1) : sc * dzj;
+                                const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
+                                if (!(d < a.D && h < a.H && w < a.W)) dy = 0.f;
+                                acc1 += dy;
+                                dyf[ti][r >> 3][r & 7] = (bf16)dy;
+                            }
+                        }
+                    }
+                }
+        if (MODE == 3) {
+            // dW[tap][n] += sum_v xcol[tap][v] * dy[v][n]: A row = tap lr, k-th element of
+            // half lh is voxel row 16 s + 8 (j >> 2) + 4 lh + (j & 3) of tile ti
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    union { unsigned short u[8]; bf16x8 v; } fr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = 32 * ti + 16 * s + 8 * (j >> 2) + 4 * lh + (j & 3);
+                        const int vb = ((m >> 6) * 10 + ((m >> 3) & 7)) * HP + (m & 7) + wbase;
+                        fr.u[j] = halo[vb + my_tap_off];
+                    }
+                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, dyf[ti][s], dwacc, 0, 0, 0);
+                }
+        }
+    }
+    // ---------------------------------------------------------------- reductions
+    if (MODE == 0 || MODE == 2 || MODE == 3) {
+        acc1 += __shfl_xor(acc1, 32, 64);
+        acc2 += __shfl_xor(acc2, 32, 64);
+        __syncthreads();
+        if (lh == 0) red[wave][lr] = acc1;
+        __syncthreads();
+        if (tid < 32) {
+            const float s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+            if (MODE == 3) { if (a.dbias) atomicAdd(&a.dbias[tid], s); }
+            else atomicAdd(&a.stats[tid], s);
+        }
+        if (MODE != 3) {
+            __syncthreads();
+            if (lh == 0) red[wave][lr] = acc2;
+            __syncthreads();
+            if (tid < 32) atomicAdd(&a.stats[32 + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+        }
+    }
+    if (MODE == 3) {
+        for (int i = tid; i < 27 * 32; i += 256) (&wred[0][0])[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tap = (r & 3) + 8 * (r >> 2) + 4 * lh;      // D row
+            if (tap < 27) atomicAdd(&wred[tap][lr], dwacc[r]);
+        }
+        __syncthreads();
+        for (int i = tid; i < 27 * 32; i += 256) atomicAdd(&a.dw[i], (&wred[0][0])[i]);
+    }
+}
+
+// dst[c][r] += src[r][c]
+__global__ void transpose_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R * C) { const int r = i / C, c = i % C; dst[(size_t)c * R + r] += src[i]; }
+}
+
+inline uint32_t thresh_l1(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+
+}  // namespace
+
+extern "C" {
+
+int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, const float* out4,
+                 const void* dout, const float* sums, float* stats, void* out, float* dw_tapmajor, float* dbias,
+                 int B, int D, int H, int W, int train, float drop_p, uint32_t seed, hipStream_t st) {
+    MM_REQUIRE(x && wimg && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1: null/invalid");
+    MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1: D,H,W must be even (MaxPool3d(2))");
+    MM_REQUIRE(mode >= 0 && mode <= 3, "conv3d_l1: mode");
+    MM_REQUIRE(mode == 0 ? stats != nullptr : out4 != nullptr, "conv3d_l1: stats/out4");
+    MM_REQUIRE(mode != 1 || out, "conv3d_l1: out");
+    MM_REQUIRE(mode < 2 || dout, "conv3d_l1: dout");
+    MM_REQUIRE(mode != 2 || stats, "conv3d_l1: sums_out");
+    MM_REQUIRE(mode != 3 || (dw_tapmajor && (!train || sums)), "conv3d_l1: dw/sums");
+    L1Args a;
+    a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = sums;
+    a.stats = stats; a.out = (bf16*)out; a.dw = dw_tapmajor; a.dbias = dbias;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
+    a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.inv_count = 1.f / ((float)B * D * H * W);
+    const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
+    const int grid = ntiles < 1024 ? ntiles : 1024;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(conv3d_l1_kernel<0>, dim3(grid), dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(conv3d_l1_kernel<1>, dim3(grid), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(conv3d_l1_kernel<2>, dim3(grid), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(conv3d_l1_kernel<3>, dim3(grid), dim3(256), 0, st, a); break;
+    }
+    return mm_check_launch("conv3d_l1");
+}
+
+int mm_transpose_add(const float* src, float* dst, int R, int C, hipStream_t st) {
+    MM_REQUIRE(src && dst && R > 0 && C > 0, "transpose_add: null");
+    hipLaunchKernelGGL(transpose_add_kernel, dim3(ceil_div(R * C, 256)), dim3(256), 0, st, src, dst, R, C);
+    return mm_check_launch("transpose_add");
+}
+
+}  // extern "C"

@@ -106,9 +106,9 @@ class _WeightCache:
     def invalidate(self):
         self._gen += 1
 
-    def get(self, w: torch.Tensor, need_dgrad: bool):
-        key = id(w)
-        ver = (w.data_ptr(), w._version, self._gen)
+    def get(self, w: torch.Tensor, need_dgrad: bool, key=None):
+        key = id(w if key is None else key)
+        ver = (w.data_ptr(), (w if key is None else w)._version, self._gen, tuple(w.shape))
         hit = self._store.get(key)
         if hit is not None and hit[0] == ver and (hit[2] is not None or not need_dgrad):
             return hit[1], hit[2], hit[3], hit[4]
@@ -402,12 +402,39 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     return out, saved
 
 
+def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float):
+    """fused first layer on the raw fp32 volume (B, 1, D, H, W); see conv3d_l1.hip."""
+    B, _, D, H, W = x.shape
+    wimg = weights.get(conv.weight.view(32, 27, 1), False, key=conv.weight)[0]
+    out = _empty((B, D // 2, H // 2, W // 2, 32), _BF, x)
+    p = drop_p if training else 0.0
+    seed = _next_seed() if p > 0 else 0
+    if training:
+        stats = _zeros((2, 32), x)
+        _hip.call("mm_conv3d_l1", 0, x, wimg, conv.bias, None, None, None, stats, None, None, None,
+                  B, D, H, W, 1, 0.0, 0)
+        out4 = bn_finalize_train(bn, stats, B * D * H * W)
+        bias = conv.bias
+    else:
+        out4 = bn_fold_eval(bn, conv.bias)
+        bias = None
+    _hip.call("mm_conv3d_l1", 1, x, wimg, bias, out4, None, None, None, out, None, None,
+              B, D, H, W, 1 if training else 0, float(p), seed)
+    saved = dict(l1=True, x=x, wimg=wimg, out4=out4, drop_p=p, seed=seed, conv=conv, bn=bn) if training else None
+    return out, saved
+
+
 def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool):
     cl = m.conv_layers
     p = m.drop_p
-    xv = pack_volume(x)
     saved = []
-    h, s = conv3d_bn_act(xv, cl[0], cl[1], pool=True, training=training, drop_p=p, need_dgrad=need_dgrad)
+    B, C, D, H, W = x.shape
+    x = x.contiguous()
+    if C == 1 and cl[0].out_channels == 32 and D % 2 == 0 and H % 2 == 0 and W % 2 == 0:
+        h, s = conv3d_l1_bn_act(x, cl[0], cl[1], training=training, drop_p=p)
+    else:
+        h, s = conv3d_bn_act(pack_volume(x), cl[0], cl[1], pool=True, training=training, drop_p=p,
+                             need_dgrad=need_dgrad)
     saved.append(s)
     h, s = conv3d_bn_act(h, cl[5], cl[6], pool=True, training=training, drop_p=p, need_dgrad=need_dgrad)
     saved.append(s)

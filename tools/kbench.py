@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of individual C-ABI kernels at the C2 training-step shapes
+(HIP events, interleaved rounds, median).  Usage: python tools/kbench.py [filter]"""
+import math
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multimodal_eeg_fmri_amd import _hip, ops  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=20, rounds=5):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    meds = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        meds.append(a.elapsed_time(b) / iters * 1e3)
+    return statistics.median(meds)
+
+
+def linear_case(M, K, N, out_f32=False, residual=False, act="none"):
+    x = torch.randn(M, K, device="cuda").to(BF)
+    w = torch.randn(N, K, device="cuda") / math.sqrt(K)
+    b = torch.randn(N, device="cuda")
+    wf = torch.empty(N, 1, K, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.view(N, K, 1).contiguous(), wf, None, N, K, 1, K, 0)
+    res = torch.randn(M, N, device="cuda") if residual else None
+    of = torch.empty(M, N, device="cuda") if out_f32 else None
+    ob = None if out_f32 else torch.empty(M, N, dtype=BF, device="cuda")
+
+    def fn():
+        _hip.call("mm_conv1d_fwd", x, wf, 1, M, K, N, 1, 0, None, b, ops.ACT[act], res, None, 1, None, of, ob, None, 0.0, 0)
+    us = timeit(fn)
+    fl = 2.0 * M * K * N
+    print(f"linear M={M} K={K} N={N} f32={out_f32} res={residual} act={act}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
+
+
+def conv1d_case(B, T, Cin, Cout, k):
+    x = torch.randn(B, T, Cin, device="cuda").to(BF)
+    w = torch.randn(Cout, Cin, k, device="cuda") / math.sqrt(Cin * k)
+    wf = torch.empty(Cout, k, Cin, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, k, Cin, 0)
+    of = torch.empty(B, T, Cout, device="cuda")
+    stats = torch.zeros(2, Cout, device="cuda")
+    b = torch.randn(Cout, device="cuda")
+
+    def fn():
+        _hip.call("mm_conv1d_fwd", x, wf, B, T, Cin, Cout, k, k // 2, None, b, 0, None, None, 1, stats, of, None, None, 0.0, 0)
+    us = timeit(fn)
+    fl = 2.0 * B * T * Cin * Cout * k
+    print(f"conv1d B={B} T={T} Cin={Cin} Cout={Cout} k={k}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
+
+
+def conv1d_wgrad_case(B, T, Cin, Cout, k):
+    x = torch.randn(B, T, Cin, device="cuda").to(BF)
+    dy = torch.randn(B, T, Cout, device="cuda").to(BF)
+    ws = torch.zeros(Cout, k, Cin, device="cuda")
+    db = torch.zeros(Cout, device="cuda")
+
+    def fn():
+        _hip.call("mm_conv1d_wgrad", dy, x, ws, db, B, T, Cin, Cout, k, k // 2, Cin, k * Cin, 1, Cin)
+    us = timeit(fn)
+    fl = 2.0 * B * T * Cin * Cout * k
+    print(f"wgrad1d B={B} T={T} Cin={Cin} Cout={Cout} k={k}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
+
+
+def conv3d_case(B, S, Cin, Cout):
+    x = torch.randn(B, S, S, S, Cin, device="cuda").to(BF)
+    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
+    wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
+    of = torch.empty(B, S, S, S, Cout, device="cuda")
+    stats = torch.zeros(2, Cout, device="cuda")
+    b = torch.randn(Cout, device="cuda")
+
+    def fn():
+        _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, of, None)
+    us = timeit(fn)
+    fl = 2.0 * B * S ** 3 * Cin * Cout * 27
+    print(f"conv3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
+    dy = torch.randn(B, S, S, S, Cout, device="cuda").to(BF)
+    ws = torch.zeros(Cout, 27, Cin, device="cuda")
+
+    def fn2():
+        _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin)
+    us = timeit(fn2)
+    print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
+
+
+def main():
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    M = 32 * 512
+    if "lin" in flt or not flt:
+        linear_case(M, 128, 384)
+        linear_case(M, 128, 128, out_f32=True, residual=True)
+        linear_case(M, 128, 512, act="gelu")
+        linear_case(M, 512, 128, out_f32=True, residual=True)
+        linear_case(M, 384, 128)
+    if "conv1" in flt or not flt:
+        conv1d_case(32, 1024, 64, 64, 7)
+        conv1d_case(32, 1024, 64, 128, 5)
+        conv1d_case(32, 512, 128, 128, 3)
+        conv1d_wgrad_case(32, 1024, 64, 64, 7)
+        conv1d_wgrad_case(32, 1024, 64, 128, 5)
+        conv1d_wgrad_case(32, 512, 128, 128, 3)
+        conv1d_wgrad_case(1, M, 128, 512, 1)
+    if "conv3" in flt or not flt:
+        conv3d_case(32, 16, 32, 64)
+        conv3d_case(32, 8, 64, 128)
+
+
+if __name__ == "__main__":
+    main()
