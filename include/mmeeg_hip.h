@@ -155,11 +155,13 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
 int mm_transpose_add(const float* src, float* dst, int R, int C, hipStream_t stream);
 
 /* ---- small fp32 row kernels (projection bridge, tabular fMRI/conn MLPs) ------
- * y = dropout(act(x W^T + b)), optional pre-activation copy.  nn.Linear on
+ * y = dropout(act((x W^T + b) * scale + shift)) (scale/shift = folded eval
+ * BatchNorm1d, may be NULL), optional pre-activation copy.  nn.Linear on
  * (B, K) feature rows: bridge_utils.py:34-45,60-66; fmri_utils.py:26-35,44-53;
  * crossmodal_v4_enhancements.py:695-723. */
-int mm_small_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* pre, int B,
-                        int K, int N, int act, float drop_p, uint32_t seed, hipStream_t stream);
+int mm_small_linear_fwd(const float* x, const float* W, const float* bias, const float* scale,
+                        const float* shift, float* y, float* pre, int B, int K, int N, int act,
+                        float drop_p, uint32_t seed, hipStream_t stream);
 /* dx = dy W ; dW += dy^T x ; db += colsum(dy)   (dy already through act') */
 int mm_small_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db,
                         int B, int K, int N, hipStream_t stream);
@@ -180,6 +182,24 @@ int mm_l2norm_bwd(const float* dz, const float* z, const float* nrm, float* dh, 
  * Extension a-X2: the reference trains a CE classifier (_test_bridge.py:858). */
 int mm_clip_loss(const float* z_local, const float* z_all, const float* logit_scale, float* scal4,
                  float* dz_all, int B, int Bg, int N, int row0, hipStream_t stream);
+
+/* ---- fused tails of the small models (forward) ------------------------------ */
+/* fMRIFusionNet weighted concat (fmri_utils.py:93-96) */
+int mm_softmax2_concat(const float* a, const float* c, const float* pa, const float* pc, float* out, int B,
+                       int Ha, int Hc, hipStream_t stream);
+/* LearnedFusionModule combine (enhanced_models_v4.py:468-484); dyn = gate_net output [B][M] */
+int mm_learned_fusion(const float* f0, const float* f1, const float* f2, const float* dyn,
+                      const float* logits, const float* temperature, float* fused, float* weights, int B,
+                      int H, int M, hipStream_t stream);
+/* bridge cross-attention core, 1 query x 2 keys (bridge_utils.py:75-82) */
+int mm_attn_1x2(const float* proj_e, const float* proj_f, float* ctx, float* attw, int B, int E, int nhead,
+                hipStream_t stream);
+/* HybridFusionModule gate + mix + conn boost (crossmodal_v4_enhancements.py:787-797) */
+int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float* conn, float* comb,
+                 float* gate, int B, int H, float boost, hipStream_t stream);
+int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
+/* AdaptiveAvgPool1d(1) of the Lite encoders on bf16 [R][S][N] */
+int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t stream);
 
 /* ---- optimizer: clip_grad_norm_(max_norm) + AdamW.step() on one flat bucket
  * (run_training_lite.py:487-488; _test_bridge.py:784-786).  state (device, 8 floats):

@@ -10,7 +10,8 @@ namespace {
 
 // y[b][n] = dropout(act(x[b][:] . W[n][:] + bias[n])); one wave per (b, 64 outputs)
 __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                        const float* __restrict__ bias, float* __restrict__ y,
+                                        const float* __restrict__ bias, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, float* __restrict__ y,
                                         float* __restrict__ pre, int B, int K, int N, int act,
                                         uint32_t thresh, uint32_t seed, float inv_keep) {
     extern __shared__ float xs[];                   // one input row
@@ -24,6 +25,7 @@ __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float
         s = wave_sum(s);
         if (lane == 0) {
             s += bias ? bias[n] : 0.f;
+            if (scale) s = s * scale[n] + shift[n];
             const size_t idx = (size_t)b * N + n;
             if (pre) pre[idx] = s;
             s = apply_act(s, act);
@@ -250,6 +252,111 @@ __global__ void adamw_finish_kernel(float* __restrict__ state, float max_norm, f
     state[1] = 0.f;
 }
 
+
+// ---------------------------------------------------------------------------
+// tiny fused tails of the tabular / bridge models (forward)
+// ---------------------------------------------------------------------------
+// out[b] = [ w0 * a[b][:Ha] | w1 * c[b][:Hc] ],  (w0, w1) = softmax(pa[0], pc[0])   (fmri_utils.py:93-96)
+__global__ void softmax2_concat_kernel(const float* __restrict__ a, const float* __restrict__ c,
+                                       const float* __restrict__ pa, const float* __restrict__ pc,
+                                       float* __restrict__ out, int B, int Ha, int Hc) {
+    const float m = fmaxf(pa[0], pc[0]);
+    const float ea = __expf(pa[0] - m), ec = __expf(pc[0] - m);
+    const float w0 = ea / (ea + ec), w1 = ec / (ea + ec);
+    const int H = Ha + Hc;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * H; i += gridDim.x * blockDim.x) {
+        const int b = i / H, j = i % H;
+        out[i] = j < Ha ? w0 * a[(size_t)b * Ha + j] : w1 * c[(size_t)b * Hc + (j - Ha)];
+    }
+}
+
+// LearnedFusionModule tail (enhanced_models_v4.py:468-484): w = 0.5 softmax(logits/T) +
+// 0.5 softmax(dyn[b]/T); fused[b] = sum_m w[b][m] feat_m[b].   M <= 4, one wave per row.
+__global__ void learned_fusion_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                      const float* __restrict__ f2, const float* __restrict__ dyn,
+                                      const float* __restrict__ logits, const float* __restrict__ temp,
+                                      float* __restrict__ fused, float* __restrict__ wout, int B, int H, int M) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float T = temp[0];
+    float st[4], dy[4], w[4];
+    float ms = -INFINITY, md = -INFINITY;
+    for (int m = 0; m < M; ++m) {
+        st[m] = logits[m] / T; dy[m] = dyn[(size_t)row * M + m] / T;
+        ms = fmaxf(ms, st[m]); md = fmaxf(md, dy[m]);
+    }
+    float ss = 0.f, sd = 0.f;
+    for (int m = 0; m < M; ++m) { st[m] = __expf(st[m] - ms); dy[m] = __expf(dy[m] - md); ss += st[m]; sd += dy[m]; }
+    for (int m = 0; m < M; ++m) w[m] = 0.5f * st[m] / ss + 0.5f * dy[m] / sd;
+    const float* fs[3] = {f0, f1, f2};
+    for (int h = lane; h < H; h += 64) {
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += w[m] * fs[m][(size_t)row * H + h];
+        fused[(size_t)row * H + h] = acc;
+    }
+    if (lane < M && wout) wout[(size_t)row * M + lane] = w[lane];
+}
+
+// bridge cross-attention core (bridge_utils.py:75-82): one query (EEG token) over two
+// keys [EEG, fMRI], nhead heads of dh.  pe / pf = in_proj outputs [B][3E] (q|k|v) of the
+// two tokens.  ctx [B][E], attw [B][2] = head-averaged probabilities.
+__global__ void attn_1x2_kernel(const float* __restrict__ pe, const float* __restrict__ pf,
+                                float* __restrict__ ctx, float* __restrict__ attw, int B, int E, int nhead) {
+    const int b = blockIdx.x;
+    const int dh = E / nhead;
+    __shared__ float p0s[16], p1s[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* q = pe + (size_t)b * 3 * E;
+    const float* ke = q + E; const float* ve = q + 2 * E;
+    const float* kf = pf + (size_t)b * 3 * E + E; const float* vf = kf + E;
+    for (int h = wave; h < nhead; h += (blockDim.x >> 6)) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int d = lane; d < dh; d += 64) { s0 += q[h * dh + d] * ke[h * dh + d]; s1 += q[h * dh + d] * kf[h * dh + d]; }
+        s0 = wave_sum(s0) * rsqrtf((float)dh); s1 = wave_sum(s1) * rsqrtf((float)dh);
+        const float m = fmaxf(s0, s1);
+        const float e0 = __expf(s0 - m), e1 = __expf(s1 - m);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        for (int d = lane; d < dh; d += 64) ctx[(size_t)b * E + h * dh + d] = p0 * ve[h * dh + d] + p1 * vf[h * dh + d];
+        if (lane == 0) { p0s[h] = p0; p1s[h] = p1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int h = 0; h < nhead; ++h) { a0 += p0s[h]; a1 += p1s[h]; }
+        attw[2 * b] = a0 / nhead; attw[2 * b + 1] = a1 / nhead;
+    }
+}
+
+// HybridFusionModule mix (crossmodal_v4_enhancements.py:787-797):
+// gate = softmax(g[b][0:2]); comb[b] = [ gate0*erp + gate1*pw | conn * boost ]
+__global__ void gate2_mix_kernel(const float* __restrict__ g, const float* __restrict__ erp, const float* __restrict__ pw,
+                                 const float* __restrict__ conn, float* __restrict__ comb, float* __restrict__ gate,
+                                 int B, int H, float boost) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * 2 * H; i += gridDim.x * blockDim.x) {
+        const int b = i / (2 * H), j = i % (2 * H);
+        const float g0 = g[2 * b], g1 = g[2 * b + 1], m = fmaxf(g0, g1);
+        const float e0 = __expf(g0 - m), e1 = __expf(g1 - m);
+        const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
+        comb[i] = j < H ? w0 * erp[(size_t)b * H + j] + w1 * pw[(size_t)b * H + j] : conn[(size_t)b * H + (j - H)] * boost;
+        if (j == 0 && gate) { gate[2 * b] = w0; gate[2 * b + 1] = w1; }
+    }
+}
+
+__global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
+}
+
+// mean over S of bf16 [R][S][N] -> fp32 [R][N]   (AdaptiveAvgPool1d(1) of the Lite encoders)
+__global__ void meanpool_bf16_kernel(const bf16* __restrict__ x, float* __restrict__ out, int S, int N) {
+    const int r = blockIdx.x;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += (float)x[((size_t)r * S + t) * N + n];
+        out[(size_t)r * N + n] = s / (float)S;
+    }
+}
+
 inline uint32_t thresh_h(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 inline int grid_h(size_t n, int cap = 2048) { size_t g = (n + 255) / 256; return (int)(g < (size_t)cap ? (g ? g : 1) : cap); }
 
@@ -257,13 +364,15 @@ inline int grid_h(size_t n, int cap = 2048) { size_t g = (n + 255) / 256; return
 
 extern "C" {
 
-int mm_small_linear_fwd(const float* x, const float* W, const float* bias, float* y, float* pre, int B, int K, int N,
-                        int act, float drop_p, uint32_t seed, hipStream_t st) {
+int mm_small_linear_fwd(const float* x, const float* W, const float* bias, const float* scale, const float* shift,
+                        float* y, float* pre, int B, int K, int N, int act, float drop_p, uint32_t seed,
+                        hipStream_t st) {
     MM_REQUIRE(x && W && y && B > 0 && K > 0 && N > 0, "small_linear_fwd: null/invalid");
+    MM_REQUIRE((scale == nullptr) == (shift == nullptr), "small_linear_fwd: scale/shift come in pairs");
     MM_REQUIRE((size_t)K * 4 <= 64 * 1024, "small_linear_fwd: K=%d too large", K);
     const int gy = ceil_div(N, 4) < 64 ? ceil_div(N, 4) : 64;
-    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(B, gy), dim3(256), K * sizeof(float), st, x, W, bias, y, pre, B,
-                       K, N, act, thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+    hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(B, gy), dim3(256), K * sizeof(float), st, x, W, bias, scale, shift,
+                       y, pre, B, K, N, act, thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
     return mm_check_launch("small_linear_fwd");
 }
 
@@ -333,6 +442,48 @@ int mm_adamw_clip(float* p, const float* g, float* m, float* v, float* state, in
                        beta2, eps, weight_decay, max_norm, grad_scale);
     hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(1), 0, st, state, max_norm, grad_scale);
     return mm_check_launch("adamw_clip");
+}
+
+int mm_softmax2_concat(const float* a, const float* c, const float* pa, const float* pc, float* out, int B, int Ha,
+                       int Hc, hipStream_t st) {
+    MM_REQUIRE(a && c && pa && pc && out && B > 0 && Ha > 0 && Hc > 0, "softmax2_concat: null");
+    hipLaunchKernelGGL(softmax2_concat_kernel, dim3(grid_h((size_t)B * (Ha + Hc))), dim3(256), 0, st, a, c, pa, pc, out, B, Ha, Hc);
+    return mm_check_launch("softmax2_concat");
+}
+
+int mm_learned_fusion(const float* f0, const float* f1, const float* f2, const float* dyn, const float* logits,
+                      const float* temperature, float* fused, float* weights, int B, int H, int M, hipStream_t st) {
+    MM_REQUIRE(f0 && f1 && dyn && logits && temperature && fused && B > 0 && H > 0, "learned_fusion: null");
+    MM_REQUIRE(M >= 2 && M <= 3 && (M == 2 || f2), "learned_fusion: M=%d (2 or 3)", M);
+    hipLaunchKernelGGL(learned_fusion_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, f0, f1, f2, dyn, logits,
+                       temperature, fused, weights, B, H, M);
+    return mm_check_launch("learned_fusion");
+}
+
+int mm_attn_1x2(const float* proj_e, const float* proj_f, float* ctx, float* attw, int B, int E, int nhead,
+                hipStream_t st) {
+    MM_REQUIRE(proj_e && proj_f && ctx && attw && B > 0 && nhead > 0 && nhead <= 16 && E % nhead == 0, "attn_1x2: bad args");
+    hipLaunchKernelGGL(attn_1x2_kernel, dim3(B), dim3(256), 0, st, proj_e, proj_f, ctx, attw, B, E, nhead);
+    return mm_check_launch("attn_1x2");
+}
+
+int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float* conn, float* comb, float* gate, int B,
+                 int H, float boost, hipStream_t st) {
+    MM_REQUIRE(g && erp && pw && conn && comb && B > 0 && H > 0, "gate2_mix: null");
+    hipLaunchKernelGGL(gate2_mix_kernel, dim3(grid_h((size_t)B * 2 * H)), dim3(256), 0, st, g, erp, pw, conn, comb, gate, B, H, boost);
+    return mm_check_launch("gate2_mix");
+}
+
+int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
+    MM_REQUIRE(a && b && out && n > 0, "mul_f32: null");
+    hipLaunchKernelGGL(mul_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, a, b, out, (size_t)n);
+    return mm_check_launch("mul_f32");
+}
+
+int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t st) {
+    MM_REQUIRE(x && out && R > 0 && S > 0 && N > 0, "meanpool_bf16: null");
+    hipLaunchKernelGGL(meanpool_bf16_kernel, dim3(R), dim3(128), 0, st, (const bf16*)x, out, S, N);
+    return mm_check_launch("meanpool_bf16");
 }
 
 }  // extern "C"

@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int KC = 32;        // Cin chunk staged per step
+
 constexpr int KPAD = 8;       // +16 B per LDS row
 
 struct EpiArgs {
@@ -42,11 +42,91 @@ struct ConvArgs {
     EpiArgs e;
 };
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv1d_fwd_kernel(ConvArgs a) {
+// Epilogue through LDS: the accumulator tile is parked as fp32 [BM][BN+4], then
+// every thread owns one 4-column group (fixed per thread) and walks rows, so
+// residual / positional loads and all stores are 16-byte, row-contiguous.
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
+                                              int n0, int N, float* sstat) {
+    constexpr int LDC = BN + 4;
+    constexpr int CG = BN / 4;                 // column groups
+    constexpr int RPP = 256 / CG;              // rows per pass
+    const int cg = tid % CG, rr = tid / CG;
+    const int n = n0 + cg * 4;
+    const bool nok = n < N;                    // N % 4 == 0 is required
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nok) {
+        if (e.scale) sc = *reinterpret_cast<const float4*>(e.scale + n);
+        if (e.shift) sh = *reinterpret_cast<const float4*>(e.shift + n);
+    }
+    const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const int To = T / e.pool;
+    const int step = e.pool;                   // rows consumed per item
+    for (int r0 = rr * step; r0 < BM; r0 += RPP * step) {
+        float o[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        bool any = false;
+        for (int q = 0; q < step; ++q) {
+            const int row = r0 + q, t = t0 + row;
+            if (t >= T || !nok) continue;
+            any = true;
+            const float4 a4 = *reinterpret_cast<const float4*>(Cs + row * LDC + cg * 4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const size_t idx = ((size_t)b * T + t) * N + n;
+            float4 res = make_float4(0.f, 0.f, 0.f, 0.f), pe = res;
+            if (e.residual) res = *reinterpret_cast<const float4*>(e.residual + idx);
+            if (e.pe) pe = *reinterpret_cast<const float4*>(e.pe + (size_t)t * N + n);
+            const float rs[4] = {res.x, res.y, res.z, res.w}, ps[4] = {pe.x, pe.y, pe.z, pe.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float val = v[c] * scs[c] + shs[c];
+                s1[c] += val; s2[c] += val * val;
+                v[c] = val;
+            }
+            if (e.out_pre) {
+                bf16x4 pv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(e.out_pre + idx) = pv;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float val = apply_act(v[c], e.act);
+                if (e.drop_thresh) val *= dropout_scale(e.drop_seed, (uint32_t)(idx + c), e.drop_thresh, e.drop_inv_keep);
+                val += rs[c] + ps[c];
+                o[c] = fmaxf(o[c], val);
+            }
+        }
+        if (!any) continue;
+        const int t = t0 + r0;
+        const size_t oi = ((size_t)b * To + t / step) * N + n;
+        if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
+        if (e.out_bf16) {
+            bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+            *reinterpret_cast<bf16x4*>(e.out_bf16 + oi) = ov;
+        }
+    }
+    if (e.stats) {
+        if (nok)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                atomicAdd(&sstat[cg * 4 + c], s1[c]);
+                atomicAdd(&sstat[BN + cg * 4 + c], s2[c]);
+            }
+        __syncthreads();
+        for (int i = tid; i < BN; i += 256)
+            if (n0 + i < N) {
+                atomicAdd(&e.stats[n0 + i], sstat[i]);
+                atomicAdd(&e.stats[N + n0 + i], sstat[BN + i]);
+            }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int KCT>
+__global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     static_assert(WM * WN == 4, "4 waves");
+    constexpr int AS = KCT + KPAD;                // LDS row stride (elements)
+    constexpr int SEGS = KCT / 8;                 // 16-B segments per row
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -57,12 +137,9 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(ConvArgs a) {
     const int b = blockIdx.x / tilesT;
     const int t0 = (blockIdx.x % tilesT) * BM;
     const int n0 = blockIdx.y * BN;
-    const int kc = a.Cin < KC ? a.Cin : KC;       // 16 or 32
-    const int AS = kc + KPAD;                     // LDS row stride (elements)
     const int arows = BM + a.taps - 1;
     bf16* As = reinterpret_cast<bf16*>(smem);
     bf16* Ws = As + arows * AS;
-    const int segs = kc / 8;                      // 16-B segments per row
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -74,30 +151,30 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(ConvArgs a) {
 
     const bf16* xb = a.x + (size_t)b * a.T * a.Cin;
     const int lr = lane & 31, lh = lane >> 5;
+    const int wrows = BN * a.taps;
+    const int wvalid = (a.Cout - n0) * a.taps;    // rows >= wvalid are beyond Cout -> zeros
 
-    for (int c0 = 0; c0 < a.Cin; c0 += kc) {
-        // ---- stage halo tile of X
-        for (int s = tid; s < arows * segs; s += 256) {
-            const int r = s / segs, sg = s - r * segs;
+    for (int c0 = 0; c0 < a.Cin; c0 += KCT) {
+        if (c0) __syncthreads();
+        for (int s = tid; s < arows * SEGS; s += 256) {
+            const int r = s / SEGS, sg = s % SEGS;
             const int t = t0 - a.pad + r;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (t >= 0 && t < a.T)
                 v = *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c0 + sg * 8);
             *reinterpret_cast<uint4*>(As + r * AS + sg * 8) = v;
         }
-        // ---- stage W[n0..n0+BN)[taps][c0..c0+kc)
-        const int wrows = BN * a.taps;
-        for (int s = tid; s < wrows * segs; s += 256) {
-            const int r = s / segs, sg = s - r * segs;      // r = n_local*taps + tap
-            const int n = n0 + r / a.taps;
+        for (int s = tid; s < wrows * SEGS; s += 256) {
+            const int r = s / SEGS, sg = s % SEGS;         // r = n_local * taps + tap
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (n < a.Cout)
+            if (r < wvalid)
                 v = *reinterpret_cast<const uint4*>(a.w + ((size_t)n0 * a.taps + r) * a.Cin + c0 + sg * 8);
             *reinterpret_cast<uint4*>(Ws + r * AS + sg * 8) = v;
         }
         __syncthreads();
         for (int tap = 0; tap < a.taps; ++tap) {
-            for (int ks = 0; ks < kc; ks += 16) {
+#pragma unroll
+            for (int ks = 0; ks < KCT; ks += 16) {
                 bf16x8 af[TM], bfr[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -116,96 +193,33 @@ __global__ __launch_bounds__(256) void conv1d_fwd_kernel(ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
     }
-
-    // ---------------------------------------------------------------- epilogue
-    const EpiArgs& e = a.e;
-    float* sstat = reinterpret_cast<float*>(smem);      // [2][BN] (LDS reuse; synced above)
-    if (e.stats) {
+    __syncthreads();                               // staging LDS is dead: reuse as the C tile
+    constexpr int LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);
+    float* sstat = Cs + BM * LDC;                  // [2][BN]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Cs[row * LDC + (wn * TN + j) * 32 + lr] = acc[i][j][r];
+            }
+    if (a.e.stats)
         for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
-        __syncthreads();
-    }
-    const int N = a.Cout;
-    const int To = a.T / e.pool;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + lr;
-        const bool nok = n < N;
-        const float sc = (e.scale && nok) ? e.scale[n] : 1.f;
-        const float sh = (e.shift && nok) ? e.shift[n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int rp = 0; rp < 16; rp += 2) {
-                float v[2];
-                int tt[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int r = rp + q;
-                    const int ml = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int t = t0 + ml;
-                    tt[q] = t;
-                    float val = acc[i][j][r] * sc + sh;
-                    const bool ok = nok && t < a.T;
-                    if (ok) {
-                        s1 += val; s2 += val * val;
-                        const size_t idx = ((size_t)b * a.T + t) * N + n;
-                        if (e.out_pre) e.out_pre[idx] = (bf16)val;
-                        val = apply_act(val, e.act);
-                        if (e.drop_thresh) val *= dropout_scale(e.drop_seed, (uint32_t)idx, e.drop_thresh, e.drop_inv_keep);
-                        if (e.residual) val += e.residual[idx];
-                        if (e.pe) val += e.pe[(size_t)t * N + n];
-                    }
-                    v[q] = val;
-                }
-                if (!nok) continue;
-                if (e.pool == 2) {
-                    if (tt[0] + 1 < a.T) {
-                        const float m = fmaxf(v[0], v[1]);
-                        const size_t o = ((size_t)b * To + (tt[0] >> 1)) * N + n;
-                        if (e.out_f32) e.out_f32[o] = m;
-                        if (e.out_bf16) e.out_bf16[o] = (bf16)m;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        if (tt[q] < a.T) {
-                            const size_t o = ((size_t)b * a.T + tt[q]) * N + n;
-                            if (e.out_f32) e.out_f32[o] = v[q];
-                            if (e.out_bf16) e.out_bf16[o] = (bf16)v[q];
-                        }
-                }
-            }
-        }
-        if (e.stats) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lh == 0) {
-                const int nl = (wn * TN + j) * 32 + lr;
-                atomicAdd(&sstat[nl], s1);
-                atomicAdd(&sstat[BN + nl], s2);
-            }
-        }
-    }
-    if (e.stats) {
-        __syncthreads();
-        for (int i = tid; i < BN; i += 256)
-            if (n0 + i < N) {
-                atomicAdd(&e.stats[n0 + i], sstat[i]);
-                atomicAdd(&e.stats[N + n0 + i], sstat[BN + i]);
-            }
-    }
+    __syncthreads();
+    epilogue_rows<BM, BN>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KCT>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
-    const int kc = a.Cin < KC ? a.Cin : KC;
-    const size_t lds = (size_t)(BM + a.taps - 1 + BN * a.taps) * (kc + KPAD) * sizeof(bf16);
-    const size_t need = lds > 2 * BN * sizeof(float) ? lds : 2 * BN * sizeof(float);
+    const size_t stage = (size_t)(BM + a.taps - 1 + BN * a.taps) * (KCT + KPAD) * sizeof(bf16);
+    const size_t ctile = (size_t)(BM * (BN + 4) + 2 * BN) * sizeof(float);
+    const size_t need = stage > ctile ? stage : ctile;
     if (need > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_fwd: LDS %zu B > 160 KiB", need);
-    auto kern = conv1d_fwd_kernel<BM, BN, WM, WN>;
+    auto kern = conv1d_fwd_kernel<BM, BN, WM, WN, KCT>;
     if (need > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
     dim3 grid(a.B * ceil_div(a.T, BM), ceil_div(a.Cout, BN));
@@ -428,9 +442,10 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
                   float drop_p, uint32_t drop_seed, hipStream_t st) {
     MM_REQUIRE(x && w, "conv1d_fwd: null operand");
     MM_REQUIRE(B > 0 && T > 0 && Cout > 0 && taps >= 1 && taps <= 9 && pad >= 0 && pad < taps, "conv1d_fwd: bad dims");
-    MM_REQUIRE(Cin % 16 == 0 && (Cin <= 32 ? (Cin == 16 || Cin == 32) : Cin % 32 == 0), "conv1d_fwd: Cin=%d must be 16 or a multiple of 32", Cin);
+    MM_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv1d_fwd: Cin=%d must be a multiple of 16", Cin);
     MM_REQUIRE(pool == 1 || (pool == 2 && T % 2 == 0), "conv1d_fwd: pool=%d T=%d", pool, T);
     MM_REQUIRE(out_f32 || out_bf16 || out_pre, "conv1d_fwd: no output");
+    MM_REQUIRE(Cout % 4 == 0, "conv1d_fwd: Cout=%d must be a multiple of 4", Cout);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1d_fwd: drop_p");
     ConvArgs a;
     a.x = (const bf16*)x; a.w = (const bf16*)w;
@@ -441,13 +456,20 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     a.e.drop_seed = drop_seed;
     a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
-    const long tiles128 = (long)B * ceil_div(T, 128);
-    if (Cout <= 64) {
-        if (tiles128 >= 256 || T < 64) return launch_fwd<128, 64, 4, 1>(a, st);
-        return launch_fwd<64, 64, 2, 2>(a, st);
+    // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
+    // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS
+    const int kct = (taps == 1 && Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : (Cin % 32 == 0 ? 32 : 16));
+    const bool narrow = Cout <= 64 || taps > 1;
+#define MM_FWD(BM_, BN_, WM_, WN_)                                               \
+    switch (kct) {                                                               \
+        case 16: return launch_fwd<BM_, BN_, WM_, WN_, 16>(a, st);               \
+        case 32: return launch_fwd<BM_, BN_, WM_, WN_, 32>(a, st);               \
+        case 64: return launch_fwd<BM_, BN_, WM_, WN_, 64>(a, st);               \
+        default: return launch_fwd<BM_, BN_, WM_, WN_, 128>(a, st);              \
     }
-    if (tiles128 * ceil_div(Cout, 128) >= 256 || T < 64) return launch_fwd<128, 128, 2, 2>(a, st);
-    return launch_fwd<64, 128, 2, 2>(a, st);
+    if (narrow) { MM_FWD(64, 64, 2, 2) }
+    MM_FWD(64, 128, 2, 2)
+#undef MM_FWD
 }
 
 int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin, int Cout,

@@ -36,9 +36,9 @@ def _need_gpu(*tensors):
 
 
 def cpad(c: int) -> int:
-    """channel count as the MFMA K-chunking wants it: 16, 32 or a multiple of 32."""
+    """channel count as the MFMA K-chunking wants it: a multiple of 16."""
     c16 = max(16, (c + 15) // 16 * 16)
-    return c16 if c16 <= 32 else (c16 + 31) // 32 * 32
+    return c16
 
 
 def _empty(shape, dtype, like):
@@ -454,13 +454,21 @@ def volume_encoder_forward(m, x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------- projection bridge (fp32)
-def small_linear(x: torch.Tensor, lin, *, act="none", drop_p=0.0, seed=0, want_pre=False):
-    """fp32 (B, K) -> (B, N): dropout(act(x W^T + b)); optional pre-activation."""
+def small_linear(x: torch.Tensor, lin, *, act="none", drop_p=0.0, seed=0, want_pre=False, bn=None,
+                 weight=None, bias=None):
+    """fp32 (B, K) -> (B, N): dropout(act((x W^T + b) * scale + shift)); scale/shift
+    = eval-mode BatchNorm1d ``bn`` folded; optional pre-activation copy."""
+    W = lin.weight if weight is None else weight
+    bvec = (lin.bias if lin is not None else None) if bias is None else bias
     B, K = x.shape
-    N = lin.weight.shape[0]
+    N = W.shape[0]
     y = _empty((B, N), _F32, x)
     pre = _empty((B, N), _F32, x) if want_pre else None
-    _hip.call("mm_small_linear_fwd", x, lin.weight, lin.bias, y, pre, B, K, N, ACT[act], float(drop_p), int(seed))
+    sc = sh = None
+    if bn is not None:
+        out4 = bn_fold_eval(bn, None)
+        sc, sh = out4[0], out4[1]
+    _hip.call("mm_small_linear_fwd", x, W, bvec, sc, sh, y, pre, B, K, N, ACT[act], float(drop_p), int(seed))
     return y, pre
 
 
@@ -507,3 +515,178 @@ def clip_loss(ze, zf, logit_scale, group=None):
     from .autograd import ClipLossFn
     z = ze._base if (ze._base is not None and ze._base is zf._base) else torch.cat([ze, zf], dim=1)
     return ClipLossFn.apply(z, logit_scale, group)
+
+
+
+# ----------------------------------------------------- small models (forward)
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float().contiguous()
+
+
+def _eval_only(what: str, training: bool):
+    if training and torch.is_grad_enabled():
+        raise NotImplementedError(
+            f"{what}: training on the HIP path is not built yet (eval/inference only this round; "
+            "see DESIGN.md 'next'); call .eval() and torch.no_grad()")
+
+
+def learned_fusion(m, feats: List[torch.Tensor], training: bool):
+    """LearnedFusionModule.forward -> (fused (B, H), weights (B, M))."""
+    _need_gpu(*feats)
+    _eval_only("LearnedFusionModule", training)
+    M = len(feats)
+    fs = [_f32c(f) for f in feats]
+    B, H = fs[0].shape
+    g, _ = small_linear(torch.cat(fs, dim=1), m.gate_net[0], act="gelu")
+    dyn, _ = small_linear(g, m.gate_net[3])
+    fused = _empty((B, H), _F32, fs[0])
+    w = _empty((B, M), _F32, fs[0])
+    _hip.call("mm_learned_fusion", fs[0], fs[1], fs[2] if M > 2 else None, dyn, _f32c(m.fusion_logits),
+              _f32c(m.temperature).reshape(1), fused, w, B, H, M)
+    return fused, w
+
+
+def bridge_forward(m, eeg, fmri):
+    """EEGfMRIBridgeFusionNet.forward -> (logits, fused, fusion_w (B,2), attn_w (B,1,2))."""
+    _need_gpu(eeg, fmri)
+    _eval_only("EEGfMRIBridgeFusionNet (classifier path)", m.training)
+    with torch.no_grad():
+        ep, _ = proj_head_fwd(m.eeg_proj, _f32c(eeg), False, 0.0)
+        fp, _ = proj_head_fwd(m.fmri_proj, _f32c(fmri), False, 0.0)
+        B, E = ep.shape
+        ca = m.cross_attn
+        pe, _ = small_linear(ep, None, weight=ca.in_proj_weight, bias=ca.in_proj_bias)
+        pf, _ = small_linear(fp, None, weight=ca.in_proj_weight, bias=ca.in_proj_bias)
+        ctx = _empty((B, E), _F32, ep)
+        attw = _empty((B, 2), _F32, ep)
+        _hip.call("mm_attn_1x2", pe, pf, ctx, attw, B, E, m.num_heads)
+        att, _ = small_linear(ctx, ca.out_proj)
+        fused, fw = learned_fusion(m.fusion, [att, fp], False)
+        h1, _ = small_linear(fused, m.classifier[0])
+        ln = m.classifier[1]
+        hn = _empty(h1.shape, _F32, h1)
+        _hip.call("mm_layernorm_fwd", h1, ln.weight, ln.bias, None, hn, None, B, h1.shape[1], float(ln.eps))
+        hr = _empty(h1.shape, _F32, h1)
+        _hip.call("mm_act_f32", hn, hr, hn.numel(), ACT["relu"], 0.0, 0)
+        logits, _ = small_linear(hr, m.classifier[4])
+    return logits, fused, fw, attw.view(B, 1, 2)
+
+
+def fmri_mlp_forward(seq, x, drop_p, training):
+    """Linear-BN-ReLU x2 (fmri_utils.py:26-35), eval-mode BN folded."""
+    _need_gpu(x)
+    _eval_only("ActivationEncoder/ConnectivityEncoder", training)
+    h, _ = small_linear(_f32c(x), seq[0], act="relu", bn=seq[1])
+    h, _ = small_linear(h, seq[4], act="relu", bn=seq[5])
+    return h
+
+
+def fmri_fusion_forward(m, activation, connectivity):
+    _need_gpu(activation, connectivity)
+    _eval_only("fMRIFusionNet", m.training)
+    with torch.no_grad():
+        a = fmri_mlp_forward(m.activation_encoder.encoder, activation, 0.0, False)
+        c = fmri_mlp_forward(m.connectivity_encoder.encoder, connectivity, 0.0, False)
+        B, H = a.shape
+        comb = _empty((B, 2 * H), _F32, a)
+        _hip.call("mm_softmax2_concat", a, c, _f32c(m.activation_weight), _f32c(m.connectivity_weight), comb, B, H, H)
+        fused, _ = small_linear(comb, m.fusion[0], act="relu", bn=m.fusion[1])
+        h, _ = small_linear(fused, m.head[0], act="relu")
+        out, _ = small_linear(h, m.head[3])
+    return out, fused
+
+
+def conn_encoder_forward(m, x):
+    _need_gpu(x)
+    _eval_only("EnhancedConnEncoder", m.training)
+    with torch.no_grad():
+        h, _ = small_linear(_f32c(x), m.proj1[0], act="gelu", bn=m.proj1[1])
+        h, _ = small_linear(h, m.proj2[0], act="gelu", bn=m.proj2[1])
+        t, _ = small_linear(h, m.attention[0], act="tanh")
+        g, _ = small_linear(t, m.attention[2], act="sigmoid")
+        hg = torch.empty_like(h)
+        _hip.call("mm_mul_f32", h, g, hg, h.numel())
+        out, _ = small_linear(hg, m.output[0], act="gelu", bn=m.output[1])
+    return out
+
+
+def hybrid_fusion_forward(m, erp, pw, conn):
+    _need_gpu(erp, pw, conn)
+    _eval_only("HybridFusionModule", m.training)
+    with torch.no_grad():
+        e, p, c = _f32c(erp), _f32c(pw), _f32c(conn)
+        B, H = e.shape
+        g1, _ = small_linear(torch.cat([e, p], dim=1), m.erp_pw_gate[0], act="gelu")
+        g2, _ = small_linear(g1, m.erp_pw_gate[3])
+        comb = _empty((B, 2 * H), _F32, e)
+        gate = _empty((B, 2), _F32, e)
+        _hip.call("mm_gate2_mix", g2, e, p, c, comb, gate, B, H, float(m.conn_boost))
+        fused, _ = small_linear(comb, m.late_fusion[0], act="gelu", bn=m.late_fusion[1])
+    return fused, gate
+
+
+def bn_classifier_forward(seq, fused, drop_p, training):
+    """Linear-BN-GELU-Drop-Linear (crossmodal_v4_enhancements.py:909-915)."""
+    _need_gpu(fused)
+    _eval_only("EnhancedTriModalFusionNetV4Lite.classifier", training)
+    with torch.no_grad():
+        h, _ = small_linear(_f32c(fused), seq[0], act="gelu", bn=seq[1])
+        out, _ = small_linear(h, seq[4])
+    return out
+
+
+def lite_encoder_forward(m, x):
+    """LiteERPEncoder / LitePowerEncoder (crossmodal_v4_enhancements.py:817-877)."""
+    _need_gpu(x)
+    _eval_only("LiteERPEncoder/LitePowerEncoder", m.training)
+    with torch.no_grad():
+        cl = m.conv_layers
+        xb = pack_nct(x.float())
+        r, _ = conv_bn_act(xb, cl[0], cl[1], pool=2, training=False)
+        r, _ = conv_bn_act(r["bf16"], cl[5], cl[6], training=False)
+        h = r["bf16"]
+        B, T, N = h.shape
+        pooled = _empty((B, N), _F32, h)
+        _hip.call("mm_meanpool_bf16", h, pooled, B, T, N)
+        out, _ = small_linear(pooled, m.output[1], act="gelu")
+    return out
+
+
+def _power_merged(m, device):
+    """the three parallel Conv1d(C->64, k in {3,5,7}) as ONE k=7 conv with 192
+    outputs (shorter kernels zero-padded around the centre tap) + folded BN."""
+    ws, bs, o4 = [], [], []
+    for seq in (m.conv_scale1, m.conv_scale2, m.conv_scale3):
+        w = seq[0].weight.detach()
+        k = w.shape[2]
+        ws.append(torch.nn.functional.pad(w, ((7 - k) // 2, (7 - k) // 2)))
+        o4.append(bn_fold_eval(seq[1], seq[0].bias))
+    return torch.cat(ws, dim=0).contiguous(), torch.cat(o4, dim=1).contiguous()
+
+
+def power_encoder_forward(m, x):
+    """EnhancedPowerEncoder (enhanced_models_v4.py:258-285)."""
+    _need_gpu(x)
+    _eval_only("EnhancedPowerEncoder", m.training)
+    with torch.no_grad():
+        xb = pack_nct(x.float())
+        B, T, cp = xb.shape
+        w192, o4 = _power_merged(m, x.device)
+        wf = _empty((192, 7, cp), _BF, xb)
+        _hip.call("mm_prep_conv_weight", w192, wf, None, 192, w192.shape[1], 7, cp, 0)
+        h = igemm(xb, wf, 7, 3, 192, scale=o4[0], shift=o4[1], act="gelu")["bf16"]
+        r, _ = conv_bn_act(h, m.fusion[0], m.fusion[1], training=False, pe=pe_table(m.pos_encoder, T),
+                           want_f32=True, want_bf16=False)
+        tok = r["f32"]
+        for blk in m.transformer_layers:
+            tok, _ = transformer_block_fwd(tok, blk, False)
+        out, _ = pooled_head_fwd(tok, m.output_proj[2])
+    return out
+
+
+def drop_path(x, drop_prob):
+    raise NotImplementedError("DropPath is unused on the reference hot path (crossmodal_v4_enhancements.py:639-658)")
+
+
+def smoothed_cross_entropy(pred, target, smoothing):
+    raise NotImplementedError("LabelSmoothingCrossEntropy on the HIP path arrives with Lite-model training (DESIGN.md 'next')")

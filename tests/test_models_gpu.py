@@ -144,3 +144,91 @@ def test_volume_encoder_train_grads_vs_oracle():
     w32 = _worst(mg.named_parameters(), g32)
     assert w16[1] <= 5e-2, ("vs bf16-operand oracle", w16)
     assert w32[1] <= 2e-1, ("vs fp32 oracle", w32)
+
+
+import multimodal_eeg_fmri_amd.bridge_utils as Bu
+import multimodal_eeg_fmri_amd.crossmodal_v4_enhancements as Cv
+
+
+def _close(a, b, rtol, atol, what=""):
+    torch.testing.assert_close(a.detach().float().cpu(), torch.as_tensor(b), rtol=rtol, atol=atol, msg=lambda m: what + ": " + m)
+
+
+def test_a4_power_encoder_eval_vs_golden(golden):
+    fx = golden("a4_power.npz")
+    m = build(E.EnhancedPowerEncoder, int(fx["seed"]), 64, 128, 2, 4, 0.3).eval()
+    np.testing.assert_allclose(checksum(m), fx["cks"], rtol=1e-6, atol=1e-6)
+    x = seeded_randn(int(fx["x_seed"]), *[int(v) for v in fx["shape"]])
+    with torch.no_grad():
+        y = m.cuda()(x.cuda()).cpu()
+    want = torch.as_tensor(fx["out"])
+    assert cos_min(y, want) >= 1 - COS_TOL, cos_min(y, want)
+    assert rel_err(y, want) < 2e-2
+
+
+@pytest.mark.parametrize("M", [2, 3])
+def test_a5_learned_fusion_vs_golden(golden, M):
+    """fp32 kernels end to end -> 1e-5."""
+    fx = golden("a5_fusion.npz")
+    m = build(E.LearnedFusionModule, 16 + M, M, 128, perturb=False).eval()
+    with torch.no_grad():
+        m.fusion_logits.copy_(torch.linspace(0.5, 1.5, M))
+        m.temperature.fill_(0.7)
+    feats = [seeded_randn(110 + i, 8, 128).cuda() for i in range(M)]
+    with torch.no_grad():
+        f, w = m.cuda()(feats, return_weights=True)
+    _close(f, fx[f"fused{M}"], 1e-5, 1e-5, "fused")
+    _close(w, fx[f"w{M}"], 1e-5, 1e-6, "weights")
+
+
+def test_a7_trimodal_lite_eval_vs_golden(golden):
+    """a6 Lite conv encoders are bf16-MFMA (2e-2 rel-L2); a7 MLP/gates are fp32."""
+    fx = golden("a7_lite.npz")
+    m = build(Cv.EnhancedTriModalFusionNetV4Lite, int(fx["seed"]), 8, 8, 459).eval()
+    np.testing.assert_allclose(checksum(m), fx["cks"], rtol=1e-6, atol=1e-6)
+    s = [int(v) for v in fx["x_seeds"]]
+    erp, pw, conn = seeded_randn(s[0], 8, 8, 256).cuda(), seeded_randn(s[1], 8, 8, 256).cuda(), seeded_randn(s[2], 8, 459).cuda()
+    mg = m.cuda()
+    with torch.no_grad():
+        e, p, c = mg.erp_encoder(erp), mg.pw_encoder(pw), mg.conn_encoder(conn)
+        logits, fused = mg(erp, pw, conn, return_fused_feats=True)
+        _, wdict = mg(erp, pw, conn, return_fusion_weights=True)
+    _close(c, fx["conn_feat"], 1e-4, 1e-5, "conn_feat")
+    assert rel_err(e.cpu(), torch.as_tensor(fx["erp_feat"])) < 2e-2
+    assert rel_err(p.cpu(), torch.as_tensor(fx["pw_feat"])) < 2e-2
+    assert rel_err(fused.cpu(), torch.as_tensor(fx["fused"])) < 2e-2
+    assert rel_err(logits.cpu(), torch.as_tensor(fx["logits"])) < 3e-2
+    assert set(wdict) == {"erp_weight", "pw_weight", "conn_weight"}
+
+
+def test_a9_fmri_fusion_eval_vs_golden(golden):
+    fx = golden("a9_fmri.npz")
+    m = build(Fm.fMRIFusionNet, int(fx["seed"]), 100, 200).eval()
+    s = [int(v) for v in fx["x_seeds"]]
+    with torch.no_grad():
+        out, fused = m.cuda()(seeded_randn(s[0], 8, 100).cuda(), seeded_randn(s[1], 8, 200).cuda(), return_features=True)
+    _close(out, fx["out"], 1e-4, 1e-5, "out")
+    _close(fused, fx["fused"], 1e-4, 1e-5, "fused")
+    g = m.get_fusion_weights()
+    assert abs(g["activation"] + g["connectivity"] - 1.0) < 1e-6
+
+
+def test_a11_bridge_eval_vs_golden(golden):
+    """all four outputs + the reference's shape smoke test (_test_bridge.py:710-727)."""
+    fx = golden("a11_bridge.npz")
+    m = build(Bu.EEGfMRIBridgeFusionNet, int(fx["seed"])).eval()
+    np.testing.assert_allclose(checksum(m), fx["cks"], rtol=1e-6, atol=1e-6)
+    s = [int(v) for v in fx["x_seeds"]]
+    eeg, fmri = seeded_randn(s[0], 8, 128).cuda(), seeded_randn(s[1], 8, 64).cuda()
+    mg = m.cuda()
+    with torch.no_grad():
+        logits, fused, fw, aw = mg(eeg, fmri, return_features=True, return_weights=True)
+        only = mg(eeg, fmri)
+    assert logits.shape == (8, 2) and fused.shape == (8, 128) and fw.shape == (8, 2) and aw.shape == (8, 1, 2)
+    assert torch.equal(only, logits)
+    _close(logits, fx["logits"], 1e-4, 1e-5, "logits")
+    _close(fused, fx["fused"], 1e-4, 1e-5, "fused")
+    _close(fw, fx["fusion_w"], 1e-4, 1e-6, "fusion_w")
+    _close(aw, fx["attn_w"], 1e-4, 1e-6, "attn_w")
+    g = mg.get_fusion_weights()
+    np.testing.assert_allclose([g["eeg_weight"], g["fmri_weight"], g["temperature"]], fx["gfw"], atol=1e-6)
