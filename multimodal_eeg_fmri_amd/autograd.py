@@ -357,28 +357,19 @@ class ClipLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, logit_scale, group):
-        import torch.distributed as dist
+        from . import dp
         z = z.contiguous()
         B, N2 = z.shape
         N = N2 // 2
-        world = dist.get_world_size(group) if group is not None else 1
-        rank = dist.get_rank(group) if group is not None else 0
-        if world > 1:
-            z_all = _empty((world * B, N2), _F32, z)
-            dist.all_gather_into_tensor(z_all, z, group=group)
-        else:
-            z_all = z
+        world, rank = dp.world_size(group), dp.rank(group)
+        z_all = dp.gather_embeddings(z, group)
         need_grad = z.requires_grad or logit_scale.requires_grad
         scal = _zeros((4,), z)
         dz_all = _zeros((world * B, N2), z) if need_grad else None
         ls = logit_scale.detach().reshape(1).float().contiguous()
         _hip.call("mm_clip_loss", z, z_all, ls, scal, dz_all, B, world * B, N, rank * B)
         if need_grad:
-            if world > 1:
-                dz = _empty((B, N2), _F32, z)
-                dist.reduce_scatter_tensor(dz, dz_all, op=dist.ReduceOp.SUM, group=group)
-            else:
-                dz = dz_all
+            dz = dp.scatter_column_grads(dz_all, group)
             ctx.save_for_backward(dz, scal)
         ctx.mark_non_differentiable(*(()))
         return scal[0].clone(), scal[1].clone(), scal[2].clone()

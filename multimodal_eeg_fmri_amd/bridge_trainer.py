@@ -20,7 +20,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from . import _hip, ops
+from . import _hip, dp, ops
 from .bridge_utils import EEGfMRIContrastiveBridge
 from .enhanced_models_v4 import EnhancedERPEncoder
 from .fmri_utils import fMRIVolumeEncoder3D
@@ -109,9 +109,7 @@ class BridgeTrainer(nn.Module):
         loss.backward()
         b.absorb_autograd_grads()
         world = self.world
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(b.g, op=dist.ReduceOp.SUM, group=self.group)
+        dp.allreduce_sum_(b.g, self.group)
         _hip.call("mm_sumsq", b.g, b.state, b.n)
         _hip.call("mm_adamw_clip", b.p, b.g, b.m, b.v, b.state, b.n, self.betas[0], self.betas[1],
                   self.eps, self.weight_decay, self.grad_clip, 1.0 / world)

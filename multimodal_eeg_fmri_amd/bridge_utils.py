@@ -98,7 +98,7 @@ class BridgeFeatureDataset(Dataset):
         lab = {int(k): v for k, v in labels.items()}
         self.samples = [
             {"eeg": eeg[s], "fmri": fmri[s], "label": lab[s], "subject": s}
-            for s in (int(x) for x in sorted(subject_list))
+            for s in sorted(int(x) for x in subject_list)
             if s in eeg and s in fmri and s in lab]
         if not self.samples:
             logger.error("!!! NO SAMPLES ALIGNED !!! Check subject IDs in EEG and fMRI feature dicts.")

@@ -245,6 +245,19 @@ def main():
                         ls_loss=np.array(ls.item()), lrs=lrs, es_scores=np.array(scores), es_stops=stops)
     report.append("a8 ok")
 
+    # ------------------------------------------------ state_dict key/shape layout
+    import json
+    layout = {}
+    for name, mod in (("EnhancedERPEncoder", cv4.EnhancedERPEncoder(64)),
+                      ("EnhancedPowerEncoder", cv4.EnhancedPowerEncoder(64)),
+                      ("LearnedFusionModule", cv4.LearnedFusionModule(3, 128)),
+                      ("EnhancedTriModalFusionNetV4Lite", cv4.EnhancedTriModalFusionNetV4Lite(8, 8, 459)),
+                      ("fMRIFusionNet", fm.fMRIFusionNet(100, 200)),
+                      ("EEGfMRIBridgeFusionNet", br.EEGfMRIBridgeFusionNet())):
+        layout[name] = [[k, list(v.shape)] for k, v in mod.state_dict().items()]
+    with open(os.path.join(OUT, "state_dict_layout.json"), "w") as fh:
+        json.dump(layout, fh, indent=0)
+
     print("\n".join(report))
     print("fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
