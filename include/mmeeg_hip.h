@@ -82,14 +82,17 @@ int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, fl
  *  enhanced_models_v4.py:130-143, 49-54) */
 int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe,
                   void* out_bf16, float* out_f32, int R, int S, int N, int act, int pool,
-                  int drop_first, float drop_p, uint32_t seed, hipStream_t stream);
+                  int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
+                  hipStream_t stream);
+/* drop2 = the PositionalEncoding dropout applied AFTER the table add (:55) */
 int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16,
                          const float* dout_f32, float* sums_out, int R, int S, int N, int act,
-                         int pool, int drop_first, float drop_p, uint32_t seed, hipStream_t stream);
+                         int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p,
+                         uint32_t seed2, hipStream_t stream);
 int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16,
-                        const float* dout_f32, const float* sums, void* dy, int R, int S, int N,
-                        int act, int pool, int drop_first, float drop_p, uint32_t seed, int train,
-                        hipStream_t stream);
+                        const float* dout_f32, const float* sums, void* dy, float* dy_f32, int R,
+                        int S, int N, int act, int pool, int drop_first, float drop_p, uint32_t seed,
+                        float drop2_p, uint32_t seed2, int train, hipStream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm, enhanced_models_v4.py:80-81; bridge_utils.py:36,42,62) */
 int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16,
@@ -100,12 +103,13 @@ int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, c
 
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,
- * lse [B][H][L] fp32.  The head-averaged weights the reference computes and
- * discards (:99) are not produced. */
+ * lse [B][H][L] fp32.  drop_p = attention-probability dropout (train mode).  The
+ * head-averaged weights the reference computes and discards (:99) are not produced. */
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim,
-                float scale, hipStream_t stream);
+                float scale, float drop_p, uint32_t seed, hipStream_t stream);
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                float* delta_ws, int B, int L, int H, int head_dim, float scale, hipStream_t stream);
+                float* delta_ws, int B, int L, int H, int head_dim, float scale, float drop_p,
+                uint32_t seed, hipStream_t stream);
 
 /* ---- small reductions / elementwise --------------------------------------- */
 int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, hipStream_t stream);

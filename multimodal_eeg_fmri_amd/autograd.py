@@ -76,10 +76,12 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     y, out4, xb = s["y"], s["out4"], s["xb"]
     B, T, N = y.shape
     sums = _zeros((2, N), y)
-    args = (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]))
+    d2 = s.get("drop2", (0.0, 0))
+    args = (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]),
+            float(d2[0]), int(d2[1]))
     _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
     dy = _empty((B, T, N), _BF, y)
-    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sums, dy, *args, 1)
+    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sums, dy, None, *args, 1)
     gb, gg = bag.target(bn.bias), bag.target(bn.weight)
     if gb is not None:
         gb.add_(sums[0])
@@ -127,7 +129,9 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor) -> torch.Ten
     dqkv = _empty((B, L, 3 * D), _BF, dx2)
     delta = _empty((B, blk.nhead, L), _F32, dx2)
     dh = D // blk.nhead
-    _hip.call("mm_attn_bwd", s["qkv"], s["o"], do, s["lse"], dqkv, delta, B, L, blk.nhead, dh, float(dh) ** -0.5)
+    pa, sa = s.get("attn_drop", (0.0, 0))
+    _hip.call("mm_attn_bwd", s["qkv"], s["o"], do, s["lse"], dqkv, delta, B, L, blk.nhead, dh, float(dh) ** -0.5,
+              float(pa), int(sa))
     dh1 = linear_bwd(bag, dqkv.view(M, 3 * D), s["h1"], at.in_proj_weight, at.in_proj_bias)
     dx0 = _empty((M, D), _F32, dx2)
     _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, None,
@@ -237,9 +241,9 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
         _hip.call("mm_pool3d_bn_act_bwd_apply", y, out4, dout, sums, dy, B, D, H, W, N, gelu, float(s["drop_p"]),
                   int(s["seed"]), 1)
     else:
-        args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]))
+        args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0)
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
-        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, *args, 1)
+        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, None, *args, 1)
     gb, gg = bag.target(bn.bias), bag.target(bn.weight)
     if gb is not None:
         gb.add_(sums[0])

@@ -73,6 +73,8 @@ class BridgeTrainer(nn.Module):
         self.head = EEGfMRIContrastiveBridge(hidden_dim, fmri_dim, bridge_dim, dropout)
         self.to(device)
         self.group = group
+        self.two_streams = True
+        self._side = torch.cuda.Stream()
         self.lr, self.weight_decay, self.grad_clip = lr, weight_decay, grad_clip
         self.betas, self.eps = betas, eps
         br = self.head.bridge
@@ -97,8 +99,18 @@ class BridgeTrainer(nn.Module):
         self.bucket.state[2] = lr
 
     def forward(self, eeg: torch.Tensor, fmri: torch.Tensor):
+        """the two encoders are independent until the heads: they run on two HIP
+        streams (autograd replays each backward on its forward stream), so the
+        many sub-chip kernels of one branch overlap the other's latency."""
+        if not self.two_streams:
+            return self.head(self.eeg_encoder(eeg), self.fmri_encoder(fmri), self.group)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            ff = self.fmri_encoder(fmri)
         fe = self.eeg_encoder(eeg)
-        ff = self.fmri_encoder(fmri)
+        main.wait_stream(self._side)
+        ff.record_stream(main)
         return self.head(fe, ff, self.group)
 
     def train_step(self, eeg: torch.Tensor, fmri: torch.Tensor) -> Dict[str, torch.Tensor]:

@@ -27,8 +27,16 @@ __device__ __forceinline__ int vperm(int key) {       // swap bits 2 and 3 of th
     return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
 }
 
+// attention-probability dropout (nn.MultiheadAttention(dropout=p)): the softmax
+// row sum uses the un-dropped probabilities, only the P operand of P.V is masked.
+__device__ __forceinline__ float attn_keep(uint32_t seed, int bh, int q, int key, int L, uint32_t thresh, float inv_keep) {
+    const uint32_t idx = ((uint32_t)bh * (uint32_t)L + (uint32_t)q) * (uint32_t)L + (uint32_t)key;
+    return dropout_scale(seed, idx, thresh, inv_keep);
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                       float* __restrict__ lse, int L, int H, float scale_log2) {
+                                                       float* __restrict__ lse, int L, int H, float scale_log2,
+                                                       uint32_t dthresh, uint32_t dseed, float dinv) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vt[DH * VS];
     const int E = H * DH, E3 = 3 * E;
@@ -96,8 +104,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             bf16x8 pf[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(sacc[r] - m_new);
+                float p = exp2f(sacc[r] - m_new);
                 ps += p;
+                if (dthresh) p *= attn_keep(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv);
                 pf[r >> 3][r & 7] = (bf16)p;
             }
             l_run = l_run * alpha + ps;
@@ -138,7 +147,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16* __restrict__ dqkv, float* __restrict__ delta,
-                                                          int L, int H, float scale) {
+                                                          int L, int H, float scale, uint32_t dthresh,
+                                                          uint32_t dseed, float dinv) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Kt[DH * VS];
@@ -210,7 +220,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float p = key < kn ? exp2f(sacc[r] * scale_log2 - lse2) : 0.f;
-                dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] - dl));
+                float dpr = dp[r];
+                if (dthresh) dpr *= attn_keep(dseed, b * H + h, q, k0 + key, L, dthresh, dinv);
+                dsf[r >> 3][r & 7] = (bf16)(p * (dpr - dl));
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -234,7 +246,8 @@ constexpr int QS = QCH + 8;              // transposed row stride
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           bf16* __restrict__ dqkv, int L, int H, float scale) {
+                                                           bf16* __restrict__ dqkv, int L, int H, float scale,
+                                                           uint32_t dthresh, uint32_t dseed, float dinv) {
     __shared__ __attribute__((aligned(16))) bf16 Qs[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Ds[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Qt[DH * QS];
@@ -309,8 +322,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             for (int r = 0; r < 16; ++r) {
                 const int qi = qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float p = kok ? exp2f(sacc[r] * scale_log2 - Ls[qi]) : 0.f;
-                pf[r >> 3][r & 7] = (bf16)p;
-                dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] - Dl[qi]));
+                const float keep = dthresh ? attn_keep(dseed, b * H + h, q0 + qi, key, L, dthresh, dinv) : 1.f;
+                pf[r >> 3][r & 7] = (bf16)(p * keep);
+                dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] * keep - Dl[qi]));
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -338,27 +352,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 
 extern "C" {
 
+static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, float scale,
-                hipStream_t st) {
+                float drop_p, uint32_t seed, hipStream_t st) {
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_fwd: drop_p");
     MM_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0, "attn_fwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_fwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
-                       scale * 1.4426950408889634f);
+                       scale * 1.4426950408889634f, attn_thresh(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
     return mm_check_launch("attn_fwd");
 }
 
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
-                int B, int L, int H, int head_dim, float scale, hipStream_t st) {
+                int B, int L, int H, int head_dim, float scale, float drop_p, uint32_t seed, hipStream_t st) {
+    const uint32_t dth = attn_thresh(drop_p);
+    const float dinv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_bwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)out,
-                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale);
+                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv);
     int rc = mm_check_launch("attn_bwd_dq");
     if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
-                       delta_ws, (bf16*)dqkv, L, H, scale);
+                       delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv);
     return mm_check_launch("attn_bwd_dkv");
 }
 

@@ -47,6 +47,7 @@ struct BnActArgs {
     bf16* out_bf16; float* out_f32;
     int R, S, N, act, pool, drop_first;
     uint32_t thresh, seed; float inv_keep;
+    uint32_t thresh2, seed2; float inv_keep2;
 };
 
 __device__ __forceinline__ float bnact_one(const BnActArgs& a, float y, float sc, float sh, uint32_t idx, bool drop_here) {
@@ -91,6 +92,9 @@ __global__ void bn_act_fwd_kernel(BnActArgs a) {
             const float4 p = *reinterpret_cast<const float4*>(a.pe + (size_t)so * a.N + n4);
             o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w;
         }
+        if (a.thresh2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] *= dropout_scale(a.seed2, (uint32_t)(oidx + q), a.thresh2, a.inv_keep2);
         if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + oidx) = make_float4(o[0], o[1], o[2], o[3]);
         if (a.out_bf16) {
             bf16x4 b = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
@@ -108,9 +112,10 @@ __global__ void bn_act_fwd_kernel(BnActArgs a) {
 struct BnBwdArgs {
     const float* y; const float* scale; const float* shift; const float* mean; const float* rstd;
     const bf16* dout_bf16; const float* dout_f32; const float* sums;
-    float* sums_out; bf16* dy;
+    float* sums_out; bf16* dy; float* dy_f32;
     int R, S, N, act, pool, drop_first, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
+    uint32_t thresh2, seed2; float inv_keep2;
 };
 
 // computes dz for the (up to) two inputs of one pooled output element
@@ -173,6 +178,9 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
                 const bf16x4 t = *reinterpret_cast<const bf16x4*>(a.dout_bf16 + oidx);
                 g[0] = (float)t[0]; g[1] = (float)t[1]; g[2] = (float)t[2]; g[3] = (float)t[3];
             }
+            if (a.thresh2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] *= dropout_scale(a.seed2, (uint32_t)(oidx + q), a.thresh2, a.inv_keep2);
             const float4 y0 = *reinterpret_cast<const float4*>(a.y + in0);
             float4 y1 = y0;
             if (a.pool == 2) y1 = *reinterpret_cast<const float4*>(a.y + in0 + a.N);
@@ -196,11 +204,17 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
                 }
             }
             if (APPLY) {
-                bf16x4 b0 = {(bf16)d0[0], (bf16)d0[1], (bf16)d0[2], (bf16)d0[3]};
-                *reinterpret_cast<bf16x4*>(a.dy + in0) = b0;
-                if (a.pool == 2) {
-                    bf16x4 b1 = {(bf16)d1[0], (bf16)d1[1], (bf16)d1[2], (bf16)d1[3]};
-                    *reinterpret_cast<bf16x4*>(a.dy + in0 + a.N) = b1;
+                if (a.dy) {
+                    bf16x4 b0 = {(bf16)d0[0], (bf16)d0[1], (bf16)d0[2], (bf16)d0[3]};
+                    *reinterpret_cast<bf16x4*>(a.dy + in0) = b0;
+                    if (a.pool == 2) {
+                        bf16x4 b1 = {(bf16)d1[0], (bf16)d1[1], (bf16)d1[2], (bf16)d1[3]};
+                        *reinterpret_cast<bf16x4*>(a.dy + in0 + a.N) = b1;
+                    }
+                }
+                if (a.dy_f32) {
+                    *reinterpret_cast<float4*>(a.dy_f32 + in0) = make_float4(d0[0], d0[1], d0[2], d0[3]);
+                    if (a.pool == 2) *reinterpret_cast<float4*>(a.dy_f32 + in0 + a.N) = make_float4(d1[0], d1[1], d1[2], d1[3]);
                 }
             }
         }
@@ -396,28 +410,31 @@ int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, fl
 
 int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe, void* out_bf16,
                   float* out_f32, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
-                  uint32_t seed, hipStream_t st) {
+                  uint32_t seed, float drop2_p, uint32_t seed2, hipStream_t st) {
     MM_REQUIRE(y && scale && shift && (out_bf16 || out_f32), "bn_act_fwd: null");
     MM_REQUIRE(N % 4 == 0 && (pool == 1 || (pool == 2 && S % 2 == 0)), "bn_act_fwd: N%%4, pool");
     BnActArgs a{y, scale, shift, pe, (bf16*)out_bf16, out_f32, R, S, N, act, pool, drop_first,
-                thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
+                thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
+                thresh_of(drop2_p), seed2, drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f};
     const size_t total = (size_t)R * (S / pool) * (N / 4);
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, a);
     return mm_check_launch("bn_act_fwd");
 }
 
 static int bn_bwd_common(bool apply, const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
-                         const float* sums_in, float* sums_out, void* dy, int R, int S, int N, int act, int pool,
-                         int drop_first, float drop_p, uint32_t seed, int train, hipStream_t st) {
+                         const float* sums_in, float* sums_out, void* dy, float* dy_f32, int R, int S, int N, int act,
+                         int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
+                         int train, hipStream_t st) {
     MM_REQUIRE(y && out4 && (dout_bf16 || dout_f32), "bn_act_bwd: null");
     MM_REQUIRE(N % 4 == 0 && N <= 1024 && (N / 4) <= 256, "bn_act_bwd: N");
     BnBwdArgs a;
     a.y = y; a.scale = out4; a.shift = out4 + N; a.mean = out4 + 2 * N; a.rstd = out4 + 3 * N;
     a.dout_bf16 = (const bf16*)dout_bf16; a.dout_f32 = dout_f32; a.sums = sums_in; a.sums_out = sums_out;
-    a.dy = (bf16*)dy; a.R = R; a.S = S; a.N = N; a.act = act; a.pool = pool; a.drop_first = drop_first;
+    a.dy = (bf16*)dy; a.dy_f32 = dy_f32; a.R = R; a.S = S; a.N = N; a.act = act; a.pool = pool; a.drop_first = drop_first;
     a.train = train; a.thresh = thresh_of(drop_p); a.seed = seed;
     a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)R * (float)S);
+    a.thresh2 = thresh_of(drop2_p); a.seed2 = seed2; a.inv_keep2 = drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f;
     const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
     const size_t rows = (size_t)R * (S / pool);
     int grid = (int)((rows + rpb - 1) / rpb);
@@ -429,18 +446,19 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
 
 int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
                          float* sums_out, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
-                         uint32_t seed, hipStream_t st) {
+                         uint32_t seed, float drop2_p, uint32_t seed2, hipStream_t st) {
     MM_REQUIRE(sums_out, "bn_act_bwd_reduce: null sums");
-    return bn_bwd_common(false, y, out4, dout_bf16, dout_f32, nullptr, sums_out, nullptr, R, S, N, act, pool,
-                         drop_first, drop_p, seed, 1, st);
+    return bn_bwd_common(false, y, out4, dout_bf16, dout_f32, nullptr, sums_out, nullptr, nullptr, R, S, N, act,
+                         pool, drop_first, drop_p, seed, drop2_p, seed2, 1, st);
 }
 
 int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
-                        const float* sums, void* dy, int R, int S, int N, int act, int pool, int drop_first,
-                        float drop_p, uint32_t seed, int train, hipStream_t st) {
-    MM_REQUIRE(dy && (!train || sums), "bn_act_bwd_apply: null");
-    return bn_bwd_common(true, y, out4, dout_bf16, dout_f32, sums, nullptr, dy, R, S, N, act, pool, drop_first,
-                         drop_p, seed, train, st);
+                        const float* sums, void* dy, float* dy_f32, int R, int S, int N, int act, int pool,
+                        int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2, int train,
+                        hipStream_t st) {
+    MM_REQUIRE((dy || dy_f32) && (!train || sums), "bn_act_bwd_apply: null");
+    return bn_bwd_common(true, y, out4, dout_bf16, dout_f32, sums, nullptr, dy, dy_f32, R, S, N, act, pool,
+                         drop_first, drop_p, seed, drop2_p, seed2, train, st);
 }
 
 #define LN_DISPATCH(D, CALL)                                   \

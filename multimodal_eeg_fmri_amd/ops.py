@@ -202,19 +202,19 @@ def layernorm(x2d: torch.Tensor, ln, want_stat: bool):
     return out, stat
 
 
-def attention(qkv: torch.Tensor, nhead: int, want_lse: bool):
+def attention(qkv: torch.Tensor, nhead: int, want_lse: bool, drop_p: float = 0.0, seed: int = 0):
     B, L, E3 = qkv.shape
     E = E3 // 3
     dh = E // nhead
     out = _empty((B, L, E), _BF, qkv)
     lse = _empty((B, nhead, L), _F32, qkv) if want_lse else None
-    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh))
+    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), int(seed))
     return out, lse
 
 
 # ------------------------------------------------------------------- stages
 def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=False, drop_p=0.0,
-                drop_first=True, pe=None, want_f32=False, want_bf16=True, need_dgrad=False):
+                drop_first=True, pe=None, pe_drop_p=0.0, want_f32=False, want_bf16=True, need_dgrad=False):
     """Conv1d -> BatchNorm1d -> act [-> MaxPool(2)] [-> Dropout] on (B, T, Cp) bf16.
 
     eval : one kernel (BN folded into the GEMM epilogue).
@@ -235,12 +235,13 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
     y = igemm(xb, wf, k, pad, cout, shift=conv.bias, stats=stats, out_f32=True, out_bf16=False)["f32"]
     out4 = bn_finalize_train(bn, stats, B * T)
     seed = _next_seed() if drop_p > 0 else 0
+    seed2 = _next_seed() if pe_drop_p > 0 else 0
     of = _empty((B, T // pool, cout), _F32, xb) if want_f32 else None
     ob = _empty((B, T // pool, cout), _BF, xb) if want_bf16 else None
     _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, B, T, cout, ACT[act], pool,
-              1 if drop_first else 0, float(drop_p), seed)
+              1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2)
     saved = dict(xb=xb, y=y, out4=out4, act=act, pool=pool, drop_p=drop_p, seed=seed,
-                 drop_first=drop_first, conv=conv, bn=bn)
+                 drop2=(float(pe_drop_p), seed2), drop_first=drop_first, conv=conv, bn=bn)
     return {"f32": of, "bf16": ob, "pre": None}, saved
 
 
@@ -256,7 +257,9 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
     h1, st1 = layernorm(x2, blk.norm1, save)
     qkv = linear_rows(h1, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias,
                       need_dgrad=need_dgrad)["bf16"]
-    o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save)
+    pa = float(blk.self_attn.dropout) if training else 0.0      # attention-probability dropout
+    sa = _next_seed() if pa > 0 else 0
+    o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save, pa, sa)
     s1 = _next_seed() if p > 0 else 0
     x1 = linear_rows(o.view(M, D), blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias,
                      residual=x2, out_f32=True, out_bf16=False, drop_p=p, seed=s1,
@@ -271,7 +274,7 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
     saved = None
     if save:
         saved = dict(x=x2, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2,
-                     z=f1["pre"], g=f1["bf16"], p=p, seeds=(s1, s2, s3), B=B, L=L, blk=blk)
+                     z=f1["pre"], g=f1["bf16"], p=p, seeds=(s1, s2, s3), attn_drop=(pa, sa), B=B, L=L, blk=blk)
     return x2o.view(B, L, D), saved
 
 
@@ -312,8 +315,8 @@ def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool):
     saved.append(s)
     L = r["bf16"].shape[1]
     r, s = conv_bn_act(r["bf16"], cl[9], cl[10], training=training, drop_p=p,
-                       pe=pe_table(m.pos_encoder, L), want_f32=True, want_bf16=False,
-                       need_dgrad=need_dgrad)
+                       pe=pe_table(m.pos_encoder, L), pe_drop_p=(m.pos_encoder.dropout.p if training else 0.0),
+                       want_f32=True, want_bf16=False, need_dgrad=need_dgrad)
     saved.append(s)
     h = r["f32"]
     blocks = []
@@ -397,7 +400,7 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     else:
         out = _empty((B, D * H * W, cout), _F32, xv)
         _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], None, None, out, B, D * H * W, cout,
-                  ACT["gelu"], 1, 1, float(p), seed)
+                  ACT["gelu"], 1, 1, float(p), seed, 0.0, 0)
     saved = dict(xv=xv, y=y, out4=out4, pool=pool, drop_p=p, seed=seed, conv=conv, bn=bn) if training else None
     return out, saved
 

