@@ -103,7 +103,6 @@ def main():
 
     for _ in range(args.warmup):
         tr.train_step(eeg, fmri)
-    ops.kernel_timer.reset("conv3d_fwd_c32")
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -116,6 +115,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
 
+    # roofline line: the timed steps are hipGraph replays (no host code runs inside
+    # them), so the layer-2 conv3d kernel is bracketed with HIP events on its launch
+    # stream in a few extra steps of the SAME step run eagerly right after the timed
+    # region (same data, same kernels, other stream busy as in the real step).
+    tr.mode = "manual"
+    tr.train_step(eeg, fmri)
+    ops.kernel_timer.reset("conv3d_fwd_c32")
+    for _ in range(8):
+        tr.train_step(eeg, fmri)
     kt = ops.kernel_timer.mean_ms("conv3d_fwd_c32")
     ev = tr.evaluate(eeg, fmri)
     if rank != 0:
@@ -132,7 +140,8 @@ def main():
         "config": {"workload": "C2 bridge train step: 64ch x 1024 EEG (EnhancedERPEncoder) + 32^3 fMRI "
                                "(3-D conv encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW",
                    "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": global_batch, "parallelism": f"dp{world}",
-                   "dropout": args.dropout, "mfma_operands": "bf16", "accumulate": "fp32"},
+                   "dropout": args.dropout, "mfma_operands": "bf16", "accumulate": "fp32",
+                   "execution": "hipGraph replay" if world == 1 else "4 hipGraph segments + 3 RCCL collectives"},
         "top1_retrieval_acc": {"eeg_to_fmri": ev["top1_e2f"].item(), "fmri_to_eeg": ev["top1_f2e"].item(),
                                "chance": 1.0 / global_batch, "note": "on the training batch after the timed steps"},
         "final_loss": out["loss"].item(),

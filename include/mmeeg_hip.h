@@ -20,6 +20,8 @@
  *   - activation codes: 0 none, 1 GELU(erf), 2 ReLU, 3 tanh, 4 sigmoid;
  *   - dropout: keep iff hash(seed, element index) >= p * 2^32, scaled 1/(1-p);
  *     the backward entry points recompute the same mask from (p, seed).
+ *     `seed_epoch` (nullable device word) is mixed into the seed on the device, so
+ *     a launch recorded in a hipGraph draws a new mask on every replay.
  */
 #ifndef MMEEG_HIP_H
 #define MMEEG_HIP_H
@@ -58,7 +60,7 @@ int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, in
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual,
                   const float* pe, int pool, float* stats, float* out_f32, void* out_bf16,
-                  void* out_pre, float drop_p, uint32_t drop_seed, hipStream_t stream);
+                  void* out_pre, float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, hipStream_t stream);
 /* dW[n][c][tap] (fp32, strides sn/sc/stap in elements) += sum_{b,t} dY[b,t,n]*X[b,t+tap-pad,c];
  * optional dbias[n] += sum dY.  Replaces the weight/bias gradients autograd
  * derives for the layers above (loss.backward(), run_training_lite.py:486). */
@@ -83,16 +85,16 @@ int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, fl
 int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe,
                   void* out_bf16, float* out_f32, int R, int S, int N, int act, int pool,
                   int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
-                  hipStream_t stream);
+                  const uint32_t* seed_epoch, hipStream_t stream);
 /* drop2 = the PositionalEncoding dropout applied AFTER the table add (:55) */
 int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16,
                          const float* dout_f32, float* sums_out, int R, int S, int N, int act,
                          int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p,
-                         uint32_t seed2, hipStream_t stream);
+                         uint32_t seed2, const uint32_t* seed_epoch, hipStream_t stream);
 int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16,
                         const float* dout_f32, const float* sums, void* dy, float* dy_f32, int R,
                         int S, int N, int act, int pool, int drop_first, float drop_p, uint32_t seed,
-                        float drop2_p, uint32_t seed2, int train, hipStream_t stream);
+                        float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, int train, hipStream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm, enhanced_models_v4.py:80-81; bridge_utils.py:36,42,62) */
 int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16,
@@ -106,10 +108,10 @@ int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, c
  * lse [B][H][L] fp32.  drop_p = attention-probability dropout (train mode).  The
  * head-averaged weights the reference computes and discards (:99) are not produced. */
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim,
-                float scale, float drop_p, uint32_t seed, hipStream_t stream);
+                float scale, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                 float* delta_ws, int B, int L, int H, int head_dim, float scale, float drop_p,
-                uint32_t seed, hipStream_t stream);
+                uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 
 /* ---- small reductions / elementwise --------------------------------------- */
 int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, hipStream_t stream);
@@ -120,7 +122,7 @@ int mm_cast_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
 int mm_cast_f32(const void* x, float* y, int64_t n, hipStream_t stream);
 /* out = bf16( g * dropout_mask * act'(z) ) */
 int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out, int64_t n, int act,
-               float drop_p, uint32_t seed, hipStream_t stream);
+               float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 
 /* ---- 3-D voxel convolution, k=3 pad=1 (north-star extension: the reference has
  * no volume code, SURVEY.md section 0; semantics = torch.nn.Conv3d / BatchNorm3d /
@@ -137,13 +139,13 @@ int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
                     hipStream_t stream);
 /* y fp32 [B][D][H][W][N] -> act(BN(y)) -> MaxPool3d(2) -> dropout -> bf16 [B][D/2][H/2][W/2][N] */
 int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, int B, int D, int H, int W,
-                         int N, int act, float drop_p, uint32_t seed, hipStream_t stream);
+                         int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 int mm_pool3d_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, float* sums_out,
                                 int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
-                                hipStream_t stream);
+                                const uint32_t* seed_epoch, hipStream_t stream);
 int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* sums,
                                void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
-                               uint32_t seed, int train, hipStream_t stream);
+                               uint32_t seed, const uint32_t* seed_epoch, int train, hipStream_t stream);
 
 /* Fused first voxel layer Conv3d(1->32,k3,p1)+BatchNorm3d+GELU+MaxPool3d(2)[+Dropout]
  * on fp32 [B][D][H][W] volumes; the 32x larger pre-BN tensor is recomputed, never
@@ -154,7 +156,7 @@ int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* do
 int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, const float* out4,
                  const void* dout, const float* sums, float* stats, void* out, float* dw_tapmajor,
                  float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
-                 hipStream_t stream);
+                 const uint32_t* seed_epoch, hipStream_t stream);
 /* dst[c][r] += src[r][c] */
 int mm_transpose_add(const float* src, float* dst, int R, int C, hipStream_t stream);
 
@@ -165,13 +167,13 @@ int mm_transpose_add(const float* src, float* dst, int R, int C, hipStream_t str
  * crossmodal_v4_enhancements.py:695-723. */
 int mm_small_linear_fwd(const float* x, const float* W, const float* bias, const float* scale,
                         const float* shift, float* y, float* pre, int B, int K, int N, int act,
-                        float drop_p, uint32_t seed, hipStream_t stream);
+                        float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 /* dx = dy W ; dW += dy^T x ; db += colsum(dy)   (dy already through act') */
 int mm_small_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db,
                         int B, int K, int N, hipStream_t stream);
-int mm_act_f32(const float* z, float* y, int64_t n, int act, float drop_p, uint32_t seed, hipStream_t stream);
+int mm_act_f32(const float* z, float* y, int64_t n, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 int mm_act_bwd_f32(const float* g, const float* z, float* out, int64_t n, int act, float drop_p,
-                   uint32_t seed, hipStream_t stream);
+                   uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 /* stats[0][n] = sum_b x, stats[1][n] = sum_b x^2 (BatchNorm1d over (B, N)) */
 int mm_colstats(const float* x, float* stats, int B, int N, hipStream_t stream);
 /* F.normalize(h, dim=1): z = h / max(||h||, 1e-12)  (extension a-X2) */

@@ -45,7 +45,7 @@ def _mask_cast(g_f32=None, g_bf16=None, z=None, act="none", drop_p=0.0, seed=0):
     """bf16( g * dropout_mask * act'(z) )"""
     src = g_f32 if g_f32 is not None else g_bf16
     out = _empty(src.shape, _BF, src)
-    _hip.call("mm_act_bwd", g_f32, g_bf16, z, out, src.numel(), ACT[act], float(drop_p), int(seed))
+    _hip.call("mm_act_bwd", g_f32, g_bf16, z, out, src.numel(), ACT[act], float(drop_p), int(seed), ops.EP())
     return out
 
 
@@ -78,7 +78,7 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     sums = _zeros((2, N), y)
     d2 = s.get("drop2", (0.0, 0))
     args = (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]),
-            float(d2[0]), int(d2[1]))
+            float(d2[0]), int(d2[1]), ops.EP())
     _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
     dy = _empty((B, T, N), _BF, y)
     _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sums, dy, None, *args, 1)
@@ -131,7 +131,7 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor) -> torch.Ten
     dh = D // blk.nhead
     pa, sa = s.get("attn_drop", (0.0, 0))
     _hip.call("mm_attn_bwd", s["qkv"], s["o"], do, s["lse"], dqkv, delta, B, L, blk.nhead, dh, float(dh) ** -0.5,
-              float(pa), int(sa))
+              float(pa), int(sa), ops.EP())
     dh1 = linear_bwd(bag, dqkv.view(M, 3 * D), s["h1"], at.in_proj_weight, at.in_proj_bias)
     dx0 = _empty((M, D), _F32, dx2)
     _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, None,
@@ -163,6 +163,25 @@ class _ModuleFn(torch.autograd.Function):
         return (None, dx) + tuple(bag.result(p) for p in params)
 
 
+def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = False):
+    """backward of ops._erp_forward_impl (train mode); dout fp32 (B, H)."""
+    d = pooled_head_bwd(bag, sv["head"], dout)
+    B, L, D = d.shape
+    d = d.view(B * L, D)
+    for s in reversed(sv["blocks"]):
+        d = transformer_block_bwd(bag, s, d)
+    c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
+    g = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D))
+    g = conv_bn_act_bwd(bag, c2, dout_bf16=g)
+    g = conv_bn_act_bwd(bag, c1, dout_bf16=g, need_dx=need_dx)
+    if not need_dx:
+        return None
+    Bx, C, T = sv["x_shape"]
+    dx = _empty((Bx, C, T), _F32, dout)
+    _hip.call("mm_unpack_ntc_f32", g, dx, Bx, C, T, g.shape[2])
+    return dx
+
+
 class ErpEncoderFn(_ModuleFn):
     @staticmethod
     def run(m, x):
@@ -184,22 +203,8 @@ class ErpEncoderFn(_ModuleFn):
             raise NotImplementedError(
                 "backward through an eval-mode EnhancedERPEncoder (frozen BatchNorm) is not built yet; "
                 "call .train() or wrap the forward in torch.no_grad()")
-        m, sv = ctx.m, ctx.saved
         bag = GradBag()
-        d = pooled_head_bwd(bag, sv["head"], dout)
-        B, L, D = d.shape
-        d = d.view(B * L, D)
-        for s in reversed(sv["blocks"]):
-            d = transformer_block_bwd(bag, s, d)
-        c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
-        g = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D))
-        g = conv_bn_act_bwd(bag, c2, dout_bf16=g)
-        g = conv_bn_act_bwd(bag, c1, dout_bf16=g, need_dx=ctx.need_dx)
-        dx = None
-        if ctx.need_dx:
-            Bx, C, T = sv["x_shape"]
-            dx = _empty((Bx, C, T), _F32, dout)
-            _hip.call("mm_unpack_ntc_f32", g, dx, Bx, C, T, g.shape[2])
+        dx = erp_encoder_bwd(bag, ctx.saved, dout, ctx.need_dx)
         return _ModuleFn._finish(ctx, bag, ctx.params, dx)
 
 
@@ -237,11 +242,12 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
     dy = _empty((B, D, H, W, N), _BF, y)
     gelu = ACT["gelu"]
     if s["pool"]:
-        _hip.call("mm_pool3d_bn_act_bwd_reduce", y, out4, dout, sums, B, D, H, W, N, gelu, float(s["drop_p"]), int(s["seed"]))
+        _hip.call("mm_pool3d_bn_act_bwd_reduce", y, out4, dout, sums, B, D, H, W, N, gelu, float(s["drop_p"]),
+                  int(s["seed"]), ops.EP())
         _hip.call("mm_pool3d_bn_act_bwd_apply", y, out4, dout, sums, dy, B, D, H, W, N, gelu, float(s["drop_p"]),
-                  int(s["seed"]), 1)
+                  int(s["seed"]), ops.EP(), 1)
     else:
-        args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0)
+        args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
         _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, None, *args, 1)
     gb, gg = bag.target(bn.bias), bag.target(bn.weight)
@@ -272,10 +278,10 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
     B, _, D, H, W = x.shape
     sums = _zeros((2, 32), x)
     _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
-              B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]))
+              B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
     ws = _zeros((27, 32), x)
     _hip.call("mm_conv3d_l1", 3, x, s["wimg"], conv.bias, s["out4"], dout, sums, None, None, ws,
-              bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]))
+              bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
     gb, gg = bag.target(bn.bias), bag.target(bn.weight)
     if gb is not None:
         gb.add_(sums[0])
@@ -284,6 +290,17 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
     dw = bag.target(conv.weight)
     if dw is not None:
         _hip.call("mm_transpose_add", ws, dw, 27, 32)
+
+
+def volume_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor):
+    """backward of ops._vol_forward_impl (train mode); dout fp32 (B, out_dim)."""
+    d = pooled_head_bwd(bag, sv["head"], dout)                # fp32 (B, V, N)
+    g = conv3d_bn_act_bwd(bag, sv["convs"][2], d)
+    g = conv3d_bn_act_bwd(bag, sv["convs"][1], g)
+    if sv["convs"][0].get("l1"):
+        conv3d_l1_bwd(bag, sv["convs"][0], g)
+    else:
+        conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=False)
 
 
 class VolumeEncoderFn(_ModuleFn):
@@ -299,15 +316,8 @@ class VolumeEncoderFn(_ModuleFn):
 
     @staticmethod
     def backward(ctx, dout):
-        sv = ctx.saved
         bag = GradBag()
-        d = pooled_head_bwd(bag, sv["head"], dout)            # fp32 (B, V, N)
-        g = conv3d_bn_act_bwd(bag, sv["convs"][2], d)
-        g = conv3d_bn_act_bwd(bag, sv["convs"][1], g)
-        if sv["convs"][0].get("l1"):
-            conv3d_l1_bwd(bag, sv["convs"][0], g)
-        else:
-            conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=False)
+        volume_encoder_bwd(bag, ctx.saved, dout)
         return _ModuleFn._finish(ctx, bag, ctx.params, None)
 
 
@@ -317,13 +327,23 @@ def proj_head_bwd(bag: GradBag, s: dict, da: torch.Tensor, need_dx=True):
     B, N = da.shape
     K = lin.weight.shape[1]
     dhn = _empty((B, N), _F32, da)
-    _hip.call("mm_act_bwd_f32", da, s["hn"], dhn, B * N, ACT["gelu"], float(s["p"]), int(s["seed"]))
+    _hip.call("mm_act_bwd_f32", da, s["hn"], dhn, B * N, ACT["gelu"], float(s["p"]), int(s["seed"]), ops.EP())
     dz1 = _empty((B, N), _F32, da)
     _hip.call("mm_layernorm_bwd", None, dhn, s["z1"], s["stat"], ln.weight, None, dz1, None,
               bag.target(ln.weight), bag.target(ln.bias), B, N)
     dx = _empty((B, K), _F32, da) if need_dx else None
     _hip.call("mm_small_linear_bwd", dz1, s["x"], lin.weight, dx, bag.target(lin.weight), bag.target(lin.bias), B, K, N)
     return dx
+
+
+def contrastive_embed_bwd(bag: GradBag, s: dict, dz: torch.Tensor, need=(True, True)):
+    """dz (B, 2N) packed -> (d eeg_feat (B, eeg_dim), d fmri_feat (B, fmri_dim))"""
+    B, N = s["B"], s["N"]
+    da_e = _empty((B, N), _F32, dz)
+    da_f = _empty((B, N), _F32, dz)
+    _hip.call("mm_l2norm_bwd", dz.data_ptr(), s["z"].data_ptr(), s["nrm"][0], da_e, B, N, 2 * N)
+    _hip.call("mm_l2norm_bwd", dz.data_ptr() + 4 * N, s["z"].data_ptr() + 4 * N, s["nrm"][1], da_f, B, N, 2 * N)
+    return proj_head_bwd(bag, s["e"], da_e, need[0]), proj_head_bwd(bag, s["f"], da_f, need[1])
 
 
 class ContrastiveEmbedFn(torch.autograd.Function):
@@ -341,16 +361,8 @@ class ContrastiveEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
-        s = ctx.saved
-        B, N = s["B"], s["N"]
-        dz = dz.contiguous()
         bag = GradBag()
-        da_e = _empty((B, N), _F32, dz)
-        da_f = _empty((B, N), _F32, dz)
-        _hip.call("mm_l2norm_bwd", dz.data_ptr(), s["z"].data_ptr(), s["nrm"][0], da_e, B, N, 2 * N)
-        _hip.call("mm_l2norm_bwd", dz.data_ptr() + 4 * N, s["z"].data_ptr() + 4 * N, s["nrm"][1], da_f, B, N, 2 * N)
-        dxe = proj_head_bwd(bag, s["e"], da_e, ctx.need[0])
-        dxf = proj_head_bwd(bag, s["f"], da_f, ctx.need[1])
+        dxe, dxf = contrastive_embed_bwd(bag, ctx.saved, dz.contiguous(), ctx.need)
         return (None, dxe, dxf) + tuple(bag.result(p) for p in ctx.params)
 
 

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip, dp, ops
+from .autograd import GradBag, contrastive_embed_bwd, erp_encoder_bwd, volume_encoder_bwd
 from .bridge_utils import EEGfMRIContrastiveBridge
 from .enhanced_models_v4 import EnhancedERPEncoder
 from .fmri_utils import fMRIVolumeEncoder3D
@@ -66,7 +67,7 @@ class BridgeTrainer(nn.Module):
     def __init__(self, eeg_channels: int = 64, hidden_dim: int = 128, fmri_dim: int = 64,
                  bridge_dim: int = 128, dropout: float = 0.3, lr: float = 1e-4,
                  weight_decay: float = 1e-4, grad_clip: float = 1.0, betas=(0.9, 0.999),
-                 eps: float = 1e-8, group=None, device="cuda"):
+                 eps: float = 1e-8, group=None, device="cuda", mode: str = "graph"):
         super().__init__()
         self.eeg_encoder = EnhancedERPEncoder(eeg_channels, hidden_dim, 2, 4, dropout)
         self.fmri_encoder = fMRIVolumeEncoder3D(1, fmri_dim, dropout=dropout)
@@ -74,6 +75,8 @@ class BridgeTrainer(nn.Module):
         self.to(device)
         self.group = group
         self.two_streams = True
+        self.mode = mode
+        self._cap = None
         self._side = torch.cuda.Stream()
         self.lr, self.weight_decay, self.grad_clip = lr, weight_decay, grad_clip
         self.betas, self.eps = betas, eps
@@ -113,25 +116,170 @@ class BridgeTrainer(nn.Module):
         ff.record_stream(main)
         return self.head(fe, ff, self.group)
 
+    # ------------------------------------------------------------------ step
     def train_step(self, eeg: torch.Tensor, fmri: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """zero_grad -> forward -> backward -> (all-reduce) -> clip + AdamW."""
+        """zero_grad -> forward -> backward -> (all-reduce) -> clip + AdamW.
+
+        ``mode``: "graph" (default) replays the step from hipGraphs captured on
+        first use (one graph at world 1; four segments around the three
+        collectives otherwise); "manual" runs the same autograd-free tape eagerly;
+        "autograd" goes through the public nn.Module / torch.autograd surface."""
+        if self.mode == "autograd":
+            return self._step_autograd(eeg, fmri)
+        if self.mode == "manual":
+            with torch.no_grad():
+                return self._step_manual(eeg, fmri)
+        return self._step_graph(eeg, fmri)
+
+    def _step_autograd(self, eeg, fmri):
         b = self.bucket
         b.zero_grad()
         loss, acc_e, acc_f = self.forward(eeg, fmri)
         loss.backward()
         b.absorb_autograd_grads()
-        world = self.world
+        self._seg_optimizer()
+        return {"loss": loss.detach(), "top1_e2f": acc_e, "top1_f2e": acc_f}
+
+    # ---- the four segments of the autograd-free tape -------------------------
+    def _seg_forward(self, eeg, fmri):
+        self.bucket.g.zero_()
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            ff, sv_f = ops._vol_forward_impl(self.fmri_encoder, fmri, True, True)
+        fe, sv_e = ops._erp_forward_impl(self.eeg_encoder, eeg, True, True)
+        main.wait_stream(self._side)
+        z, sv_h = ops.contrastive_embed_impl(self.head.bridge, fe, ff, True)
+        return z, (sv_e, sv_f, sv_h)
+
+    def _seg_loss(self, z, z_all, scal, dz_all):
+        B, N2 = z.shape
+        scal.zero_()
+        dz_all.zero_()
+        ls = self.head.logit_scale.detach().reshape(1)
+        _hip.call("mm_clip_loss", z, z_all, ls, scal, dz_all, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
+
+    def _seg_backward(self, saved, dz, scal):
+        sv_e, sv_f, sv_h = saved
+        bag = GradBag()
+        self.head.logit_scale._mm_grad.add_(scal[3])
+        dfe, dff = contrastive_embed_bwd(bag, sv_h, dz)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            volume_encoder_bwd(bag, sv_f, dff)
+        erp_encoder_bwd(bag, sv_e, dfe)
+        main.wait_stream(self._side)
+
+    def _seg_optimizer(self):
+        b = self.bucket
         dp.allreduce_sum_(b.g, self.group)
+        self._seg_adamw()
+
+    def _seg_adamw(self):
+        b = self.bucket
         _hip.call("mm_sumsq", b.g, b.state, b.n)
         _hip.call("mm_adamw_clip", b.p, b.g, b.m, b.v, b.state, b.n, self.betas[0], self.betas[1],
-                  self.eps, self.weight_decay, self.grad_clip, 1.0 / world)
+                  self.eps, self.weight_decay, self.grad_clip, 1.0 / self.world)
         ops.weights_changed()
-        return {"loss": loss.detach(), "top1_e2f": acc_e, "top1_f2e": acc_f}
+
+    def _step_manual(self, eeg, fmri):
+        z, saved = self._seg_forward(eeg, fmri)
+        z_all = dp.gather_embeddings(z, self.group)
+        scal = torch.empty(4, device=z.device)
+        dz_all = torch.empty_like(z_all)
+        self._seg_loss(z, z_all, scal, dz_all)
+        dz = dp.scatter_column_grads(dz_all, self.group)
+        self._seg_backward(saved, dz, scal)
+        self._seg_optimizer()
+        return {"loss": scal[0], "top1_e2f": scal[1], "top1_f2e": scal[2]}
+
+    # ---- hipGraph capture ------------------------------------------------------
+    def _capture(self, eeg, fmri):
+        dev = eeg.device
+        world = self.world
+        c = {"eeg": eeg.clone(), "fmri": fmri.clone(), "epoch": torch.zeros(1, dtype=torch.int32, device=dev)}
+        ops.set_seed_epoch(c["epoch"])
+        # warm-up outside capture (lazy inits, allocator priming) on a snapshot of the
+        # training state, so that the first replay is really step 1
+        b = self.bucket
+        snap = [t.clone() for t in (b.p, b.m, b.v, b.state)]
+        bufs = [t for t in self.buffers() if t is not None]
+        snap_bufs = [t.clone() for t in bufs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                self._step_manual(c["eeg"], c["fmri"])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for t, sv in zip((b.p, b.m, b.v, b.state), snap):
+                t.copy_(sv)
+            for t, sv in zip(bufs, snap_bufs):
+                t.copy_(sv)
+        ops.weights_changed()                                     # weight-image kernels must be recorded
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+
+        def record(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                fn()
+            graphs.append(g)
+
+        B = eeg.shape[0]
+        N2 = 2 * self.head.bridge.bridge_dim
+        c["scal"] = torch.zeros(4, device=dev)
+        if world == 1:
+            def whole():
+                c["epoch"].add_(1)
+                z, saved = self._seg_forward(c["eeg"], c["fmri"])
+                c["dz_all"] = torch.empty_like(z)
+                self._seg_loss(z, z, c["scal"], c["dz_all"])
+                self._seg_backward(saved, c["dz_all"], c["scal"])
+                self._seg_adamw()
+            record(whole)
+        else:
+            def seg1():
+                c["epoch"].add_(1)
+                c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"])
+            record(seg1)
+            c["z_all"] = torch.empty(world * B, N2, device=dev)
+            c["dz_all"] = torch.empty(world * B, N2, device=dev)
+            c["dz"] = torch.empty(B, N2, device=dev)
+            record(lambda: self._seg_loss(c["z"], c["z_all"], c["scal"], c["dz_all"]))
+            record(lambda: self._seg_backward(c["saved"], c["dz"], c["scal"]))
+            record(self._seg_adamw)
+        c["graphs"] = graphs
+        self._cap = c
+
+    def _step_graph(self, eeg, fmri):
+        if self._cap is None or self._cap["eeg"].shape != eeg.shape or self._cap["fmri"].shape != fmri.shape:
+            self._capture(eeg, fmri)
+        c = self._cap
+        if eeg.data_ptr() != c["eeg"].data_ptr():
+            c["eeg"].copy_(eeg)
+            c["fmri"].copy_(fmri)
+        g = c["graphs"]
+        if len(g) == 1:
+            g[0].replay()
+        else:
+            import torch.distributed as dist
+            g[0].replay()
+            dist.all_gather_into_tensor(c["z_all"], c["z"], group=self.group)
+            g[1].replay()
+            dist.reduce_scatter_tensor(c["dz"], c["dz_all"], op=dist.ReduceOp.SUM, group=self.group)
+            g[2].replay()
+            dist.all_reduce(self.bucket.g, op=dist.ReduceOp.SUM, group=self.group)
+            g[3].replay()
+        return {"loss": c["scal"][0], "top1_e2f": c["scal"][1], "top1_f2e": c["scal"][2]}
 
     @torch.no_grad()
     def evaluate(self, eeg, fmri):
         was = self.training
         self.eval()
+        ops.weights_changed()                      # graph replays bypass the python-side version counter
         try:
             loss, acc_e, acc_f = self.forward(eeg, fmri)
         finally:

@@ -36,7 +36,9 @@ __device__ __forceinline__ float attn_keep(uint32_t seed, int bh, int q, int key
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int L, int H, float scale_log2,
-                                                       uint32_t dthresh, uint32_t dseed, float dinv) {
+                                                       uint32_t dthresh, uint32_t dseed, float dinv,
+                                                       const uint32_t* epoch) {
+    dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vt[DH * VS];
     const int E = H * DH, E3 = 3 * E;
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16* __restrict__ dqkv, float* __restrict__ delta,
                                                           int L, int H, float scale, uint32_t dthresh,
-                                                          uint32_t dseed, float dinv) {
+                                                          uint32_t dseed, float dinv, const uint32_t* epoch) {
+    dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Kt[DH * VS];
@@ -247,7 +250,9 @@ constexpr int QS = QCH + 8;              // transposed row stride
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16* __restrict__ dqkv, int L, int H, float scale,
-                                                           uint32_t dthresh, uint32_t dseed, float dinv) {
+                                                           uint32_t dthresh, uint32_t dseed, float dinv,
+                                                           const uint32_t* epoch) {
+    dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Qs[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Ds[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Qt[DH * QS];
@@ -355,29 +360,31 @@ extern "C" {
 static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, float scale,
-                float drop_p, uint32_t seed, hipStream_t st) {
+                float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_fwd: drop_p");
     MM_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0, "attn_fwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_fwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
-                       scale * 1.4426950408889634f, attn_thresh(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+                       scale * 1.4426950408889634f, attn_thresh(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
+                       seed_epoch);
     return mm_check_launch("attn_fwd");
 }
 
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
-                int B, int L, int H, int head_dim, float scale, float drop_p, uint32_t seed, hipStream_t st) {
+                int B, int L, int H, int head_dim, float scale, float drop_p, uint32_t seed,
+                const uint32_t* seed_epoch, hipStream_t st) {
     const uint32_t dth = attn_thresh(drop_p);
     const float dinv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_bwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)out,
-                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv);
+                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv, seed_epoch);
     int rc = mm_check_launch("attn_bwd_dq");
     if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
-                       delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv);
+                       delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv, seed_epoch);
     return mm_check_launch("attn_bwd_dkv");
 }
 

@@ -85,4 +85,10 @@ __device__ __forceinline__ float dropout_scale(uint32_t seed, uint32_t idx, uint
     return mm_hash(seed, idx) >= thresh ? inv_keep : 0.f;
 }
 
+// effective dropout seed: `base` is fixed at launch-record time, `epoch` (device
+// word, may be null) changes between replays of a captured hipGraph
+__device__ __forceinline__ uint32_t mm_eff_seed(uint32_t base, const uint32_t* epoch) {
+    return epoch ? base ^ (epoch[0] * 0x85EBCA6Bu + 0xC2B2AE35u) : base;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -302,10 +302,12 @@ struct Pool3Args {
     bf16* out; float* sums_out; bf16* dy;
     int B, D, H, W, N, act, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
+    const uint32_t* epoch;
 };
 
 template <int MODE>   // 0 fwd, 1 bwd-reduce, 2 bwd-apply
 __global__ void pool3_bn_act_kernel(Pool3Args a) {
+    a.seed = mm_eff_seed(a.seed, a.epoch);
     const int nv = a.N / 4;
     const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
     const size_t nrows = (size_t)a.B * Do * Ho * Wo;
@@ -401,7 +403,7 @@ inline uint32_t thresh3(float p) { return p > 0.f ? (uint32_t)((double)p * 42949
 
 int pool3_launch(int mode, const float* y, const float* out4, const void* dout, const float* sums, void* out,
                  float* sums_out, void* dy, int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
-                 int train, hipStream_t st) {
+                 const uint32_t* seed_epoch, int train, hipStream_t st) {
     MM_REQUIRE(y && out4 && B > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "pool3d_bn_act: dims must be even");
     MM_REQUIRE(N % 4 == 0 && N <= 1024, "pool3d_bn_act: N");
     Pool3Args a;
@@ -409,6 +411,7 @@ int pool3_launch(int mode, const float* y, const float* out4, const void* dout, 
     a.dy = (bf16*)dy; a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.train = train;
     a.thresh = thresh3(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)B * D * H * W);
+    a.epoch = seed_epoch;
     const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
     const size_t rows = (size_t)B * (D / 2) * (H / 2) * (W / 2);
     int grid = (int)((rows + rpb - 1) / rpb);
@@ -467,22 +470,26 @@ int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
 }
 
 int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, int B, int D, int H, int W, int N,
-                         int act, float drop_p, uint32_t seed, hipStream_t st) {
+                         int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(out_bf16, "pool3d_bn_act_fwd: null out");
-    return pool3_launch(0, y, out4, nullptr, nullptr, out_bf16, nullptr, nullptr, B, D, H, W, N, act, drop_p, seed, 0, st);
+    return pool3_launch(0, y, out4, nullptr, nullptr, out_bf16, nullptr, nullptr, B, D, H, W, N, act, drop_p, seed,
+                        seed_epoch, 0, st);
 }
 
 int mm_pool3d_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, float* sums_out, int B,
-                                int D, int H, int W, int N, int act, float drop_p, uint32_t seed, hipStream_t st) {
+                                int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
+                                const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(dout_bf16 && sums_out, "pool3d_bn_act_bwd_reduce: null");
-    return pool3_launch(1, y, out4, dout_bf16, nullptr, nullptr, sums_out, nullptr, B, D, H, W, N, act, drop_p, seed, 1, st);
+    return pool3_launch(1, y, out4, dout_bf16, nullptr, nullptr, sums_out, nullptr, B, D, H, W, N, act, drop_p, seed,
+                        seed_epoch, 1, st);
 }
 
 int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* sums, void* dy,
-                               int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed, int train,
-                               hipStream_t st) {
+                               int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
+                               const uint32_t* seed_epoch, int train, hipStream_t st) {
     MM_REQUIRE(dout_bf16 && dy && (!train || sums), "pool3d_bn_act_bwd_apply: null");
-    return pool3_launch(2, y, out4, dout_bf16, sums, nullptr, nullptr, dy, B, D, H, W, N, act, drop_p, seed, train, st);
+    return pool3_launch(2, y, out4, dout_bf16, sums, nullptr, nullptr, dy, B, D, H, W, N, act, drop_p, seed,
+                        seed_epoch, train, st);
 }
 
 }  // extern "C"

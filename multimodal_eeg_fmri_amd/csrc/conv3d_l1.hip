@@ -37,6 +37,7 @@ struct L1Args {
     float* dbias;          // mode 3
     int B, D, H, W, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
+    const uint32_t* epoch;
 };
 
 __device__ __forceinline__ int tap_off(int tap) {          // halo offset of tap (0..26), pads -> 0
@@ -47,6 +48,7 @@ __device__ __forceinline__ int tap_off(int tap) {          // halo offset of tap
 
 template <int MODE>
 __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
+    a.seed = mm_eff_seed(a.seed, a.epoch);
     __shared__ __attribute__((aligned(16))) unsigned short halo[HSZ];
     __shared__ float red[4][32];
     __shared__ float wred[27][32];
@@ -255,7 +257,8 @@ extern "C" {
 
 int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, const float* out4,
                  const void* dout, const float* sums, float* stats, void* out, float* dw_tapmajor, float* dbias,
-                 int B, int D, int H, int W, int train, float drop_p, uint32_t seed, hipStream_t st) {
+                 int B, int D, int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                 hipStream_t st) {
     MM_REQUIRE(x && wimg && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1: null/invalid");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1: D,H,W must be even (MaxPool3d(2))");
     MM_REQUIRE(mode >= 0 && mode <= 3, "conv3d_l1: mode");
@@ -270,6 +273,7 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
     a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)B * D * H * W);
+    a.epoch = seed_epoch;
     const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
     const int grid = ntiles < 1024 ? ntiles : 1024;
     switch (mode) {

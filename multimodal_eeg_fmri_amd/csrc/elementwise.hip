@@ -48,6 +48,7 @@ struct BnActArgs {
     int R, S, N, act, pool, drop_first;
     uint32_t thresh, seed; float inv_keep;
     uint32_t thresh2, seed2; float inv_keep2;
+    const uint32_t* epoch;
 };
 
 __device__ __forceinline__ float bnact_one(const BnActArgs& a, float y, float sc, float sh, uint32_t idx, bool drop_here) {
@@ -57,6 +58,8 @@ __device__ __forceinline__ float bnact_one(const BnActArgs& a, float y, float sc
 }
 
 __global__ void bn_act_fwd_kernel(BnActArgs a) {
+    a.seed = mm_eff_seed(a.seed, a.epoch);
+    a.seed2 = mm_eff_seed(a.seed2, a.epoch);
     const int So = a.S / a.pool;
     const int nv = a.N / 4;
     const size_t total = (size_t)a.R * So * nv;
@@ -116,6 +119,7 @@ struct BnBwdArgs {
     int R, S, N, act, pool, drop_first, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
     uint32_t thresh2, seed2; float inv_keep2;
+    const uint32_t* epoch;
 };
 
 // computes dz for the (up to) two inputs of one pooled output element
@@ -147,6 +151,8 @@ __device__ __forceinline__ void bn_dz_pair(const BnBwdArgs& a, float y0, float y
 
 template <bool APPLY>
 __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
+    a.seed = mm_eff_seed(a.seed, a.epoch);
+    a.seed2 = mm_eff_seed(a.seed2, a.epoch);
     // block = 256 threads = (N/4 channel-vectors) x rows; grid-stride over pooled rows
     const int nv = a.N / 4;
     const int So = a.S / a.pool;
@@ -379,7 +385,8 @@ __global__ void cast_f32_kernel(const bf16* __restrict__ x, float* __restrict__ 
 // dz = g * dropout_mask * act'(z): elementwise gradient through act+dropout
 __global__ void act_bwd_kernel(const float* __restrict__ g_f32, const bf16* __restrict__ g_bf16,
                                const bf16* __restrict__ z, bf16* __restrict__ out, size_t n, int act,
-                               uint32_t thresh, uint32_t seed, float inv_keep) {
+                               uint32_t thresh, uint32_t seed, float inv_keep, const uint32_t* epoch) {
+    seed = mm_eff_seed(seed, epoch);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float g = g_f32 ? g_f32[i] : (float)g_bf16[i];
         if (thresh) g *= dropout_scale(seed, (uint32_t)i, thresh, inv_keep);
@@ -410,12 +417,12 @@ int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, fl
 
 int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe, void* out_bf16,
                   float* out_f32, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
-                  uint32_t seed, float drop2_p, uint32_t seed2, hipStream_t st) {
+                  uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(y && scale && shift && (out_bf16 || out_f32), "bn_act_fwd: null");
     MM_REQUIRE(N % 4 == 0 && (pool == 1 || (pool == 2 && S % 2 == 0)), "bn_act_fwd: N%%4, pool");
     BnActArgs a{y, scale, shift, pe, (bf16*)out_bf16, out_f32, R, S, N, act, pool, drop_first,
                 thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
-                thresh_of(drop2_p), seed2, drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f};
+                thresh_of(drop2_p), seed2, drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f, seed_epoch};
     const size_t total = (size_t)R * (S / pool) * (N / 4);
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, a);
     return mm_check_launch("bn_act_fwd");
@@ -424,7 +431,7 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
 static int bn_bwd_common(bool apply, const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
                          const float* sums_in, float* sums_out, void* dy, float* dy_f32, int R, int S, int N, int act,
                          int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
-                         int train, hipStream_t st) {
+                         const uint32_t* seed_epoch, int train, hipStream_t st) {
     MM_REQUIRE(y && out4 && (dout_bf16 || dout_f32), "bn_act_bwd: null");
     MM_REQUIRE(N % 4 == 0 && N <= 1024 && (N / 4) <= 256, "bn_act_bwd: N");
     BnBwdArgs a;
@@ -435,6 +442,7 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
     a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)R * (float)S);
     a.thresh2 = thresh_of(drop2_p); a.seed2 = seed2; a.inv_keep2 = drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f;
+    a.epoch = seed_epoch;
     const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
     const size_t rows = (size_t)R * (S / pool);
     int grid = (int)((rows + rpb - 1) / rpb);
@@ -446,19 +454,19 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
 
 int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
                          float* sums_out, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
-                         uint32_t seed, float drop2_p, uint32_t seed2, hipStream_t st) {
+                         uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(sums_out, "bn_act_bwd_reduce: null sums");
     return bn_bwd_common(false, y, out4, dout_bf16, dout_f32, nullptr, sums_out, nullptr, nullptr, R, S, N, act,
-                         pool, drop_first, drop_p, seed, drop2_p, seed2, 1, st);
+                         pool, drop_first, drop_p, seed, drop2_p, seed2, seed_epoch, 1, st);
 }
 
 int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
                         const float* sums, void* dy, float* dy_f32, int R, int S, int N, int act, int pool,
-                        int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2, int train,
-                        hipStream_t st) {
+                        int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
+                        const uint32_t* seed_epoch, int train, hipStream_t st) {
     MM_REQUIRE((dy || dy_f32) && (!train || sums), "bn_act_bwd_apply: null");
     return bn_bwd_common(true, y, out4, dout_bf16, dout_f32, sums, nullptr, dy, dy_f32, R, S, N, act, pool,
-                         drop_first, drop_p, seed, drop2_p, seed2, train, st);
+                         drop_first, drop_p, seed, drop2_p, seed2, seed_epoch, train, st);
 }
 
 #define LN_DISPATCH(D, CALL)                                   \
@@ -524,11 +532,11 @@ int mm_cast_f32(const void* x, float* y, int64_t n, hipStream_t st) {
 }
 
 int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out, int64_t n, int act, float drop_p,
-               uint32_t seed, hipStream_t st) {
+               uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE((g_f32 || g_bf16) && out && n > 0, "act_bwd: null");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, g_f32, (const bf16*)g_bf16,
                        (const bf16*)z, (bf16*)out, (size_t)n, act, thresh_of(drop_p), seed,
-                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch);
     return mm_check_launch("act_bwd");
 }
 

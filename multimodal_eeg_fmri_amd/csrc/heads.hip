@@ -13,7 +13,8 @@ __global__ void small_linear_fwd_kernel(const float* __restrict__ x, const float
                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                         const float* __restrict__ shift, float* __restrict__ y,
                                         float* __restrict__ pre, int B, int K, int N, int act,
-                                        uint32_t thresh, uint32_t seed, float inv_keep) {
+                                        uint32_t thresh, uint32_t seed, float inv_keep, const uint32_t* epoch) {
+    seed = mm_eff_seed(seed, epoch);
     extern __shared__ float xs[];                   // one input row
     const int b = blockIdx.x;
     for (int k = threadIdx.x; k < K; k += blockDim.x) xs[k] = x[(size_t)b * K + k];
@@ -66,7 +67,8 @@ __global__ void small_linear_dw_kernel(const float* __restrict__ dy, const float
 }
 
 __global__ void act_f32_kernel(const float* __restrict__ z, float* __restrict__ y, size_t n, int act,
-                               uint32_t thresh, uint32_t seed, float inv_keep) {
+                               uint32_t thresh, uint32_t seed, float inv_keep, const uint32_t* epoch) {
+    seed = mm_eff_seed(seed, epoch);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float v = apply_act(z[i], act);
         if (thresh) v *= dropout_scale(seed, (uint32_t)i, thresh, inv_keep);
@@ -74,7 +76,9 @@ __global__ void act_f32_kernel(const float* __restrict__ z, float* __restrict__ 
     }
 }
 __global__ void act_bwd_f32_kernel(const float* __restrict__ g, const float* __restrict__ z, float* __restrict__ out,
-                                   size_t n, int act, uint32_t thresh, uint32_t seed, float inv_keep) {
+                                   size_t n, int act, uint32_t thresh, uint32_t seed, float inv_keep,
+                                   const uint32_t* epoch) {
+    seed = mm_eff_seed(seed, epoch);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float v = g[i];
         if (thresh) v *= dropout_scale(seed, (uint32_t)i, thresh, inv_keep);
@@ -366,13 +370,13 @@ extern "C" {
 
 int mm_small_linear_fwd(const float* x, const float* W, const float* bias, const float* scale, const float* shift,
                         float* y, float* pre, int B, int K, int N, int act, float drop_p, uint32_t seed,
-                        hipStream_t st) {
+                        const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(x && W && y && B > 0 && K > 0 && N > 0, "small_linear_fwd: null/invalid");
     MM_REQUIRE((scale == nullptr) == (shift == nullptr), "small_linear_fwd: scale/shift come in pairs");
     MM_REQUIRE((size_t)K * 4 <= 64 * 1024, "small_linear_fwd: K=%d too large", K);
     const int gy = ceil_div(N, 4) < 64 ? ceil_div(N, 4) : 64;
     hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(B, gy), dim3(256), K * sizeof(float), st, x, W, bias, scale, shift,
-                       y, pre, B, K, N, act, thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+                       y, pre, B, K, N, act, thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch);
     return mm_check_launch("small_linear_fwd");
 }
 
@@ -385,18 +389,19 @@ int mm_small_linear_bwd(const float* dy, const float* x, const float* W, float* 
     return mm_check_launch("small_linear_bwd");
 }
 
-int mm_act_f32(const float* z, float* y, int64_t n, int act, float drop_p, uint32_t seed, hipStream_t st) {
+int mm_act_f32(const float* z, float* y, int64_t n, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+               hipStream_t st) {
     MM_REQUIRE(z && y && n > 0, "act_f32: null");
     hipLaunchKernelGGL(act_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, z, y, (size_t)n, act, thresh_h(drop_p),
-                       seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+                       seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch);
     return mm_check_launch("act_f32");
 }
 
 int mm_act_bwd_f32(const float* g, const float* z, float* out, int64_t n, int act, float drop_p, uint32_t seed,
-                   hipStream_t st) {
+                   const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(g && out && n > 0, "act_bwd_f32: null");
     hipLaunchKernelGGL(act_bwd_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, g, z, out, (size_t)n, act,
-                       thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f);
+                       thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch);
     return mm_check_launch("act_bwd_f32");
 }
 

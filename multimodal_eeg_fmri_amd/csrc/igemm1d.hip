@@ -33,6 +33,7 @@ struct EpiArgs {
     uint32_t drop_thresh;     // 0 = no dropout
     uint32_t drop_seed;
     float drop_inv_keep;
+    const uint32_t* drop_epoch;
 };
 
 struct ConvArgs {
@@ -61,6 +62,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
     }
     const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const uint32_t dseed = e.drop_thresh ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
     const int To = T / e.pool;
     const int step = e.pool;                   // rows consumed per item
     for (int r0 = rr * step; r0 < BM; r0 += RPP * step) {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float val = apply_act(v[c], e.act);
-                if (e.drop_thresh) val *= dropout_scale(e.drop_seed, (uint32_t)(idx + c), e.drop_thresh, e.drop_inv_keep);
+                if (e.drop_thresh) val *= dropout_scale(dseed, (uint32_t)(idx + c), e.drop_thresh, e.drop_inv_keep);
                 val += rs[c] + ps[c];
                 o[c] = fmaxf(o[c], val);
             }
@@ -439,7 +441,7 @@ int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, in
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual, const float* pe,
                   int pool, float* stats, float* out_f32, void* out_bf16, void* out_pre,
-                  float drop_p, uint32_t drop_seed, hipStream_t st) {
+                  float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(x && w, "conv1d_fwd: null operand");
     MM_REQUIRE(B > 0 && T > 0 && Cout > 0 && taps >= 1 && taps <= 9 && pad >= 0 && pad < taps, "conv1d_fwd: bad dims");
     MM_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv1d_fwd: Cin=%d must be a multiple of 16", Cin);
@@ -455,6 +457,7 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.act = act; a.e.pool = pool;
     a.e.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     a.e.drop_seed = drop_seed;
+    a.e.drop_epoch = seed_epoch;
     a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
     // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
     // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS

@@ -49,7 +49,17 @@ def _zeros(shape, like, dtype=_F32):
     return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
-_seed_state = {"base": 0x1234567, "step": 0}
+_seed_state = {"base": 0x1234567, "step": 0, "epoch": None}
+
+
+def set_seed_epoch(t: Optional[torch.Tensor]):
+    """device int32 word mixed into every dropout seed ON THE DEVICE; lets a
+    hipGraph-captured step draw fresh masks on every replay (None = off)."""
+    _seed_state["epoch"] = t
+
+
+def EP():
+    return _seed_state["epoch"]
 
 
 def set_dropout_seed(seed: int):
@@ -156,7 +166,7 @@ def igemm(x: torch.Tensor, wf: torch.Tensor, taps: int, pad: int, cout: int, *,
     ob = _empty((B, T // pool, cout), _BF, x) if out_bf16 else None
     op = _empty((B, T, cout), _BF, x) if out_pre else None
     _hip.call("mm_conv1d_fwd", x, wf, B, T, cin, cout, taps, pad, scale, shift, ACT[act], residual, pe,
-              pool, stats, of, ob, op, float(drop_p), int(seed))
+              pool, stats, of, ob, op, float(drop_p), int(seed), EP())
     res["f32"], res["bf16"], res["pre"] = of, ob, op
     return res
 
@@ -208,7 +218,7 @@ def attention(qkv: torch.Tensor, nhead: int, want_lse: bool, drop_p: float = 0.0
     dh = E // nhead
     out = _empty((B, L, E), _BF, qkv)
     lse = _empty((B, nhead, L), _F32, qkv) if want_lse else None
-    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), int(seed))
+    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), int(seed), EP())
     return out, lse
 
 
@@ -239,7 +249,7 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
     of = _empty((B, T // pool, cout), _F32, xb) if want_f32 else None
     ob = _empty((B, T // pool, cout), _BF, xb) if want_bf16 else None
     _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, B, T, cout, ACT[act], pool,
-              1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2)
+              1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2, EP())
     saved = dict(xb=xb, y=y, out4=out4, act=act, pool=pool, drop_p=drop_p, seed=seed,
                  drop2=(float(pe_drop_p), seed2), drop_first=drop_first, conv=conv, bn=bn)
     return {"f32": of, "bf16": ob, "pre": None}, saved
@@ -396,11 +406,11 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     p = drop_p if training else 0.0
     if pool:
         out = _empty((B, D // 2, H // 2, W // 2, cout), _BF, xv)
-        _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, B, D, H, W, cout, ACT["gelu"], float(p), seed)
+        _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
     else:
         out = _empty((B, D * H * W, cout), _F32, xv)
         _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], None, None, out, B, D * H * W, cout,
-                  ACT["gelu"], 1, 1, float(p), seed, 0.0, 0)
+                  ACT["gelu"], 1, 1, float(p), seed, 0.0, 0, EP())
     saved = dict(xv=xv, y=y, out4=out4, pool=pool, drop_p=p, seed=seed, conv=conv, bn=bn) if training else None
     return out, saved
 
@@ -415,14 +425,14 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     if training:
         stats = _zeros((2, 32), x)
         _hip.call("mm_conv3d_l1", 0, x, wimg, conv.bias, None, None, None, stats, None, None, None,
-                  B, D, H, W, 1, 0.0, 0)
+                  B, D, H, W, 1, 0.0, 0, None)
         out4 = bn_finalize_train(bn, stats, B * D * H * W)
         bias = conv.bias
     else:
         out4 = bn_fold_eval(bn, conv.bias)
         bias = None
     _hip.call("mm_conv3d_l1", 1, x, wimg, bias, out4, None, None, None, out, None, None,
-              B, D, H, W, 1 if training else 0, float(p), seed)
+              B, D, H, W, 1 if training else 0, float(p), seed, EP())
     saved = dict(l1=True, x=x, wimg=wimg, out4=out4, drop_p=p, seed=seed, conv=conv, bn=bn) if training else None
     return out, saved
 
@@ -471,7 +481,7 @@ def small_linear(x: torch.Tensor, lin, *, act="none", drop_p=0.0, seed=0, want_p
     if bn is not None:
         out4 = bn_fold_eval(bn, None)
         sc, sh = out4[0], out4[1]
-    _hip.call("mm_small_linear_fwd", x, W, bvec, sc, sh, y, pre, B, K, N, ACT[act], float(drop_p), int(seed))
+    _hip.call("mm_small_linear_fwd", x, W, bvec, sc, sh, y, pre, B, K, N, ACT[act], float(drop_p), int(seed), EP())
     return y, pre
 
 
@@ -487,7 +497,7 @@ def proj_head_fwd(seq, x: torch.Tensor, training: bool, drop_p: float):
     p = drop_p if training else 0.0
     seed = _next_seed() if p > 0 else 0
     a = _empty((B, N), _F32, x)
-    _hip.call("mm_act_f32", hn, a, B * N, ACT["gelu"], float(p), seed)
+    _hip.call("mm_act_f32", hn, a, B * N, ACT["gelu"], float(p), seed, EP())
     return a, dict(x=x, z1=z1, hn=hn, stat=stat, p=p, seed=seed, seq=seq)
 
 
@@ -570,7 +580,7 @@ def bridge_forward(m, eeg, fmri):
         hn = _empty(h1.shape, _F32, h1)
         _hip.call("mm_layernorm_fwd", h1, ln.weight, ln.bias, None, hn, None, B, h1.shape[1], float(ln.eps))
         hr = _empty(h1.shape, _F32, h1)
-        _hip.call("mm_act_f32", hn, hr, hn.numel(), ACT["relu"], 0.0, 0)
+        _hip.call("mm_act_f32", hn, hr, hn.numel(), ACT["relu"], 0.0, 0, None)
         logits, _ = small_linear(hr, m.classifier[4])
     return logits, fused, fw, attw.view(B, 1, 2)
 

@@ -53,7 +53,7 @@ def test_conv1d_fwd_matches_torch(B, C, T, Cout, k):
     wf, _ = _prep_w(hip, w, cp)
     out = torch.empty(B, T, Cout, dtype=torch.float32, device="cuda")
     hip.call("mm_conv1d_fwd", xg, wf, B, T, cp, Cout, k, k // 2, None, bias.cuda(), 0, None, None, 1,
-             None, out, None, None, 0.0, 0)
+             None, out, None, None, 0.0, 0, None)
     want = F.conv1d(_bf(x), _bf(w), bias, padding=k // 2).transpose(1, 2)
     torch.testing.assert_close(out.cpu(), want, rtol=1e-4, atol=1e-4)
 
@@ -72,7 +72,7 @@ def test_conv1d_fwd_epilogue_bn_gelu_pool_stats():
     out = torch.empty(B, T // 2, Cout, dtype=torch.bfloat16, device="cuda")
     stats = torch.zeros(2, Cout, device="cuda")
     hip.call("mm_conv1d_fwd", xg, wf, B, T, C, Cout, k, k // 2, scale.cuda(), shift.cuda(), 1, None, None, 2,
-             stats, None, out, None, 0.0, 0)
+             stats, None, out, None, 0.0, 0, None)
     z = F.conv1d(_bf(x), _bf(w), None, padding=k // 2) * scale[None, :, None] + shift[None, :, None]
     want = F.max_pool1d(F.gelu(z), 2).transpose(1, 2)
     torch.testing.assert_close(out.float().cpu(), want, rtol=1e-2, atol=1e-2)
@@ -101,7 +101,7 @@ def test_attention_fwd_bwd(B, L, H):
     qg = qkv.cuda().to(torch.bfloat16)
     out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0)
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None)
     qr = qkv.clone().requires_grad_(True)
     o_ref, lse_ref = _attn_ref(qr, H)
     torch.testing.assert_close(out.float().cpu(), o_ref.detach(), rtol=2e-2, atol=2e-2)
@@ -109,7 +109,7 @@ def test_attention_fwd_bwd(B, L, H):
     o_ref.backward(do)
     dqkv = torch.empty_like(qg)
     delta = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0)
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None)
     got, want = dqkv.float().cpu(), qr.grad
     assert ((got - want).norm() / want.norm()).item() < 2e-2
     torch.testing.assert_close(got, want, rtol=5e-2, atol=3e-2)
@@ -149,7 +149,7 @@ def test_conv1d_dgrad_via_forward_kernel():
     dyg = dy.transpose(1, 2).contiguous().cuda().to(torch.bfloat16)
     dx = torch.empty(B, T, C, device="cuda")
     hip.call("mm_conv1d_fwd", dyg, wd, B, T, Cout, C, k, k - 1 - k // 2, None, None, 0, None, None, 1,
-             None, dx, None, None, 0.0, 0)
+             None, dx, None, None, 0.0, 0, None)
     torch.testing.assert_close(dx.cpu().transpose(1, 2), x.grad, rtol=1e-3, atol=1e-3)
 
 
@@ -207,15 +207,15 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     torch.testing.assert_close(rmg.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rvg.cpu(), rv_ref, rtol=1e-4, atol=1e-5)
     ob = torch.empty(R, S // pool, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_bn_act_fwd", yg, out4[0], out4[1], None, ob, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0)
+    hip.call("mm_bn_act_fwd", yg, out4[0], out4[1], None, ob, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None)
     torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
     sums = torch.zeros(2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
-    hip.call("mm_bn_act_bwd_reduce", yg, out4, dg, None, sums, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0)
+    hip.call("mm_bn_act_bwd_reduce", yg, out4, dg, None, sums, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None)
     torch.testing.assert_close(sums[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(sums[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, 1)
+    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
 
 
@@ -273,15 +273,15 @@ def test_pool3d_bn_act_train_fwd_bwd():
     hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"),
              None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0)
     ob = torch.empty(B, D // 2, H // 2, W // 2, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob, B, D, H, W, N, 1, 0.0, 0)
+    hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob, B, D, H, W, N, 1, 0.0, 0, None)
     torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
     sums = torch.zeros(2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
-    hip.call("mm_pool3d_bn_act_bwd_reduce", yg, out4, dg, sums, B, D, H, W, N, 1, 0.0, 0)
+    hip.call("mm_pool3d_bn_act_bwd_reduce", yg, out4, dg, sums, B, D, H, W, N, 1, 0.0, 0, None)
     torch.testing.assert_close(sums[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(sums[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(B, D, H, W, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_pool3d_bn_act_bwd_apply", yg, out4, dg, sums, dy, B, D, H, W, N, 1, 0.0, 0, 1)
+    hip.call("mm_pool3d_bn_act_bwd_apply", yg, out4, dg, sums, dy, B, D, H, W, N, 1, 0.0, 0, None, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
 
 
@@ -298,9 +298,9 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd():
     qg = qkv.cuda().to(torch.bfloat16)
     out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), p, seed)
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), p, seed, None)
     out0 = torch.empty_like(out)
-    hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0)
+    hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None)
     # recover the mask from V = identity-like probe: compare row sums of kept probabilities
     # host replica of the counter hash (common.h: mm_hash)
     def keep_mask():
@@ -321,6 +321,6 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd():
     o_ref.backward(do.double())
     dqkv = torch.empty_like(qg)
     delta = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed)
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed, None)
     dq_got = dqkv.float().cpu()[:, :, :E].view(B, L, H, 32).transpose(1, 2)
     assert ((dq_got - q.grad.float()).norm() / q.grad.float().norm()).item() < 3e-2

@@ -53,3 +53,37 @@ def test_trainer_steps_reduce_loss_and_retrieve():
     ev = tr.evaluate(eeg, fmri)
     assert ev["top1_e2f"].item() > 1.0 / 16
     assert float(tr.bucket.state[0]) == 30.0
+
+
+@pytest.mark.parametrize("mode", ["autograd", "manual", "graph"])
+def test_trainer_modes_agree_on_first_steps(mode):
+    """the autograd surface, the autograd-free tape and the hipGraph replay run the
+    same kernels: with dropout 0 their losses over the first steps agree."""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    from multimodal_eeg_fmri_amd import ops
+    ops.set_seed_epoch(None)
+    eeg, fmri = synthetic_pairs(8, 16, 256, (16, 16, 16))
+
+    def run(m):
+        torch.manual_seed(0)
+        tr = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-3, mode=m).train()
+        losses = []
+        for _ in range(6):
+            losses.append(tr.train_step(eeg, fmri)["loss"].item())
+        ops.set_seed_epoch(None)
+        return losses
+    ref = run("autograd")
+    got = run(mode)
+    for a, b in zip(ref, got):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), (ref, got)
+
+
+def test_graph_mode_draws_new_dropout_masks_each_replay():
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    from multimodal_eeg_fmri_amd import ops
+    torch.manual_seed(0)
+    tr = BridgeTrainer(eeg_channels=16, dropout=0.5, lr=0.0, weight_decay=0.0, mode="graph").train()
+    eeg, fmri = synthetic_pairs(8, 16, 256, (16, 16, 16))
+    losses = [tr.train_step(eeg, fmri)["loss"].item() for _ in range(4)]
+    ops.set_seed_epoch(None)
+    assert len({round(l, 5) for l in losses}) > 1, losses      # lr = 0: only the masks change
