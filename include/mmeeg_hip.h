@@ -17,6 +17,13 @@
  *     -3 unsupported shape); mm_last_error() gives the thread-local message;
  *   - `void*` tensors are bf16, `float*` fp32; channels-last layouts:
  *     1-D activations [B][T][C], tokens [M][D], volumes [B][D][H][W][C];
+ *   - per-channel accumulators written by many workgroups (`stats`, `sums_out`, `dbias`,
+ *     dgamma/dbeta scratch, wgrad workspaces) are REPLICATED: [32][...] zeroed buffers;
+ *     a workgroup adds into replica blockIdx % 32 (same-address fp32 atomics from
+ *     hundreds of workgroups serialise in L2).  mm_bn_finalize / mm_wgrad_scatter /
+ *     mm_transpose_add sum the replicas themselves; everything else goes through
+ *     mm_reduce_replicas.  The `sums` INPUT of the *_bwd_apply entry points is the
+ *     compact [2][N] result;
  *   - activation codes: 0 none, 1 GELU(erf), 2 ReLU, 3 tanh, 4 sigmoid;
  *   - dropout: keep iff hash(seed, element index) >= p * 2^32, scaled 1/(1-p);
  *     the backward entry points recompute the same mask from (p, seed).
@@ -66,11 +73,14 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
  * derives for the layers above (loss.backward(), run_training_lite.py:486). */
 int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin,
                     int Cout, int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap,
-                    hipStream_t stream);
+                    int nrep, int64_t rep_stride, hipStream_t stream);
 /* dw[n][c][tap] += ws[n][tap][c]: conv weight gradients are accumulated by the
  * wgrad kernels in a channel-contiguous workspace (contiguous fp32 atomics run
  * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */
-int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, hipStream_t stream);
+int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, int nrep,
+                     hipStream_t stream);
+/* dst[k] += sum_rep src[rep * rep_stride + k],  k < K */
+int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t rep_stride, hipStream_t stream);
 
 /* ---- BatchNorm / activation / pool ----------------------------------------
  * mode 0 (train): stats{sum,sumsq}/count -> out4 = {scale, shift, mean, rstd},
@@ -99,9 +109,10 @@ int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16
 /* ---- LayerNorm (nn.LayerNorm, enhanced_models_v4.py:80-81; bridge_utils.py:36,42,62) */
 int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16,
                      float* out_f32, float* stat, int M, int D, float eps, hipStream_t stream);
+/* dgb_repl = zeroed scratch [32][2][D]: replicated {dgamma, dbeta} partial sums */
 int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stat,
-                     const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
-                     float* dbeta, int M, int D, hipStream_t stream);
+                     const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
+                     int M, int D, hipStream_t stream);
 
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,
@@ -127,6 +138,9 @@ int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out,
 /* ---- 3-D voxel convolution, k=3 pad=1 (north-star extension: the reference has
  * no volume code, SURVEY.md section 0; semantics = torch.nn.Conv3d / BatchNorm3d /
  * MaxPool3d(2)).  Volumes are channels-last [B][D][H][W][C] bf16. */
+/* ablation switches for tools/kbench.py (bit0 skip stores, bit1 skip MFMA loop, bit2 skip
+ * halo prefetch in the W-resident conv3d kernel); 0 in production */
+int mm_debug_flags(int flags, hipStream_t stream);
 /* (B,1,D,H,W) fp32 -> [B][D][H][W][Cp] bf16, channel 0 = voxel value, rest 0 */
 int mm_pack_volume_bf16(const float* x, void* y, int64_t nvox, int Cp, hipStream_t stream);
 /* Y = X (*) W + shift; W image [Cout][27][Cin] (mm_prep_conv_weight with k=27);
@@ -135,8 +149,8 @@ int mm_pack_volume_bf16(const float* x, void* y, int64_t nvox, int Cp, hipStream
 int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int Cin, int Cout,
                   const float* shift, float* stats, float* out_f32, void* out_bf16, hipStream_t stream);
 int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W,
-                    int Cin, int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap,
-                    hipStream_t stream);
+                    int Cin, int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep,
+                    int64_t rep_stride, hipStream_t stream);
 /* y fp32 [B][D][H][W][N] -> act(BN(y)) -> MaxPool3d(2) -> dropout -> bf16 [B][D/2][H/2][W/2][N] */
 int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, int B, int D, int H, int W,
                          int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
@@ -157,8 +171,8 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
                  const void* dout, const float* sums, float* stats, void* out, float* dw_tapmajor,
                  float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
                  const uint32_t* seed_epoch, hipStream_t stream);
-/* dst[c][r] += src[r][c] */
-int mm_transpose_add(const float* src, float* dst, int R, int C, hipStream_t stream);
+/* dst[c][r] += sum_rep src[rep][r][c] */
+int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t stream);
 
 /* ---- small fp32 row kernels (projection bridge, tabular fMRI/conn MLPs) ------
  * y = dropout(act((x W^T + b) * scale + shift)) (scale/shift = folded eval

@@ -14,7 +14,36 @@ import torch
 
 from . import _hip
 from . import ops
-from .ops import ACT, _BF, _F32, _empty, _zeros
+from .ops import ACT, REPL, WREP, _BF, _F32, _empty, _zeros
+
+
+def _reduce_into(dst, src, K, stride, offset=0, nrep=REPL):
+    """dst[k] += sum_rep src[rep*stride + offset + k]"""
+    if dst is not None:
+        _hip.call("mm_reduce_replicas", src.data_ptr() + 4 * offset, dst, K, nrep, stride)
+
+
+def _ln_param_grads(bag, ln, dgb, D):
+    """dgb = replicated [REPL][2][D] {dgamma row, dbeta row}"""
+    gw, gb = bag.target(ln.weight), bag.target(ln.bias)
+    if gw is not None and gb is not None and gw.data_ptr() + 4 * D == gb.data_ptr():
+        _hip.call("mm_reduce_replicas", dgb, gw, 2 * D, REPL, 2 * D)      # adjacent in the flat bucket
+        return
+    _reduce_into(gw, dgb, D, 2 * D, 0)
+    _reduce_into(gb, dgb, D, 2 * D, D)
+
+
+def _compact(rep_buf, K):
+    """[REPL][K] replicated accumulator -> compact [K] (one parallel reduction)"""
+    out = _zeros((K,), rep_buf)
+    _hip.call("mm_reduce_replicas", rep_buf, out, K, REPL, K)
+    return out
+
+
+def _bn_param_grads(bag, bn, sums_c, N):
+    """sums_c = [sum dz (dbeta) | sum dz*xhat (dgamma)]"""
+    _reduce_into(bag.target(bn.bias), sums_c, N, N, 0, nrep=1)
+    _reduce_into(bag.target(bn.weight), sums_c, N, N, N, nrep=1)
 
 
 # ------------------------------------------------------------ gradient sinks
@@ -57,10 +86,13 @@ def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *,
     K = weight.shape[1]
     dw = bag.target(weight)
     db = bag.target(bias)
+    dbr = _zeros((REPL, N), dy) if db is not None else None
     if dw is not None:
-        _hip.call("mm_conv1d_wgrad", dy, x, dw, db, 1, M, Kp, N, 1, 0, K, K, 1, 0)
+        _hip.call("mm_conv1d_wgrad", dy, x, dw, dbr, 1, M, Kp, N, 1, 0, K, K, 1, 0, 1, 0)
     elif db is not None:
-        _hip.call("mm_colsum", dy, None, db, M, N)
+        _hip.call("mm_colsum", dy, None, dbr, M, N)
+    if db is not None:
+        _reduce_into(db, dbr, N, N)
     if not need_dx:
         return None
     _, wd, cinp, coutp = ops.weights.get(weight, True)
@@ -75,30 +107,31 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     conv, bn = s["conv"], s["bn"]
     y, out4, xb = s["y"], s["out4"], s["xb"]
     B, T, N = y.shape
-    sums = _zeros((2, N), y)
+    sums = _zeros((REPL, 2, N), y)
     d2 = s.get("drop2", (0.0, 0))
     args = (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]),
             float(d2[0]), int(d2[1]), ops.EP())
     _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
+    sc = _compact(sums, 2 * N)
     dy = _empty((B, T, N), _BF, y)
-    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sums, dy, None, *args, 1)
-    gb, gg = bag.target(bn.bias), bag.target(bn.weight)
-    if gb is not None:
-        gb.add_(sums[0])
-    if gg is not None:
-        gg.add_(sums[1])
+    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sc, dy, None, *args, 1)
+    _bn_param_grads(bag, bn, sc, N)
     k, pad = conv.kernel_size[0], conv.padding[0]
     cin = conv.in_channels
     dw = bag.target(conv.weight)
     if dw is not None:
         cinp_x = xb.shape[2]
+        db = bag.target(conv.bias)
+        dbr = _zeros((REPL, N), y) if db is not None else None
         if k == 1:
-            _hip.call("mm_conv1d_wgrad", dy, xb, dw, bag.target(conv.bias), B, T, cinp_x, N, 1, 0, cin, cin, 1, 0)
+            _hip.call("mm_conv1d_wgrad", dy, xb, dw, dbr, B, T, cinp_x, N, 1, 0, cin, cin, 1, 0, 1, 0)
         else:
-            ws = _zeros((N, k, cinp_x), y)                     # channel-contiguous atomics
-            _hip.call("mm_conv1d_wgrad", dy, xb, ws, bag.target(conv.bias), B, T, cinp_x, N, k, pad, cinp_x,
-                      k * cinp_x, 1, cinp_x)
-            _hip.call("mm_wgrad_scatter", ws, dw, N, cin, k, cinp_x)
+            ws = _zeros((WREP, N, k, cinp_x), y)               # replicated, channel-contiguous atomics
+            _hip.call("mm_conv1d_wgrad", dy, xb, ws, dbr, B, T, cinp_x, N, k, pad, cinp_x,
+                      k * cinp_x, 1, cinp_x, WREP, N * k * cinp_x)
+            _hip.call("mm_wgrad_scatter", ws, dw, N, cin, k, cinp_x, WREP)
+        if db is not None:
+            _reduce_into(db, dbr, N, N)
     if not need_dx:
         return None
     _, wd, cinp, coutp = ops.weights.get(conv.weight, True)
@@ -121,8 +154,9 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor) -> torch.Ten
     dz = _mask_cast(g_bf16=dg, z=s["z"], act=blk._act, drop_p=p, seed=s2)
     dh2 = linear_bwd(bag, dz, s["h2"], blk.linear1.weight, blk.linear1.bias)
     dx1 = _empty((M, D), _F32, dx2)
-    _hip.call("mm_layernorm_bwd", dh2, None, s["x1"], s["st2"], blk.norm2.weight, dx2, dx1, None,
-              bag.target(blk.norm2.weight), bag.target(blk.norm2.bias), M, D)
+    dgb = _zeros((REPL, 2, D), dx2)
+    _hip.call("mm_layernorm_bwd", dh2, None, s["x1"], s["st2"], blk.norm2.weight, dx2, dx1, None, dgb, M, D)
+    _ln_param_grads(bag, blk.norm2, dgb, D)
     # attention output projection:  x1 = x0 + drop(o Wo^T + bo)
     dyo = _mask_cast(g_f32=dx1, drop_p=p, seed=s1)
     do = linear_bwd(bag, dyo, s["o"].view(M, D), at.out_proj.weight, at.out_proj.bias)
@@ -134,8 +168,9 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor) -> torch.Ten
               float(pa), int(sa), ops.EP())
     dh1 = linear_bwd(bag, dqkv.view(M, 3 * D), s["h1"], at.in_proj_weight, at.in_proj_bias)
     dx0 = _empty((M, D), _F32, dx2)
-    _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, None,
-              bag.target(blk.norm1.weight), bag.target(blk.norm1.bias), M, D)
+    dgb = _zeros((REPL, 2, D), dx2)
+    _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, None, dgb, M, D)
+    _ln_param_grads(bag, blk.norm1, dgb, D)
     return dx0
 
 
@@ -238,31 +273,33 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
     conv, bn = s["conv"], s["bn"]
     y, out4, xv = s["y"], s["out4"], s["xv"]
     B, D, H, W, N = y.shape
-    sums = _zeros((2, N), y)
+    sums = _zeros((REPL, 2, N), y)
     dy = _empty((B, D, H, W, N), _BF, y)
     gelu = ACT["gelu"]
     if s["pool"]:
         _hip.call("mm_pool3d_bn_act_bwd_reduce", y, out4, dout, sums, B, D, H, W, N, gelu, float(s["drop_p"]),
                   int(s["seed"]), ops.EP())
-        _hip.call("mm_pool3d_bn_act_bwd_apply", y, out4, dout, sums, dy, B, D, H, W, N, gelu, float(s["drop_p"]),
+        sc = _compact(sums, 2 * N)
+        _hip.call("mm_pool3d_bn_act_bwd_apply", y, out4, dout, sc, dy, B, D, H, W, N, gelu, float(s["drop_p"]),
                   int(s["seed"]), ops.EP(), 1)
     else:
         args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
-        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, None, *args, 1)
-    gb, gg = bag.target(bn.bias), bag.target(bn.weight)
-    if gb is not None:
-        gb.add_(sums[0])
-    if gg is not None:
-        gg.add_(sums[1])
+        sc = _compact(sums, 2 * N)
+        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sc, dy, None, *args, 1)
+    _bn_param_grads(bag, bn, sc, N)
     cin = conv.in_channels
     dw = bag.target(conv.weight)
     if dw is not None:
         cinp_x = xv.shape[4]
-        ws = _zeros((N, 27, cinp_x), y)                        # channel-contiguous atomics
-        _hip.call("mm_conv3d_wgrad", dy, xv, ws, bag.target(conv.bias), B, D, H, W, cinp_x, N, cinp_x,
-                  27 * cinp_x, 1, cinp_x)
-        _hip.call("mm_wgrad_scatter", ws, dw, N, cin, 27, cinp_x)
+        db = bag.target(conv.bias)
+        dbr = _zeros((REPL, N), y) if db is not None else None
+        ws = _zeros((WREP, N, 27, cinp_x), y)                  # replicated, channel-contiguous atomics
+        _hip.call("mm_conv3d_wgrad", dy, xv, ws, dbr, B, D, H, W, cinp_x, N, cinp_x,
+                  27 * cinp_x, 1, cinp_x, WREP, N * 27 * cinp_x)
+        _hip.call("mm_wgrad_scatter", ws, dw, N, cin, 27, cinp_x, WREP)
+        if db is not None:
+            _reduce_into(db, dbr, N, N)
     if not need_dx:
         return None
     _, wd, cinp, coutp = ops.weights.get(conv.weight, True)
@@ -276,20 +313,21 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
     """backward of ops.conv3d_l1_bn_act (no input gradient: the volume is data)."""
     conv, bn, x = s["conv"], s["bn"], s["x"]
     B, _, D, H, W = x.shape
-    sums = _zeros((2, 32), x)
+    sums = _zeros((REPL, 2, 32), x)
     _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
               B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
-    ws = _zeros((27, 32), x)
-    _hip.call("mm_conv3d_l1", 3, x, s["wimg"], conv.bias, s["out4"], dout, sums, None, None, ws,
-              bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
-    gb, gg = bag.target(bn.bias), bag.target(bn.weight)
-    if gb is not None:
-        gb.add_(sums[0])
-    if gg is not None:
-        gg.add_(sums[1])
+    ws = _zeros((REPL, 27, 32), x)
+    db = bag.target(conv.bias)
+    dbr = _zeros((REPL, 32), x) if db is not None else None
+    sc = _compact(sums, 64)
+    _hip.call("mm_conv3d_l1", 3, x, s["wimg"], conv.bias, s["out4"], dout, sc, None, None, ws,
+              dbr, B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
+    _bn_param_grads(bag, bn, sc, 32)
+    if db is not None:
+        _reduce_into(db, dbr, 32, 32)
     dw = bag.target(conv.weight)
     if dw is not None:
-        _hip.call("mm_transpose_add", ws, dw, 27, 32)
+        _hip.call("mm_transpose_add", ws, dw, 27, 32, REPL)
 
 
 def volume_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor):
@@ -329,8 +367,9 @@ def proj_head_bwd(bag: GradBag, s: dict, da: torch.Tensor, need_dx=True):
     dhn = _empty((B, N), _F32, da)
     _hip.call("mm_act_bwd_f32", da, s["hn"], dhn, B * N, ACT["gelu"], float(s["p"]), int(s["seed"]), ops.EP())
     dz1 = _empty((B, N), _F32, da)
-    _hip.call("mm_layernorm_bwd", None, dhn, s["z1"], s["stat"], ln.weight, None, dz1, None,
-              bag.target(ln.weight), bag.target(ln.bias), B, N)
+    dgb = _zeros((REPL, 2, N), da)
+    _hip.call("mm_layernorm_bwd", None, dhn, s["z1"], s["stat"], ln.weight, None, dz1, None, dgb, B, N)
+    _ln_param_grads(bag, ln, dgb, N)
     dx = _empty((B, K), _F32, da) if need_dx else None
     _hip.call("mm_small_linear_bwd", dz1, s["x"], lin.weight, dx, bag.target(lin.weight), bag.target(lin.bias), B, K, N)
     return dx

@@ -142,6 +142,7 @@ class BridgeTrainer(nn.Module):
 
     # ---- the four segments of the autograd-free tape -------------------------
     def _seg_forward(self, eeg, fmri):
+        ops.arena.begin(eeg.device)
         self.bucket.g.zero_()
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
@@ -182,6 +183,7 @@ class BridgeTrainer(nn.Module):
         _hip.call("mm_adamw_clip", b.p, b.g, b.m, b.v, b.state, b.n, self.betas[0], self.betas[1],
                   self.eps, self.weight_decay, self.grad_clip, 1.0 / self.world)
         ops.weights_changed()
+        ops.arena.end()
 
     def _step_manual(self, eeg, fmri):
         z, saved = self._seg_forward(eeg, fmri)

@@ -91,4 +91,11 @@ __device__ __forceinline__ uint32_t mm_eff_seed(uint32_t base, const uint32_t* e
     return epoch ? base ^ (epoch[0] * 0x85EBCA6Bu + 0xC2B2AE35u) : base;
 }
 
+// Per-channel reductions (BN statistics, dgamma/dbeta, dbias, weight-gradient
+// partials) are accumulated with fp32 atomics.  Hundreds of workgroups adding to
+// the SAME address serialise in L2 (~25 ns each), so every such accumulator is
+// replicated MM_REPL times; a workgroup adds into replica (blockIdx.x % MM_REPL)
+// and the consumer sums the replicas.
+#define MM_REPL 32
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -23,6 +23,7 @@ struct Conv3dArgs {
     const bf16* x; const bf16* w;
     int B, D, H, W, Cin, Cout;
     const float* shift;           // [Cout] bias (nullptr = 0)
+    int dbg;                      // ablation switches for tools/kbench.py (0 in production)
     float* stats;                 // [2][Cout] sum / sumsq of (acc + shift)   (nullptr)
     float* out_f32;               // [B][D][H][W][Cout]
     bf16* out_bf16;
@@ -151,10 +152,11 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
     }
     if (a.stats) {
         __syncthreads();
+        float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * a.Cout;
         for (int i = tid; i < BN; i += 256)
             if (n0 + i < a.Cout) {
-                atomicAdd(&a.stats[n0 + i], sstat[i]);
-                atomicAdd(&a.stats[a.Cout + n0 + i], sstat[BN + i]);
+                atomicAdd(&rep[n0 + i], sstat[i]);
+                atomicAdd(&rep[a.Cout + n0 + i], sstat[BN + i]);
             }
     }
 }
@@ -170,6 +172,186 @@ int launch3d(const Conv3dArgs& a, hipStream_t st) {
     dim3 grid(a.B * ceil_div(a.D, TD) * ceil_div(a.H, 8) * ceil_div(a.W, 8), ceil_div(a.Cout, BN));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     return mm_check_launch("conv3d_fwd");
+}
+
+
+// ---------------------------------------------------------------------------
+// W-resident persistent variant for layers whose whole weight image fits LDS
+// (Cin = 32, Cout <= 64: 64 x 27 x 32 bf16 = 108 KiB).  One workgroup per CU
+// keeps ALL taps in LDS for its lifetime and walks 2x8x8 output tiles; the next
+// tile's (4x10x10)-row halo is fetched into registers while the current tile
+// runs its 27 x 2 x 2 MFMAs per wave, then swapped in behind one barrier pair.
+// LDS rows are unpadded 64-B rows; the 16-B chunk index is XOR-swizzled with
+// (row >> 2) & 3 (halo) / (n >> 2) & 3 (weights) so the 16-lane groups of
+// ds_read_b128 spread over all sixteen 16-B slots of a 256-B bank row.
+// ---------------------------------------------------------------------------
+constexpr int WR_CIN = 32;
+constexpr int WR_BN = 64;
+constexpr int WR_HROWS = 4 * HB * HB;                 // 400
+constexpr int WR_HREGS = (WR_HROWS * 4 + 255) / 256;  // uint4 per thread per halo tile (7)
+
+__device__ __forceinline__ int swz(int row_key, int seg) { return seg ^ ((row_key >> 2) & 3); }
+
+__global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Wl = reinterpret_cast<bf16*>(smem);                       // [64*27][32]
+    bf16* Hl = Wl + WR_BN * 27 * WR_CIN;                             // [400][32]
+    float* sstat = reinterpret_cast<float*>(Hl + WR_HROWS * WR_CIN); // [2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8, td = (a.D + 1) / 2;
+    const int ntiles = a.B * td * th * tw;
+
+    // ---- weights: once per workgroup.  All 27 loads of a thread are issued before
+    // the first LDS write (a load->store loop would serialise on load latency).
+    {
+        constexpr int WREGS = WR_BN * 27 * 4 / 256;      // 27
+        uint4 wv[WREGS];
+        const int wvalid = a.Cout * 27;
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            const int s = tid + i * 256, r = s >> 2, sg = s & 3;      // r = n * 27 + tap
+            wv[i] = (r < wvalid && !(a.dbg & 8)) ? *reinterpret_cast<const uint4*>(a.w + (size_t)r * WR_CIN + sg * 8) : make_uint4(0, 0, 0, 0);
+        }
+        if (!(a.dbg & 32))
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            const int s = tid + i * 256, r = s >> 2, sg = s & 3;
+            *reinterpret_cast<uint4*>(Wl + r * WR_CIN + swz(r / 27, sg) * 8) = wv[i];
+        }
+    }
+    if (a.stats)
+        for (int i = tid; i < 2 * WR_BN; i += 256) sstat[i] = 0.f;
+
+    auto load_halo = [&](int tile, uint4 (&regs)[WR_HREGS]) {
+        int q = tile;
+        const int w0 = (q % tw) * 8; q /= tw;
+        const int h0 = (q % th) * 8; q /= th;
+        const int d0 = (q % td) * 2; q /= td;
+        const bf16* xb = a.x + (size_t)q * a.D * a.H * a.W * WR_CIN;
+#pragma unroll
+        for (int i = 0; i < WR_HREGS; ++i) {
+            const int s = tid + i * 256;
+            const int r = s >> 2, sg = s & 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < WR_HROWS) {
+                const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
+                const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+                if (d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
+                    v = *reinterpret_cast<const uint4*>(xb + (((size_t)d * a.H + h) * a.W + w) * WR_CIN + sg * 8);
+            }
+            regs[i] = v;
+        }
+    };
+    auto store_halo = [&](const uint4 (&regs)[WR_HREGS]) {
+#pragma unroll
+        for (int i = 0; i < WR_HREGS; ++i) {
+            const int s = tid + i * 256;
+            const int r = s >> 2, sg = s & 3;
+            if (r < WR_HROWS) *reinterpret_cast<uint4*>(Hl + r * WR_CIN + swz(r, sg) * 8) = regs[i];
+        }
+    };
+
+    const int m = wave * 32 + lr;                                   // this lane's A row in the tile
+    const int abase = ((m >> 6) * HB + ((m >> 3) & 7)) * HB + (m & 7);
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float shv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = j * 32 + lr;
+        shv[j] = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    }
+
+    uint4 nxt[WR_HREGS];
+    int tile = blockIdx.x;
+    if (a.dbg & 16) tile = ntiles;
+    if (tile < ntiles) load_halo(tile, nxt);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                            // previous tile's reads are done
+        store_halo(nxt);
+        __syncthreads();
+        const int tnext = tile + gridDim.x;
+        if (tnext < ntiles && !(a.dbg & 4)) load_halo(tnext, nxt);  // in flight during the MFMAs below
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        if (!(a.dbg & 2))
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int arow = abase + (tap / 9) * HB * HB + ((tap / 3) % 3) * HB + (tap % 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int sg = ks * 2 + lh;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(Hl + arow * WR_CIN + swz(arow, sg) * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = j * 32 + lr;
+                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(Wl + (n * 27 + tap) * WR_CIN + swz(n, sg) * 8);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue straight from the accumulators
+        int q = tile;
+        const int w0 = (q % tw) * 8; q /= tw;
+        const int h0 = (q % th) * 8; q /= th;
+        const int d0 = (q % td) * 2; q /= td;
+        const int b = q;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = j * 32 + lr;
+            if (n >= a.Cout) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int d = d0 + (mm >> 6), h = h0 + ((mm >> 3) & 7), w = w0 + (mm & 7);
+                if (d < a.D && h < a.H && w < a.W) {
+                    const float v = acc[j][r] + shv[j];
+                    s1[j] += v; s2[j] += v * v;
+                    const size_t o = ((((size_t)b * a.D + d) * a.H + h) * a.W + w) * a.Cout + n;
+                    if (!(a.dbg & 1)) {
+                        if (a.out_f32) a.out_f32[o] = v;
+                        if (a.out_bf16) a.out_bf16[o] = (bf16)v;
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats && !(a.dbg & 64)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+            if (lh == 0) {
+                atomicAdd(&sstat[j * 32 + lr], s1[j]);
+                atomicAdd(&sstat[WR_BN + j * 32 + lr], s2[j]);
+            }
+        }
+        __syncthreads();
+        float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * a.Cout;
+        for (int i = tid; i < WR_BN; i += 256)
+            if (i < a.Cout) {
+                atomicAdd(&rep[i], sstat[i]);
+                atomicAdd(&rep[a.Cout + i], sstat[WR_BN + i]);
+            }
+    }
+}
+
+int launch3d_wres(const Conv3dArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(WR_BN * 27 + WR_HROWS) * WR_CIN * sizeof(bf16) + 2 * WR_BN * sizeof(float);
+    auto kern = conv3d_fwd_wres_kernel;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int ntiles = a.B * ceil_div(a.D, 2) * ceil_div(a.H, 8) * ceil_div(a.W, 8);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    return mm_check_launch("conv3d_fwd_wres");
 }
 
 // ---------------------------------------------------------------------------
@@ -193,8 +375,8 @@ __device__ __forceinline__ bf16x8 tr_frag_rows(const bf16* tile, int rowA, int r
 
 struct Wgrad3dArgs {
     const bf16* dy; const bf16* x; float* dw; float* dbias;
-    int B, D, H, W, Cin, Cout, Cin_real, tiles_per_wg;
-    long sn, sc, stap;
+    int B, D, H, W, Cin, Cout, Cin_real, tiles_per_wg, nrep;
+    long sn, sc, stap, rep_stride;
 };
 
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
@@ -262,19 +444,20 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
         }
     }
     const int c = c0 + wc * 32 + (lane & 31);
+    float* dwr = a.dw + (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
     if (c < a.Cin_real) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < a.Cout) atomicAdd(a.dw + n * a.sn + c * a.sc + (kd * 9 + t9) * a.stap, acc[t9][r]);
+                if (n < a.Cout) atomicAdd(dwr + n * a.sn + c * a.sc + (kd * 9 + t9) * a.stap, acc[t9][r]);
             }
     }
     if (a.dbias && kd == 0 && cblk == 0 && wc == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         const int n = n0 + wn * 32 + (lane & 31);
-        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + n, bsum);
+        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(blockIdx.x % MM_REPL) * a.Cout + n, bsum);
     }
 }
 
@@ -320,7 +503,7 @@ __global__ void pool3_bn_act_kernel(Pool3Args a) {
     for (int q = 0; q < 4; ++q) {
         sc[q] = a.out4[n4 + q]; sh[q] = a.out4[a.N + n4 + q];
         mu[q] = a.out4[2 * a.N + n4 + q]; rs[q] = a.out4[3 * a.N + n4 + q];
-        c0[q] = (MODE == 2 && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;
+        c0[q] = (MODE == 2 && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;    // compact [2][N] sums
         c1[q] = (MODE == 2 && a.train) ? a.sums[a.N + n4 + q] * a.inv_count : 0.f;
     }
     if (active)
@@ -392,9 +575,10 @@ __global__ void pool3_bn_act_kernel(Pool3Args a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) { atomicAdd(&red[0][n4 + c], s0[c]); atomicAdd(&red[1][n4 + c], s1[c]); }
         __syncthreads();
+        float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
         for (int i = threadIdx.x; i < a.N; i += 256) {
-            atomicAdd(&a.sums_out[i], red[0][i]);
-            atomicAdd(&a.sums_out[a.N + i], red[1][i]);
+            atomicAdd(&rep[i], red[0][i]);
+            atomicAdd(&rep[a.N + i], red[1][i]);
         }
     }
 }
@@ -424,7 +608,11 @@ int pool3_launch(int mode, const float* y, const float* out4, const void* dout, 
 
 }  // namespace
 
+static int g_dbg = 0;
+
 extern "C" {
+
+int mm_debug_flags(int flags, hipStream_t) { g_dbg = flags; return 0; }
 
 int mm_pack_volume_bf16(const float* x, void* y, int64_t nvox, int Cp, hipStream_t st) {
     MM_REQUIRE(x && y && nvox > 0 && Cp % 8 == 0, "pack_volume: bad args");
@@ -439,8 +627,9 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
                   float* stats, float* out_f32, void* out_bf16, hipStream_t st) {
     MM_REQUIRE(x && w && (out_f32 || out_bf16) && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: null/invalid");
     MM_REQUIRE(Cin == 16 || Cin % 32 == 0, "conv3d_fwd: Cin=%d must be 16 or a multiple of 32", Cin);
-    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, stats, out_f32, (bf16*)out_bf16};
+    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, g_dbg, stats, out_f32, (bf16*)out_bf16};
     const long tiles2 = (long)B * ceil_div(D, 2) * ceil_div(H, 8) * ceil_div(W, 8);
+    if (Cin == WR_CIN && Cout <= WR_BN && Cout > 32 && D % 2 == 0 && tiles2 >= 256) return launch3d_wres(a, st);
     if (Cout <= 32) return launch3d<2, 32, 4, 1>(a, st);
     if (Cout <= 64) {
         if (tiles2 >= 256 && D % 2 == 0) return launch3d<2, 64, 4, 1>(a, st);
@@ -451,13 +640,15 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
 }
 
 int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W, int Cin,
-                    int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, hipStream_t st) {
+                    int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep, int64_t rep_stride,
+                    hipStream_t st) {
     MM_REQUIRE(dy && x && dw && B > 0, "conv3d_wgrad: null/invalid");
+    MM_REQUIRE(nrep >= 1 && nrep <= 64, "conv3d_wgrad: nrep");
     MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cin_real <= Cin, "conv3d_wgrad: channels");
     Wgrad3dArgs a;
     a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cin_real = Cin_real;
-    a.sn = sn; a.sc = sc; a.stap = stap;
+    a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride;
     const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
     const int par = ceil_div(Cout, 64) * 3 * ceil_div(Cin, 64);
     int chunks = ceil_div(384, par);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
     float sc = 1.f, sh = 0.f, mu = 0.f, rs = 1.f, c0 = 0.f, c1 = 0.f;
     if (MODE >= 1) {
         sc = a.out4[lr]; sh = a.out4[32 + lr]; mu = a.out4[64 + lr]; rs = a.out4[96 + lr];
-        if (MODE == 3 && a.train) { c0 = a.sums[lr] * a.inv_count; c1 = a.sums[32 + lr] * a.inv_count; }
+        if (MODE == 3 && a.train) { c0 = a.sums[lr] * a.inv_count; c1 = a.sums[32 + lr] * a.inv_count; }   // compact sums
     }
     float acc1 = 0.f, acc2 = 0.f;          // per-lane channel sums (modes 0, 2) / dbias (mode 3)
     f32x16 dwacc;                          // mode 3: D[tap][n]
@@ -218,16 +218,17 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
         __syncthreads();
         if (lh == 0) red[wave][lr] = acc1;
         __syncthreads();
+        const int rep = blockIdx.x % MM_REPL;
         if (tid < 32) {
             const float s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-            if (MODE == 3) { if (a.dbias) atomicAdd(&a.dbias[tid], s); }
-            else atomicAdd(&a.stats[tid], s);
+            if (MODE == 3) { if (a.dbias) atomicAdd(&a.dbias[rep * 32 + tid], s); }
+            else atomicAdd(&a.stats[rep * 64 + tid], s);
         }
         if (MODE != 3) {
             __syncthreads();
             if (lh == 0) red[wave][lr] = acc2;
             __syncthreads();
-            if (tid < 32) atomicAdd(&a.stats[32 + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+            if (tid < 32) atomicAdd(&a.stats[rep * 64 + 32 + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
         }
     }
     if (MODE == 3) {
@@ -239,14 +240,20 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
             if (tap < 27) atomicAdd(&wred[tap][lr], dwacc[r]);
         }
         __syncthreads();
-        for (int i = tid; i < 27 * 32; i += 256) atomicAdd(&a.dw[i], (&wred[0][0])[i]);
+        float* dwr = a.dw + (size_t)(blockIdx.x % MM_REPL) * 27 * 32;
+        for (int i = tid; i < 27 * 32; i += 256) atomicAdd(&dwr[i], (&wred[0][0])[i]);
     }
 }
 
-// dst[c][r] += src[r][c]
-__global__ void transpose_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+// dst[c][r] += sum_rep src[rep][r][c]
+__global__ void transpose_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, int nrep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R * C) { const int r = i / C, c = i % C; dst[(size_t)c * R + r] += src[i]; }
+    if (i < R * C) {
+        const int r = i / C, c = i % C;
+        float s = 0.f;
+        for (int k = 0; k < nrep; ++k) s += src[(size_t)k * R * C + i];
+        dst[(size_t)c * R + r] += s;
+    }
 }
 
 inline uint32_t thresh_l1(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
@@ -285,9 +292,9 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     return mm_check_launch("conv3d_l1");
 }
 
-int mm_transpose_add(const float* src, float* dst, int R, int C, hipStream_t st) {
-    MM_REQUIRE(src && dst && R > 0 && C > 0, "transpose_add: null");
-    hipLaunchKernelGGL(transpose_add_kernel, dim3(ceil_div(R * C, 256)), dim3(256), 0, st, src, dst, R, C);
+int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t st) {
+    MM_REQUIRE(src && dst && R > 0 && C > 0 && nrep >= 1, "transpose_add: null");
+    hipLaunchKernelGGL(transpose_add_kernel, dim3(ceil_div(R * C, 256)), dim3(256), 0, st, src, dst, R, C, nrep);
     return mm_check_launch("transpose_add");
 }
 

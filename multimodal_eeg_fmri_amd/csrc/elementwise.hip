@@ -19,8 +19,10 @@ __global__ void bn_finalize_kernel(const float* stats, const float* gamma, const
     if (n >= N) return;
     float mean, var;
     if (mode == 0) {
-        mean = stats[n] / count;
-        var = fmaxf(stats[N + n] / count - mean * mean, 0.f);
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < MM_REPL; ++r) { s1 += stats[(size_t)r * 2 * N + n]; s2 += stats[(size_t)r * 2 * N + N + n]; }
+        mean = s1 / count;
+        var = fmaxf(s2 / count - mean * mean, 0.f);
         run_mean[n] = (1.f - momentum) * run_mean[n] + momentum * mean;
         const float unb = count > 1.f ? var * count / (count - 1.f) : var;
         run_var[n] = (1.f - momentum) * run_var[n] + momentum * unb;
@@ -167,7 +169,7 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     for (int q = 0; q < 4; ++q) {
         scs[q] = a.scale[n4 + q]; shs[q] = a.shift[n4 + q];
         mus[q] = a.mean ? a.mean[n4 + q] : 0.f; rss[q] = a.rstd ? a.rstd[n4 + q] : 1.f;
-        c0[q] = (APPLY && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;
+        c0[q] = (APPLY && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;       // compact [2][N] sums
         c1[q] = (APPLY && a.train) ? a.sums[a.N + n4 + q] * a.inv_count : 0.f;
     }
     if (active)
@@ -235,9 +237,10 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
                 atomicAdd(&red[1][n4 + q], s1[q]);
             }
         __syncthreads();
+        float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
         for (int i = threadIdx.x; i < a.N; i += 256) {
-            atomicAdd(&a.sums_out[i], red[0][i]);
-            atomicAdd(&a.sums_out[a.N + i], red[1][i]);
+            atomicAdd(&rep[i], red[0][i]);
+            atomicAdd(&rep[a.N + i], red[1][i]);
         }
     }
 }
@@ -280,8 +283,7 @@ __global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const flo
                                      const float* __restrict__ x, const float* __restrict__ stat,
                                      const float* __restrict__ g, const float* __restrict__ dres,
                                      float* __restrict__ dx, bf16* __restrict__ dx_bf16,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                     int rows_per_wave) {
+                                     float* __restrict__ dgb, int M, int rows_per_wave) {
     constexpr int D = VPL * 64;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -325,9 +327,13 @@ __global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const flo
         atomicAdd(&red[1][i * 64 + lane], ab[i]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += blockDim.x) {
-        if (dgamma) atomicAdd(&dgamma[i], red[0][i]);
-        if (dbeta) atomicAdd(&dbeta[i], red[1][i]);
+    // dgb = replicated [MM_REPL][2][D] scratch (gamma row, beta row)
+    if (dgb) {
+        float* rep = dgb + (size_t)(blockIdx.x % MM_REPL) * 2 * D;
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+            atomicAdd(&rep[i], red[0][i]);
+            atomicAdd(&rep[D + i], red[1][i]);
+        }
     }
 }
 
@@ -339,7 +345,7 @@ __global__ void colsum_kernel(const bf16* __restrict__ a_bf16, const float* __re
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.f;
         for (int m = m0; m < m1; ++m) s += a_bf16 ? (float)a_bf16[(size_t)m * N + n] : a_f32[(size_t)m * N + n];
-        atomicAdd(&out[n], s);
+        atomicAdd(&out[(size_t)(blockIdx.x % MM_REPL) * N + n], s);
     }
 }
 
@@ -489,13 +495,12 @@ int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void
 }
 
 int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stat, const float* gamma,
-                     const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int M, int D,
-                     hipStream_t st) {
+                     const float* dres, float* dx, void* dx_bf16, float* dgb_repl, int M, int D, hipStream_t st) {
     MM_REQUIRE((dy_bf16 || dy_f32) && x && stat && gamma && (dx || dx_bf16), "layernorm_bwd: null");
     const int rpw = M >= 8192 ? 8 : (M >= 1024 ? 2 : 1);
     const dim3 grid(ceil_div(M, 4 * rpw)), block(256);
     LN_DISPATCH(D, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, 0, st, (const bf16*)dy_bf16, dy_f32, x,
-                                      stat, gamma, dres, dx, (bf16*)dx_bf16, dgamma, dbeta, M, rpw));
+                                      stat, gamma, dres, dx, (bf16*)dx_bf16, dgb_repl, M, rpw));
     return mm_check_launch("layernorm_bwd");
 }
 

@@ -114,10 +114,11 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
                 atomicAdd(&sstat[BN + cg * 4 + c], s2[c]);
             }
         __syncthreads();
+        float* rep = e.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * N;
         for (int i = tid; i < BN; i += 256)
             if (n0 + i < N) {
-                atomicAdd(&e.stats[n0 + i], sstat[i]);
-                atomicAdd(&e.stats[N + n0 + i], sstat[BN + i]);
+                atomicAdd(&rep[n0 + i], sstat[i]);
+                atomicAdd(&rep[N + n0 + i], sstat[BN + i]);
             }
     }
 }
@@ -313,8 +314,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int row0, int col0, 
 
 struct WgradArgs {
     const bf16* dy; const bf16* x; float* dw; float* dbias;
-    int B, T, Cin, Cout, pad, Cin_real, rows_per_wg;
-    long sn, sc, stap;
+    int B, T, Cin, Cout, pad, Cin_real, rows_per_wg, nrep;
+    long sn, sc, stap, rep_stride;
 };
 
 template <int TAPS>
@@ -370,32 +371,51 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
     }
     // D[i = n][j = c]: lane owns column c, rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int c = c0 + wc * 32 + (lane & 31);
+    float* dwr = a.dw + (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
     if (c < a.Cin_real) {
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < a.Cout) atomicAdd(a.dw + n * a.sn + c * a.sc + tp * a.stap, acc[tp][r]);
+                if (n < a.Cout) atomicAdd(dwr + n * a.sn + c * a.sc + tp * a.stap, acc[tp][r]);
             }
     }
     if (a.dbias && blockIdx.z == 0 && wc == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         const int n = n0 + wn * 32 + (lane & 31);
-        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + n, bsum);
+        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(blockIdx.x % MM_REPL) * a.Cout + n, bsum);
     }
 }
 
-// dw[n][c][tap] += ws[n][tap][c]   (contiguous-atomics workspace -> PyTorch layout)
+// dw[n][c][tap] += sum_rep ws[rep][n][tap][c]   (replicated contiguous-atomics workspace -> PyTorch layout)
 __global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps,
-                                     int Cinp) {
+                                     int Cinp, int nrep) {
     const size_t total = (size_t)Cout * Cin * taps;
+    const size_t rstride = (size_t)Cout * taps * Cinp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int tap = (int)(i % taps);
         const int c = (int)((i / taps) % Cin);
         const int n = (int)(i / ((size_t)taps * Cin));
-        dw[i] += ws[((size_t)n * taps + tap) * Cinp + c];
+        float s = 0.f;
+        for (int r = 0; r < nrep; ++r) s += ws[r * rstride + ((size_t)n * taps + tap) * Cinp + c];
+        dw[i] += s;
     }
+}
+
+// dst[k] += sum_rep src[rep][k]
+// one replica per lane (32 lanes per output), one shuffle reduction: a single
+// load round trip instead of a 32-deep dependent chain
+__global__ void reduce_replicas_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int nrep,
+                                       long rep_stride) {
+    const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int r0 = threadIdx.x & 31;
+    float s = 0.f;
+    if (k < K)
+        for (int r = r0; r < nrep; r += 32) s += src[(size_t)r * rep_stride + k];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (k < K && r0 == 0) dst[k] += s;
 }
 
 template <int TAPS>
@@ -476,14 +496,16 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
 }
 
 int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin, int Cout,
-                    int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap, hipStream_t st) {
+                    int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep,
+                    int64_t rep_stride, hipStream_t st) {
     MM_REQUIRE(dy && x && dw && B > 0 && T > 0, "conv1d_wgrad: null/invalid");
+    MM_REQUIRE(nrep >= 1 && nrep <= 64, "conv1d_wgrad: nrep");
     MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "conv1d_wgrad: Cin=%d Cout=%d must be multiples of 8", Cin, Cout);
     MM_REQUIRE(Cin_real > 0 && Cin_real <= Cin, "conv1d_wgrad: Cin_real");
     WgradArgs a;
     a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
     a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.pad = pad; a.Cin_real = Cin_real;
-    a.sn = sn; a.sc = sc; a.stap = stap;
+    a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride;
     // aim for ~384 workgroups: split each batch item's T into chunks of whole 64-row tiles
     const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
     const int tilesT = ceil_div(T, WG_MK);
@@ -500,12 +522,18 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
     }
 }
 
-int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, hipStream_t st) {
-    MM_REQUIRE(ws && dw && Cout > 0 && Cin > 0 && taps > 0 && Cinp >= Cin, "wgrad_scatter: bad args");
+int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t rep_stride, hipStream_t st) {
+    MM_REQUIRE(src && dst && K > 0 && nrep >= 1 && rep_stride >= K, "reduce_replicas: bad args");
+    hipLaunchKernelGGL(reduce_replicas_kernel, dim3(ceil_div(K, 8)), dim3(256), 0, st, src, dst, K, nrep, (long)rep_stride);
+    return mm_check_launch("reduce_replicas");
+}
+
+int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, int nrep, hipStream_t st) {
+    MM_REQUIRE(ws && dw && Cout > 0 && Cin > 0 && taps > 0 && Cinp >= Cin && nrep >= 1, "wgrad_scatter: bad args");
     const size_t total = (size_t)Cout * Cin * taps;
     int grid = (int)((total + 255) / 256);
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(grid), dim3(256), 0, st, ws, dw, Cout, Cin, taps, Cinp);
+    hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(grid), dim3(256), 0, st, ws, dw, Cout, Cin, taps, Cinp, nrep);
     return mm_check_launch("wgrad_scatter");
 }
 

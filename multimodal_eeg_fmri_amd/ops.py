@@ -14,6 +14,7 @@ Conventions
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -45,7 +46,49 @@ def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+REPL = 32          # replica count of every per-channel accumulator (csrc/common.h: MM_REPL)
+WREP = 8           # replicas of the conv weight-gradient workspaces
+
+
+class _Arena:
+    """one zeroed fp32 scratch buffer per training step: every accumulator the
+    kernels add into (stats, sums, wgrad workspaces ...) is a slice of it, so a
+    step pays ONE memset instead of ~40 tiny fill launches."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.active = False
+
+    def begin(self, device, nfloats: int = 6 << 20):
+        if self.buf is None or self.buf.device != device or self.buf.numel() < nfloats:
+            self.buf = torch.empty(nfloats, dtype=_F32, device=device)
+        self.buf.zero_()
+        self.off = 0
+        self.active = True
+
+    def end(self):
+        self.active = False
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if not self.active or self.buf.device != device or self.off + n > self.buf.numel():
+            return None
+        out = self.buf[self.off:self.off + n].view(shape)
+        self.off += (n + 63) // 64 * 64
+        return out
+
+
+arena = _Arena()
+
+
 def _zeros(shape, like, dtype=_F32):
+    if dtype == _F32:
+        t = arena.take(tuple(shape), like.device)
+        if t is not None:
+            return t
     return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
@@ -117,10 +160,13 @@ class _WeightCache:
         self._gen += 1
 
     def get(self, w: torch.Tensor, need_dgrad: bool, key=None):
-        key = id(w if key is None else key)
-        ver = (w.data_ptr(), (w if key is None else w)._version, self._gen, tuple(w.shape))
-        hit = self._store.get(key)
-        if hit is not None and hit[0] == ver and (hit[2] is not None or not need_dgrad):
+        owner = w if key is None else key          # the nn.Parameter the image belongs to
+        k = id(owner)
+        ver = (owner.data_ptr(), owner._version, self._gen, tuple(w.shape))
+        hit = self._store.get(k)
+        # the weak reference rules out a dead parameter whose id/address got reused
+        if (hit is not None and hit[5]() is owner and hit[0] == ver
+                and (hit[2] is not None or not need_dgrad)):
             return hit[1], hit[2], hit[3], hit[4]
         wd3 = w.detach()
         if wd3.dim() == 2:
@@ -128,12 +174,14 @@ class _WeightCache:
         if wd3.dim() == 5:
             wd3 = wd3.reshape(wd3.shape[0], wd3.shape[1], -1)
         wd3 = wd3.contiguous()
-        cout, cin, k = wd3.shape
+        cout, cin, k3 = wd3.shape
         cinp, coutp = cpad(cin), cpad(cout)
-        wf = _empty((cout, k, cinp), _BF, w)
-        wd = _empty((cinp, k, coutp), _BF, w) if need_dgrad else None
-        _hip.call("mm_prep_conv_weight", wd3, wf, wd, cout, cin, k, cinp, coutp if need_dgrad else 0)
-        self._store[key] = (ver, wf, wd, cinp, coutp)
+        wf = _empty((cout, k3, cinp), _BF, w)
+        wd = _empty((cinp, k3, coutp), _BF, w) if need_dgrad else None
+        _hip.call("mm_prep_conv_weight", wd3, wf, wd, cout, cin, k3, cinp, coutp if need_dgrad else 0)
+        if len(self._store) > 4096:
+            self._store = {i: e for i, e in self._store.items() if e[5]() is not None}
+        self._store[k] = (ver, wf, wd, cinp, coutp, weakref.ref(owner))
         return wf, wd, cinp, coutp
 
 
@@ -241,7 +289,7 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
         r = igemm(xb, wf, k, pad, cout, scale=out4[0], shift=out4[1], act=act, pe=pe, pool=pool,
                   out_f32=want_f32, out_bf16=want_bf16)
         return r, None
-    stats = _zeros((2, cout), xb)
+    stats = _zeros((REPL, 2, cout), xb)
     y = igemm(xb, wf, k, pad, cout, shift=conv.bias, stats=stats, out_f32=True, out_bf16=False)["f32"]
     out4 = bn_finalize_train(bn, stats, B * T)
     seed = _next_seed() if drop_p > 0 else 0
@@ -393,7 +441,7 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     assert cp == cinp, (cp, cinp)
     y = _empty((B, D, H, W, cout), _F32, xv)
     if training:
-        stats = _zeros((2, cout), xv)
+        stats = _zeros((REPL, 2, cout), xv)
         end = kernel_timer.bracket(f"conv3d_fwd_c{cinp}")
         _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, stats, y, None)
         if end is not None:
@@ -423,7 +471,7 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     p = drop_p if training else 0.0
     seed = _next_seed() if p > 0 else 0
     if training:
-        stats = _zeros((2, 32), x)
+        stats = _zeros((REPL, 2, 32), x)
         _hip.call("mm_conv3d_l1", 0, x, wimg, conv.bias, None, None, None, stats, None, None, None,
                   B, D, H, W, 1, 0.0, 0, None)
         out4 = bn_finalize_train(bn, stats, B * D * H * W)

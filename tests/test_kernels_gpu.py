@@ -70,9 +70,10 @@ def test_conv1d_fwd_epilogue_bn_gelu_pool_stats():
     hip.call("mm_pack_nct_bf16", x.cuda(), xg, B, C, T, C)
     wf, _ = _prep_w(hip, w, C)
     out = torch.empty(B, T // 2, Cout, dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros(2, Cout, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
     hip.call("mm_conv1d_fwd", xg, wf, B, T, C, Cout, k, k // 2, scale.cuda(), shift.cuda(), 1, None, None, 2,
              stats, None, out, None, 0.0, 0, None)
+    stats = stats.sum(0)
     z = F.conv1d(_bf(x), _bf(w), None, padding=k // 2) * scale[None, :, None] + shift[None, :, None]
     want = F.max_pool1d(F.gelu(z), 2).transpose(1, 2)
     torch.testing.assert_close(out.float().cpu(), want, rtol=1e-2, atol=1e-2)
@@ -129,9 +130,10 @@ def test_conv1d_wgrad_matches_autograd(B, C, T, Cout, k):
     xg = torch.empty(B, T, cp, dtype=torch.bfloat16, device="cuda")
     hip.call("mm_pack_nct_bf16", x.cuda(), xg, B, C, T, cp)
     dyg = dy.transpose(1, 2).contiguous().cuda().to(torch.bfloat16)
-    dw = torch.zeros(Cout, C, k, device="cuda")
-    db = torch.zeros(Cout, device="cuda")
-    hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1)
+    dw = torch.zeros(2, Cout, C, k, device="cuda")
+    db = torch.zeros(32, Cout, device="cuda")
+    hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1, 2, Cout * C * k)
+    dw, db = dw.sum(0), db.sum(0)
     torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
 
@@ -170,10 +172,10 @@ def test_layernorm_fwd_bwd(M, D):
     hip.call("mm_layernorm_fwd", x.cuda(), gam.cuda(), bet.cuda(), out, None, stat, M, D, 1e-5)
     torch.testing.assert_close(out.float().cpu(), y.detach(), rtol=1e-2, atol=1e-2)
     dx = torch.empty(M, D, device="cuda")
-    dg = torch.zeros(D, device="cuda")
-    db = torch.zeros(D, device="cuda")
+    dgb = torch.zeros(32, 2, D, device="cuda")
     hip.call("mm_layernorm_bwd", dy.cuda().to(torch.bfloat16), None, x.cuda(), stat, gam.cuda(), dres.cuda(), dx, None,
-             dg, db, M, D)
+             dgb, M, D)
+    dg, db = dgb.sum(0)[0], dgb.sum(0)[1]
     torch.testing.assert_close(dx.cpu(), xr.grad + dres, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-3)
@@ -198,7 +200,9 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     dout = _bf(torch.randn(R, S // pool, N, generator=g))
     a.backward(dout)
     yg = y.cuda()
-    stats = torch.stack([y.sum(dim=(0, 1)), (y * y).sum(dim=(0, 1))]).cuda()
+    stats = torch.zeros(32, 2, N)
+    stats[3] = torch.stack([y.sum(dim=(0, 1)), (y * y).sum(dim=(0, 1))])
+    stats = stats.cuda()
     rmg, rvg = rm.cuda(), rv.cuda()
     out4 = torch.empty(4, N, device="cuda")
     hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), rmg, rvg, None, out4, N, float(R * S), 0.1, 1e-5, 0)
@@ -209,13 +213,13 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     ob = torch.empty(R, S // pool, N, dtype=torch.bfloat16, device="cuda")
     hip.call("mm_bn_act_fwd", yg, out4[0], out4[1], None, ob, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None)
     torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
-    sums = torch.zeros(2, N, device="cuda")
+    sums = torch.zeros(32, 2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
     hip.call("mm_bn_act_bwd_reduce", yg, out4, dg, None, sums, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None)
-    torch.testing.assert_close(sums[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(sums[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(sums.sum(0)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(sums.sum(0)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1)
+    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums.sum(0).contiguous(), dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
 
 
@@ -237,16 +241,18 @@ def test_conv3d_fwd_wgrad_dgrad(B, Cin, Cout, D, H, W):
     wf, wd = _prep_w(hip, w.detach().reshape(Cout, Cin, 27), Cin, Cout)
     xg = _vol_cl(x.detach())
     out = torch.empty(B, D, H, W, Cout, device="cuda")
-    stats = torch.zeros(2, Cout, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
     hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, bias.detach().cuda(), stats, out, None)
+    stats = stats.sum(0)
     want = y.detach().permute(0, 2, 3, 4, 1)
     torch.testing.assert_close(out.cpu(), want, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(stats[0].cpu(), want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(stats[1].cpu(), (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1e-2)
     dyg = _vol_cl(dy)
-    dw = torch.zeros(Cout, Cin, 27, device="cuda")
-    db = torch.zeros(Cout, device="cuda")
-    hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1)
+    dw = torch.zeros(3, Cout, Cin, 27, device="cuda")
+    db = torch.zeros(32, Cout, device="cuda")
+    hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1, 3, Cout * Cin * 27)
+    dw, db = dw.sum(0), db.sum(0)
     torch.testing.assert_close(dw.cpu().view_as(w), w.grad, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
     dx = torch.empty(B, D, H, W, Cin, device="cuda")
@@ -268,20 +274,25 @@ def test_pool3d_bn_act_train_fwd_bwd():
     a.backward(dout)
     yg = y.cuda()
     flat = y.reshape(-1, N)
-    stats = torch.stack([flat.sum(0), (flat * flat).sum(0)]).cuda()
+    stats = torch.zeros(32, 2, N)
+    stats[0] = torch.stack([flat.sum(0), (flat * flat).sum(0)])
+    stats = stats.cuda()
     out4 = torch.empty(4, N, device="cuda")
     hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"),
              None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0)
     ob = torch.empty(B, D // 2, H // 2, W // 2, N, dtype=torch.bfloat16, device="cuda")
     hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob, B, D, H, W, N, 1, 0.0, 0, None)
     torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
-    sums = torch.zeros(2, N, device="cuda")
+    sums = torch.zeros(32, 2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
     hip.call("mm_pool3d_bn_act_bwd_reduce", yg, out4, dg, sums, B, D, H, W, N, 1, 0.0, 0, None)
-    torch.testing.assert_close(sums[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(sums[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(sums.sum(0)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(sums.sum(0)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(B, D, H, W, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_pool3d_bn_act_bwd_apply", yg, out4, dg, sums, dy, B, D, H, W, N, 1, 0.0, 0, None, 1)
+    sc = torch.zeros(2 * N, device="cuda")
+    hip.call("mm_reduce_replicas", sums, sc, 2 * N, 32, 2 * N)
+    torch.testing.assert_close(sc.cpu(), sums.sum(0).flatten().cpu(), rtol=1e-5, atol=1e-5)
+    hip.call("mm_pool3d_bn_act_bwd_apply", yg, out4, dg, sc, dy, B, D, H, W, N, 1, 0.0, 0, None, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
 
 

@@ -53,7 +53,7 @@ def conv1d_case(B, T, Cin, Cout, k):
     wf = torch.empty(Cout, k, Cin, dtype=BF, device="cuda")
     _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, k, Cin, 0)
     of = torch.empty(B, T, Cout, device="cuda")
-    stats = torch.zeros(2, Cout, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
     b = torch.randn(Cout, device="cuda")
 
     def fn():
@@ -66,41 +66,77 @@ def conv1d_case(B, T, Cin, Cout, k):
 def conv1d_wgrad_case(B, T, Cin, Cout, k):
     x = torch.randn(B, T, Cin, device="cuda").to(BF)
     dy = torch.randn(B, T, Cout, device="cuda").to(BF)
-    ws = torch.zeros(Cout, k, Cin, device="cuda")
-    db = torch.zeros(Cout, device="cuda")
+    ws = torch.zeros(8, Cout, k, Cin, device="cuda")
+    db = torch.zeros(32, Cout, device="cuda")
 
     def fn():
-        _hip.call("mm_conv1d_wgrad", dy, x, ws, db, B, T, Cin, Cout, k, k // 2, Cin, k * Cin, 1, Cin)
+        _hip.call("mm_conv1d_wgrad", dy, x, ws, db, B, T, Cin, Cout, k, k // 2, Cin, k * Cin, 1, Cin, 8, Cout * k * Cin)
     us = timeit(fn)
     fl = 2.0 * B * T * Cin * Cout * k
     print(f"wgrad1d B={B} T={T} Cin={Cin} Cout={Cout} k={k}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
 
 
-def conv3d_case(B, S, Cin, Cout):
+def conv3d_case(B, S, Cin, Cout, wgrad=True):
     x = torch.randn(B, S, S, S, Cin, device="cuda").to(BF)
     w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
     wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
     _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
     of = torch.empty(B, S, S, S, Cout, device="cuda")
-    stats = torch.zeros(2, Cout, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
     b = torch.randn(Cout, device="cuda")
 
     def fn():
         _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, of, None)
-    us = timeit(fn)
+    us = graph_time(fn)
     fl = 2.0 * B * S ** 3 * Cin * Cout * 27
-    print(f"conv3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
+    print(f"conv3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s (graph-replayed)")
+    if not wgrad:
+        return
     dy = torch.randn(B, S, S, S, Cout, device="cuda").to(BF)
-    ws = torch.zeros(Cout, 27, Cin, device="cuda")
+    ws = torch.zeros(8, Cout, 27, Cin, device="cuda")
 
     def fn2():
-        _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin)
+        _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin, 8, Cout * 27 * Cin)
     us = timeit(fn2)
     print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
 
 
+def floor_case():
+    x = torch.zeros(64, device="cuda")
+    y = torch.zeros(64, dtype=BF, device="cuda")
+    us = timeit(lambda: _hip.call("mm_cast_bf16", x, y, 64))
+    print(f"harness floor (64-element cast through _hip.call): {us:8.1f} us")
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _hip.call("mm_cast_bf16", x, y, 64)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            _hip.call("mm_cast_bf16", x, y, 64)
+    us = timeit(g.replay, iters=5) / 20
+    print(f"same, 20 launches per hipGraph replay: {us:8.1f} us per kernel")
+
+
+def graph_time(fn, n=20):
+    """per-launch time of fn when n launches are replayed from one hipGraph"""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    return timeit(g.replay, iters=5) / n
+
+
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    if "floor" in flt:
+        floor_case()
     M = 32 * 512
     if "lin" in flt or not flt:
         linear_case(M, 128, 384)
@@ -116,6 +152,12 @@ def main():
         conv1d_wgrad_case(32, 1024, 64, 128, 5)
         conv1d_wgrad_case(32, 512, 128, 128, 3)
         conv1d_wgrad_case(1, M, 128, 512, 1)
+    if "abl" in flt:
+        for f in (24, 24 + 32, 24 + 64, 24 + 96):
+            _hip.call("mm_debug_flags", f)
+            print("dbg flags", f, end=": ")
+            conv3d_case(32, 16, 32, 64, wgrad=False)
+        _hip.call("mm_debug_flags", 0)
     if "conv3" in flt or not flt:
         conv3d_case(32, 16, 32, 64)
         conv3d_case(32, 8, 64, 128)
