@@ -79,6 +79,10 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
  * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */
 int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, int nrep,
                      hipStream_t stream);
+/* ndesc independent replica reductions in one launch per 64 descriptors; desc_host =
+ * HOST array of {const float* src; float* dst; int64 K, nrep, rep_stride} (40 bytes
+ * each), copied into the kernel arguments (capturable in a hipGraph) */
+int mm_reduce_many(const void* desc_host, int ndesc, hipStream_t stream);
 /* dst[k] += sum_rep src[rep * rep_stride + k],  k < K */
 int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t rep_stride, hipStream_t stream);
 

@@ -17,17 +17,44 @@ from . import ops
 from .ops import ACT, REPL, WREP, _BF, _F32, _empty, _zeros
 
 
+_BAG = {"cur": None}
+
+
 def _reduce_into(dst, src, K, stride, offset=0, nrep=REPL):
-    """dst[k] += sum_rep src[rep*stride + offset + k]"""
-    if dst is not None:
+    """dst[k] += sum_rep src[rep*stride + offset + k]   (deferred to GradBag.flush when a bag is active)"""
+    if dst is None:
+        return
+    bag = _BAG["cur"]
+    if bag is not None:
+        bag.defer(src.data_ptr() + 4 * offset, dst, K, nrep, stride, keep=src)
+    else:
         _hip.call("mm_reduce_replicas", src.data_ptr() + 4 * offset, dst, K, nrep, stride)
+
+
+class deferred:
+    """context: parameter-gradient replica reductions issued inside are collected
+    in ``bag`` and executed as one mm_reduce_many launch on exit."""
+
+    def __init__(self, bag, device):
+        self.bag, self.device = bag, device
+
+    def __enter__(self):
+        self.prev = _BAG["cur"]
+        _BAG["cur"] = self.bag
+        return self.bag
+
+    def __exit__(self, *exc):
+        _BAG["cur"] = self.prev
+        if exc[0] is None:
+            self.bag.flush(self.device)
+        return False
 
 
 def _ln_param_grads(bag, ln, dgb, D):
     """dgb = replicated [REPL][2][D] {dgamma row, dbeta row}"""
     gw, gb = bag.target(ln.weight), bag.target(ln.bias)
     if gw is not None and gb is not None and gw.data_ptr() + 4 * D == gb.data_ptr():
-        _hip.call("mm_reduce_replicas", dgb, gw, 2 * D, REPL, 2 * D)      # adjacent in the flat bucket
+        _reduce_into(gw, dgb, 2 * D, 2 * D)                                # adjacent in the flat bucket
         return
     _reduce_into(gw, dgb, D, 2 * D, 0)
     _reduce_into(gb, dgb, D, 2 * D, D)
@@ -48,10 +75,27 @@ def _bn_param_grads(bag, bn, sums_c, N):
 
 # ------------------------------------------------------------ gradient sinks
 class GradBag:
-    """collects parameter gradients of one backward call."""
+    """collects parameter gradients of one backward call.  Replica reductions
+    into parameter gradients are deferred and flushed as ONE kernel launch."""
 
     def __init__(self):
         self.fresh: Dict[int, torch.Tensor] = {}
+        self.pending = []            # (src_ptr, dst_ptr, K, nrep, stride)
+        self._keep = []
+
+    def defer(self, src_ptr: int, dst: torch.Tensor, K: int, nrep: int, stride: int, keep=None):
+        self.pending.append((src_ptr, dst.data_ptr(), K, nrep, stride))
+        self._keep.append((dst, keep))
+
+    def flush(self, device):
+        if not self.pending:
+            return
+        import struct
+        raw = b"".join(struct.pack("<QQqqq", *d) for d in self.pending)
+        import ctypes
+        host = ctypes.create_string_buffer(raw, len(raw))      # descriptors travel as kernel arguments
+        _hip.call("mm_reduce_many", ctypes.addressof(host), len(self.pending))
+        self.pending = []
 
     def target(self, p: torch.Tensor) -> Optional[torch.Tensor]:
         """fp32 buffer (PyTorch layout of ``p``) the kernels accumulate into."""
@@ -239,7 +283,8 @@ class ErpEncoderFn(_ModuleFn):
                 "backward through an eval-mode EnhancedERPEncoder (frozen BatchNorm) is not built yet; "
                 "call .train() or wrap the forward in torch.no_grad()")
         bag = GradBag()
-        dx = erp_encoder_bwd(bag, ctx.saved, dout, ctx.need_dx)
+        with deferred(bag, dout.device):
+            dx = erp_encoder_bwd(bag, ctx.saved, dout, ctx.need_dx)
         return _ModuleFn._finish(ctx, bag, ctx.params, dx)
 
 
@@ -263,7 +308,8 @@ class TransformerBlockFn(_ModuleFn):
     def backward(ctx, dout):
         bag = GradBag()
         B, L, D = dout.shape
-        dx = transformer_block_bwd(bag, ctx.saved, dout.contiguous().view(B * L, D).float())
+        with deferred(bag, dout.device):
+            dx = transformer_block_bwd(bag, ctx.saved, dout.contiguous().view(B * L, D).float())
         return _ModuleFn._finish(ctx, bag, ctx.params, dx.view(B, L, D))
 
 
@@ -355,7 +401,8 @@ class VolumeEncoderFn(_ModuleFn):
     @staticmethod
     def backward(ctx, dout):
         bag = GradBag()
-        volume_encoder_bwd(bag, ctx.saved, dout)
+        with deferred(bag, dout.device):
+            volume_encoder_bwd(bag, ctx.saved, dout)
         return _ModuleFn._finish(ctx, bag, ctx.params, None)
 
 
@@ -401,7 +448,8 @@ class ContrastiveEmbedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         bag = GradBag()
-        dxe, dxf = contrastive_embed_bwd(bag, ctx.saved, dz.contiguous(), ctx.need)
+        with deferred(bag, dz.device):
+            dxe, dxf = contrastive_embed_bwd(bag, ctx.saved, dz.contiguous(), ctx.need)
         return (None, dxe, dxf) + tuple(bag.result(p) for p in ctx.params)
 
 

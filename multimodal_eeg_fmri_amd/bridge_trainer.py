@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip, dp, ops
-from .autograd import GradBag, contrastive_embed_bwd, erp_encoder_bwd, volume_encoder_bwd
+from .autograd import GradBag, contrastive_embed_bwd, deferred, erp_encoder_bwd, volume_encoder_bwd
 from .bridge_utils import EEGfMRIContrastiveBridge
 from .enhanced_models_v4 import EnhancedERPEncoder
 from .fmri_utils import fMRIVolumeEncoder3D
@@ -164,13 +164,15 @@ class BridgeTrainer(nn.Module):
         sv_e, sv_f, sv_h = saved
         bag = GradBag()
         self.head.logit_scale._mm_grad.add_(scal[3])
-        dfe, dff = contrastive_embed_bwd(bag, sv_h, dz)
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            volume_encoder_bwd(bag, sv_f, dff)
-        erp_encoder_bwd(bag, sv_e, dfe)
-        main.wait_stream(self._side)
+        with deferred(bag, dz.device):           # ONE batched reduction after both branches joined
+            dfe, dff = contrastive_embed_bwd(bag, sv_h, dz)
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                volume_encoder_bwd(bag, sv_f, dff)
+            erp_encoder_bwd(bag, sv_e, dfe)
+            main.wait_stream(self._side)
+        self._bags = getattr(self, "_bags", [])[-3:] + [bag]   # keep descriptor tables alive for graph replays
 
     def _seg_optimizer(self):
         b = self.bucket

@@ -350,15 +350,26 @@ __global__ void colsum_kernel(const bf16* __restrict__ a_bf16, const float* __re
 }
 
 // mean over L of fp32 [B][L][D] -> [B][D] fp32 + bf16
-__global__ void meanpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out_f32,
-                                    bf16* __restrict__ out_bf16, int L, int D) {
+// 1024 threads per (b, 64-column group): 16 waves stride over L with 8 loads in flight each
+__global__ __launch_bounds__(1024) void meanpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out_f32,
+                                                            bf16* __restrict__ out_bf16, int L, int D) {
     const int b = blockIdx.x;
     const int d = blockIdx.y * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6, parts = blockDim.x >> 6;
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     float s = 0.f;
-    if (d < D)
-        for (int l = part; l < L; l += parts) s += x[((size_t)b * L + l) * D + d];
+    if (d < D) {
+        const float* p = x + (size_t)b * L * D + d;
+        int l = part;
+        for (; l + 7 * parts < L; l += 8 * parts) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = p[(size_t)(l + i * parts) * D];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+        for (; l < L; l += parts) s += p[(size_t)l * D];
+    }
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
     if (part == 0 && d < D) {
@@ -514,7 +525,7 @@ int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, 
 
 int mm_meanpool_fwd(const float* x, float* out_f32, void* out_bf16, int B, int L, int D, hipStream_t st) {
     MM_REQUIRE(x && (out_f32 || out_bf16) && B > 0 && L > 0 && D > 0, "meanpool_fwd: null");
-    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, ceil_div(D, 64)), dim3(256), 0, st, x, out_f32, (bf16*)out_bf16, L, D);
+    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B, ceil_div(D, 64)), dim3(1024), 0, st, x, out_f32, (bf16*)out_bf16, L, D);
     return mm_check_launch("meanpool_fwd");
 }
 

@@ -157,22 +157,42 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     const int wrows = BN * a.taps;
     const int wvalid = (a.Cout - n0) * a.taps;    // rows >= wvalid are beyond Cout -> zeros
 
+    // staging goes through register batches: all loads of a batch are in flight
+    // before the first LDS write (a load->store loop serialises on load latency)
+    constexpr int NB = 8;
+    const bf16* wb = a.w + (size_t)n0 * a.taps * a.Cin;
     for (int c0 = 0; c0 < a.Cin; c0 += KCT) {
         if (c0) __syncthreads();
-        for (int s = tid; s < arows * SEGS; s += 256) {
-            const int r = s / SEGS, sg = s % SEGS;
-            const int t = t0 - a.pad + r;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (t >= 0 && t < a.T)
-                v = *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c0 + sg * 8);
-            *reinterpret_cast<uint4*>(As + r * AS + sg * 8) = v;
+        for (int base = 0; base < arows * SEGS; base += NB * 256) {
+            uint4 v[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int s = base + i * 256 + tid;
+                const int r = s / SEGS, sg = s % SEGS;
+                const int t = t0 - a.pad + r;
+                v[i] = (s < arows * SEGS && t >= 0 && t < a.T)
+                           ? *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c0 + sg * 8) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int s = base + i * 256 + tid;
+                if (s < arows * SEGS) *reinterpret_cast<uint4*>(As + (s / SEGS) * AS + (s % SEGS) * 8) = v[i];
+            }
         }
-        for (int s = tid; s < wrows * SEGS; s += 256) {
-            const int r = s / SEGS, sg = s % SEGS;         // r = n_local * taps + tap
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < wvalid)
-                v = *reinterpret_cast<const uint4*>(a.w + ((size_t)n0 * a.taps + r) * a.Cin + c0 + sg * 8);
-            *reinterpret_cast<uint4*>(Ws + r * AS + sg * 8) = v;
+        for (int base = 0; base < wrows * SEGS; base += NB * 256) {
+            uint4 v[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int s = base + i * 256 + tid;
+                const int r = s / SEGS, sg = s % SEGS;         // r = n_local * taps + tap
+                v[i] = (s < wrows * SEGS && r < wvalid)
+                           ? *reinterpret_cast<const uint4*>(wb + (size_t)r * a.Cin + c0 + sg * 8) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int s = base + i * 256 + tid;
+                if (s < wrows * SEGS) *reinterpret_cast<uint4*>(Ws + (s / SEGS) * AS + (s % SEGS) * 8) = v[i];
+            }
         }
         __syncthreads();
         for (int tap = 0; tap < a.taps; ++tap) {
@@ -520,6 +540,36 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
         case 7: return launch_wgrad<7>(a, st);
         default: return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_wgrad: taps=%d (1,3,5,7)", taps);
     }
+}
+
+// many independent replica reductions in one launch: desc[i] = {src, dst, K, nrep, stride}
+struct ReduceDesc { const float* src; float* dst; long K, nrep, stride; };
+constexpr int RM_MAX = 64;
+struct ReduceTable { ReduceDesc d[RM_MAX]; };      // passed BY VALUE (kernel argument): no memcpy node,
+                                                   // so the launch can be recorded in a hipGraph
+__global__ void reduce_many_kernel(ReduceTable tab) {
+    const ReduceDesc d = tab.d[blockIdx.y];
+    const int r0 = threadIdx.x & 31;
+    for (long k = blockIdx.x * 8 + (threadIdx.x >> 5); k < ((d.K + 7) / 8) * 8; k += (long)gridDim.x * 8) {
+        float s = 0.f;
+        if (k < d.K)
+            for (long r = r0; r < d.nrep; r += 32) s += d.src[r * d.stride + k];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (k < d.K && r0 == 0) d.dst[k] += s;
+    }
+}
+
+int mm_reduce_many(const void* desc_host, int ndesc, hipStream_t st) {
+    MM_REQUIRE(desc_host && ndesc > 0, "reduce_many: bad args");
+    const ReduceDesc* src = (const ReduceDesc*)desc_host;
+    for (int base = 0; base < ndesc; base += RM_MAX) {
+        ReduceTable tab;
+        const int n = ndesc - base < RM_MAX ? ndesc - base : RM_MAX;
+        for (int i = 0; i < n; ++i) tab.d[i] = src[base + i];
+        hipLaunchKernelGGL(reduce_many_kernel, dim3(16, n), dim3(256), 0, st, tab);
+    }
+    return mm_check_launch("reduce_many");
 }
 
 int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t rep_stride, hipStream_t st) {
