@@ -187,8 +187,10 @@ int launch3d(const Conv3dArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------
 constexpr int WR_CIN = 32;
 constexpr int WR_BN = 64;
-constexpr int WR_HROWS = 4 * HB * HB;                 // 400
-constexpr int WR_HREGS = (WR_HROWS * 4 + 255) / 256;  // uint4 per thread per halo tile (7)
+constexpr int WR_TD = 4;                              // tile depth: 4 x 8 x 8 = 256 GEMM rows
+constexpr int WR_TM = WR_TD / 2;                      // 32-row sub-tiles per wave (4 waves x 64 rows)
+constexpr int WR_HROWS = (WR_TD + 2) * HB * HB;       // 600
+constexpr int WR_HREGS = (WR_HROWS * 4 + 255) / 256;  // uint4 per thread per halo tile (10)
 
 __device__ __forceinline__ int swz(int row_key, int seg) { return seg ^ ((row_key >> 2) & 3); }
 
@@ -199,27 +201,9 @@ __global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
     float* sstat = reinterpret_cast<float*>(Hl + WR_HROWS * WR_CIN); // [2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8, td = (a.D + 1) / 2;
+    const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8, td = (a.D + WR_TD - 1) / WR_TD;
     const int ntiles = a.B * td * th * tw;
 
-    // ---- weights: once per workgroup.  All 27 loads of a thread are issued before
-    // the first LDS write (a load->store loop would serialise on load latency).
-    {
-        constexpr int WREGS = WR_BN * 27 * 4 / 256;      // 27
-        uint4 wv[WREGS];
-        const int wvalid = a.Cout * 27;
-#pragma unroll
-        for (int i = 0; i < WREGS; ++i) {
-            const int s = tid + i * 256, r = s >> 2, sg = s & 3;      // r = n * 27 + tap
-            wv[i] = (r < wvalid && !(a.dbg & 8)) ? *reinterpret_cast<const uint4*>(a.w + (size_t)r * WR_CIN + sg * 8) : make_uint4(0, 0, 0, 0);
-        }
-        if (!(a.dbg & 32))
-#pragma unroll
-        for (int i = 0; i < WREGS; ++i) {
-            const int s = tid + i * 256, r = s >> 2, sg = s & 3;
-            *reinterpret_cast<uint4*>(Wl + r * WR_CIN + swz(r / 27, sg) * 8) = wv[i];
-        }
-    }
     if (a.stats)
         for (int i = tid; i < 2 * WR_BN; i += 256) sstat[i] = 0.f;
 
@@ -227,7 +211,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
         int q = tile;
         const int w0 = (q % tw) * 8; q /= tw;
         const int h0 = (q % th) * 8; q /= th;
-        const int d0 = (q % td) * 2; q /= td;
+        const int d0 = (q % td) * WR_TD; q /= td;
         const bf16* xb = a.x + (size_t)q * a.D * a.H * a.W * WR_CIN;
 #pragma unroll
         for (int i = 0; i < WR_HREGS; ++i) {
@@ -252,84 +236,141 @@ __global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
         }
     };
 
-    const int m = wave * 32 + lr;                                   // this lane's A row in the tile
-    const int abase = ((m >> 6) * HB + ((m >> 3) & 7)) * HB + (m & 7);
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    float shv[2];
+    int abase[WR_TM];                                               // this lane's A rows in the tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = j * 32 + lr;
-        shv[j] = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+    for (int i = 0; i < WR_TM; ++i) {
+        const int m = (wave * WR_TM + i) * 32 + lr;
+        abase[i] = ((m >> 6) * HB + ((m >> 3) & 7)) * HB + (m & 7);
+    }
+    float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, sh4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = (tid & 15) * 4 + c;
+        sh4[c] = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
     }
 
     uint4 nxt[WR_HREGS];
     int tile = blockIdx.x;
     if (a.dbg & 16) tile = ntiles;
-    if (tile < ntiles) load_halo(tile, nxt);
+    if (tile < ntiles) load_halo(tile, nxt);            // in flight while the weights are staged
+    // ---- weights: once per workgroup.  All 27 loads of a thread are issued before
+    // the first LDS write (a load->store loop would serialise on load latency).
+    {
+        constexpr int WREGS = WR_BN * 27 * 4 / 256;      // 27
+        uint4 wv[WREGS];
+        const int wvalid = a.Cout * 27;
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            const int s = tid + i * 256, r = s >> 2, sg = s & 3;      // r = n * 27 + tap
+            wv[i] = (r < wvalid && !(a.dbg & 8)) ? *reinterpret_cast<const uint4*>(a.w + (size_t)r * WR_CIN + sg * 8) : make_uint4(0, 0, 0, 0);
+        }
+        if (!(a.dbg & 32))
+#pragma unroll
+        for (int i = 0; i < WREGS; ++i) {
+            const int s = tid + i * 256, r = s >> 2, sg = s & 3;
+            *reinterpret_cast<uint4*>(Wl + r * WR_CIN + swz(r / 27, sg) * 8) = wv[i];
+        }
+    }
+
     for (; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                                            // previous tile's reads are done
-        store_halo(nxt);
+        if (!(a.dbg & 256)) store_halo(nxt);
         __syncthreads();
         const int tnext = tile + gridDim.x;
         if (tnext < ntiles && !(a.dbg & 4)) load_halo(tnext, nxt);  // in flight during the MFMAs below
 
-        f32x16 acc[2];
+        f32x16 acc[WR_TM][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < WR_TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         if (!(a.dbg & 2))
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            const int arow = abase + (tap / 9) * HB * HB + ((tap / 3) % 3) * HB + (tap % 3);
+            const int toff = (tap / 9) * HB * HB + ((tap / 3) % 3) * HB + (tap % 3);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int sg = ks * 2 + lh;
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(Hl + arow * WR_CIN + swz(arow, sg) * 8);
+                bf16x8 af[WR_TM], bfr[2];
+#pragma unroll
+                for (int i = 0; i < WR_TM; ++i) {
+                    const int arow = abase[i] + toff;
+                    af[i] = *reinterpret_cast<const bf16x8*>(Hl + arow * WR_CIN + swz(arow, sg) * 8);
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int n = j * 32 + lr;
-                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(Wl + (n * 27 + tap) * WR_CIN + swz(n, sg) * 8);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(Wl + (n * 27 + tap) * WR_CIN + swz(n, sg) * 8);
                 }
+#pragma unroll
+                for (int i = 0; i < WR_TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
         }
-        // ---- epilogue straight from the accumulators
+        // ---- epilogue through LDS (the halo region is dead once every wave left the
+        // MFMA loop): two 128-row halves of fp32 [128][64+4]; each thread then owns one
+        // 4-column group and writes row-contiguous 16-byte vectors (8 per half).
         int q = tile;
         const int w0 = (q % tw) * 8; q /= tw;
         const int h0 = (q % th) * 8; q /= th;
-        const int d0 = (q % td) * 2; q /= td;
+        const int d0 = (q % td) * WR_TD; q /= td;
         const int b = q;
+        if (a.dbg & 128) continue;
+        const bool full = d0 + WR_TD <= a.D && h0 + 8 <= a.H && w0 + 8 <= a.W;
+        float* Cs = reinterpret_cast<float*>(Hl);
+        constexpr int LDC = WR_BN + 4;
+        const int cg = tid & 15, rr = tid >> 4;                    // column group, first row
+        const bool cok = cg * 4 < a.Cout;
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = j * 32 + lr;
-            if (n >= a.Cout) continue;
+        for (int half = 0; half < 2; ++half) {
+            if ((wave >> 1) == half) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int mm = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int d = d0 + (mm >> 6), h = h0 + ((mm >> 3) & 7), w = w0 + (mm & 7);
-                if (d < a.D && h < a.H && w < a.W) {
-                    const float v = acc[j][r] + shv[j];
-                    s1[j] += v; s2[j] += v * v;
-                    const size_t o = ((((size_t)b * a.D + d) * a.H + h) * a.W + w) * a.Cout + n;
+                for (int i = 0; i < WR_TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (wave & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            Cs[row * LDC + j * 32 + lr] = acc[i][j][r];
+                        }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int row = rr + 16 * c;                      // 0..127 inside the half
+                const int mg = half * 128 + row;
+                const int d = d0 + (mg >> 6), h = h0 + ((mg >> 3) & 7), w = w0 + (mg & 7);
+                if (cok && (full || (d < a.D && h < a.H && w < a.W))) {
+                    const float4 t = *reinterpret_cast<const float4*>(Cs + row * LDC + cg * 4);
+                    const float v0 = t.x + sh4[0], v1 = t.y + sh4[1], v2 = t.z + sh4[2], v3 = t.w + sh4[3];
+                    st1[0] += v0; st1[1] += v1; st1[2] += v2; st1[3] += v3;
+                    st2[0] += v0 * v0; st2[1] += v1 * v1; st2[2] += v2 * v2; st2[3] += v3 * v3;
+                    const size_t o = ((((size_t)b * a.D + d) * a.H + h) * a.W + w) * a.Cout + cg * 4;
                     if (!(a.dbg & 1)) {
-                        if (a.out_f32) a.out_f32[o] = v;
-                        if (a.out_bf16) a.out_bf16[o] = (bf16)v;
+                        if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + o) = make_float4(v0, v1, v2, v3);
+                        if (a.out_bf16) {
+                            bf16x4 ob = {(bf16)v0, (bf16)v1, (bf16)v2, (bf16)v3};
+                            *reinterpret_cast<bf16x4*>(a.out_bf16 + o) = ob;
+                        }
                     }
                 }
             }
+            if (half == 0) __syncthreads();
         }
     }
     if (a.stats && !(a.dbg & 64)) {
+        __syncthreads();                                            // Cs reads done; sstat lives past Hl
+        if ((tid & 15) * 4 < a.Cout)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            s1[j] += __shfl_xor(s1[j], 32, 64);
-            s2[j] += __shfl_xor(s2[j], 32, 64);
-            if (lh == 0) {
-                atomicAdd(&sstat[j * 32 + lr], s1[j]);
-                atomicAdd(&sstat[WR_BN + j * 32 + lr], s2[j]);
+            for (int c = 0; c < 4; ++c) {
+                atomicAdd(&sstat[(tid & 15) * 4 + c], st1[c]);
+                atomicAdd(&sstat[WR_BN + (tid & 15) * 4 + c], st2[c]);
             }
-        }
         __syncthreads();
         float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * a.Cout;
         for (int i = tid; i < WR_BN; i += 256)
@@ -348,7 +389,7 @@ int launch3d_wres(const Conv3dArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int ntiles = a.B * ceil_div(a.D, 2) * ceil_div(a.H, 8) * ceil_div(a.W, 8);
+    const int ntiles = a.B * ceil_div(a.D, WR_TD) * ceil_div(a.H, 8) * ceil_div(a.W, 8);
     const int grid = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
     return mm_check_launch("conv3d_fwd_wres");
@@ -629,7 +670,7 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
     MM_REQUIRE(Cin == 16 || Cin % 32 == 0, "conv3d_fwd: Cin=%d must be 16 or a multiple of 32", Cin);
     Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, g_dbg, stats, out_f32, (bf16*)out_bf16};
     const long tiles2 = (long)B * ceil_div(D, 2) * ceil_div(H, 8) * ceil_div(W, 8);
-    if (Cin == WR_CIN && Cout <= WR_BN && Cout > 32 && D % 2 == 0 && tiles2 >= 256) return launch3d_wres(a, st);
+    if (Cin == WR_CIN && Cout <= WR_BN && Cout > 32 && Cout % 4 == 0 && tiles2 >= 512) return launch3d_wres(a, st);
     if (Cout <= 32) return launch3d<2, 32, 4, 1>(a, st);
     if (Cout <= 64) {
         if (tiles2 >= 256 && D % 2 == 0) return launch3d<2, 64, 4, 1>(a, st);

@@ -153,7 +153,7 @@ def main():
         conv1d_wgrad_case(32, 512, 128, 128, 3)
         conv1d_wgrad_case(1, M, 128, 512, 1)
     if "abl" in flt:
-        for f in (24, 24 + 32, 24 + 64, 24 + 96):
+        for f in (0, 1, 2, 3):
             _hip.call("mm_debug_flags", f)
             print("dbg flags", f, end=": ")
             conv3d_case(32, 16, 32, 64, wgrad=False)
