@@ -148,10 +148,13 @@ def main():
         "top1_retrieval_acc": {"eeg_to_fmri": ev["top1_e2f"].item(), "fmri_to_eeg": ev["top1_f2e"].item(),
                                "chance": 1.0 / global_batch, "note": "on the training batch after the timed steps"},
         "final_loss": out["loss"].item(),
-        "roofline": {"kernel": "conv3d_fwd_kernel (layer 2: 32->64 ch @16^3, implicit GEMM M=131072 N=64 K=864)",
+        "roofline": {"kernel": "conv3d_fwd_wres_kernel (layer 2: 32->64 ch @16^3, implicit GEMM M=131072 N=64 K=864)",
                      "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_BF16_MFMA_TFLOPS) if achieved else None,
-                     "flops_per_launch": flops, "avg_launch_ms": kt, "traffic": None},
+                     "flops_per_launch": flops, "avg_launch_ms": kt,
+                     # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+                     # WRITE_SIZE, separate passes): profiles/r01_pmc_conv3d_wres.txt; compulsory = 42.0 MB
+                     "traffic": 51.2e6, "traffic_source": "profiles/r01_pmc_conv3d_wres.txt"},
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(PAIRS_PER_GPU)

@@ -221,6 +221,12 @@ int mm_attn_1x2(const float* proj_e, const float* proj_f, float* ctx, float* att
 /* HybridFusionModule gate + mix + conn boost (crossmodal_v4_enhancements.py:787-797) */
 int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float* conn, float* comb,
                  float* gate, int B, int H, float boost, hipStream_t stream);
+int mm_gate2_mix_bwd(const float* dcomb, const float* g, const float* erp, const float* pw, float* derp,
+                     float* dpw, float* dconn, float* dg, int B, int H, float boost, hipStream_t stream);
+/* LabelSmoothingCrossEntropy (crossmodal_v4_enhancements.py:665-677): loss_out[0] += loss (zeroed by
+ * the caller), dlogits = d loss / d logits; target is int64 class indices */
+int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out, float* dlogits, int B,
+                   int C, float smoothing, hipStream_t stream);
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 /* AdaptiveAvgPool1d(1) of the Lite encoders on bf16 [R][S][N] */
 int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t stream);

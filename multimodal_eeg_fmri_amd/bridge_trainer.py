@@ -25,42 +25,7 @@ from .autograd import GradBag, contrastive_embed_bwd, deferred, erp_encoder_bwd,
 from .bridge_utils import EEGfMRIContrastiveBridge
 from .enhanced_models_v4 import EnhancedERPEncoder
 from .fmri_utils import fMRIVolumeEncoder3D
-
-
-class FlatBucket:
-    """All trainable parameters (and their gradients / Adam moments) as single
-    contiguous fp32 buffers; ``param.data`` and ``param._mm_grad`` are views, so
-    kernels accumulate gradients in place and one collective covers the step."""
-
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.n = n
-        self.p = torch.empty(n, dtype=torch.float32, device=dev)
-        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
-            k = p.numel()
-            self.p[off:off + k].copy_(p.detach().reshape(-1))
-            p.data = self.p[off:off + k].view(p.shape)
-            p._mm_grad = self.g[off:off + k].view(p.shape)
-            off += k
-
-    def zero_grad(self):
-        self.g.zero_()
-        for p in self.params:
-            p.grad = None
-
-    def absorb_autograd_grads(self):
-        """parameters whose gradient came back through autograd (not a kernel sink)"""
-        for p in self.params:
-            if p.grad is not None:
-                p._mm_grad.add_(p.grad)
-                p.grad = None
+from .optim import FlatBucket
 
 
 class BridgeTrainer(nn.Module):

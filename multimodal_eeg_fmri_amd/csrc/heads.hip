@@ -347,6 +347,56 @@ __global__ void gate2_mix_kernel(const float* __restrict__ g, const float* __res
     }
 }
 
+// backward of gate2_mix: given d comb [B][2H] -> d erp, d pw, d conn [B][H], d gate logits [B][2]
+__global__ void gate2_mix_bwd_kernel(const float* __restrict__ dcomb, const float* __restrict__ g,
+                                     const float* __restrict__ erp, const float* __restrict__ pw,
+                                     float* __restrict__ derp, float* __restrict__ dpw, float* __restrict__ dconn,
+                                     float* __restrict__ dg, int B, int H, float boost) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const float g0 = g[2 * b], g1 = g[2 * b + 1], m = fmaxf(g0, g1);
+    const float e0 = __expf(g0 - m), e1 = __expf(g1 - m);
+    const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
+    float a0 = 0.f, a1 = 0.f;
+    for (int h = lane; h < H; h += 64) {
+        const float dm = dcomb[(size_t)b * 2 * H + h];
+        derp[(size_t)b * H + h] = w0 * dm;
+        dpw[(size_t)b * H + h] = w1 * dm;
+        dconn[(size_t)b * H + h] = boost * dcomb[(size_t)b * 2 * H + H + h];
+        a0 += dm * erp[(size_t)b * H + h];
+        a1 += dm * pw[(size_t)b * H + h];
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1);
+    if (lane == 0) {
+        const float dot = w0 * a0 + w1 * a1;
+        dg[2 * b] = w0 * (a0 - dot);
+        dg[2 * b + 1] = w1 * (a1 - dot);
+    }
+}
+
+// LabelSmoothingCrossEntropy (crossmodal_v4_enhancements.py:665-677): loss = mean_b[(1-s)*nll + s*mean_c(-logp)]
+// out[0] += loss ; dlogits[b][c] = (softmax - (1-s)*onehot - s/C) / B
+__global__ void smoothed_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                   float* __restrict__ out, float* __restrict__ dlogits, int B, int C, float smoothing) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* z = logits + (size_t)b * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+    float se = 0.f, sz = 0.f;
+    for (int c = 0; c < C; ++c) { se += __expf(z[c] - m); sz += z[c]; }
+    const float lse = m + __logf(se);
+    const int t = (int)target[b];
+    const float nll = lse - z[t], smooth = lse - sz / (float)C;
+    atomicAdd(out, ((1.f - smoothing) * nll + smoothing * smooth) / (float)B);
+    if (dlogits)
+        for (int c = 0; c < C; ++c) {
+            const float p = __expf(z[c] - lse);
+            dlogits[(size_t)b * C + c] = (p - (c == t ? 1.f - smoothing : 0.f) - smoothing / (float)C) / (float)B;
+        }
+}
+
 __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
 }
@@ -477,6 +527,21 @@ int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float*
     MM_REQUIRE(g && erp && pw && conn && comb && B > 0 && H > 0, "gate2_mix: null");
     hipLaunchKernelGGL(gate2_mix_kernel, dim3(grid_h((size_t)B * 2 * H)), dim3(256), 0, st, g, erp, pw, conn, comb, gate, B, H, boost);
     return mm_check_launch("gate2_mix");
+}
+
+int mm_gate2_mix_bwd(const float* dcomb, const float* g, const float* erp, const float* pw, float* derp, float* dpw,
+                     float* dconn, float* dg, int B, int H, float boost, hipStream_t st) {
+    MM_REQUIRE(dcomb && g && erp && pw && derp && dpw && dconn && dg && B > 0 && H > 0, "gate2_mix_bwd: null");
+    hipLaunchKernelGGL(gate2_mix_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, dcomb, g, erp, pw, derp, dpw, dconn, dg, B, H, boost);
+    return mm_check_launch("gate2_mix_bwd");
+}
+
+int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out, float* dlogits, int B, int C,
+                   float smoothing, hipStream_t st) {
+    MM_REQUIRE(logits && target_i64 && loss_out && B > 0 && C > 0 && smoothing >= 0.f && smoothing < 1.f, "smoothed_ce: bad args");
+    hipLaunchKernelGGL(smoothed_ce_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, logits, (const long long*)target_i64,
+                       loss_out, dlogits, B, C, smoothing);
+    return mm_check_launch("smoothed_ce");
 }
 
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {

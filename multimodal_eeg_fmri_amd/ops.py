@@ -634,9 +634,12 @@ def bridge_forward(m, eeg, fmri):
 
 
 def fmri_mlp_forward(seq, x, drop_p, training):
-    """Linear-BN-ReLU x2 (fmri_utils.py:26-35), eval-mode BN folded."""
+    """Linear-BN-ReLU-Drop x2 (fmri_utils.py:26-35); eval-mode BN is folded."""
     _need_gpu(x)
-    _eval_only("ActivationEncoder/ConnectivityEncoder", training)
+    if training:
+        from . import small_autograd as sa
+        h = sa.linear_bn_act(x, seq[0], seq[1], "relu", drop_p)
+        return sa.linear_bn_act(h, seq[4], seq[5], "relu", drop_p)
     h, _ = small_linear(_f32c(x), seq[0], act="relu", bn=seq[1])
     h, _ = small_linear(h, seq[4], act="relu", bn=seq[5])
     return h
@@ -659,7 +662,13 @@ def fmri_fusion_forward(m, activation, connectivity):
 
 def conn_encoder_forward(m, x):
     _need_gpu(x)
-    _eval_only("EnhancedConnEncoder", m.training)
+    if m.training:
+        from . import small_autograd as sa
+        p = m.drop_p
+        h = sa.linear_bn_act(x, m.proj1[0], m.proj1[1], "gelu", p)
+        h = sa.linear_bn_act(h, m.proj2[0], m.proj2[1], "gelu", p)
+        gate = sa.linear(sa.linear(h, m.attention[0], "tanh"), m.attention[2], "sigmoid")
+        return sa.linear_bn_act(sa.MulFn.apply(h, gate), m.output[0], m.output[1], "gelu", p)
     with torch.no_grad():
         h, _ = small_linear(_f32c(x), m.proj1[0], act="gelu", bn=m.proj1[1])
         h, _ = small_linear(h, m.proj2[0], act="gelu", bn=m.proj2[1])
@@ -673,7 +682,12 @@ def conn_encoder_forward(m, x):
 
 def hybrid_fusion_forward(m, erp, pw, conn):
     _need_gpu(erp, pw, conn)
-    _eval_only("HybridFusionModule", m.training)
+    if m.training:
+        from . import small_autograd as sa
+        p = m.drop_p
+        g = sa.linear(sa.linear(torch.cat([erp, pw], dim=1), m.erp_pw_gate[0], "gelu", p), m.erp_pw_gate[3])
+        comb, gate = sa.Gate2MixFn.apply(g, erp, pw, conn, float(m.conn_boost))
+        return sa.linear_bn_act(comb, m.late_fusion[0], m.late_fusion[1], "gelu", p), gate
     with torch.no_grad():
         e, p, c = _f32c(erp), _f32c(pw), _f32c(conn)
         B, H = e.shape
@@ -689,7 +703,9 @@ def hybrid_fusion_forward(m, erp, pw, conn):
 def bn_classifier_forward(seq, fused, drop_p, training):
     """Linear-BN-GELU-Drop-Linear (crossmodal_v4_enhancements.py:909-915)."""
     _need_gpu(fused)
-    _eval_only("EnhancedTriModalFusionNetV4Lite.classifier", training)
+    if training:
+        from . import small_autograd as sa
+        return sa.linear(sa.linear_bn_act(fused, seq[0], seq[1], "gelu", drop_p), seq[4])
     with torch.no_grad():
         h, _ = small_linear(_f32c(fused), seq[0], act="gelu", bn=seq[1])
         out, _ = small_linear(h, seq[4])
@@ -699,7 +715,10 @@ def bn_classifier_forward(seq, fused, drop_p, training):
 def lite_encoder_forward(m, x):
     """LiteERPEncoder / LitePowerEncoder (crossmodal_v4_enhancements.py:817-877)."""
     _need_gpu(x)
-    _eval_only("LiteERPEncoder/LitePowerEncoder", m.training)
+    if m.training:
+        from . import small_autograd as sa
+        pooled = sa.LiteConvFn.apply(m, x, *list(m.conv_layers.parameters()))
+        return sa.linear(pooled, m.output[1], "gelu", m.drop_p)
     with torch.no_grad():
         cl = m.conv_layers
         xb = pack_nct(x.float())
@@ -750,4 +769,6 @@ def drop_path(x, drop_prob):
 
 
 def smoothed_cross_entropy(pred, target, smoothing):
-    raise NotImplementedError("LabelSmoothingCrossEntropy on the HIP path arrives with Lite-model training (DESIGN.md 'next')")
+    _need_gpu(pred, target)
+    from . import small_autograd as sa
+    return sa.SmoothedCEFn.apply(pred, target, float(smoothing))

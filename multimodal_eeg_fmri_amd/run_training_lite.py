@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from .config import Config, set_seed
+from .optim import FusedAdamW
 from .crossmodal_v4_enhancements import (CosineAnnealingWarmup, EarlyStopping,
                                          EnhancedTriModalFusionNetV4Lite,
                                          LabelSmoothingCrossEntropy, get_lite_fusion_weights)
@@ -170,7 +171,8 @@ def main(config: Optional[Config] = None, max_epochs: Optional[int] = None):
         model = ImprovedTriModalFusionNetLite(pw_ch, erp_ch, conn_dim, fusion_dim=96, num_classes=n_classes,
                                               dropout=0.4, conn_boost=1.3).to(device)
         criterion = LabelSmoothingCrossEntropy(smoothing=0.1)
-        optimizer = torch.optim.AdamW(model.parameters(), lr=config.learning_rate, weight_decay=0.01)
+        # clip_grad_norm_(1.0) + AdamW(weight_decay=0.01) (reference :466,:487-488) as one fused kernel pair
+        optimizer = FusedAdamW(model.parameters(), lr=config.learning_rate, weight_decay=0.01, max_grad_norm=1.0)
         scheduler = CosineAnnealingWarmup(optimizer, warmup_epochs=3, total_epochs=epochs)
         stopper = EarlyStopping(patience=15, mode="max")
         best_f1, best_state = 0.0, None
@@ -180,7 +182,6 @@ def main(config: Optional[Config] = None, max_epochs: Optional[int] = None):
                 optimizer.zero_grad()
                 loss = criterion(model(pw.to(device), erp.to(device), conn.to(device)), y.to(device))
                 loss.backward()
-                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
                 optimizer.step()
             scheduler.step()
             preds, targets = _evaluate(model, test_loader, device)

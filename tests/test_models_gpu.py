@@ -232,3 +232,47 @@ def test_a11_bridge_eval_vs_golden(golden):
     _close(aw, fx["attn_w"], 1e-4, 1e-6, "attn_w")
     g = mg.get_fusion_weights()
     np.testing.assert_allclose([g["eeg_weight"], g["fmri_weight"], g["temperature"]], fx["gfw"], atol=1e-6)
+
+
+def test_a7_trimodal_lite_train_grads_vs_oracle():
+    """train-mode (batch-stat BN, dropout 0) logits + every parameter gradient of the
+    V4-Lite net against the CPU oracle's autograd; conv encoders are bf16-MFMA
+    (5e-2 vs the bf16-operand oracle), the MLP/gate half is fp32."""
+    from oracle.bf16_emulation import bf16_operands
+    m = build(Cv.EnhancedTriModalFusionNetV4Lite, 51, 8, 8, 459, dropout=0.0).train()
+    erp, pw, conn = seeded_randn(151, 8, 8, 256), seeded_randn(152, 8, 8, 256), seeded_randn(153, 8, 459)
+    tgt = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1])
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    with bf16_operands():
+        logits_o, _, _ = RF.trimodal_lite(sd, erp, pw, conn, train=True)
+    loss_o = RF.label_smoothing_ce(logits_o, tgt, 0.1)
+    loss_o.backward()
+    mg = m.cuda()
+    logits = mg(erp.cuda(), pw.cuda(), conn.cuda())
+    loss = Cv.LabelSmoothingCrossEntropy(0.1)(logits, tgt.cuda())
+    loss.backward()
+    assert rel_err(logits.detach().cpu(), logits_o.detach()) < 3e-2
+    assert abs(loss.item() - loss_o.item()) < 2e-2
+    bad = []
+    for n, p in mg.named_parameters():
+        w = sd[n].grad
+        if w is None or w.norm() < 1e-5:
+            continue
+        assert p.grad is not None, n
+        e = rel_err(p.grad.cpu(), w)
+        if e > 8e-2:
+            bad.append((n, round(e, 4)))
+    assert not bad, bad
+
+
+def test_run_training_lite_main_trains_on_gpu(tmp_path, monkeypatch):
+    """BASELINE config #1 entry point: 2 folds x 3 epochs of the real loop."""
+    import multimodal_eeg_fmri_amd.run_training_lite as R
+    from multimodal_eeg_fmri_amd.config import Config
+    monkeypatch.chdir(tmp_path)
+    cfg = Config(None)
+    cfg.n_splits = 2
+    cfg.learning_rate = 2e-3
+    cfg.synthetic["subjects"] = 24
+    res = R.main(cfg, max_epochs=3)
+    assert len(res) == 2 and all(0.0 <= r["Accuracy"] <= 1.0 for r in res)

@@ -152,6 +152,9 @@ def main():
         conv1d_wgrad_case(32, 1024, 64, 128, 5)
         conv1d_wgrad_case(32, 512, 128, 128, 3)
         conv1d_wgrad_case(1, M, 128, 512, 1)
+    if "pmc3d" in flt:
+        conv3d_case(32, 16, 32, 64, wgrad=False)
+        return
     if "abl" in flt:
         for f in (0, 1, 2, 3):
             _hip.call("mm_debug_flags", f)
