@@ -227,6 +227,12 @@ int mm_gate2_mix_bwd(const float* dcomb, const float* g, const float* erp, const
  * the caller), dlogits = d loss / d logits; target is int64 class indices */
 int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out, float* dlogits, int B,
                    int C, float smoothing, hipStream_t stream);
+/* Multi-scale STFT power front-end (extension a-X3; semantics = torch.stft(center=True,
+ * pad_mode="reflect", periodic Hann) then |.|^2): x (B,C,T) fp32 -> channels-last
+ * out[b][frame][ch_off + c*F + f], F = nfft/2+1, frames = T/hop+1, row width ch_total
+ * (several scales write side by side into one activation tensor). */
+int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, int T, int nfft, int hop,
+                  int ch_off, int ch_total, hipStream_t stream);
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 /* AdaptiveAvgPool1d(1) of the Lite encoders on bf16 [R][S][N] */
 int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t stream);

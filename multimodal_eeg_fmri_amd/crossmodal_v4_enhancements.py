@@ -110,6 +110,24 @@ def get_lite_fusion_weights(model):
 
 
 # ----------------------------------------------------------------- encoders
+class MultiScaleSTFTPowerEncoder(nn.Module):
+    """BASELINE config #5 front-end (north-star extension a-X3; the reference loads
+    MATLAB spectra instead, eeg_data_utils.py:86-119): raw EEG (B, C, T) -> Hann STFT
+    power at several window sizes -> (B, C * sum(F), frames) -> EnhancedPowerEncoder.
+    Semantics of the spectra = torch.stft(center=True, reflect) ** 2 per channel."""
+
+    def __init__(self, in_channels: int, n_ffts=(64, 128), hop: int = 32, hidden_dim: int = 128,
+                 num_transformer_layers: int = 2, num_heads: int = 4, dropout: float = 0.3):
+        super().__init__()
+        self.n_ffts, self.hop = tuple(int(n) for n in n_ffts), int(hop)
+        self.spec_channels = in_channels * sum(n // 2 + 1 for n in self.n_ffts)
+        self.encoder = EnhancedPowerEncoder(self.spec_channels, hidden_dim, num_transformer_layers,
+                                            num_heads, dropout)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.stft_power_encoder_forward(self, x)
+
+
 class EnhancedConnEncoder(nn.Module):
     """conn -> 256 -> 128 (Linear-BN-GELU) -> sigmoid feature gate -> hidden."""
 

@@ -397,6 +397,59 @@ __global__ void smoothed_ce_kernel(const float* __restrict__ logits, const long 
         }
 }
 
+// ---------------------------------------------------------------------------
+// multi-scale STFT power front-end (extension a-X3; torch.stft(center=True, reflect,
+// periodic Hann) semantics): x (B, C, T) fp32 -> power written CHANNELS-LAST as bf16
+// out[b][frame][ch_off + c*F + f] = |sum_n w[n] x[b,c,frame*hop + n - nfft/2] e^{-2 pi i f n / nfft}|^2
+// so the result is directly the (B, L, Cin) activation of the Power encoder's first
+// conv.  One workgroup per (b, c, frame-block); twiddles and the windowed frame in LDS.
+// ---------------------------------------------------------------------------
+__global__ void stft_power_kernel(const float* __restrict__ x, bf16* __restrict__ out, float* __restrict__ out_f32,
+                                  int C, int T, int nfft, int hop, int frames, int ch_off, int ch_total) {
+    extern __shared__ float sm[];
+    float* tw_c = sm;                  // [nfft]
+    float* tw_s = tw_c + nfft;         // [nfft]
+    float* fr = tw_s + nfft;           // [8][nfft] windowed frames
+    const int b = blockIdx.z, c = blockIdx.y, f0 = blockIdx.x * 8;
+    const int F = nfft / 2 + 1;
+    for (int n = threadIdx.x; n < nfft; n += blockDim.x) {
+        float s, co;
+        __sincosf(6.283185307179586f * (float)n / (float)nfft, &s, &co);
+        tw_c[n] = co; tw_s[n] = s;
+    }
+    const float* xr = x + ((size_t)b * C + c) * T;
+    for (int i = threadIdx.x; i < 8 * nfft; i += blockDim.x) {
+        const int fi = i / nfft, n = i % nfft;
+        const int frame = f0 + fi;
+        float v = 0.f;
+        if (frame < frames) {
+            int t = frame * hop + n - nfft / 2;
+            if (t < 0) t = -t;                              // reflect padding
+            if (t >= T) t = 2 * (T - 1) - t;
+            const float win = 0.5f - 0.5f * __cosf(6.283185307179586f * (float)n / (float)nfft);
+            v = xr[t] * win;
+        }
+        fr[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * F; i += blockDim.x) {
+        const int fi = i / F, f = i % F;
+        const int frame = f0 + fi;
+        if (frame >= frames) continue;
+        float re = 0.f, im = 0.f;
+        const float* fv = fr + fi * nfft;
+        for (int n = 0; n < nfft; ++n) {
+            const int k = (f * n) & (nfft - 1);             // nfft is a power of two
+            re += fv[n] * tw_c[k];
+            im -= fv[n] * tw_s[k];
+        }
+        const float p = re * re + im * im;
+        const size_t o = ((size_t)b * frames + frame) * ch_total + ch_off + (size_t)c * F + f;
+        if (out) out[o] = (bf16)p;
+        if (out_f32) out_f32[o] = p;
+    }
+}
+
 __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
 }
@@ -542,6 +595,19 @@ int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out,
     hipLaunchKernelGGL(smoothed_ce_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, logits, (const long long*)target_i64,
                        loss_out, dlogits, B, C, smoothing);
     return mm_check_launch("smoothed_ce");
+}
+
+int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, int T, int nfft, int hop, int ch_off,
+                  int ch_total, hipStream_t st) {
+    MM_REQUIRE(x && (out_bf16 || out_f32) && B > 0 && C > 0 && T > 0, "stft_power: null/invalid");
+    MM_REQUIRE(nfft >= 8 && nfft <= 1024 && (nfft & (nfft - 1)) == 0 && hop > 0 && T > nfft / 2, "stft_power: nfft=%d hop=%d", nfft, hop);
+    const int frames = T / hop + 1;
+    const int F = nfft / 2 + 1;
+    MM_REQUIRE(ch_off >= 0 && ch_off + C * F <= ch_total, "stft_power: channel window");
+    const size_t lds = (size_t)(2 * nfft + 8 * nfft) * sizeof(float);
+    hipLaunchKernelGGL(stft_power_kernel, dim3(ceil_div(frames, 8), C, B), dim3(256), lds, st, x, (bf16*)out_bf16, out_f32,
+                       C, T, nfft, hop, frames, ch_off, ch_total);
+    return mm_check_launch("stft_power");
 }
 
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {

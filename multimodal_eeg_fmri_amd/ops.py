@@ -744,23 +744,51 @@ def _power_merged(m, device):
     return torch.cat(ws, dim=0).contiguous(), torch.cat(o4, dim=1).contiguous()
 
 
+def stft_front_end(x: torch.Tensor, n_ffts, hop: int) -> torch.Tensor:
+    """(B, C, T) fp32 -> channels-last bf16 (B, frames, Cp) multi-scale STFT power,
+    channel order [scale][c][f] as torch.cat([stft_power(x, n) ...], dim=1)."""
+    B, C, T = x.shape
+    widths = [C * (n // 2 + 1) for n in n_ffts]
+    total = sum(widths)
+    cp = cpad(total)
+    frames = T // hop + 1
+    out = torch.zeros((B, frames, cp), dtype=_BF, device=x.device) if cp != total else _empty((B, frames, cp), _BF, x)
+    off = 0
+    xc = x.float().contiguous()
+    for n, wdt in zip(n_ffts, widths):
+        _hip.call("mm_stft_power", xc, out, None, B, C, T, int(n), int(hop), off, cp)
+        off += wdt
+    return out
+
+
+def stft_power_encoder_forward(m, x):
+    """MultiScaleSTFTPowerEncoder: STFT power front-end -> EnhancedPowerEncoder."""
+    _need_gpu(x)
+    _eval_only("MultiScaleSTFTPowerEncoder", m.training)
+    with torch.no_grad():
+        return _power_forward_ntc(m.encoder, stft_front_end(x, m.n_ffts, m.hop))
+
+
 def power_encoder_forward(m, x):
     """EnhancedPowerEncoder (enhanced_models_v4.py:258-285)."""
     _need_gpu(x)
     _eval_only("EnhancedPowerEncoder", m.training)
     with torch.no_grad():
-        xb = pack_nct(x.float())
-        B, T, cp = xb.shape
-        w192, o4 = _power_merged(m, x.device)
-        wf = _empty((192, 7, cp), _BF, xb)
-        _hip.call("mm_prep_conv_weight", w192, wf, None, 192, w192.shape[1], 7, cp, 0)
-        h = igemm(xb, wf, 7, 3, 192, scale=o4[0], shift=o4[1], act="gelu")["bf16"]
-        r, _ = conv_bn_act(h, m.fusion[0], m.fusion[1], training=False, pe=pe_table(m.pos_encoder, T),
-                           want_f32=True, want_bf16=False)
-        tok = r["f32"]
-        for blk in m.transformer_layers:
-            tok, _ = transformer_block_fwd(tok, blk, False)
-        out, _ = pooled_head_fwd(tok, m.output_proj[2])
+        return _power_forward_ntc(m, pack_nct(x.float()))
+
+
+def _power_forward_ntc(m, xb):
+    B, T, cp = xb.shape
+    w192, o4 = _power_merged(m, xb.device)
+    wf = _empty((192, 7, cp), _BF, xb)
+    _hip.call("mm_prep_conv_weight", w192, wf, None, 192, w192.shape[1], 7, cp, 0)
+    h = igemm(xb, wf, 7, 3, 192, scale=o4[0], shift=o4[1], act="gelu")["bf16"]
+    r, _ = conv_bn_act(h, m.fusion[0], m.fusion[1], training=False, pe=pe_table(m.pos_encoder, T),
+                       want_f32=True, want_bf16=False)
+    tok = r["f32"]
+    for blk in m.transformer_layers:
+        tok, _ = transformer_block_fwd(tok, blk, False)
+    out, _ = pooled_head_fwd(tok, m.output_proj[2])
     return out
 
 

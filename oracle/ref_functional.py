@@ -335,6 +335,12 @@ def clip_loss(ze, zf_all, ze_all, zf, logit_scale, row0: int = 0):
     return loss, acc_e, acc_f, s_ef
 
 
+def stft_power_encoder(sd: SD, x, n_ffts=(64, 128), hop: int = 32, p: str = "encoder.", nhead: int = 4):
+    """a-X3 + a4: multi-scale STFT power (channel-concatenated) -> EnhancedPowerEncoder."""
+    spec = torch.cat([stft_power(x, n, hop) for n in n_ffts], dim=1)
+    return power_encoder(sd, spec, p, nhead)
+
+
 def stft_power(x, n_fft: int, hop: int):
     """a-X3: per-channel Hann STFT power, (B,C,T) -> (B, C*F, frames)."""
     B, C, T = x.shape

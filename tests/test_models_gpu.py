@@ -276,3 +276,22 @@ def test_run_training_lite_main_trains_on_gpu(tmp_path, monkeypatch):
     cfg.synthetic["subjects"] = 24
     res = R.main(cfg, max_epochs=3)
     assert len(res) == 2 and all(0.0 <= r["Accuracy"] <= 1.0 for r in res)
+
+
+def test_aX3_stft_front_end_and_encoder_vs_oracle():
+    """extension a-X3 (parity unpinned by the reference; pinned to torch.stft): spectra to 2e-2
+    rel (bf16 storage) and the encoder output on top of them to cosine >= 1 - 1e-3 (the spectra
+    span ~6 decades, so bf16 operand rounding weighs more than on z-scored inputs)."""
+    from multimodal_eeg_fmri_amd import ops
+    x = seeded_randn(161, 2, 8, 512)
+    spec = torch.cat([RF.stft_power(x, n, 32) for n in (64, 128)], dim=1)          # (B, C*F, frames)
+    got = ops.stft_front_end(x.cuda(), (64, 128), 32).float().cpu()              # (B, frames, Cp)
+    want = spec.transpose(1, 2)
+    assert got.shape[1] == want.shape[1] == 17
+    torch.testing.assert_close(got[:, :, :want.shape[2]], want, rtol=2e-2, atol=2e-2)
+    m = build(Cv.MultiScaleSTFTPowerEncoder, 61, 8).eval()
+    with torch.no_grad():
+        want_y = RF.stft_power_encoder(m.state_dict(), x)
+        y = m.cuda()(x.cuda()).cpu()
+    assert y.shape == (2, 128)
+    assert cos_min(y, want_y) >= 1 - 1e-3, cos_min(y, want_y)
