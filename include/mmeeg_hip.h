@@ -218,6 +218,22 @@ int mm_learned_fusion(const float* f0, const float* f1, const float* f2, const f
 /* bridge cross-attention core, 1 query x 2 keys (bridge_utils.py:75-82) */
 int mm_attn_1x2(const float* proj_e, const float* proj_f, float* ctx, float* attw, int B, int E, int nhead,
                 hipStream_t stream);
+/* trainable form of the 1x2 cross-attention core (with attention-probability dropout):
+ * backward == 0: ctx/attw from proj_e/proj_f;  backward == 1: dproj_e/dproj_f [B][3E] from dctx */
+int mm_attn_1x2_train(const float* proj_e, const float* proj_f, const float* dctx, float* ctx, float* attw,
+                      float* dproj_e, float* dproj_f, int B, int E, int nhead, float drop_p, uint32_t seed,
+                      const uint32_t* seed_epoch, int backward, hipStream_t stream);
+/* backward of mm_learned_fusion: df_m, ddyn, and (atomically, over rows) dlogits[M], dtemp[1] */
+int mm_learned_fusion_bwd(const float* f0, const float* f1, const float* f2, const float* dyn,
+                          const float* logits, const float* temperature, const float* dfused, float* df0,
+                          float* df1, float* df2, float* ddyn, float* dlogits, float* dtemp, int B, int H,
+                          int M, hipStream_t stream);
+int mm_softmax2_concat_bwd(const float* dout, const float* a, const float* c, const float* pa,
+                           const float* pc, float* da, float* dc, float* dpa, float* dpc, int B, int Ha,
+                           int Hc, hipStream_t stream);
+/* nn.CrossEntropyLoss(weight=class_weight) (_test_bridge.py:858; run_fmri_v11.py): loss_out[0] += loss */
+int mm_weighted_ce(const float* logits, const void* target_i64, const float* class_weight, float* loss_out,
+                   float* dlogits, int B, int C, hipStream_t stream);
 /* HybridFusionModule gate + mix + conn boost (crossmodal_v4_enhancements.py:787-797) */
 int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float* conn, float* comb,
                  float* gate, int B, int H, float boost, hipStream_t stream);

@@ -113,6 +113,32 @@ class BridgeFeatureDataset(Dataset):
         return s["eeg"], s["fmri"], s["label"], s["subject"]
 
 
+class WeightedCrossEntropy(nn.Module):
+    """``nn.CrossEntropyLoss(weight=class_w)`` of the bridge loop (_test_bridge.py:858) as one kernel."""
+
+    def __init__(self, weight=None):
+        super().__init__()
+        self.register_buffer("weight", weight if weight is None else weight.clone().float())
+
+    def forward(self, logits, target):
+        return ops.weighted_cross_entropy(logits, target, self.weight)
+
+
+def train_bridge_epoch(model, loader, optimizer, criterion, device, grad_clip=1.0):
+    """one epoch of the reference bridge loop (_test_bridge.py:775-788); ``optimizer`` is a
+    ``multimodal_eeg_fmri_amd.optim.FusedAdamW`` (its step already clips to ``max_grad_norm``)."""
+    model.train()
+    total, n = 0.0, 0
+    for eeg, fmri, labels, _ in loader:
+        optimizer.zero_grad()
+        loss = criterion(model(eeg.to(device), fmri.to(device)), labels.to(device))
+        loss.backward()
+        optimizer.step()
+        total += loss.item()
+        n += 1
+    return total / max(n, 1)
+
+
 def collate_bridge(batch):
     """(``_test_bridge.py:755-760``) stack features, long labels, subject list."""
     eeg = torch.stack([b[0] for b in batch])

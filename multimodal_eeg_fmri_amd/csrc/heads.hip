@@ -332,6 +332,179 @@ __global__ void attn_1x2_kernel(const float* __restrict__ pe, const float* __res
     }
 }
 
+// backward of attn_1x2 (attention-probability dropout p applied to the two
+// probabilities before mixing, recomputed from (seed, b, h, key)):
+//   d proj_e [B][3E] = [dq | dk_e | dv_e],  d proj_f [B][3E] = [0 | dk_f | dv_f]
+__global__ void attn_1x2_fused_kernel(const float* __restrict__ pe, const float* __restrict__ pf,
+                                      const float* __restrict__ dctx, float* __restrict__ ctx,
+                                      float* __restrict__ attw, float* __restrict__ dpe, float* __restrict__ dpf,
+                                      int B, int E, int nhead, uint32_t thresh, uint32_t seed, float inv_keep,
+                                      const uint32_t* epoch, int backward) {
+    seed = mm_eff_seed(seed, epoch);
+    const int b = blockIdx.x;
+    const int dh = E / nhead;
+    __shared__ float p0s[16], p1s[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* q = pe + (size_t)b * 3 * E;
+    const float* ke = q + E; const float* ve = q + 2 * E;
+    const float* kf = pf + (size_t)b * 3 * E + E; const float* vf = kf + E;
+    const float isq = rsqrtf((float)dh);
+    for (int h = wave; h < nhead; h += (blockDim.x >> 6)) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int d = lane; d < dh; d += 64) { s0 += q[h * dh + d] * ke[h * dh + d]; s1 += q[h * dh + d] * kf[h * dh + d]; }
+        s0 = wave_sum(s0) * isq; s1 = wave_sum(s1) * isq;
+        const float m = fmaxf(s0, s1);
+        const float e0 = __expf(s0 - m), e1 = __expf(s1 - m);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        float k0 = 1.f, k1 = 1.f;
+        if (thresh) {
+            k0 = dropout_scale(seed, (uint32_t)((b * nhead + h) * 2), thresh, inv_keep);
+            k1 = dropout_scale(seed, (uint32_t)((b * nhead + h) * 2 + 1), thresh, inv_keep);
+        }
+        if (!backward) {
+            for (int d = lane; d < dh; d += 64)
+                ctx[(size_t)b * E + h * dh + d] = p0 * k0 * ve[h * dh + d] + p1 * k1 * vf[h * dh + d];
+            if (lane == 0) { p0s[h] = p0; p1s[h] = p1; }
+        } else {
+            const float* dc = dctx + (size_t)b * E + h * dh;
+            float dp0 = 0.f, dp1 = 0.f;
+            for (int d = lane; d < dh; d += 64) { dp0 += dc[d] * ve[h * dh + d]; dp1 += dc[d] * vf[h * dh + d]; }
+            dp0 = wave_sum(dp0) * k0; dp1 = wave_sum(dp1) * k1;
+            const float dot = p0 * dp0 + p1 * dp1;
+            const float ds0 = p0 * (dp0 - dot) * isq, ds1 = p1 * (dp1 - dot) * isq;
+            float* dq = dpe + (size_t)b * 3 * E;
+            float* dkf_ = dpf + (size_t)b * 3 * E;
+            for (int d = lane; d < dh; d += 64) {
+                const int i = h * dh + d;
+                dq[i] = ds0 * ke[i] + ds1 * kf[i];
+                dq[E + i] = ds0 * q[i];
+                dq[2 * E + i] = p0 * k0 * dc[d];
+                dkf_[i] = 0.f;
+                dkf_[E + i] = ds1 * q[i];
+                dkf_[2 * E + i] = p1 * k1 * dc[d];
+            }
+        }
+    }
+    if (!backward) {
+        __syncthreads();
+        if (threadIdx.x == 0 && attw) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int h = 0; h < nhead; ++h) { a0 += p0s[h]; a1 += p1s[h]; }
+            attw[2 * b] = a0 / nhead; attw[2 * b + 1] = a1 / nhead;
+        }
+    }
+}
+
+// backward of learned_fusion_kernel.  One wave per row; parameter gradients
+// (logits [M], temperature) are summed over rows with atomics into dlogits / dtemp.
+__global__ void learned_fusion_bwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                          const float* __restrict__ f2, const float* __restrict__ dyn,
+                                          const float* __restrict__ logits, const float* __restrict__ temp,
+                                          const float* __restrict__ dfused, float* __restrict__ df0,
+                                          float* __restrict__ df1, float* __restrict__ df2, float* __restrict__ ddyn,
+                                          float* __restrict__ dlogits, float* __restrict__ dtemp, int B, int H, int M) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float T = temp[0];
+    float us[4], ud[4], st[4], dy[4], w[4], dw[4] = {0.f, 0.f, 0.f, 0.f};
+    float ms = -INFINITY, md = -INFINITY;
+    for (int m = 0; m < M; ++m) {
+        us[m] = logits[m] / T; ud[m] = dyn[(size_t)row * M + m] / T;
+        ms = fmaxf(ms, us[m]); md = fmaxf(md, ud[m]);
+    }
+    float ss = 0.f, sd = 0.f;
+    for (int m = 0; m < M; ++m) { st[m] = __expf(us[m] - ms); dy[m] = __expf(ud[m] - md); ss += st[m]; sd += dy[m]; }
+    for (int m = 0; m < M; ++m) { st[m] /= ss; dy[m] /= sd; w[m] = 0.5f * st[m] + 0.5f * dy[m]; }
+    const float* fs[3] = {f0, f1, f2};
+    float* dfs[3] = {df0, df1, df2};
+    for (int h = lane; h < H; h += 64) {
+        const float g = dfused[(size_t)row * H + h];
+        for (int m = 0; m < M; ++m) {
+            dw[m] += g * fs[m][(size_t)row * H + h];
+            dfs[m][(size_t)row * H + h] = w[m] * g;
+        }
+    }
+    for (int m = 0; m < M; ++m) dw[m] = wave_sum(dw[m]);
+    if (lane == 0) {
+        float dots = 0.f, dotd = 0.f;
+        for (int m = 0; m < M; ++m) { dots += st[m] * dw[m]; dotd += dy[m] * dw[m]; }
+        float dT = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float gs = 0.5f * st[m] * (dw[m] - dots);      // d L / d (logits_m / T)
+            const float gd = 0.5f * dy[m] * (dw[m] - dotd);      // d L / d (dyn_m / T)
+            ddyn[(size_t)row * M + m] = gd / T;
+            atomicAdd(&dlogits[m], gs / T);
+            dT -= (gs * us[m] + gd * ud[m]) / T;
+        }
+        atomicAdd(dtemp, dT);
+    }
+}
+
+// backward of softmax2_concat: d a, d c and the two scalar weight-logit gradients
+__global__ void softmax2_concat_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                           const float* __restrict__ c, const float* __restrict__ pa,
+                                           const float* __restrict__ pc, float* __restrict__ da, float* __restrict__ dc,
+                                           float* __restrict__ dpa, float* __restrict__ dpc, int B, int Ha, int Hc) {
+    const float m = fmaxf(pa[0], pc[0]);
+    const float ea = __expf(pa[0] - m), ec = __expf(pc[0] - m);
+    const float w0 = ea / (ea + ec), w1 = ec / (ea + ec);
+    const int H = Ha + Hc;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < B * H; i += blockDim.x) {
+        const int b = i / H, j = i % H;
+        const float g = dout[i];
+        if (j < Ha) { da[(size_t)b * Ha + j] = w0 * g; s0 += g * a[(size_t)b * Ha + j]; }
+        else { dc[(size_t)b * Hc + (j - Ha)] = w1 * g; s1 += g * c[(size_t)b * Hc + (j - Ha)]; }
+    }
+    __shared__ float r0[16], r1[16];
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = s0; r1[threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { t0 += r0[k]; t1 += r1[k]; }
+        const float dot = w0 * t0 + w1 * t1;
+        dpa[0] += w0 * (t0 - dot);
+        dpc[0] += w1 * (t1 - dot);
+    }
+}
+
+// nn.CrossEntropyLoss(weight=w): loss = sum_b w[t_b] nll_b / sum_b w[t_b]   (single block, B small)
+__global__ void weighted_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                   const float* __restrict__ cw, float* __restrict__ out, float* __restrict__ dlogits,
+                                   int B, int C) {
+    __shared__ float wsum_s, loss_s;
+    if (threadIdx.x == 0) {
+        float ws = 0.f, ls = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* z = logits + (size_t)b * C;
+            float m = -INFINITY;
+            for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += __expf(z[c] - m);
+            const int t = (int)target[b];
+            const float w = cw ? cw[t] : 1.f;
+            ws += w; ls += w * (m + __logf(se) - z[t]);
+        }
+        wsum_s = ws; loss_s = ls;
+        out[0] += ls / ws;
+    }
+    __syncthreads();
+    if (!dlogits) return;
+    for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
+        const int b = i / C, c = i % C;
+        const float* z = logits + (size_t)b * C;
+        float m = -INFINITY;
+        for (int k = 0; k < C; ++k) m = fmaxf(m, z[k]);
+        float se = 0.f;
+        for (int k = 0; k < C; ++k) se += __expf(z[k] - m);
+        const int t = (int)target[b];
+        const float w = cw ? cw[t] : 1.f;
+        dlogits[i] = w * (__expf(z[c] - m) / se - (c == t ? 1.f : 0.f)) / wsum_s;
+    }
+}
+
 // HybridFusionModule mix (crossmodal_v4_enhancements.py:787-797):
 // gate = softmax(g[b][0:2]); comb[b] = [ gate0*erp + gate1*pw | conn * boost ]
 __global__ void gate2_mix_kernel(const float* __restrict__ g, const float* __restrict__ erp, const float* __restrict__ pw,
@@ -573,6 +746,43 @@ int mm_attn_1x2(const float* proj_e, const float* proj_f, float* ctx, float* att
     MM_REQUIRE(proj_e && proj_f && ctx && attw && B > 0 && nhead > 0 && nhead <= 16 && E % nhead == 0, "attn_1x2: bad args");
     hipLaunchKernelGGL(attn_1x2_kernel, dim3(B), dim3(256), 0, st, proj_e, proj_f, ctx, attw, B, E, nhead);
     return mm_check_launch("attn_1x2");
+}
+
+int mm_attn_1x2_train(const float* proj_e, const float* proj_f, const float* dctx, float* ctx, float* attw,
+                      float* dproj_e, float* dproj_f, int B, int E, int nhead, float drop_p, uint32_t seed,
+                      const uint32_t* seed_epoch, int backward, hipStream_t st) {
+    MM_REQUIRE(proj_e && proj_f && B > 0 && nhead > 0 && nhead <= 16 && E % nhead == 0, "attn_1x2_train: bad args");
+    MM_REQUIRE(backward ? (dctx && dproj_e && dproj_f) : (ctx != nullptr), "attn_1x2_train: outputs");
+    hipLaunchKernelGGL(attn_1x2_fused_kernel, dim3(B), dim3(256), 0, st, proj_e, proj_f, dctx, ctx, attw, dproj_e,
+                       dproj_f, B, E, nhead, thresh_h(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
+                       seed_epoch, backward);
+    return mm_check_launch("attn_1x2_train");
+}
+
+int mm_learned_fusion_bwd(const float* f0, const float* f1, const float* f2, const float* dyn, const float* logits,
+                          const float* temperature, const float* dfused, float* df0, float* df1, float* df2,
+                          float* ddyn, float* dlogits, float* dtemp, int B, int H, int M, hipStream_t st) {
+    MM_REQUIRE(f0 && f1 && dyn && logits && temperature && dfused && df0 && df1 && ddyn && dlogits && dtemp,
+               "learned_fusion_bwd: null");
+    MM_REQUIRE(M >= 2 && M <= 3 && (M == 2 || (f2 && df2)), "learned_fusion_bwd: M=%d", M);
+    hipLaunchKernelGGL(learned_fusion_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, f0, f1, f2, dyn, logits,
+                       temperature, dfused, df0, df1, df2, ddyn, dlogits, dtemp, B, H, M);
+    return mm_check_launch("learned_fusion_bwd");
+}
+
+int mm_softmax2_concat_bwd(const float* dout, const float* a, const float* c, const float* pa, const float* pc,
+                           float* da, float* dc, float* dpa, float* dpc, int B, int Ha, int Hc, hipStream_t st) {
+    MM_REQUIRE(dout && a && c && pa && pc && da && dc && dpa && dpc && B > 0, "softmax2_concat_bwd: null");
+    hipLaunchKernelGGL(softmax2_concat_bwd_kernel, dim3(1), dim3(1024), 0, st, dout, a, c, pa, pc, da, dc, dpa, dpc, B, Ha, Hc);
+    return mm_check_launch("softmax2_concat_bwd");
+}
+
+int mm_weighted_ce(const float* logits, const void* target_i64, const float* class_weight, float* loss_out,
+                   float* dlogits, int B, int C, hipStream_t st) {
+    MM_REQUIRE(logits && target_i64 && loss_out && B > 0 && C > 0, "weighted_ce: bad args");
+    hipLaunchKernelGGL(weighted_ce_kernel, dim3(1), dim3(256), 0, st, logits, (const long long*)target_i64, class_weight,
+                       loss_out, dlogits, B, C);
+    return mm_check_launch("weighted_ce");
 }
 
 int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float* conn, float* comb, float* gate, int B,

@@ -594,7 +594,11 @@ def _eval_only(what: str, training: bool):
 def learned_fusion(m, feats: List[torch.Tensor], training: bool):
     """LearnedFusionModule.forward -> (fused (B, H), weights (B, M))."""
     _need_gpu(*feats)
-    _eval_only("LearnedFusionModule", training)
+    if training:
+        from . import small_autograd as sa
+        g = sa.linear(torch.cat(list(feats), dim=1), m.gate_net[0], "gelu", m.gate_net[2].p)
+        dyn = sa.linear(g, m.gate_net[3])
+        return sa.LearnedFusionFn.apply(dyn, m.fusion_logits, m.temperature, *feats)
     M = len(feats)
     fs = [_f32c(f) for f in feats]
     B, H = fs[0].shape
@@ -610,7 +614,20 @@ def learned_fusion(m, feats: List[torch.Tensor], training: bool):
 def bridge_forward(m, eeg, fmri):
     """EEGfMRIBridgeFusionNet.forward -> (logits, fused, fusion_w (B,2), attn_w (B,1,2))."""
     _need_gpu(eeg, fmri)
-    _eval_only("EEGfMRIBridgeFusionNet (classifier path)", m.training)
+    if m.training:
+        from . import small_autograd as sa
+        p = m.drop_p
+        ca = m.cross_attn
+        ep = sa.proj_head(eeg, m.eeg_proj, p)
+        fp = sa.proj_head(fmri, m.fmri_proj, p)
+        pe = sa.SmallLinearFn.apply(ep, ca.in_proj_weight, ca.in_proj_bias, "none", 0.0)
+        pf = sa.SmallLinearFn.apply(fp, ca.in_proj_weight, ca.in_proj_bias, "none", 0.0)
+        ctx, attw = sa.Attn1x2Fn.apply(pe, pf, m.num_heads, float(ca.dropout))
+        att = sa.linear(ctx, ca.out_proj)
+        fused, fw = learned_fusion(m.fusion, [att, fp], True)
+        c = m.classifier
+        h = sa.ActFn.apply(sa.LayerNormFn.apply(sa.linear(fused, c[0]), c[1].weight, c[1].bias, c[1].eps), "relu", p)
+        return sa.linear(h, c[4]), fused, fw, attw.view(-1, 1, 2)
     with torch.no_grad():
         ep, _ = proj_head_fwd(m.eeg_proj, _f32c(eeg), False, 0.0)
         fp, _ = proj_head_fwd(m.fmri_proj, _f32c(fmri), False, 0.0)
@@ -647,7 +664,14 @@ def fmri_mlp_forward(seq, x, drop_p, training):
 
 def fmri_fusion_forward(m, activation, connectivity):
     _need_gpu(activation, connectivity)
-    _eval_only("fMRIFusionNet", m.training)
+    if m.training:
+        from . import small_autograd as sa
+        p = m.drop_p
+        a = fmri_mlp_forward(m.activation_encoder.encoder, activation, p, True)
+        c = fmri_mlp_forward(m.connectivity_encoder.encoder, connectivity, p, True)
+        comb = sa.Softmax2ConcatFn.apply(a, c, m.activation_weight, m.connectivity_weight)
+        fused = sa.linear_bn_act(comb, m.fusion[0], m.fusion[1], "relu", p)
+        return sa.linear(sa.linear(fused, m.head[0], "relu", p), m.head[3]), fused
     with torch.no_grad():
         a = fmri_mlp_forward(m.activation_encoder.encoder, activation, 0.0, False)
         c = fmri_mlp_forward(m.connectivity_encoder.encoder, connectivity, 0.0, False)
@@ -790,6 +814,14 @@ def _power_forward_ntc(m, xb):
         tok, _ = transformer_block_fwd(tok, blk, False)
     out, _ = pooled_head_fwd(tok, m.output_proj[2])
     return out
+
+
+def weighted_cross_entropy(logits, target, weight=None):
+    """nn.CrossEntropyLoss(weight=...) on the HIP path (_test_bridge.py:858)."""
+    _need_gpu(logits, target)
+    from . import small_autograd as sa
+    w = weight.float().contiguous() if weight is not None else None
+    return sa.WeightedCEFn.apply(logits, target, w)
 
 
 def drop_path(x, drop_prob):

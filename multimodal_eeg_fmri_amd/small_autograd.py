@@ -192,3 +192,165 @@ def linear(x, lin, act="none", drop_p=0.0):
 def linear_bn_act(x, lin, bn, act, drop_p):
     """Linear -> BatchNorm1d(train) -> act -> Dropout"""
     return BNRowsActFn.apply(linear(x, lin), bn.weight, bn.bias, bn, act, float(drop_p))
+
+
+class LayerNormFn(torch.autograd.Function):
+    """fp32 LayerNorm over the last dim of (B, D) rows."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _f(x)
+        B, D = x.shape
+        y = _empty((B, D), _F32, x)
+        stat = _empty((B, 2), _F32, x)
+        _hip.call("mm_layernorm_fwd", x, gamma, beta, None, y, stat, B, D, float(eps))
+        ctx.save_for_backward(x, stat)
+        ctx.g, ctx.b = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stat = ctx.saved_tensors
+        B, D = x.shape
+        dx = _empty((B, D), _F32, x)
+        dgb = _zeros((REPL, 2, D), x)
+        _hip.call("mm_layernorm_bwd", None, _f(dy), x, stat, ctx.g, None, dx, None, dgb, B, D)
+        bag = GradBag()
+        gw, gb = bag.target(ctx.g), bag.target(ctx.b)
+        if gw is not None:
+            _hip.call("mm_reduce_replicas", dgb, gw, D, REPL, 2 * D)
+        if gb is not None:
+            _hip.call("mm_reduce_replicas", dgb.data_ptr() + 4 * D, gb, D, REPL, 2 * D)
+        return dx, bag.result(ctx.g), bag.result(ctx.b), None
+
+
+class ActFn(torch.autograd.Function):
+    """y = dropout(act(z)) elementwise, fp32."""
+
+    @staticmethod
+    def forward(ctx, z, act, drop_p):
+        z = _f(z)
+        seed = ops._next_seed() if drop_p > 0 else 0
+        y = torch.empty_like(z)
+        _hip.call("mm_act_f32", z, y, z.numel(), ACT[act], float(drop_p), seed, ops.EP())
+        ctx.save_for_backward(z)
+        ctx.meta = (act, float(drop_p), seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        act, p, seed = ctx.meta
+        out = torch.empty_like(z)
+        _hip.call("mm_act_bwd_f32", _f(g), z, out, z.numel(), ACT[act], p, seed, ops.EP())
+        return out, None, None
+
+
+class Attn1x2Fn(torch.autograd.Function):
+    """bridge cross-attention core: (proj_e, proj_f) (B, 3E) -> ctx (B, E), attw (B, 2)"""
+
+    @staticmethod
+    def forward(ctx, pe, pf, nhead, drop_p):
+        pe, pf = _f(pe), _f(pf)
+        B, E3 = pe.shape
+        E = E3 // 3
+        seed = ops._next_seed() if drop_p > 0 else 0
+        out = _empty((B, E), _F32, pe)
+        attw = _empty((B, 2), _F32, pe)
+        _hip.call("mm_attn_1x2_train", pe, pf, None, out, attw, None, None, B, E, int(nhead), float(drop_p), seed,
+                  ops.EP(), 0)
+        ctx.save_for_backward(pe, pf)
+        ctx.meta = (int(nhead), float(drop_p), seed)
+        ctx.mark_non_differentiable(attw)
+        return out, attw
+
+    @staticmethod
+    def backward(ctx, dctx, _dattw):
+        pe, pf = ctx.saved_tensors
+        nhead, p, seed = ctx.meta
+        B, E3 = pe.shape
+        dpe, dpf = torch.empty_like(pe), torch.empty_like(pf)
+        _hip.call("mm_attn_1x2_train", pe, pf, _f(dctx), None, None, dpe, dpf, B, E3 // 3, nhead, p, seed, ops.EP(), 1)
+        return dpe, dpf, None, None
+
+
+class LearnedFusionFn(torch.autograd.Function):
+    """LearnedFusionModule combine: (dyn (B, M), logits (M), temperature (), f_0..f_{M-1}) -> (fused, w)"""
+
+    @staticmethod
+    def forward(ctx, dyn, logits, temp, *feats):
+        feats = [_f(f) for f in feats]
+        M = len(feats)
+        B, H = feats[0].shape
+        dyn = _f(dyn)
+        fused = _empty((B, H), _F32, dyn)
+        w = _empty((B, M), _F32, dyn)
+        tl = temp.detach().reshape(1).float().contiguous()
+        ll = logits.detach().float().contiguous()
+        _hip.call("mm_learned_fusion", feats[0], feats[1], feats[2] if M > 2 else None, dyn, ll, tl, fused, w, B, H, M)
+        ctx.save_for_backward(dyn, ll, tl, *feats)
+        ctx.params = (logits, temp)
+        ctx.mark_non_differentiable(w)
+        return fused, w
+
+    @staticmethod
+    def backward(ctx, dfused, _dw):
+        dyn, ll, tl, *feats = ctx.saved_tensors
+        logits, temp = ctx.params
+        M = len(feats)
+        B, H = feats[0].shape
+        dfs = [torch.empty_like(f) for f in feats]
+        ddyn = torch.empty_like(dyn)
+        dl = _zeros((M,), dyn)
+        dt = _zeros((1,), dyn)
+        _hip.call("mm_learned_fusion_bwd", feats[0], feats[1], feats[2] if M > 2 else None, dyn, ll, tl, _f(dfused),
+                  dfs[0], dfs[1], dfs[2] if M > 2 else None, ddyn, dl, dt, B, H, M)
+        dtemp = dt.reshape(()) if temp.requires_grad else None
+        return (ddyn, dl if logits.requires_grad else None, dtemp) + tuple(dfs)
+
+
+class Softmax2ConcatFn(torch.autograd.Function):
+    """fMRIFusionNet weighted concat: [softmax(pa,pc)_0 * a | softmax_1 * c]"""
+
+    @staticmethod
+    def forward(ctx, a, c, pa, pc):
+        a, c = _f(a), _f(c)
+        B, Ha = a.shape
+        Hc = c.shape[1]
+        out = _empty((B, Ha + Hc), _F32, a)
+        pa_, pc_ = pa.detach().float().contiguous(), pc.detach().float().contiguous()
+        _hip.call("mm_softmax2_concat", a, c, pa_, pc_, out, B, Ha, Hc)
+        ctx.save_for_backward(a, c, pa_, pc_)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, c, pa_, pc_ = ctx.saved_tensors
+        B, Ha = a.shape
+        Hc = c.shape[1]
+        da, dc = torch.empty_like(a), torch.empty_like(c)
+        dpa, dpc = _zeros((1,), a), _zeros((1,), a)
+        _hip.call("mm_softmax2_concat_bwd", _f(g), a, c, pa_, pc_, da, dc, dpa, dpc, B, Ha, Hc)
+        return da, dc, dpa, dpc
+
+
+class WeightedCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        logits = _f(logits)
+        B, C = logits.shape
+        out = _zeros((1,), logits)
+        dl = _empty((B, C), _F32, logits)
+        _hip.call("mm_weighted_ce", logits, target.contiguous(), weight, out, dl, B, C)
+        ctx.save_for_backward(dl)
+        return out.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None
+
+
+def proj_head(x, seq, drop_p):
+    """Linear -> LayerNorm -> GELU -> Dropout (bridge_utils.py:34-45)"""
+    return ActFn.apply(LayerNormFn.apply(linear(x, seq[0]), seq[1].weight, seq[1].bias, seq[1].eps), "gelu", float(drop_p))

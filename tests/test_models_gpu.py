@@ -295,3 +295,48 @@ def test_aX3_stft_front_end_and_encoder_vs_oracle():
         y = m.cuda()(x.cuda()).cpu()
     assert y.shape == (2, 128)
     assert cos_min(y, want_y) >= 1 - 1e-3, cos_min(y, want_y)
+
+
+def test_a11_bridge_train_grads_vs_reference_golden(golden):
+    """golden (vii): weighted-CE loss, input gradients and every parameter gradient norm of
+    the bridge in train mode (dropout 0) as computed by the REFERENCE's autograd; plus full
+    tensors vs the oracle.  fp32 kernels -> 1e-3."""
+    fx = golden("a11_bridge_train_grads.npz")
+    m = build(Bu.EEGfMRIBridgeFusionNet, int(fx["seed"]), dropout=0.0).train()
+    m.fusion.gate_net[2].p = 0.0                      # hard-coded Dropout(0.2) (enhanced_models_v4.py:449)
+    s = [int(v) for v in fx["x_seeds"]]
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    eo = seeded_randn(s[0], 8, 128).requires_grad_(True)
+    fo = seeded_randn(s[1], 8, 64).requires_grad_(True)
+    tgt, cw = torch.as_tensor(fx["target"]), torch.as_tensor(fx["class_w"])
+    F.cross_entropy(RF.bridge_net(sd, eo, fo)[0], tgt, weight=cw).backward()
+    mg = m.cuda()
+    eeg = seeded_randn(s[0], 8, 128).cuda().requires_grad_(True)
+    fmri = seeded_randn(s[1], 8, 64).cuda().requires_grad_(True)
+    loss = Bu.WeightedCrossEntropy(cw.cuda())(mg(eeg, fmri), tgt.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) < 1e-4
+    torch.testing.assert_close(eeg.grad.cpu(), torch.as_tensor(fx["d_eeg"]), rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(fmri.grad.cpu(), torch.as_tensor(fx["d_fmri"]), rtol=1e-3, atol=1e-5)
+    params = dict(mg.named_parameters())
+    for n, gn in zip((str(n) for n in fx["gnames"]), fx["gnorms"]):
+        g = params[n].grad
+        assert g is not None, n
+        assert abs(g.double().norm().item() - gn) <= 1e-3 * max(gn, 1e-3), (n, g.double().norm().item(), gn)
+        torch.testing.assert_close(g.cpu(), sd[n].grad, rtol=2e-3, atol=2e-5, msg=lambda t: n + ": " + t)
+
+
+def test_a9_fmri_fusion_trains():
+    m = build(Fm.fMRIFusionNet, 71, 100, 200, dropout=0.0).train()
+    act, con = seeded_randn(171, 16, 100), seeded_randn(172, 16, 200)
+    tgt = (seeded_randn(173, 16) > 0).long()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    out_o, _ = RF.fmri_fusion_net(sd, act, con, train=True)
+    F.cross_entropy(out_o, tgt).backward()
+    mg = m.cuda()
+    out = mg(act.cuda(), con.cuda())
+    loss = Bu.WeightedCrossEntropy()(out, tgt.cuda())
+    loss.backward()
+    torch.testing.assert_close(out.detach().cpu(), out_o.detach(), rtol=1e-3, atol=1e-4)
+    for n, p in mg.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), sd[n].grad, rtol=5e-3, atol=5e-5, msg=lambda t: n + ": " + t)
