@@ -36,7 +36,8 @@ def test_argument_errors_are_reported_not_crashed():
     lib = _hip.load()
     rc = lib.mm_pack_nct_bf16(None, None, 0, 0, 0, 0, None)
     assert rc == -1 and b"pack_nct" in lib.mm_last_error()
-    rc = lib.mm_attn_fwd(ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 16, 4, 64, ctypes.c_float(0.1), None)
+    rc = lib.mm_attn_fwd(ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 16, 4, 64, ctypes.c_float(0.1),
+                         ctypes.c_float(0.0), 0, None, None)
     assert rc == -1 and b"head_dim" in lib.mm_last_error()
 
 
