@@ -359,23 +359,41 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
     float bsum = 0.f;
 
+    // tiles are fetched into registers one iteration ahead (all loads in flight
+    // before any LDS write, and in flight during the previous tile's MFMAs)
+    constexpr int YREG = WG_MK * 8 / 256;                           // 2
+    constexpr int XREG = ((WG_MK + TAPS - 1) * 8 + 255) / 256;      // 3
+    uint4 yv[YREG], xv[XREG];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < YREG; ++i) {
+            const int s = tid + i * 256, r = s >> 3, sg = s & 7;
+            const int t = t0 + r, n = n0 + sg * 8;
+            yv[i] = (t < tend && n < a.Cout) ? *reinterpret_cast<const uint4*>(dyb + (size_t)t * a.Cout + n) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XREG; ++i) {
+            const int s = tid + i * 256, r = s >> 3, sg = s & 7;
+            const int t = t0 - a.pad + r, c = c0 + sg * 8;
+            xv[i] = (s < (WG_MK + TAPS - 1) * 8 && t >= 0 && t < a.T && c < a.Cin)
+                        ? *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (tbeg < tend) fetch(tbeg);
     for (int t0 = tbeg; t0 < tend; t0 += WG_MK) {
         __syncthreads();
-        for (int s = tid; s < WG_MK * 8; s += 256) {               // dY tile: 64 rows x 8 segs
-            const int r = s >> 3, sg = s & 7;
-            const int t = t0 + r, n = n0 + sg * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (t < tend && n < a.Cout) v = *reinterpret_cast<const uint4*>(dyb + (size_t)t * a.Cout + n);
-            *reinterpret_cast<uint4*>(Ys + r * WG_LD + sg * 8) = v;
+#pragma unroll
+        for (int i = 0; i < YREG; ++i) {
+            const int s = tid + i * 256;
+            *reinterpret_cast<uint4*>(Ys + (s >> 3) * WG_LD + (s & 7) * 8) = yv[i];
         }
-        for (int s = tid; s < (WG_MK + TAPS - 1) * 8; s += 256) {  // X halo tile
-            const int r = s >> 3, sg = s & 7;
-            const int t = t0 - a.pad + r, c = c0 + sg * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (t >= 0 && t < a.T && c < a.Cin) v = *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c);
-            *reinterpret_cast<uint4*>(Xs + r * WG_LD + sg * 8) = v;
+#pragma unroll
+        for (int i = 0; i < XREG; ++i) {
+            const int s = tid + i * 256;
+            if (s < (WG_MK + TAPS - 1) * 8) *reinterpret_cast<uint4*>(Xs + (s >> 3) * WG_LD + (s & 7) * 8) = xv[i];
         }
         __syncthreads();
+        if (t0 + WG_MK < tend) fetch(t0 + WG_MK);
 #pragma unroll
         for (int kk = 0; kk < WG_MK; kk += 16) {
             const bf16x8 af = tr_frag(Ys, kk, wn * 32, lane);
@@ -511,6 +529,8 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
         default: return launch_fwd<BM_, BN_, WM_, WN_, 128>(a, st);              \
     }
     if (narrow) { MM_FWD(64, 64, 2, 2) }
+    // few row tiles (M <= 16k): halve BM so that >= 2 workgroups share a CU and overlap
+    if ((long)B * ceil_div(T, 64) * ceil_div(Cout, 128) <= 512) { MM_FWD(32, 128, 1, 4) }
     MM_FWD(64, 128, 2, 2)
 #undef MM_FWD
 }
