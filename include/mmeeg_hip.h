@@ -60,6 +60,8 @@ int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, in
  * epilogue: v = acc*scale[n] + shift[n]; stats[0][n]+=v, stats[1][n]+=v*v;
  *           out_pre = v; v = act(v); v *= dropout; v += residual; v += pe[t][n];
  *           max over t pairs if pool == 2; store fp32 and/or bf16.
+ * backward fusion: with gradz != NULL, v *= act'(gradz[idx]) before the dropout mask, so
+ * the data-gradient GEMM of a Linear directly yields d(pre-activation) of the layer below.
  * Replaces nn.Conv1d (+ folded eval BatchNorm1d + GELU + MaxPool1d)
  * (enhanced_models_v4.py:128-144, 210-234; crossmodal_v4_enhancements.py:822-877)
  * and, with taps == 1, every nn.Linear / MHA projection on the path
@@ -67,7 +69,8 @@ int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, in
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual,
                   const float* pe, int pool, float* stats, float* out_f32, void* out_bf16,
-                  void* out_pre, float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, hipStream_t stream);
+                  void* out_pre, float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch,
+                  const void* gradz, int gradz_act, hipStream_t stream);
 /* dW[n][c][tap] (fp32, strides sn/sc/stap in elements) += sum_{b,t} dY[b,t,n]*X[b,t+tap-pad,c];
  * optional dbias[n] += sum dY.  Replaces the weight/bias gradients autograd
  * derives for the layers above (loss.backward(), run_training_lite.py:486). */
@@ -113,10 +116,13 @@ int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16
 /* ---- LayerNorm (nn.LayerNorm, enhanced_models_v4.py:80-81; bridge_utils.py:36,42,62) */
 int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16,
                      float* out_f32, float* stat, int M, int D, float eps, hipStream_t stream);
-/* dgb_repl = zeroed scratch [32][2][D]: replicated {dgamma, dbeta} partial sums */
+/* dgb_repl = zeroed scratch [32][2][D]: replicated {dgamma, dbeta} partial sums;
+ * dx_bf16 (optional) = bf16(dx * dropout_mask(drop_p, seed)): the masked GEMM operand of the
+ * residual branch feeding this LayerNorm's input */
 int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stat,
                      const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
-                     int M, int D, hipStream_t stream);
+                     int M, int D, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                     hipStream_t stream);
 
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,

@@ -123,7 +123,9 @@ def _mask_cast(g_f32=None, g_bf16=None, z=None, act="none", drop_p=0.0, seed=0):
 
 
 def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *, need_dx=True,
-               dx_f32=False):
+               dx_f32=False, below=None):
+    """``below`` = (z, act, drop_p, seed) of the layer that produced ``x``: the data-gradient
+    GEMM then returns d(pre-activation z) = (dy W) * act'(z) * dropout_mask directly."""
     """dy (M, N) bf16, x (M, Kp) bf16 -> dx (M, Kp); accumulates dW, db."""
     M, N = dy.shape
     Kp = x.shape[1]
@@ -142,7 +144,11 @@ def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *,
     _, wd, cinp, coutp = ops.weights.get(weight, True)
     if coutp != N:
         raise _hip.HipLibraryError(f"linear_bwd: dY width {N} != padded out width {coutp}")
-    r = ops.igemm(dy.view(1, M, N), wd, 1, 0, cinp, out_f32=dx_f32, out_bf16=not dx_f32)
+    kw = {}
+    if below is not None:
+        z, act, p, seed = below
+        kw = dict(gradz=z, gradz_act=act, drop_p=p, seed=seed)
+    r = ops.igemm(dy.view(1, M, N), wd, 1, 0, cinp, out_f32=dx_f32, out_bf16=not dx_f32, **kw)
     return (r["f32"] if dx_f32 else r["bf16"]).view(M, cinp)
 
 
@@ -183,26 +189,31 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"]
 
 
-def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor) -> torch.Tensor:
-    """dx2 fp32 (M, D) -> dx0 fp32 (M, D)"""
+def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, emit_for=None):
+    """dx2 fp32 (M, D) -> (dx0 fp32 (M, D), bf16(dx0 * mask) or None).
+
+    ``dy2`` = bf16(dx2 * dropout_mask(p, s3)) if the producer of dx2 already emitted it;
+    ``emit_for`` = (p, seed) of the consumer of dx0 (the FFN2 mask of the block below):
+    the last LayerNorm-backward then also writes that masked bf16 operand, so no
+    stand-alone cast/mask pass runs between GEMMs."""
     blk = s["blk"]
     p = s["p"]
     s1, s2, s3 = s["seeds"]
     B, L = s["B"], s["L"]
     M, D = dx2.shape
     at = blk.self_attn
-    # FFN second linear:  x2 = x1 + drop(g W2^T + b2)
-    dy2 = _mask_cast(g_f32=dx2, drop_p=p, seed=s3)
-    dg = linear_bwd(bag, dy2, s["g"], blk.linear2.weight, blk.linear2.bias)
-    # g = drop(act(z))
-    dz = _mask_cast(g_bf16=dg, z=s["z"], act=blk._act, drop_p=p, seed=s2)
+    # FFN second linear:  x2 = x1 + drop(g W2^T + b2);  g = drop(act(z))
+    if dy2 is None:
+        dy2 = _mask_cast(g_f32=dx2, drop_p=p, seed=s3)
+    dz = linear_bwd(bag, dy2, s["g"], blk.linear2.weight, blk.linear2.bias, below=(s["z"], blk._act, p, s2))
     dh2 = linear_bwd(bag, dz, s["h2"], blk.linear1.weight, blk.linear1.bias)
     dx1 = _empty((M, D), _F32, dx2)
+    dyo = _empty((M, D), _BF, dx2)                      # bf16(dx1 * mask1): out-proj backward operand
     dgb = _zeros((REPL, 2, D), dx2)
-    _hip.call("mm_layernorm_bwd", dh2, None, s["x1"], s["st2"], blk.norm2.weight, dx2, dx1, None, dgb, M, D)
+    _hip.call("mm_layernorm_bwd", dh2, None, s["x1"], s["st2"], blk.norm2.weight, dx2, dx1, dyo, dgb, M, D,
+              float(p), int(s1), ops.EP())
     _ln_param_grads(bag, blk.norm2, dgb, D)
     # attention output projection:  x1 = x0 + drop(o Wo^T + bo)
-    dyo = _mask_cast(g_f32=dx1, drop_p=p, seed=s1)
     do = linear_bwd(bag, dyo, s["o"].view(M, D), at.out_proj.weight, at.out_proj.bias)
     dqkv = _empty((B, L, 3 * D), _BF, dx2)
     delta = _empty((B, blk.nhead, L), _F32, dx2)
@@ -212,10 +223,13 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor) -> torch.Ten
               float(pa), int(sa), ops.EP())
     dh1 = linear_bwd(bag, dqkv.view(M, 3 * D), s["h1"], at.in_proj_weight, at.in_proj_bias)
     dx0 = _empty((M, D), _F32, dx2)
+    emit = _empty((M, D), _BF, dx2) if emit_for is not None else None
+    ep, es = emit_for if emit_for is not None else (0.0, 0)
     dgb = _zeros((REPL, 2, D), dx2)
-    _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, None, dgb, M, D)
+    _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, emit, dgb, M, D,
+              float(ep), int(es), ops.EP())
     _ln_param_grads(bag, blk.norm1, dgb, D)
-    return dx0
+    return dx0, emit
 
 
 def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor) -> torch.Tensor:
@@ -247,8 +261,11 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     d = pooled_head_bwd(bag, sv["head"], dout)
     B, L, D = d.shape
     d = d.view(B * L, D)
-    for s in reversed(sv["blocks"]):
-        d = transformer_block_bwd(bag, s, d)
+    blocks = sv["blocks"]
+    dy2 = None
+    for i in range(len(blocks) - 1, -1, -1):
+        below = (blocks[i - 1]["p"], blocks[i - 1]["seeds"][2]) if i > 0 else None
+        d, dy2 = transformer_block_bwd(bag, blocks[i], d, dy2=dy2, emit_for=below)
     c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
     g = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D))
     g = conv_bn_act_bwd(bag, c2, dout_bf16=g)
@@ -309,7 +326,7 @@ class TransformerBlockFn(_ModuleFn):
         bag = GradBag()
         B, L, D = dout.shape
         with deferred(bag, dout.device):
-            dx = transformer_block_bwd(bag, ctx.saved, dout.contiguous().view(B * L, D).float())
+            dx, _ = transformer_block_bwd(bag, ctx.saved, dout.contiguous().view(B * L, D).float())
         return _ModuleFn._finish(ctx, bag, ctx.params, dx.view(B, L, D))
 
 
@@ -415,7 +432,7 @@ def proj_head_bwd(bag: GradBag, s: dict, da: torch.Tensor, need_dx=True):
     _hip.call("mm_act_bwd_f32", da, s["hn"], dhn, B * N, ACT["gelu"], float(s["p"]), int(s["seed"]), ops.EP())
     dz1 = _empty((B, N), _F32, da)
     dgb = _zeros((REPL, 2, N), da)
-    _hip.call("mm_layernorm_bwd", None, dhn, s["z1"], s["stat"], ln.weight, None, dz1, None, dgb, B, N)
+    _hip.call("mm_layernorm_bwd", None, dhn, s["z1"], s["stat"], ln.weight, None, dz1, None, dgb, B, N, 0.0, 0, None)
     _ln_param_grads(bag, ln, dgb, N)
     dx = _empty((B, K), _F32, da) if need_dx else None
     _hip.call("mm_small_linear_bwd", dz1, s["x"], lin.weight, dx, bag.target(lin.weight), bag.target(lin.bias), B, K, N)

@@ -283,7 +283,9 @@ __global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const flo
                                      const float* __restrict__ x, const float* __restrict__ stat,
                                      const float* __restrict__ g, const float* __restrict__ dres,
                                      float* __restrict__ dx, bf16* __restrict__ dx_bf16,
-                                     float* __restrict__ dgb, int M, int rows_per_wave) {
+                                     float* __restrict__ dgb, int M, int rows_per_wave, uint32_t thresh,
+                                     uint32_t seed, float inv_keep, const uint32_t* epoch) {
+    seed = mm_eff_seed(seed, epoch);
     constexpr int D = VPL * 64;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -315,7 +317,7 @@ __global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const flo
             float o = rstd * (dyv[i] * gam[i] - s1 - xh[i] * s2);
             if (dres) o += dres[idx];
             if (dx) dx[idx] = o;
-            if (dx_bf16) dx_bf16[idx] = (bf16)o;
+            if (dx_bf16) dx_bf16[idx] = (bf16)(thresh ? o * dropout_scale(seed, (uint32_t)idx, thresh, inv_keep) : o);
         }
     }
     __shared__ float red[2][1024];
@@ -506,12 +508,14 @@ int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void
 }
 
 int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stat, const float* gamma,
-                     const float* dres, float* dx, void* dx_bf16, float* dgb_repl, int M, int D, hipStream_t st) {
+                     const float* dres, float* dx, void* dx_bf16, float* dgb_repl, int M, int D, float drop_p,
+                     uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE((dy_bf16 || dy_f32) && x && stat && gamma && (dx || dx_bf16), "layernorm_bwd: null");
     const int rpw = M >= 8192 ? 8 : (M >= 1024 ? 2 : 1);
     const dim3 grid(ceil_div(M, 4 * rpw)), block(256);
     LN_DISPATCH(D, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, 0, st, (const bf16*)dy_bf16, dy_f32, x,
-                                      stat, gamma, dres, dx, (bf16*)dx_bf16, dgb_repl, M, rpw));
+                                      stat, gamma, dres, dx, (bf16*)dx_bf16, dgb_repl, M, rpw, thresh_of(drop_p), seed,
+                                      drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch));
     return mm_check_launch("layernorm_bwd");
 }
 

@@ -34,6 +34,8 @@ struct EpiArgs {
     uint32_t drop_seed;
     float drop_inv_keep;
     const uint32_t* drop_epoch;
+    const bf16* gradz;        // backward fusion: v *= act'(gradz[idx]) (nullptr = off)
+    int gradz_act;
 };
 
 struct ConvArgs {
@@ -88,6 +90,11 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
             if (e.out_pre) {
                 bf16x4 pv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 *reinterpret_cast<bf16x4*>(e.out_pre + idx) = pv;
+            }
+            if (e.gradz) {
+                const bf16x4 zz = *reinterpret_cast<const bf16x4*>(e.gradz + idx);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] *= act_grad((float)zz[c], e.gradz_act);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -499,7 +506,8 @@ int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, in
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual, const float* pe,
                   int pool, float* stats, float* out_f32, void* out_bf16, void* out_pre,
-                  float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, hipStream_t st) {
+                  float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, const void* gradz, int gradz_act,
+                  hipStream_t st) {
     MM_REQUIRE(x && w, "conv1d_fwd: null operand");
     MM_REQUIRE(B > 0 && T > 0 && Cout > 0 && taps >= 1 && taps <= 9 && pad >= 0 && pad < taps, "conv1d_fwd: bad dims");
     MM_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv1d_fwd: Cin=%d must be a multiple of 16", Cin);
@@ -516,6 +524,7 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     a.e.drop_seed = drop_seed;
     a.e.drop_epoch = seed_epoch;
+    a.e.gradz = (const bf16*)gradz; a.e.gradz_act = gradz_act;
     a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
     // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
     // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS

@@ -206,7 +206,7 @@ def pack_nct(x: torch.Tensor) -> torch.Tensor:
 
 def igemm(x: torch.Tensor, wf: torch.Tensor, taps: int, pad: int, cout: int, *,
           scale=None, shift=None, act="none", residual=None, pe=None, pool=1, stats=None,
-          out_f32=False, out_bf16=True, out_pre=False, drop_p=0.0, seed=0):
+          out_f32=False, out_bf16=True, out_pre=False, drop_p=0.0, seed=0, gradz=None, gradz_act="none"):
     """x (B, T, Cin) bf16 -> dict(out_f32, out_bf16, out_pre) of (B, T/pool, cout)."""
     B, T, cin = x.shape
     res = {}
@@ -214,7 +214,7 @@ def igemm(x: torch.Tensor, wf: torch.Tensor, taps: int, pad: int, cout: int, *,
     ob = _empty((B, T // pool, cout), _BF, x) if out_bf16 else None
     op = _empty((B, T, cout), _BF, x) if out_pre else None
     _hip.call("mm_conv1d_fwd", x, wf, B, T, cin, cout, taps, pad, scale, shift, ACT[act], residual, pe,
-              pool, stats, of, ob, op, float(drop_p), int(seed), EP())
+              pool, stats, of, ob, op, float(drop_p), int(seed), EP(), gradz, ACT[gradz_act])
     res["f32"], res["bf16"], res["pre"] = of, ob, op
     return res
 

@@ -214,7 +214,7 @@ class LayerNormFn(torch.autograd.Function):
         B, D = x.shape
         dx = _empty((B, D), _F32, x)
         dgb = _zeros((REPL, 2, D), x)
-        _hip.call("mm_layernorm_bwd", None, _f(dy), x, stat, ctx.g, None, dx, None, dgb, B, D)
+        _hip.call("mm_layernorm_bwd", None, _f(dy), x, stat, ctx.g, None, dx, None, dgb, B, D, 0.0, 0, None)
         bag = GradBag()
         gw, gb = bag.target(ctx.g), bag.target(ctx.b)
         if gw is not None:

@@ -53,7 +53,7 @@ def test_conv1d_fwd_matches_torch(B, C, T, Cout, k):
     wf, _ = _prep_w(hip, w, cp)
     out = torch.empty(B, T, Cout, dtype=torch.float32, device="cuda")
     hip.call("mm_conv1d_fwd", xg, wf, B, T, cp, Cout, k, k // 2, None, bias.cuda(), 0, None, None, 1,
-             None, out, None, None, 0.0, 0, None)
+             None, out, None, None, 0.0, 0, None, None, 0)
     want = F.conv1d(_bf(x), _bf(w), bias, padding=k // 2).transpose(1, 2)
     torch.testing.assert_close(out.cpu(), want, rtol=1e-4, atol=1e-4)
 
@@ -72,7 +72,7 @@ def test_conv1d_fwd_epilogue_bn_gelu_pool_stats():
     out = torch.empty(B, T // 2, Cout, dtype=torch.bfloat16, device="cuda")
     stats = torch.zeros(32, 2, Cout, device="cuda")
     hip.call("mm_conv1d_fwd", xg, wf, B, T, C, Cout, k, k // 2, scale.cuda(), shift.cuda(), 1, None, None, 2,
-             stats, None, out, None, 0.0, 0, None)
+             stats, None, out, None, 0.0, 0, None, None, 0)
     stats = stats.sum(0)
     z = F.conv1d(_bf(x), _bf(w), None, padding=k // 2) * scale[None, :, None] + shift[None, :, None]
     want = F.max_pool1d(F.gelu(z), 2).transpose(1, 2)
@@ -151,7 +151,7 @@ def test_conv1d_dgrad_via_forward_kernel():
     dyg = dy.transpose(1, 2).contiguous().cuda().to(torch.bfloat16)
     dx = torch.empty(B, T, C, device="cuda")
     hip.call("mm_conv1d_fwd", dyg, wd, B, T, Cout, C, k, k - 1 - k // 2, None, None, 0, None, None, 1,
-             None, dx, None, None, 0.0, 0, None)
+             None, dx, None, None, 0.0, 0, None, None, 0)
     torch.testing.assert_close(dx.cpu().transpose(1, 2), x.grad, rtol=1e-3, atol=1e-3)
 
 
@@ -174,7 +174,7 @@ def test_layernorm_fwd_bwd(M, D):
     dx = torch.empty(M, D, device="cuda")
     dgb = torch.zeros(32, 2, D, device="cuda")
     hip.call("mm_layernorm_bwd", dy.cuda().to(torch.bfloat16), None, x.cuda(), stat, gam.cuda(), dres.cuda(), dx, None,
-             dgb, M, D)
+             dgb, M, D, 0.0, 0, None)
     dg, db = dgb.sum(0)[0], dgb.sum(0)[1]
     torch.testing.assert_close(dx.cpu(), xr.grad + dres, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-3, atol=1e-3)

@@ -41,7 +41,7 @@ def linear_case(M, K, N, out_f32=False, residual=False, act="none"):
     ob = None if out_f32 else torch.empty(M, N, dtype=BF, device="cuda")
 
     def fn():
-        _hip.call("mm_conv1d_fwd", x, wf, 1, M, K, N, 1, 0, None, b, ops.ACT[act], res, None, 1, None, of, ob, None, 0.0, 0, None)
+        _hip.call("mm_conv1d_fwd", x, wf, 1, M, K, N, 1, 0, None, b, ops.ACT[act], res, None, 1, None, of, ob, None, 0.0, 0, None, None, 0)
     us = timeit(fn)
     fl = 2.0 * M * K * N
     print(f"linear M={M} K={K} N={N} f32={out_f32} res={residual} act={act}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
@@ -57,7 +57,7 @@ def conv1d_case(B, T, Cin, Cout, k):
     b = torch.randn(Cout, device="cuda")
 
     def fn():
-        _hip.call("mm_conv1d_fwd", x, wf, B, T, Cin, Cout, k, k // 2, None, b, 0, None, None, 1, stats, of, None, None, 0.0, 0, None)
+        _hip.call("mm_conv1d_fwd", x, wf, B, T, Cin, Cout, k, k // 2, None, b, 0, None, None, 1, stats, of, None, None, 0.0, 0, None, None, 0)
     us = timeit(fn)
     fl = 2.0 * B * T * Cin * Cout * k
     print(f"conv1d B={B} T={T} Cin={Cin} Cout={Cout} k={k}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
