@@ -67,19 +67,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         const int kn32 = (kn + 31) & ~31;
         __syncthreads();
         // stage K rows and V^T (zero-padded to a multiple of 32 keys)
-        for (int s = tid; s < kn32 * 4; s += 256) {
-            const int key = s >> 2, sg = s & 3;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (key < kn) {
-                const bf16* row = base + (size_t)(k0 + key) * E3;
-                kv = *reinterpret_cast<const uint4*>(row + E + sg * 8);
-                vv = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
-            }
-            *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kv;
-            const bf16* ve = reinterpret_cast<const bf16*>(&vv);
-            const int pos = vperm(key);
+        {   // all loads of the chunk are in flight before the first LDS write
+            constexpr int NI = KCH * 4 / 256;
+            uint4 kreg[NI], vreg[NI];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[(sg * 8 + j) * VS + pos] = ve[j];
+            for (int i = 0; i < NI; ++i) {
+                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+                kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = make_uint4(0, 0, 0, 0);
+                if (key < kn) {
+                    const bf16* row = base + (size_t)(k0 + key) * E3;
+                    kreg[i] = *reinterpret_cast<const uint4*>(row + E + sg * 8);
+                    vreg[i] = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+                if (key >= kn32) continue;
+                *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
+                const bf16* ve = reinterpret_cast<const bf16*>(&vreg[i]);
+                const int pos = vperm(key);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Vt[(sg * 8 + j) * VS + pos] = ve[j];
+            }
         }
         __syncthreads();
         for (int kt = 0; kt < kn32; kt += 32) {
@@ -191,20 +201,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         const int kn = min(KCH, L - k0);
         const int kn32 = (kn + 31) & ~31;
         __syncthreads();
-        for (int s = tid; s < kn32 * 4; s += 256) {
-            const int key = s >> 2, sg = s & 3;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (key < kn) {
-                const bf16* row = base + (size_t)(k0 + key) * E3;
-                kv = *reinterpret_cast<const uint4*>(row + E + sg * 8);
-                vv = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
-            }
-            *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kv;
-            *reinterpret_cast<uint4*>(Vs + key * KS + sg * 8) = vv;
-            const bf16* ke = reinterpret_cast<const bf16*>(&kv);
-            const int pos = vperm(key);
+        {
+            constexpr int NI = KCH * 4 / 256;
+            uint4 kreg[NI], vreg[NI];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Kt[(sg * 8 + j) * VS + pos] = ke[j];
+            for (int i = 0; i < NI; ++i) {
+                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+                kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = make_uint4(0, 0, 0, 0);
+                if (key < kn) {
+                    const bf16* row = base + (size_t)(k0 + key) * E3;
+                    kreg[i] = *reinterpret_cast<const uint4*>(row + E + sg * 8);
+                    vreg[i] = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+                if (key >= kn32) continue;
+                *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
+                *reinterpret_cast<uint4*>(Vs + key * KS + sg * 8) = vreg[i];
+                const bf16* ke = reinterpret_cast<const bf16*>(&kreg[i]);
+                const int pos = vperm(key);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Kt[(sg * 8 + j) * VS + pos] = ke[j];
+            }
         }
         __syncthreads();
         for (int kt = 0; kt < kn32; kt += 32) {
@@ -286,22 +306,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
         const int qn = min(QCH, L - q0);
         const int qn32 = (qn + 31) & ~31;
         __syncthreads();
-        for (int s = tid; s < qn32 * 4; s += 256) {
-            const int qi = s >> 2, sg = s & 3;
-            uint4 qv = make_uint4(0, 0, 0, 0), dv4 = make_uint4(0, 0, 0, 0);
-            if (qi < qn) {
-                qv = *reinterpret_cast<const uint4*>(base + (size_t)(q0 + qi) * E3 + sg * 8);
-                dv4 = *reinterpret_cast<const uint4*>(dout + ((size_t)b * L + q0 + qi) * E + h * DH + sg * 8);
-            }
-            *reinterpret_cast<uint4*>(Qs + qi * KS + sg * 8) = qv;
-            *reinterpret_cast<uint4*>(Ds + qi * KS + sg * 8) = dv4;
-            const bf16* qe = reinterpret_cast<const bf16*>(&qv);
-            const bf16* de = reinterpret_cast<const bf16*>(&dv4);
-            const int pos = vperm(qi);
+        {
+            constexpr int NI = QCH * 4 / 256;
+            uint4 qreg[NI], dreg[NI];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                Qt[(sg * 8 + j) * QS + pos] = qe[j];
-                Dt[(sg * 8 + j) * QS + pos] = de[j];
+            for (int i = 0; i < NI; ++i) {
+                const int s = tid + i * 256, qi = s >> 2, sg = s & 3;
+                qreg[i] = make_uint4(0, 0, 0, 0); dreg[i] = make_uint4(0, 0, 0, 0);
+                if (qi < qn) {
+                    qreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)(q0 + qi) * E3 + sg * 8);
+                    dreg[i] = *reinterpret_cast<const uint4*>(dout + ((size_t)b * L + q0 + qi) * E + h * DH + sg * 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int s = tid + i * 256, qi = s >> 2, sg = s & 3;
+                if (qi >= qn32) continue;
+                *reinterpret_cast<uint4*>(Qs + qi * KS + sg * 8) = qreg[i];
+                *reinterpret_cast<uint4*>(Ds + qi * KS + sg * 8) = dreg[i];
+                const bf16* qe = reinterpret_cast<const bf16*>(&qreg[i]);
+                const bf16* de = reinterpret_cast<const bf16*>(&dreg[i]);
+                const int pos = vperm(qi);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    Qt[(sg * 8 + j) * QS + pos] = qe[j];
+                    Dt[(sg * 8 + j) * QS + pos] = de[j];
+                }
             }
         }
         for (int i = tid; i < qn32; i += 256) {

@@ -339,6 +339,107 @@ __global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const flo
     }
 }
 
+// ---------------------------------------------------------------------------
+// D == 128 fast path (the transformer width): one 32-lane half-wave per row, one
+// 16-byte vector per lane, two rows per wave in flight, 5-step shuffle reductions.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ void layernorm128_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                        const float* __restrict__ b, bf16* __restrict__ out_bf16,
+                                        float* __restrict__ out_f32, float* __restrict__ stat, int M, float eps) {
+    const int lane = threadIdx.x & 31;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (row >= M) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 128 + lane * 4);
+    const float mean = half_sum(v.x + v.y + v.z + v.w) * (1.f / 128.f);
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    const float rstd = rsqrtf(half_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / 128.f) + eps);
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(b + lane * 4);
+    const float o0 = d0 * rstd * gg.x + bb.x, o1 = d1 * rstd * gg.y + bb.y, o2 = d2 * rstd * gg.z + bb.z, o3 = d3 * rstd * gg.w + bb.w;
+    if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * 128 + lane * 4) = make_float4(o0, o1, o2, o3);
+    if (out_bf16) {
+        bf16x4 ob = {(bf16)o0, (bf16)o1, (bf16)o2, (bf16)o3};
+        *reinterpret_cast<bf16x4*>(out_bf16 + (size_t)row * 128 + lane * 4) = ob;
+    }
+    if (stat && lane == 0) { stat[2 * row] = mean; stat[2 * row + 1] = rstd; }
+}
+
+__global__ void layernorm128_bwd_kernel(const bf16* __restrict__ dy_bf16, const float* __restrict__ dy_f32,
+                                        const float* __restrict__ x, const float* __restrict__ stat,
+                                        const float* __restrict__ g, const float* __restrict__ dres,
+                                        float* __restrict__ dx, bf16* __restrict__ dx_bf16, float* __restrict__ dgb,
+                                        int M, int rows_per_half, uint32_t thresh, uint32_t seed, float inv_keep,
+                                        const uint32_t* epoch) {
+    seed = mm_eff_seed(seed, epoch);
+    const int lane = threadIdx.x & 31;
+    const int half = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+    const float gam[4] = {gg.x, gg.y, gg.z, gg.w};
+    float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+    const int row0 = half * rows_per_half;
+    for (int rr = 0; rr < rows_per_half; ++rr) {
+        const int row = row0 + rr;
+        if (row >= M) break;
+        const size_t base = (size_t)row * 128 + lane * 4;
+        float dyv[4];
+        if (dy_bf16) {
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(dy_bf16 + base);
+            dyv[0] = (float)t[0]; dyv[1] = (float)t[1]; dyv[2] = (float)t[2]; dyv[3] = (float)t[3];
+        } else {
+            const float4 t = *reinterpret_cast<const float4*>(dy_f32 + base);
+            dyv[0] = t.x; dyv[1] = t.y; dyv[2] = t.z; dyv[3] = t.w;
+        }
+        const float4 xv = *reinterpret_cast<const float4*>(x + base);
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dres) rv = *reinterpret_cast<const float4*>(dres + base);
+        const float mean = stat[2 * row], rstd = stat[2 * row + 1];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+        float xh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xh[c] = (xs[c] - mean) * rstd;
+            const float gh = dyv[c] * gam[c];
+            s1 += gh; s2 += gh * xh[c];
+            ag[c] += dyv[c] * xh[c]; ab[c] += dyv[c];
+        }
+        s1 = half_sum(s1) * (1.f / 128.f);
+        s2 = half_sum(s2) * (1.f / 128.f);
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = rstd * (dyv[c] * gam[c] - s1 - xh[c] * s2) + rs[c];
+        if (dx) *reinterpret_cast<float4*>(dx + base) = make_float4(o[0], o[1], o[2], o[3]);
+        if (dx_bf16) {
+            bf16x4 ob;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                ob[c] = (bf16)(thresh ? o[c] * dropout_scale(seed, (uint32_t)(base + c), thresh, inv_keep) : o[c]);
+            *reinterpret_cast<bf16x4*>(dx_bf16 + base) = ob;
+        }
+    }
+    __shared__ float red[2][128];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        atomicAdd(&red[0][lane * 4 + c], ag[c]);
+        atomicAdd(&red[1][lane * 4 + c], ab[c]);
+    }
+    __syncthreads();
+    if (dgb) {
+        float* rep = dgb + (size_t)(blockIdx.x % MM_REPL) * 256;
+        for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+            atomicAdd(&rep[i], red[0][i]);
+            atomicAdd(&rep[128 + i], red[1][i]);
+        }
+    }
+}
+
 // column sums of a bf16/fp32 [M][N] matrix into fp32 [N] (atomics; bias grads)
 __global__ void colsum_kernel(const bf16* __restrict__ a_bf16, const float* __restrict__ a_f32,
                               float* __restrict__ out, int M, int N, int rows_per_blk) {
@@ -501,6 +602,11 @@ int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16
 int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16, float* out_f32,
                      float* stat, int M, int D, float eps, hipStream_t st) {
     MM_REQUIRE(x && gamma && beta && (out_bf16 || out_f32) && M > 0, "layernorm_fwd: null");
+    if (D == 128) {
+        hipLaunchKernelGGL(layernorm128_fwd_kernel, dim3(ceil_div(M, 8)), dim3(256), 0, st, x, gamma, beta,
+                           (bf16*)out_bf16, out_f32, stat, M, eps);
+        return mm_check_launch("layernorm128_fwd");
+    }
     const dim3 grid(ceil_div(M, 4)), block(256);
     LN_DISPATCH(D, hipLaunchKernelGGL(layernorm_fwd_kernel<V>, grid, block, 0, st, x, gamma, beta, (bf16*)out_bf16,
                                       out_f32, stat, M, eps));
@@ -511,6 +617,13 @@ int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, c
                      const float* dres, float* dx, void* dx_bf16, float* dgb_repl, int M, int D, float drop_p,
                      uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE((dy_bf16 || dy_f32) && x && stat && gamma && (dx || dx_bf16), "layernorm_bwd: null");
+    if (D == 128) {
+        const int rph = M >= 8192 ? 4 : 1;                 // rows per half-wave
+        hipLaunchKernelGGL(layernorm128_bwd_kernel, dim3(ceil_div(M, 8 * rph)), dim3(256), 0, st, (const bf16*)dy_bf16,
+                           dy_f32, x, stat, gamma, dres, dx, (bf16*)dx_bf16, dgb_repl, M, rph, thresh_of(drop_p), seed,
+                           drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch);
+        return mm_check_launch("layernorm128_bwd");
+    }
     const int rpw = M >= 8192 ? 8 : (M >= 1024 ? 2 : 1);
     const dim3 grid(ceil_div(M, 4 * rpw)), block(256);
     LN_DISPATCH(D, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, 0, st, (const bf16*)dy_bf16, dy_f32, x,
