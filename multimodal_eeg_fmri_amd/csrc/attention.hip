@@ -29,9 +29,14 @@ __device__ __forceinline__ int vperm(int key) {       // swap bits 2 and 3 of th
 
 // attention-probability dropout (nn.MultiheadAttention(dropout=p)): the softmax
 // row sum uses the un-dropped probabilities, only the P operand of P.V is masked.
+// lighter index hash than common.h's (the softmax loops are VALU-bound: one Weyl multiply,
+// one xorshift-multiply round; the high bits feed the threshold compare)
 __device__ __forceinline__ float attn_keep(uint32_t seed, int bh, int q, int key, int L, uint32_t thresh, float inv_keep) {
-    const uint32_t idx = ((uint32_t)bh * (uint32_t)L + (uint32_t)q) * (uint32_t)L + (uint32_t)key;
-    return dropout_scale(seed, idx, thresh, inv_keep);
+    uint32_t x = (((uint32_t)bh * (uint32_t)L + (uint32_t)q) * (uint32_t)L + (uint32_t)key) * 0x9E3779B1u + seed;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 13;
+    return x >= thresh ? inv_keep : 0.f;
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,

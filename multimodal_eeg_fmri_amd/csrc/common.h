@@ -32,14 +32,28 @@ int mm_check_launch(const char* what);            // hipGetLastError -> code
         if (!(cond)) return mm_fail(MM_ERR_ARG, __VA_ARGS__);   \
     } while (0)
 
+// exact-erf GELU (nn.GELU() default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7,
+// i.e. fp32 rounding level): one v_rcp + one v_exp + 5 FMAs instead of ocml's ~30-instruction
+// erff; the exp(-x^2/2) is shared with the Gaussian pdf that GELU' needs.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_unnorm) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * u);
+    const float e = __expf(-u * u);                                   // = exp(-x^2 / 2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erfa = 1.0f - poly * e;                               // erf(|x| / sqrt 2)
+    cdf = 0.5f * (1.0f + copysignf(erfa, x));
+    pdf_unnorm = e;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
 }
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return cdf + x * 0.3989422804014327f * e;
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {

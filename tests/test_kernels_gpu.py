@@ -313,13 +313,12 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd():
     out0 = torch.empty_like(out)
     hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None)
     # recover the mask from V = identity-like probe: compare row sums of kept probabilities
-    # host replica of the counter hash (common.h: mm_hash)
+    # host replica of the attention kernels' index hash (attention.hip: attn_keep)
     def keep_mask():
         idx = torch.arange(B * H * L * L, dtype=torch.int64)
         x = (idx * 0x9E3779B1 + seed) & 0xFFFFFFFF
-        x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
-        x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
-        x ^= x >> 16
+        x ^= x >> 15; x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+        x ^= x >> 13
         return (x >= int(p * 4294967296.0)).view(B, H, L, L).double() / (1 - p)
     m = keep_mask()
     q, k, v = (t.view(B, L, H, 32).transpose(1, 2).double() for t in qkv.split(E, dim=2))
