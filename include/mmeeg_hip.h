@@ -260,9 +260,12 @@ int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_
 int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t stream);
 
 /* ---- optimizer: clip_grad_norm_(max_norm) + AdamW.step() on one flat bucket
- * (run_training_lite.py:487-488; _test_bridge.py:784-786).  state (device, 8 floats):
- * [0] step count, [1] sum of squared grads (mm_sumsq adds into it), [2] lr,
- * [3] clip coefficient of the last step, [4] grad norm of the last step. */
+ * (run_training_lite.py:487-488; _test_bridge.py:784-786).  state (device, MM_OPT_STATE_FLOATS
+ * = 8 + 1024 floats): [0] step count, [1] sum of squared grads of the last step, [2] lr,
+ * [3] clip coefficient of the last step, [4] grad norm of the last step, [8..) per-block
+ * partial sums written by mm_sumsq and added in a fixed order by mm_adamw_clip (no float
+ * atomics: ranks holding the same all-reduced gradient stay bit-identical). */
+#define MM_OPT_STATE_FLOATS 1032
 int mm_sumsq(const float* g, float* state, int64_t n, hipStream_t stream);
 int mm_adamw_clip(float* p, const float* g, float* m, float* v, float* state, int64_t n, float beta1,
                   float beta2, float eps, float weight_decay, float max_norm, float grad_scale,

@@ -234,13 +234,12 @@ class BridgeTrainer(nn.Module):
         if len(g) == 1:
             g[0].replay()
         else:
-            import torch.distributed as dist
             g[0].replay()
-            dist.all_gather_into_tensor(c["z_all"], c["z"], group=self.group)
+            dp.all_gather_into(c["z_all"], c["z"], self.group)
             g[1].replay()
-            dist.reduce_scatter_tensor(c["dz"], c["dz_all"], op=dist.ReduceOp.SUM, group=self.group)
+            dp.reduce_scatter_into(c["dz"], c["dz_all"], self.group)
             g[2].replay()
-            dist.all_reduce(self.bucket.g, op=dist.ReduceOp.SUM, group=self.group)
+            dp.allreduce_sum_(self.bucket.g, self.group)
             g[3].replay()
         return {"loss": c["scal"][0], "top1_e2f": c["scal"][1], "top1_f2e": c["scal"][2]}
 

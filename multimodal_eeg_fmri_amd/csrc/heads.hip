@@ -215,9 +215,14 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------
 // fused AdamW (decoupled weight decay) + global-norm clip on a flat fp32 bucket.
 // state[0] = step counter (float, incremented on device so the launch can live
-// in a hipGraph), state[1] = sum of squared gradients (filled by sumsq_kernel),
-// state[2] = learning rate (host-updatable), state[3] = last clip coefficient.
+// in a hipGraph), state[2] = learning rate (host-updatable), state[3] = last clip
+// coefficient, state[4] = last gradient norm, state[8 .. 8+1024) = per-block partial
+// sums of squared gradients.  The partials are summed in a FIXED order (no float
+// atomics), so data-parallel ranks holding the same all-reduced gradient compute
+// bit-identical clip coefficients and their parameters never drift apart.
 // ---------------------------------------------------------------------------
+constexpr int SUMSQ_SLOTS = 1024;
+
 __global__ void sumsq_kernel(const float* __restrict__ g, float* __restrict__ state, size_t n) {
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += g[i] * g[i];
@@ -225,7 +230,20 @@ __global__ void sumsq_kernel(const float* __restrict__ g, float* __restrict__ st
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&state[1], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) state[8 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0)
+        for (int i = gridDim.x + threadIdx.x; i < SUMSQ_SLOTS; i += blockDim.x) state[8 + i] = 0.f;
+}
+
+// every 256-thread block gets the same total, added in the same order
+__device__ inline float sumsq_total(const float* __restrict__ state) {
+    __shared__ float tot[4];
+    const int t = threadIdx.x;
+    float s = (state[8 + t] + state[8 + 256 + t]) + (state[8 + 512 + t] + state[8 + 768 + t]);
+    s = wave_sum(s);
+    if ((t & 63) == 0) tot[t >> 6] = s;
+    __syncthreads();
+    return (tot[0] + tot[1]) + (tot[2] + tot[3]);
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -233,7 +251,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                              float beta2, float eps, float wd, float max_norm, float grad_scale) {
     const float step = state[0] + 1.f;
     const float lr = state[2];
-    const float gn = sqrtf(state[1]) * grad_scale;
+    const float gn = sqrtf(sumsq_total(state)) * grad_scale;
     const float clip = (max_norm > 0.f) ? fminf(1.f, max_norm / (gn + 1e-6f)) : 1.f;
     const float gs = grad_scale * clip;
     const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
@@ -249,11 +267,13 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 __global__ void adamw_finish_kernel(float* __restrict__ state, float max_norm, float grad_scale) {
-    const float gn = sqrtf(state[1]) * grad_scale;
+    const float ss = sumsq_total(state);
+    if (threadIdx.x != 0) return;
+    const float gn = sqrtf(ss) * grad_scale;
     state[3] = (max_norm > 0.f) ? fminf(1.f, max_norm / (gn + 1e-6f)) : 1.f;
     state[4] = gn;
     state[0] += 1.f;
-    state[1] = 0.f;
+    state[1] = ss;
 }
 
 
@@ -721,7 +741,7 @@ int mm_adamw_clip(float* p, const float* g, float* m, float* v, float* state, in
     MM_REQUIRE(p && g && m && v && state && n > 0, "adamw_clip: null");
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, p, g, m, v, state, (size_t)n, beta1,
                        beta2, eps, weight_decay, max_norm, grad_scale);
-    hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(1), 0, st, state, max_norm, grad_scale);
+    hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(256), 0, st, state, max_norm, grad_scale);
     return mm_check_launch("adamw_clip");
 }
 

@@ -24,7 +24,7 @@ class FlatBucket:
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(8 + 1024, dtype=torch.float32, device=dev)   # MM_OPT_STATE_FLOATS
         off = 0
         for p in self.params:
             k = p.numel()
