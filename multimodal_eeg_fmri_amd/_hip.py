@@ -61,7 +61,8 @@ class HipLibraryError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    """in-tree library; MMEEG_HIP_LIB points tools/kbench.py at an ablation build instead"""
+    return os.environ.get("MMEEG_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def load():

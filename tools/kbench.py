@@ -101,6 +101,35 @@ def conv3d_case(B, S, Cin, Cout, wgrad=True):
     print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
 
 
+def timeline_case(B=32, S=16, Cin=32, Cout=64):
+    """per-workgroup phase stamps of conv3d_fwd_wres_kernel (debug flag 512; 100 MHz clock)"""
+    x = torch.randn(B, S, S, S, Cin, device="cuda").to(BF)
+    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
+    wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
+    of = torch.empty(B, S, S, S, Cout, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
+    b = torch.randn(Cout, device="cuda")
+    for _ in range(3):
+        _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, of, None)
+    dbgbuf = torch.zeros(256 * 16, dtype=torch.int64, device="cuda")
+    _hip.call("mm_debug_flags", 512)
+    _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, of, dbgbuf)
+    torch.cuda.synchronize()
+    _hip.call("mm_debug_flags", 0)
+    ts = dbgbuf.view(256, 16).cpu().double()
+    t0 = ts[:, 0].min()
+    us = (ts - t0) / 100.0
+    names = {0: "start", 1: "W plane 0 stored", 2: "halo0 in LDS", 3: "mfma0 issued", 4: "halo1 in LDS",
+             5: "mfma1+stores0 issued", 14: "tail stores issued", 15: "done"}
+    print("phase stamps, us since the first workgroup started (min / mean / max over 256 workgroups)")
+    for i, n in names.items():
+        c = us[:, i]
+        print(f"  {n:22s} {c.min():7.2f} {c.mean():7.2f} {c.max():7.2f}")
+    mhz = ((ts[:, 13] - ts[:, 12]) / ((ts[:, 15] - ts[:, 0]) / 100.0)).mean()
+    print(f"  s_memtime ticks per us over the kernel: {mhz:.0f}")
+
+
 def floor_case():
     x = torch.zeros(64, device="cuda")
     y = torch.zeros(64, dtype=BF, device="cuda")
@@ -154,6 +183,9 @@ def main():
         conv1d_wgrad_case(1, M, 128, 512, 1)
     if "pmc3d" in flt:
         conv3d_case(32, 16, 32, 64, wgrad=False)
+        return
+    if "tl" in flt:
+        timeline_case()
         return
     if "abl" in flt:
         for f in (0, 1, 2, 3):
