@@ -161,15 +161,21 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
 int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W,
                     int Cin, int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep,
                     int64_t rep_stride, hipStream_t stream);
-/* y fp32 [B][D][H][W][N] -> act(BN(y)) -> MaxPool3d(2) -> dropout -> bf16 [B][D/2][H/2][W/2][N] */
-int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, int B, int D, int H, int W,
-                         int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
-int mm_pool3d_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, float* sums_out,
+/* y fp32 [B][D][H][W][N] -> act(BN(y)) -> MaxPool3d(2) -> dropout -> bf16 [B][D/2][H/2][W/2][N].
+ * Training also keeps, per pooled element, the winner's pre-BN value (ysel fp32) and its index in
+ * the 2x2x2 window (arg, one byte: 4 d + 2 h + w); both null in eval.  The reduction of the
+ * BatchNorm gradient sums then reads only pooled data (gradients vanish off the winners) and the
+ * apply pass (dy bf16, full volume) takes the argmax from `arg`. */
+int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, float* ysel, void* arg, int B, int D,
+                         int H, int W, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                         hipStream_t stream);
+int mm_pool3d_bn_act_bwd_reduce(const float* ysel, const float* out4, const void* dout_bf16, float* sums_out,
                                 int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
                                 const uint32_t* seed_epoch, hipStream_t stream);
-int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* sums,
-                               void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
-                               uint32_t seed, const uint32_t* seed_epoch, int train, hipStream_t stream);
+int mm_pool3d_bn_act_bwd_apply(const float* y, const void* arg, const float* out4, const void* dout_bf16,
+                               const float* sums, void* dy, int B, int D, int H, int W, int N, int act,
+                               float drop_p, uint32_t seed, const uint32_t* seed_epoch, int train,
+                               hipStream_t stream);
 
 /* Fused first voxel layer Conv3d(1->32,k3,p1)+BatchNorm3d+GELU+MaxPool3d(2)[+Dropout]
  * on fp32 [B][D][H][W] volumes; the 32x larger pre-BN tensor is recomputed, never

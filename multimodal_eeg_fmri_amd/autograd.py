@@ -340,11 +340,11 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
     dy = _empty((B, D, H, W, N), _BF, y)
     gelu = ACT["gelu"]
     if s["pool"]:
-        _hip.call("mm_pool3d_bn_act_bwd_reduce", y, out4, dout, sums, B, D, H, W, N, gelu, float(s["drop_p"]),
-                  int(s["seed"]), ops.EP())
+        _hip.call("mm_pool3d_bn_act_bwd_reduce", s["ysel"], out4, dout, sums, B, D, H, W, N, gelu,
+                  float(s["drop_p"]), int(s["seed"]), ops.EP())
         sc = _compact(sums, 2 * N)
-        _hip.call("mm_pool3d_bn_act_bwd_apply", y, out4, dout, sc, dy, B, D, H, W, N, gelu, float(s["drop_p"]),
-                  int(s["seed"]), ops.EP(), 1)
+        _hip.call("mm_pool3d_bn_act_bwd_apply", y, s["arg"], out4, dout, sc, dy, B, D, H, W, N, gelu,
+                  float(s["drop_p"]), int(s["seed"]), ops.EP(), 1)
     else:
         args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)

@@ -622,25 +622,41 @@ __global__ void pack_vol_kernel(const float* __restrict__ x, bf16* __restrict__ 
 // BN/act/2x2x2-maxpool/dropout on channels-last volumes (fwd + bwd), the 3-D
 // sibling of bn_act_* in elementwise.hip.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// BatchNorm3d -> act -> MaxPool3d(2) -> dropout and its backward, on the fp32
+// pre-BN volume [B][D][H][W][N] (HBM-bound: 33.5 MB in at layer 2).
+//
+// Every supported activation is quasi-convex in z (GELU falls to z = -0.75 and
+// rises after; the others are monotone), so max_j act(z_j) over a 2x2x2 window is
+// act(max z) or act(min z): two activations per pooled element instead of eight.
+// The forward keeps the winner's pre-BN value (`ysel`, fp32) and window index
+// (`arg`, one byte), so that
+//   * the BN-gradient reduction reads 6 MB of pooled data instead of the volume
+//     (gradients are zero everywhere but at the winners), and
+//   * the apply pass evaluates one act' per pooled element and never re-derives
+//     the argmax.
+// One thread = 4 channels of one pooled voxel (8 x 16-byte loads).
+// ---------------------------------------------------------------------------
 struct Pool3Args {
     const float* y; const float* out4; const bf16* dout; const float* sums;
     bf16* out; float* sums_out; bf16* dy;
+    float* ysel; uint8_t* arg;                 // pooled [B][D/2][H/2][W/2][N]
     int B, D, H, W, N, act, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
     const uint32_t* epoch;
 };
 
-template <int MODE>   // 0 fwd, 1 bwd-reduce, 2 bwd-apply
-__global__ void pool3_bn_act_kernel(Pool3Args a) {
+template <int MODE>   // 0 fwd, 2 bwd-apply
+__global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
     a.seed = mm_eff_seed(a.seed, a.epoch);
     const int nv = a.N / 4;
     const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
     const size_t nrows = (size_t)a.B * Do * Ho * Wo;
     const int rows_per_blk = 256 / nv > 0 ? 256 / nv : 1;
     const int vi = threadIdx.x % nv, ri = threadIdx.x / nv;
-    const bool active = ri < rows_per_blk;
+    if (ri >= rows_per_blk) return;
     const int n4 = vi * 4;
-    float sc[4], sh[4], mu[4], rs[4], c0[4], c1[4], s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    float sc[4], sh[4], mu[4], rs[4], c0[4], c1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         sc[q] = a.out4[n4 + q]; sh[q] = a.out4[a.N + n4 + q];
@@ -648,103 +664,140 @@ __global__ void pool3_bn_act_kernel(Pool3Args a) {
         c0[q] = (MODE == 2 && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;    // compact [2][N] sums
         c1[q] = (MODE == 2 && a.train) ? a.sums[a.N + n4 + q] * a.inv_count : 0.f;
     }
-    if (active)
-        for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
-            size_t q = row;
-            const int ow = (int)(q % Wo); q /= Wo;
-            const int oh = (int)(q % Ho); q /= Ho;
-            const int od = (int)(q % Do); q /= Do;
-            const size_t b = q;
-            float yv[8][4], av[8][4];
-            size_t idx[8];
+    for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
+        size_t q = row;
+        const int ow = (int)(q % Wo); q /= Wo;
+        const int oh = (int)(q % Ho); q /= Ho;
+        const int od = (int)(q % Do); q /= Do;
+        const size_t base = ((((size_t)q * a.D + 2 * od) * a.H + 2 * oh) * a.W + 2 * ow) * a.N + n4;
+        const size_t sw = a.N, shh = (size_t)a.W * a.N, sd = (size_t)a.H * a.W * a.N;
+        float4 t[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = 2 * od + (j >> 2), h = 2 * oh + ((j >> 1) & 1), w = 2 * ow + (j & 1);
-                idx[j] = ((((size_t)b * a.D + d) * a.H + h) * a.W + w) * a.N + n4;
-                const float4 t = *reinterpret_cast<const float4*>(a.y + idx[j]);
-                yv[j][0] = t.x; yv[j][1] = t.y; yv[j][2] = t.z; yv[j][3] = t.w;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) av[j][c] = apply_act(yv[j][c] * sc[c] + sh[c], a.act);
-            }
-            const size_t oidx = row * a.N + n4;
-            int arg[4];
-            float mx[4];
+        for (int j = 0; j < 8; ++j)
+            t[j] = *reinterpret_cast<const float4*>(a.y + base + (j >> 2) * sd + ((j >> 1) & 1) * shh + (j & 1) * sw);
+        const size_t oidx = row * a.N + n4;
+        if (MODE == 0) {
+            bf16x4 o;
+            float ys[4];
+            uint32_t args = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                mx[c] = av[0][c]; arg[c] = 0;
+                float zmax = -INFINITY, zmin = INFINITY, ymax = 0.f, ymin = 0.f;
+                int jmax = 0, jmin = 0;
 #pragma unroll
-                for (int j = 1; j < 8; ++j)
-                    if (av[j][c] > mx[c]) { mx[c] = av[j][c]; arg[c] = j; }
+                for (int j = 0; j < 8; ++j) {
+                    const float yv = (&t[j].x)[c];
+                    const float z = yv * sc[c] + sh[c];
+                    if (z > zmax) { zmax = z; jmax = j; ymax = yv; }       // strict: first occurrence wins, as PyTorch
+                    if (z < zmin) { zmin = z; jmin = j; ymin = yv; }
+                }
+                const float amax = apply_act(zmax, a.act), amin = apply_act(zmin, a.act);
+                const bool lo = amin > amax;
+                float v = lo ? amin : amax;
+                ys[c] = lo ? ymin : ymax;
+                args |= (uint32_t)(lo ? jmin : jmax) << (8 * c);
+                if (a.thresh) v *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
+                o[c] = (bf16)v;
             }
-            if (MODE == 0) {
+            *reinterpret_cast<bf16x4*>(a.out + oidx) = o;
+            if (a.ysel) {
+                *reinterpret_cast<float4*>(a.ysel + oidx) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+                *reinterpret_cast<uint32_t*>(a.arg + oidx) = args;
+            }
+        } else {
+            const bf16x4 gv = *reinterpret_cast<const bf16x4*>(a.dout + oidx);
+            const uint32_t args = *reinterpret_cast<const uint32_t*>(a.arg + oidx);
+            float dzs[4];
+            int arg[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                arg[c] = (args >> (8 * c)) & 7;
+                float ysel = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ysel = (j == arg[c]) ? (&t[j].x)[c] : ysel;
+                float g = (float)gv[c];
+                if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
+                dzs[c] = g * act_grad(ysel * sc[c] + sh[c], a.act);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
                 bf16x4 o;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float v = mx[c];
-                    if (a.thresh) v *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
-                    o[c] = (bf16)v;
+                    const float dz = (j == arg[c]) ? dzs[c] : 0.f;
+                    const float xh = ((&t[j].x)[c] - mu[c]) * rs[c];
+                    o[c] = (bf16)(a.train ? sc[c] * (dz - c0[c] - xh * c1[c]) : sc[c] * dz);
                 }
-                *reinterpret_cast<bf16x4*>(a.out + oidx) = o;
-            } else {
-                const bf16x4 gv = *reinterpret_cast<const bf16x4*>(a.dout + oidx);
-                float dz[8][4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float g = (float)gv[c];
-                    if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float z = yv[j][c] * sc[c] + sh[c];
-                        dz[j][c] = (j == arg[c]) ? g * act_grad(z, a.act) : 0.f;
-                        const float xh = (yv[j][c] - mu[c]) * rs[c];
-                        if (MODE == 1) { s0[c] += dz[j][c]; s1[c] += dz[j][c] * xh; }
-                        else dz[j][c] = a.train ? sc[c] * (dz[j][c] - c0[c] - xh * c1[c]) : sc[c] * dz[j][c];
-                    }
-                }
-                if (MODE == 2)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        bf16x4 o = {(bf16)dz[j][0], (bf16)dz[j][1], (bf16)dz[j][2], (bf16)dz[j][3]};
-                        *reinterpret_cast<bf16x4*>(a.dy + idx[j]) = o;
-                    }
+                *reinterpret_cast<bf16x4*>(a.dy + base + (j >> 2) * sd + ((j >> 1) & 1) * shh + (j & 1) * sw) = o;
             }
         }
-    if (MODE == 1) {
-        __shared__ float red[2][1024];
-        for (int i = threadIdx.x; i < 2048; i += 256) (&red[0][0])[i] = 0.f;
-        __syncthreads();
-        if (active)
+    }
+}
+
+// BN-gradient partial sums from the pooled winners only:  sums[0][n] += dz, sums[1][n] += dz * xhat
+__global__ __launch_bounds__(256) void pool3_bwd_reduce_kernel(Pool3Args a) {
+    a.seed = mm_eff_seed(a.seed, a.epoch);
+    const int nv = a.N / 4;
+    const size_t nrows = (size_t)a.B * (a.D / 2) * (a.H / 2) * (a.W / 2);
+    const int rows_per_blk = 256 / nv > 0 ? 256 / nv : 1;
+    const int vi = threadIdx.x % nv, ri = threadIdx.x / nv;
+    const bool active = ri < rows_per_blk;
+    const int n4 = vi * 4;
+    float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (active) {
+        float sc[4], sh[4], mu[4], rs[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { atomicAdd(&red[0][n4 + c], s0[c]); atomicAdd(&red[1][n4 + c], s1[c]); }
-        __syncthreads();
-        float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
-        for (int i = threadIdx.x; i < a.N; i += 256) {
-            atomicAdd(&rep[i], red[0][i]);
-            atomicAdd(&rep[a.N + i], red[1][i]);
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = a.out4[n4 + q]; sh[q] = a.out4[a.N + n4 + q];
+            mu[q] = a.out4[2 * a.N + n4 + q]; rs[q] = a.out4[3 * a.N + n4 + q];
         }
+        for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
+            const size_t oidx = row * a.N + n4;
+            const float4 ys = *reinterpret_cast<const float4*>(a.ysel + oidx);
+            const bf16x4 gv = *reinterpret_cast<const bf16x4*>(a.dout + oidx);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float yv = (&ys.x)[c];
+                float g = (float)gv[c];
+                if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
+                const float dz = g * act_grad(yv * sc[c] + sh[c], a.act);
+                s0[c] += dz;
+                s1[c] += dz * (yv - mu[c]) * rs[c];
+            }
+        }
+    }
+    __shared__ float red[2][1024];
+    for (int i = threadIdx.x; i < 2 * a.N; i += 256) (&red[0][0])[i < a.N ? i : 1024 + i - a.N] = 0.f;
+    __syncthreads();
+    if (active)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { atomicAdd(&red[0][n4 + c], s0[c]); atomicAdd(&red[1][n4 + c], s1[c]); }
+    __syncthreads();
+    float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
+    for (int i = threadIdx.x; i < a.N; i += 256) {
+        atomicAdd(&rep[i], red[0][i]);
+        atomicAdd(&rep[a.N + i], red[1][i]);
     }
 }
 
 inline uint32_t thresh3(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 
-int pool3_launch(int mode, const float* y, const float* out4, const void* dout, const float* sums, void* out,
-                 float* sums_out, void* dy, int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
-                 const uint32_t* seed_epoch, int train, hipStream_t st) {
-    MM_REQUIRE(y && out4 && B > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "pool3d_bn_act: dims must be even");
-    MM_REQUIRE(N % 4 == 0 && N <= 1024, "pool3d_bn_act: N");
-    Pool3Args a;
-    a.y = y; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = sums; a.out = (bf16*)out; a.sums_out = sums_out;
-    a.dy = (bf16*)dy; a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.train = train;
-    a.thresh = thresh3(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    a.inv_count = 1.f / ((float)B * D * H * W);
-    a.epoch = seed_epoch;
-    const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
-    const size_t rows = (size_t)B * (D / 2) * (H / 2) * (W / 2);
+int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
+    MM_REQUIRE(a.out4 && a.B > 0 && a.D % 2 == 0 && a.H % 2 == 0 && a.W % 2 == 0, "pool3d_bn_act: dims must be even");
+    MM_REQUIRE(a.N % 4 == 0 && a.N <= 1024, "pool3d_bn_act: N");
+    a.thresh = thresh3(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.inv_count = 1.f / ((float)a.B * a.D * a.H * a.W);
+    const int rpb = 256 / (a.N / 4) > 0 ? 256 / (a.N / 4) : 1;
+    const size_t rows = (size_t)a.B * (a.D / 2) * (a.H / 2) * (a.W / 2);
     int grid = (int)((rows + rpb - 1) / rpb);
-    if (grid > 2048) grid = 2048;
-    if (mode == 0) hipLaunchKernelGGL(pool3_bn_act_kernel<0>, dim3(grid), dim3(256), 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL(pool3_bn_act_kernel<1>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(pool3_bn_act_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+    if (mode == 1) {
+        if (grid > 512) grid = 512;
+        hipLaunchKernelGGL(pool3_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (grid > 4096) grid = 4096;
+        if (mode == 0) hipLaunchKernelGGL(pool3_bn_act_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(pool3_bn_act_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+    }
     return mm_check_launch("pool3d_bn_act");
 }
 
@@ -803,27 +856,35 @@ int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
     return mm_check_launch("conv3d_wgrad");
 }
 
-int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, int B, int D, int H, int W, int N,
-                         int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
-    MM_REQUIRE(out_bf16, "pool3d_bn_act_fwd: null out");
-    return pool3_launch(0, y, out4, nullptr, nullptr, out_bf16, nullptr, nullptr, B, D, H, W, N, act, drop_p, seed,
-                        seed_epoch, 0, st);
+int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, float* ysel, void* arg, int B, int D,
+                         int H, int W, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                         hipStream_t st) {
+    MM_REQUIRE(y && out_bf16 && (!ysel == !arg), "pool3d_bn_act_fwd: null out / ysel and arg go together");
+    Pool3Args a{};
+    a.y = y; a.out4 = out4; a.out = (bf16*)out_bf16; a.ysel = ysel; a.arg = (uint8_t*)arg;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch;
+    return pool3_launch(0, a, drop_p, st);
 }
 
-int mm_pool3d_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16, float* sums_out, int B,
+int mm_pool3d_bn_act_bwd_reduce(const float* ysel, const float* out4, const void* dout_bf16, float* sums_out, int B,
                                 int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
                                 const uint32_t* seed_epoch, hipStream_t st) {
-    MM_REQUIRE(dout_bf16 && sums_out, "pool3d_bn_act_bwd_reduce: null");
-    return pool3_launch(1, y, out4, dout_bf16, nullptr, nullptr, sums_out, nullptr, B, D, H, W, N, act, drop_p, seed,
-                        seed_epoch, 1, st);
+    MM_REQUIRE(ysel && dout_bf16 && sums_out, "pool3d_bn_act_bwd_reduce: null");
+    Pool3Args a{};
+    a.ysel = const_cast<float*>(ysel); a.out4 = out4; a.dout = (const bf16*)dout_bf16; a.sums_out = sums_out;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch; a.train = 1;
+    return pool3_launch(1, a, drop_p, st);
 }
 
-int mm_pool3d_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* sums, void* dy,
-                               int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
-                               const uint32_t* seed_epoch, int train, hipStream_t st) {
-    MM_REQUIRE(dout_bf16 && dy && (!train || sums), "pool3d_bn_act_bwd_apply: null");
-    return pool3_launch(2, y, out4, dout_bf16, sums, nullptr, nullptr, dy, B, D, H, W, N, act, drop_p, seed,
-                        seed_epoch, train, st);
+int mm_pool3d_bn_act_bwd_apply(const float* y, const void* arg, const float* out4, const void* dout_bf16,
+                               const float* sums, void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
+                               uint32_t seed, const uint32_t* seed_epoch, int train, hipStream_t st) {
+    MM_REQUIRE(y && arg && dout_bf16 && dy && (!train || sums), "pool3d_bn_act_bwd_apply: null");
+    Pool3Args a{};
+    a.y = y; a.arg = (uint8_t*)const_cast<void*>(arg); a.out4 = out4; a.dout = (const bf16*)dout_bf16; a.sums = sums;
+    a.dy = (bf16*)dy; a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch;
+    a.train = train;
+    return pool3_launch(2, a, drop_p, st);
 }
 
 }  // extern "C"

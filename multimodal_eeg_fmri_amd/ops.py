@@ -452,14 +452,19 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
         out4 = bn_fold_eval(bn, conv.bias)
     seed = _next_seed() if (training and drop_p > 0) else 0
     p = drop_p if training else 0.0
+    ysel = arg = None
     if pool:
         out = _empty((B, D // 2, H // 2, W // 2, cout), _BF, xv)
-        _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
+        if training:                                   # the window winners: all that BN-backward's reduction needs
+            ysel = _empty(out.shape, _F32, xv)
+            arg = _empty(out.shape, torch.uint8, xv)
+        _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, ysel, arg, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
     else:
         out = _empty((B, D * H * W, cout), _F32, xv)
         _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], None, None, out, B, D * H * W, cout,
                   ACT["gelu"], 1, 1, float(p), seed, 0.0, 0, EP())
-    saved = dict(xv=xv, y=y, out4=out4, pool=pool, drop_p=p, seed=seed, conv=conv, bn=bn) if training else None
+    saved = dict(xv=xv, y=y, out4=out4, pool=pool, drop_p=p, seed=seed, conv=conv, bn=bn,
+                 ysel=ysel, arg=arg) if training else None
     return out, saved
 
 

@@ -281,18 +281,30 @@ def test_pool3d_bn_act_train_fwd_bwd():
     hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"),
              None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0)
     ob = torch.empty(B, D // 2, H // 2, W // 2, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob, B, D, H, W, N, 1, 0.0, 0, None)
+    ysel = torch.empty(ob.shape, device="cuda")
+    arg = torch.empty(ob.shape, dtype=torch.uint8, device="cuda")
+    hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob, ysel, arg, B, D, H, W, N, 1, 0.0, 0, None)
     torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
+    # the saved winners: window index (4 d + 2 h + w) and pre-BN value of torch's own argmax
+    _, idx = F.max_pool3d(F.gelu(z.detach()), 2, return_indices=True)          # flat index into D*H*W
+    idx = idx.permute(0, 2, 3, 4, 1)
+    d_, h_, w_ = idx // (H * W), (idx // W) % H, idx % W
+    torch.testing.assert_close(arg.cpu().long(), (d_ % 2) * 4 + (h_ % 2) * 2 + (w_ % 2))
+    want = torch.gather(y.reshape(B, D * H * W, N), 1, idx.reshape(B, -1, N)).reshape(ob.shape)
+    torch.testing.assert_close(ysel.cpu(), want)
+    ob2 = torch.empty_like(ob)                                                  # eval form: no winners kept
+    hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob2, None, None, B, D, H, W, N, 1, 0.0, 0, None)
+    assert torch.equal(ob2, ob)
     sums = torch.zeros(32, 2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
-    hip.call("mm_pool3d_bn_act_bwd_reduce", yg, out4, dg, sums, B, D, H, W, N, 1, 0.0, 0, None)
+    hip.call("mm_pool3d_bn_act_bwd_reduce", ysel, out4, dg, sums, B, D, H, W, N, 1, 0.0, 0, None)
     torch.testing.assert_close(sums.sum(0)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(sums.sum(0)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(B, D, H, W, N, dtype=torch.bfloat16, device="cuda")
     sc = torch.zeros(2 * N, device="cuda")
     hip.call("mm_reduce_replicas", sums, sc, 2 * N, 32, 2 * N)
     torch.testing.assert_close(sc.cpu(), sums.sum(0).flatten().cpu(), rtol=1e-5, atol=1e-5)
-    hip.call("mm_pool3d_bn_act_bwd_apply", yg, out4, dg, sc, dy, B, D, H, W, N, 1, 0.0, 0, None, 1)
+    hip.call("mm_pool3d_bn_act_bwd_apply", yg, arg, out4, dg, sc, dy, B, D, H, W, N, 1, 0.0, 0, None, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
 
 
