@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.3)
     ap.add_argument("--profile", action="store_true", help="skip the post-region event-timing steps (for rocprofv3 runs)")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic: in-graph phase stamps of the step (adds 13 tiny nodes; "
+                    "prints a phase table to stderr, the JSON line is then not a valid benchmark)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,6 +97,8 @@ def main():
     torch.manual_seed(0)                      # identical initial weights on every rank
     tr = BridgeTrainer(eeg_channels=EEG_CH, dropout=args.dropout, group=group).train()
     eeg, fmri = synthetic_pairs(PAIRS_PER_GPU, EEG_CH, EEG_T, VOL, seed=1234 + rank)
+    if args.stamps:
+        tr.stamps = torch.zeros(16, dtype=torch.int64, device="cuda")
 
     def sync():
         if world > 1:
@@ -115,6 +119,15 @@ def main():
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
+    if args.stamps and rank == 0:
+        acc = torch.zeros(16, dtype=torch.float64)
+        for _ in range(20):
+            tr.train_step(eeg, fmri)
+            torch.cuda.synchronize()
+            s = tr.stamps.cpu().double()
+            acc += (s - s[0]) / 100.0
+        for i, name in enumerate(tr.STAMP_NAMES):
+            print(f"  {name:22s} {acc[i].item() / 20:8.1f} us", file=sys.stderr)
 
     # roofline line: the timed steps are hipGraph replays (no host code runs inside
     # them), so the layer-2 conv3d kernel is bracketed with HIP events on its launch

@@ -82,6 +82,12 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
  * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */
 int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, int nrep,
                      hipStream_t stream);
+/* debugging: buf[idx] = 100 MHz wall clock, written in stream order (tools/ and bench --stamps) */
+int mm_debug_stamp(void* buf, int idx, hipStream_t stream);
+/* mm_prep_conv_weight for ndesc tensors in one launch per 64 descriptors; desc_host = HOST array
+ * of {const float* w; void* w_fwd; void* w_dgrad /*nullable*/; int32 Cout, Cin, k, Cinp, Coutp, 0}
+ * (48 bytes each), copied into the kernel arguments (capturable in a hipGraph) */
+int mm_prep_many(const void* desc_host, int ndesc, hipStream_t stream);
 /* ndesc independent replica reductions in one launch per 64 descriptors; desc_host =
  * HOST array of {const float* src; float* dst; int64 K, nrep, rep_stride} (40 bytes
  * each), copied into the kernel arguments (capturable in a hipGraph) */
@@ -92,10 +98,12 @@ int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t re
 /* ---- BatchNorm / activation / pool ----------------------------------------
  * mode 0 (train): stats{sum,sumsq}/count -> out4 = {scale, shift, mean, rstd},
  * running stats updated (momentum, unbiased var);  mode 1 (eval): fold running
- * stats (+conv bias).  nn.BatchNorm1d/3d (enhanced_models_v4.py:130,135,141). */
+ * stats (+conv bias).  nn.BatchNorm1d/3d (enhanced_models_v4.py:130,135,141).
+ * batches_tracked (int64 device scalar, nullable) is incremented in train mode, as
+ * nn.BatchNorm's num_batches_tracked buffer is. */
 int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, float* run_mean,
                    float* run_var, const float* conv_bias, float* out4, int N, float count,
-                   float momentum, float eps, int mode, hipStream_t stream);
+                   float momentum, float eps, int mode, void* batches_tracked, hipStream_t stream);
 /* y fp32 [R][S][N] -> act(y*scale+shift) [-> maxpool2 over S] [-> dropout] [+pe[s][n]]
  * (BN -> GELU -> MaxPool1d -> Dropout -> PositionalEncoding add,
  *  enhanced_models_v4.py:130-143, 49-54) */
@@ -206,6 +214,22 @@ int mm_act_bwd_f32(const float* g, const float* z, float* out, int64_t n, int ac
                    uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 /* stats[0][n] = sum_b x, stats[1][n] = sum_b x^2 (BatchNorm1d over (B, N)) */
 int mm_colstats(const float* x, float* stats, int B, int N, hipStream_t stream);
+/* Both projection heads of the contrastive bridge (bridge_utils.py:34-45 eeg_proj / fmri_proj:
+ * Linear(K -> N) -> LayerNorm -> GELU -> Dropout) followed by F.normalize, one launch each way.
+ * x_* fp32 [B][K_*]; W_* [N][K_*]; z packed [B][2N] = [ze | zf]; nrm [2][B].  z1 / hn / stat
+ * ([2][B][N], [2][B][N], [2][B][2]; all three or none) are what the backward needs.  The
+ * backward ADDS parameter gradients with fp32 atomics (any of them may be null) and writes dx. */
+int mm_proj_heads_fwd(const float* x_e, const float* W_e, const float* b_e, const float* g_e, const float* be_e,
+                      int K_e, const float* x_f, const float* W_f, const float* b_f, const float* g_f,
+                      const float* be_f, int K_f, float* z1, float* hn, float* stat, float* z, float* nrm, int B,
+                      int N, float eps, float drop_p, uint32_t seed_e, uint32_t seed_f,
+                      const uint32_t* seed_epoch, hipStream_t stream);
+int mm_proj_heads_bwd(const float* dz, const float* z, const float* nrm, const float* hn, const float* z1,
+                      const float* stat, const float* x_e, const float* W_e, const float* g_e, int K_e,
+                      const float* x_f, const float* W_f, const float* g_f, int K_f, float* dx_e, float* dW_e,
+                      float* db_e, float* dg_e, float* dbe_e, float* dx_f, float* dW_f, float* db_f, float* dg_f,
+                      float* dbe_f, int B, int N, float drop_p, uint32_t seed_e, uint32_t seed_f,
+                      const uint32_t* seed_epoch, hipStream_t stream);
 /* F.normalize(h, dim=1): z = h / max(||h||, 1e-12)  (extension a-X2) */
 int mm_l2norm_fwd(const float* h, float* z, float* nrm, int B, int N, int ldz, hipStream_t stream);
 int mm_l2norm_bwd(const float* dz, const float* z, const float* nrm, float* dh, int B, int N, int ldz,

@@ -442,11 +442,18 @@ def proj_head_bwd(bag: GradBag, s: dict, da: torch.Tensor, need_dx=True):
 def contrastive_embed_bwd(bag: GradBag, s: dict, dz: torch.Tensor, need=(True, True)):
     """dz (B, 2N) packed -> (d eeg_feat (B, eeg_dim), d fmri_feat (B, fmri_dim))"""
     B, N = s["B"], s["N"]
-    da_e = _empty((B, N), _F32, dz)
-    da_f = _empty((B, N), _F32, dz)
-    _hip.call("mm_l2norm_bwd", dz.data_ptr(), s["z"].data_ptr(), s["nrm"][0], da_e, B, N, 2 * N)
-    _hip.call("mm_l2norm_bwd", dz.data_ptr() + 4 * N, s["z"].data_ptr() + 4 * N, s["nrm"][1], da_f, B, N, 2 * N)
-    return proj_head_bwd(bag, s["e"], da_e, need[0]), proj_head_bwd(bag, s["f"], da_f, need[1])
+    br = s["bridge"]
+    (le, lne), (lf, lnf) = br.eeg_proj[:2], br.fmri_proj[:2]
+    xe, xf = s["xe"], s["xf"]
+    dxe = _empty(xe.shape, _F32, dz) if need[0] else None
+    dxf = _empty(xf.shape, _F32, dz) if need[1] else None
+    t = bag.target
+    _hip.call("mm_proj_heads_bwd", dz.contiguous(), s["z"], s["nrm"], s["hn"], s["z1"], s["stat"],
+              xe, le.weight, lne.weight, xe.shape[1], xf, lf.weight, lnf.weight, xf.shape[1],
+              dxe, t(le.weight), t(le.bias), t(lne.weight), t(lne.bias),
+              dxf, t(lf.weight), t(lf.bias), t(lnf.weight), t(lnf.bias),
+              B, N, float(s["p"]), int(s["seeds"][0]), int(s["seeds"][1]), ops.EP())
+    return dxe, dxf
 
 
 class ContrastiveEmbedFn(torch.autograd.Function):

@@ -42,6 +42,8 @@ class BridgeTrainer(nn.Module):
         self.two_streams = True
         self.mode = mode
         self._cap = None
+        self._weight_list = None                      # recorded by the first manual step
+        self.stamps = None                            # int64[16] device buffer when phase stamps are wanted
         self._side = torch.cuda.Stream()
         self.lr, self.weight_decay, self.grad_clip = lr, weight_decay, grad_clip
         self.betas, self.eps = betas, eps
@@ -106,16 +108,35 @@ class BridgeTrainer(nn.Module):
         return {"loss": loss.detach(), "top1_e2f": acc_e, "top1_f2e": acc_f}
 
     # ---- the four segments of the autograd-free tape -------------------------
+    STAMP_NAMES = ("step start", "weights prepared", "EEG fwd done", "fMRI fwd start", "fMRI fwd done",
+                   "heads fwd done", "loss done", "heads bwd done", "EEG bwd done", "fMRI bwd start",
+                   "fMRI bwd done", "grad reductions done", "AdamW done")
+
+    def _stamp(self, i):
+        if self.stamps is not None:
+            _hip.call("mm_debug_stamp", self.stamps, i)
+
     def _seg_forward(self, eeg, fmri):
+        self._stamp(0)
         ops.arena.begin(eeg.device)
         self.bucket.g.zero_()
+        if self._weight_list is not None:
+            ops.weights.prepare_all(self._weight_list)   # every bf16 weight image of the step, one launch
+        self._stamp(1)
         main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            ff, sv_f = ops._vol_forward_impl(self.fmri_encoder, fmri, True, True)
+        self._side.wait_stream(main)                 # fork point: recorded before any encoder kernel
+        # The EEG branch is the longer chain, so it is issued FIRST: a hipGraph replay writes its
+        # kernel packets in capture order at ~4.6 us per node, and the branch captured second
+        # cannot start before the host has written every packet of the first (profiles/README.md).
         fe, sv_e = ops._erp_forward_impl(self.eeg_encoder, eeg, True, True)
+        self._stamp(2)
+        with torch.cuda.stream(self._side):
+            self._stamp(3)
+            ff, sv_f = ops._vol_forward_impl(self.fmri_encoder, fmri, True, True)
+            self._stamp(4)
         main.wait_stream(self._side)
         z, sv_h = ops.contrastive_embed_impl(self.head.bridge, fe, ff, True)
+        self._stamp(5)
         return z, (sv_e, sv_f, sv_h)
 
     def _seg_loss(self, z, z_all, scal, dz_all):
@@ -124,6 +145,7 @@ class BridgeTrainer(nn.Module):
         dz_all.zero_()
         ls = self.head.logit_scale.detach().reshape(1)
         _hip.call("mm_clip_loss", z, z_all, ls, scal, dz_all, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
+        self._stamp(6)
 
     def _seg_backward(self, saved, dz, scal):
         sv_e, sv_f, sv_h = saved
@@ -131,12 +153,17 @@ class BridgeTrainer(nn.Module):
         self.head.logit_scale._mm_grad.add_(scal[3])
         with deferred(bag, dz.device):           # ONE batched reduction after both branches joined
             dfe, dff = contrastive_embed_bwd(bag, sv_h, dz)
+            self._stamp(7)
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
+            erp_encoder_bwd(bag, sv_e, dfe)          # longer chain first (see _seg_forward)
+            self._stamp(8)
             with torch.cuda.stream(self._side):
+                self._stamp(9)
                 volume_encoder_bwd(bag, sv_f, dff)
-            erp_encoder_bwd(bag, sv_e, dfe)
+                self._stamp(10)
             main.wait_stream(self._side)
+        self._stamp(11)
         self._bags = getattr(self, "_bags", [])[-3:] + [bag]   # keep descriptor tables alive for graph replays
 
     def _seg_optimizer(self):
@@ -151,8 +178,19 @@ class BridgeTrainer(nn.Module):
                   self.eps, self.weight_decay, self.grad_clip, 1.0 / self.world)
         ops.weights_changed()
         ops.arena.end()
+        self._stamp(12)
 
     def _step_manual(self, eeg, fmri):
+        recording = self._weight_list is None
+        if recording:                                 # first step: note every weight image the tape asks for
+            ops.weights.start_recording()
+        try:
+            return self._step_manual_body(eeg, fmri)
+        finally:
+            if recording:
+                self._weight_list = ops.weights.stop_recording()
+
+    def _step_manual_body(self, eeg, fmri):
         z, saved = self._seg_forward(eeg, fmri)
         z_all = dp.gather_embeddings(z, self.group)
         scal = torch.empty(4, device=z.device)

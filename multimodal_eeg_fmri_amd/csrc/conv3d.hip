@@ -805,7 +805,19 @@ int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
 
 static int g_dbg = 0;
 
+namespace {
+__global__ void stamp_kernel(long long* buf, int idx) { buf[idx] = wall_clock64(); }
+}
+
 extern "C" {
+
+// one 100 MHz wall-clock stamp written in stream order (a graph node like any other kernel):
+// the only way to see where a hipGraph-replayed step spends its time without a profiler attached
+int mm_debug_stamp(void* buf, int idx, hipStream_t st) {
+    MM_REQUIRE(buf && idx >= 0, "debug_stamp: bad args");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, (long long*)buf, idx);
+    return mm_check_launch("debug_stamp");
+}
 
 int mm_debug_flags(int flags, hipStream_t) { g_dbg = flags; return 0; }
 

@@ -14,9 +14,10 @@ namespace {
 __global__ void bn_finalize_kernel(const float* stats, const float* gamma, const float* beta,
                                    float* run_mean, float* run_var, const float* conv_bias,
                                    float* out /* [4][N]: scale, shift, mean, rstd */, int N,
-                                   float count, float momentum, float eps, int mode) {
+                                   float count, float momentum, float eps, int mode, long long* tracked) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    if (n == 0 && tracked && mode == 0) tracked[0] += 1;
     float mean, var;
     if (mode == 0) {
         float s1 = 0.f, s2 = 0.f;
@@ -527,11 +528,11 @@ extern "C" {
 
 int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, float* run_mean, float* run_var,
                    const float* conv_bias, float* out4, int N, float count, float momentum, float eps, int mode,
-                   hipStream_t st) {
+                   void* batches_tracked, hipStream_t st) {
     MM_REQUIRE(gamma && beta && run_mean && run_var && out4 && N > 0, "bn_finalize: null/invalid");
     MM_REQUIRE(mode == 1 || (stats && count >= 1.f), "bn_finalize: train mode needs stats");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(N, 128)), dim3(128), 0, st, stats, gamma, beta, run_mean,
-                       run_var, conv_bias, out4, N, count, momentum, eps, mode);
+                       run_var, conv_bias, out4, N, count, momentum, eps, mode, (long long*)batches_tracked);
     return mm_check_launch("bn_finalize");
 }
 

@@ -121,6 +121,109 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ dz, const float* __r
         dh[(size_t)row * N + n] = (dz[(size_t)row * ldz + n] - z[(size_t)row * ldz + n] * d) * inv;
 }
 
+
+// ---------------------------------------------------------------------------
+// Both projection heads of the contrastive bridge in ONE launch each way
+// (bridge_utils.py:34-45: Linear -> LayerNorm -> GELU -> Dropout, then F.normalize).
+// At B = 32 the eleven separate launches of this chain each way were ~130 us of
+// pure launch latency on the step's critical path.  grid = (B rows, 2 heads).
+// ---------------------------------------------------------------------------
+struct HeadSide {
+    const float* x; const float* W; const float* bias; const float* gamma; const float* beta;
+    float* dx; float* dW; float* dbias; float* dgamma; float* dbeta;
+    int K; uint32_t seed;
+};
+struct HeadsArgs {
+    HeadSide s[2];
+    float* z1; float* hn; float* stat;        // [2][B][N], [2][B][N], [2][B][2]   saved for backward
+    float* z; float* nrm;                     // [B][2N] packed embeddings, [2][B]
+    const float* dz;                          // [B][2N]
+    int B, N; float eps; uint32_t thresh; float inv_keep; const uint32_t* epoch;
+};
+constexpr int HEAD_MAXK = 1024, HEAD_MAXN = 256;
+
+__device__ __forceinline__ float block_sum256(float v, float* red /* [4] */) {
+    v = wave_sum(v);
+    __syncthreads();                          // red may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void proj_heads_fwd_kernel(HeadsArgs a) {
+    __shared__ float xs[HEAD_MAXK], v[HEAD_MAXN], red[4];
+    const int b = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const HeadSide s = a.s[m];
+    const int N = a.N, K = s.K;
+    for (int k = tid; k < K; k += 256) xs[k] = s.x[(size_t)b * K + k];
+    __syncthreads();
+    for (int n = wave; n < N; n += 4) {                      // one output per wave pass: W rows read coalesced
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc += s.W[(size_t)n * K + k] * xs[k];
+        acc = wave_sum(acc);
+        if (lane == 0) v[n] = acc + (s.bias ? s.bias[n] : 0.f);
+    }
+    __syncthreads();
+    const bool on = tid < N;
+    const float x1 = on ? v[tid] : 0.f;
+    const float mean = block_sum256(x1, red) / N;
+    const float dlt = on ? x1 - mean : 0.f;
+    const float rstd = rsqrtf(block_sum256(dlt * dlt, red) / N + a.eps);
+    float act = 0.f, hn = 0.f;
+    const size_t o = ((size_t)m * a.B + b) * N + tid;
+    if (on) {
+        hn = dlt * rstd * s.gamma[tid] + s.beta[tid];
+        act = gelu_erf(hn);
+        if (a.thresh) act *= dropout_scale(mm_eff_seed(s.seed, a.epoch), (uint32_t)(b * N + tid), a.thresh, a.inv_keep);
+        if (a.z1) { a.z1[o] = x1; a.hn[o] = hn; }
+    }
+    const float nr = fmaxf(sqrtf(block_sum256(act * act, red)), 1e-12f);
+    if (on) a.z[(size_t)b * 2 * N + m * N + tid] = act / nr;
+    if (tid == 0) {
+        a.nrm[m * a.B + b] = nr;
+        if (a.stat) { a.stat[((size_t)m * a.B + b) * 2] = mean; a.stat[((size_t)m * a.B + b) * 2 + 1] = rstd; }
+    }
+}
+
+__global__ __launch_bounds__(256) void proj_heads_bwd_kernel(HeadsArgs a) {
+    __shared__ float xs[HEAD_MAXK], d1[HEAD_MAXN], red[4];
+    const int b = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+    const HeadSide s = a.s[m];
+    const int N = a.N, K = s.K;
+    const bool on = tid < N;
+    for (int k = tid; k < K; k += 256) xs[k] = s.x[(size_t)b * K + k];
+    const size_t o = ((size_t)m * a.B + b) * N + tid, oz = (size_t)b * 2 * N + m * N + tid;
+    const float dzv = on ? a.dz[oz] : 0.f, zv = on ? a.z[oz] : 0.f;
+    // F.normalize backward: da = (dz - z (z . dz)) / ||a||
+    const float dot = block_sum256(dzv * zv, red);
+    float dh = 0.f, xh = 0.f, gd = 0.f;
+    const float mean = a.stat[((size_t)m * a.B + b) * 2], rstd = a.stat[((size_t)m * a.B + b) * 2 + 1];
+    if (on) {
+        float g = (dzv - zv * dot) / a.nrm[m * a.B + b];
+        if (a.thresh) g *= dropout_scale(mm_eff_seed(s.seed, a.epoch), (uint32_t)(b * N + tid), a.thresh, a.inv_keep);
+        dh = g * gelu_erf_grad(a.hn[o]);
+        xh = (a.z1[o] - mean) * rstd;
+        gd = dh * s.gamma[tid];
+        if (s.dgamma) atomicAdd(&s.dgamma[tid], dh * xh);
+        if (s.dbeta) atomicAdd(&s.dbeta[tid], dh);
+    }
+    const float m1 = block_sum256(gd, red) / N, m2 = block_sum256(gd * xh, red) / N;
+    const float dz1 = on ? rstd * (gd - m1 - xh * m2) : 0.f;
+    if (on) {
+        d1[tid] = dz1;
+        if (s.dbias) atomicAdd(&s.dbias[tid], dz1);
+    }
+    __syncthreads();
+    if (s.dW)
+        for (int i = tid; i < N * K; i += 256) atomicAdd(&s.dW[i], d1[i / K] * xs[i % K]);    // contiguous fp32 atomics
+    if (s.dx)
+        for (int k = tid; k < K; k += 256) {
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n) acc += d1[n] * s.W[(size_t)n * K + k];
+            s.dx[(size_t)b * K + k] = acc;
+        }
+}
+
 // ---------------------------------------------------------------------------
 // symmetric InfoNCE over local rows [row0, row0+B) vs Bg global columns.
 //   S_ef[i][j] = s * ze_i . zf_all_j     S_fe[i][j] = s * zf_i . ze_all_j
@@ -705,6 +808,44 @@ int mm_colstats(const float* x, float* stats, int B, int N, hipStream_t st) {
     MM_REQUIRE(x && stats && B > 0 && N > 0, "colstats: null");
     hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, st, x, stats, B, N);
     return mm_check_launch("colstats");
+}
+
+int mm_proj_heads_fwd(const float* x_e, const float* W_e, const float* b_e, const float* g_e, const float* be_e, int K_e,
+                      const float* x_f, const float* W_f, const float* b_f, const float* g_f, const float* be_f, int K_f,
+                      float* z1, float* hn, float* stat, float* z, float* nrm, int B, int N, float eps, float drop_p,
+                      uint32_t seed_e, uint32_t seed_f, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(x_e && W_e && g_e && be_e && x_f && W_f && g_f && be_f && z && nrm, "proj_heads_fwd: null");
+    MM_REQUIRE((!z1 && !hn && !stat) || (z1 && hn && stat), "proj_heads_fwd: z1/hn/stat go together");
+    MM_REQUIRE(B > 0 && N > 0 && N <= HEAD_MAXN && K_e > 0 && K_e <= HEAD_MAXK && K_f > 0 && K_f <= HEAD_MAXK,
+               "proj_heads_fwd: B=%d N=%d K=%d/%d", B, N, K_e, K_f);
+    HeadsArgs a{};
+    a.s[0].x = x_e; a.s[0].W = W_e; a.s[0].bias = b_e; a.s[0].gamma = g_e; a.s[0].beta = be_e; a.s[0].K = K_e; a.s[0].seed = seed_e;
+    a.s[1].x = x_f; a.s[1].W = W_f; a.s[1].bias = b_f; a.s[1].gamma = g_f; a.s[1].beta = be_f; a.s[1].K = K_f; a.s[1].seed = seed_f;
+    a.z1 = z1; a.hn = hn; a.stat = stat; a.z = z; a.nrm = nrm; a.B = B; a.N = N; a.eps = eps;
+    a.thresh = thresh_h(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.epoch = seed_epoch;
+    hipLaunchKernelGGL(proj_heads_fwd_kernel, dim3(B, 2), dim3(256), 0, st, a);
+    return mm_check_launch("proj_heads_fwd");
+}
+
+int mm_proj_heads_bwd(const float* dz, const float* z, const float* nrm, const float* hn, const float* z1,
+                      const float* stat, const float* x_e, const float* W_e, const float* g_e, int K_e,
+                      const float* x_f, const float* W_f, const float* g_f, int K_f, float* dx_e, float* dW_e,
+                      float* db_e, float* dg_e, float* dbe_e, float* dx_f, float* dW_f, float* db_f, float* dg_f,
+                      float* dbe_f, int B, int N, float drop_p, uint32_t seed_e, uint32_t seed_f,
+                      const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(dz && z && nrm && hn && z1 && stat && x_e && W_e && g_e && x_f && W_f && g_f, "proj_heads_bwd: null");
+    MM_REQUIRE(B > 0 && N > 0 && N <= HEAD_MAXN && K_e > 0 && K_e <= HEAD_MAXK && K_f > 0 && K_f <= HEAD_MAXK,
+               "proj_heads_bwd: B=%d N=%d K=%d/%d", B, N, K_e, K_f);
+    HeadsArgs a{};
+    a.s[0].x = x_e; a.s[0].W = W_e; a.s[0].gamma = g_e; a.s[0].K = K_e; a.s[0].seed = seed_e;
+    a.s[0].dx = dx_e; a.s[0].dW = dW_e; a.s[0].dbias = db_e; a.s[0].dgamma = dg_e; a.s[0].dbeta = dbe_e;
+    a.s[1].x = x_f; a.s[1].W = W_f; a.s[1].gamma = g_f; a.s[1].K = K_f; a.s[1].seed = seed_f;
+    a.s[1].dx = dx_f; a.s[1].dW = dW_f; a.s[1].dbias = db_f; a.s[1].dgamma = dg_f; a.s[1].dbeta = dbe_f;
+    a.z1 = const_cast<float*>(z1); a.hn = const_cast<float*>(hn); a.stat = const_cast<float*>(stat);
+    a.z = const_cast<float*>(z); a.nrm = const_cast<float*>(nrm); a.dz = dz; a.B = B; a.N = N;
+    a.thresh = thresh_h(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.epoch = seed_epoch;
+    hipLaunchKernelGGL(proj_heads_bwd_kernel, dim3(B, 2), dim3(256), 0, st, a);
+    return mm_check_launch("proj_heads_bwd");
 }
 
 int mm_l2norm_fwd(const float* h, float* z, float* nrm, int B, int N, int ldz, hipStream_t st) {

@@ -313,6 +313,28 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, bf16* __restrict
 }
 
 
+// every weight image of a model in one launch (blockIdx.y = tensor): a training step repacks ~40
+// small tensors after each optimizer update, and as separate ~5 us nodes they sat on the critical
+// path of the step's graph
+struct PrepDesc { const float* w; bf16* wf; bf16* wd; int Cout, Cin, k, Cinp, Coutp, pad_; };
+constexpr int PM_MAX = 64;
+struct PrepTable { PrepDesc d[PM_MAX]; };          // by value, as ReduceTable
+__global__ void prep_many_kernel(PrepTable tab) {
+    const PrepDesc d = tab.d[blockIdx.y];
+    const int total_f = d.Cout * d.k * d.Cinp;
+    const int total_d = d.wd ? d.Cinp * d.k * d.Coutp : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_f + total_d; i += gridDim.x * blockDim.x) {
+        if (i < total_f) {
+            const int c = i % d.Cinp, tap = (i / d.Cinp) % d.k, n = i / (d.Cinp * d.k);
+            d.wf[i] = (bf16)(c < d.Cin ? d.w[((size_t)n * d.Cin + c) * d.k + tap] : 0.f);
+        } else {
+            const int e = i - total_f;
+            const int n = e % d.Coutp, tap = (e / d.Coutp) % d.k, c = e / (d.Coutp * d.k);
+            d.wd[e] = (bf16)((c < d.Cin && n < d.Cout) ? d.w[((size_t)n * d.Cin + c) * d.k + (d.k - 1 - tap)] : 0.f);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // weight gradient:  dW[n][tap][c] += sum_{t in chunk} dY[b,t,n] * X[b,t+tap-pad,c]
 // MFMA view: D[i=n][j=c] = sum_k A[i][k] B[k][j] with k = t, so both operands
@@ -500,6 +522,23 @@ int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, in
     hipLaunchKernelGGL(prep_weight_kernel, dim3(ceil_div(total, 256) < 1024 ? ceil_div(total, 256) : 1024), dim3(256),
                        0, st, w, (bf16*)w_fwd, (bf16*)w_dgrad, Cout, Cin, k, Cinp, Coutp);
     return mm_check_launch("prep_conv_weight");
+}
+
+int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) {
+    MM_REQUIRE(desc_host && ndesc > 0, "prep_many: bad args");
+    const PrepDesc* src = (const PrepDesc*)desc_host;
+    for (int base = 0; base < ndesc; base += PM_MAX) {
+        PrepTable tab;
+        const int n = ndesc - base < PM_MAX ? ndesc - base : PM_MAX;
+        for (int i = 0; i < n; ++i) {
+            const PrepDesc& d = src[base + i];
+            MM_REQUIRE(d.w && d.wf && d.Cinp % 16 == 0 && d.Cinp >= d.Cin && d.Cout > 0 && d.k > 0 &&
+                       (!d.wd || (d.Coutp % 16 == 0 && d.Coutp >= d.Cout)), "prep_many: descriptor %d", base + i);
+            tab.d[i] = d;
+        }
+        hipLaunchKernelGGL(prep_many_kernel, dim3(128, n), dim3(256), 0, st, tab);
+    }
+    return mm_check_launch("prep_many");
 }
 
 // Generic forward implicit GEMM.  See include/mmeeg_hip.h for the contract.

@@ -205,7 +205,9 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     stats = stats.cuda()
     rmg, rvg = rm.cuda(), rv.cuda()
     out4 = torch.empty(4, N, device="cuda")
-    hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), rmg, rvg, None, out4, N, float(R * S), 0.1, 1e-5, 0)
+    nbt = torch.full((), 7, dtype=torch.int64, device="cuda")
+    hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), rmg, rvg, None, out4, N, float(R * S), 0.1, 1e-5, 0, nbt)
+    assert nbt.item() == 8                      # num_batches_tracked += 1, as nn.BatchNorm in train mode
     rm_ref, rv_ref = torch.zeros(N), torch.ones(N)
     F.batch_norm(y.permute(0, 2, 1), rm_ref, rv_ref, gam, bet, training=True, momentum=0.1, eps=1e-5)
     torch.testing.assert_close(rmg.cpu(), rm_ref, rtol=1e-4, atol=1e-5)
@@ -279,7 +281,7 @@ def test_pool3d_bn_act_train_fwd_bwd():
     stats = stats.cuda()
     out4 = torch.empty(4, N, device="cuda")
     hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"),
-             None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0)
+             None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0, None)
     ob = torch.empty(B, D // 2, H // 2, W // 2, N, dtype=torch.bfloat16, device="cuda")
     ysel = torch.empty(ob.shape, device="cuda")
     arg = torch.empty(ob.shape, dtype=torch.uint8, device="cuda")
