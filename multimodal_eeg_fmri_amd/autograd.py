@@ -164,7 +164,7 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
     sc = _compact(sums, 2 * N)
     dy = _empty((B, T, N), _BF, y)
-    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sc, dy, None, *args, 1)
+    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sc, dy, None, *args, 1 if s.get("train", True) else 0)
     _bn_param_grads(bag, bn, sc, N)
     k, pad = conv.kernel_size[0], conv.padding[0]
     cin = conv.in_channels
@@ -279,34 +279,88 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
 
 
 class ErpEncoderFn(_ModuleFn):
+    """train mode, or eval mode with a backward to follow (frozen BatchNorm: running statistics,
+    no dropout) - the latter serves fine-tuning on a frozen encoder and gradient saliency
+    (bridge_utils.py:158-229)."""
+
     @staticmethod
     def run(m, x):
         return ErpEncoderFn.apply(m, x, *_module_params(m))
 
     @staticmethod
     def forward(ctx, m, x, *params):
-        training = m.training
-        out, saved = ops._erp_forward_impl(m, x.float(), training, True) if training else \
-            _frozen_forward(m, x)
+        out, saved = ops._erp_forward_impl(m, x.float(), m.training, True, save=True)
         ctx.m, ctx.saved, ctx.params = m, saved, params
         ctx.need_dx = x.requires_grad
-        ctx.frozen = not training
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        if ctx.frozen:
-            raise NotImplementedError(
-                "backward through an eval-mode EnhancedERPEncoder (frozen BatchNorm) is not built yet; "
-                "call .train() or wrap the forward in torch.no_grad()")
         bag = GradBag()
         with deferred(bag, dout.device):
             dx = erp_encoder_bwd(bag, ctx.saved, dout, ctx.need_dx)
         return _ModuleFn._finish(ctx, bag, ctx.params, dx)
 
 
-def _frozen_forward(m, x):
-    return ops._erp_forward_impl(m, x.float(), False, False)[0], None
+def power_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = False):
+    """backward of ops._power_forward_impl; returns (dx packed bf16 (B, T, Cp) or None, finish) where
+    ``finish()`` must run AFTER the bag's deferred reductions were flushed: it slices the merged
+    192-channel conv / BatchNorm gradients back into the three conv_scale modules."""
+    d = pooled_head_bwd(bag, sv["head"], dout)
+    B, L, D = d.shape
+    d = d.view(B * L, D)
+    blocks = sv["blocks"]
+    dy2 = None
+    for i in range(len(blocks) - 1, -1, -1):
+        below = (blocks[i - 1]["p"], blocks[i - 1]["seeds"][2]) if i > 0 else None
+        d, dy2 = transformer_block_bwd(bag, blocks[i], d, dy2=dy2, emit_for=below)
+    g = conv_bn_act_bwd(bag, sv["convs"][1], dout_f32=d.view(B, L, D))
+    g = conv_bn_act_bwd(bag, sv["convs"][0], dout_bf16=g, need_dx=need_dx)
+    conv, bn, seqs = sv["merged"]
+
+    def finish():
+        for i, sq in enumerate(seqs):
+            k = sq[0].kernel_size[0]
+            lo = (7 - k) // 2
+            for real, merged, cut in ((sq[0].weight, conv.weight, lambda t: t[64 * i:64 * i + 64, :, lo:lo + k]),
+                                      (sq[0].bias, conv.bias, lambda t: t[64 * i:64 * i + 64]),
+                                      (sq[1].weight, bn.weight, lambda t: t[64 * i:64 * i + 64]),
+                                      (sq[1].bias, bn.bias, lambda t: t[64 * i:64 * i + 64])):
+                dst, src = bag.target(real), bag.result(merged)
+                if dst is not None and src is not None:
+                    dst.add_(cut(src))
+    return g, finish
+
+
+class PowerEncoderFn(_ModuleFn):
+    """EnhancedPowerEncoder (train, or eval with a backward to follow).  ``packed``: x is already the
+    channels-last bf16 (B, T, Cp) image (STFT front-end output) and gets no gradient."""
+
+    @staticmethod
+    def run(m, x, packed=False):
+        return PowerEncoderFn.apply(m, x, packed, *_module_params(m))
+
+    @staticmethod
+    def forward(ctx, m, x, packed, *params):
+        xb = x if packed else ops.pack_nct(x.float())
+        need_dx = (not packed) and x.requires_grad
+        out, saved = ops._power_forward_impl(m, xb, m.training, need_dx, save=True)
+        ctx.saved, ctx.params = saved, params
+        ctx.need_dx, ctx.x_shape = need_dx, tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        bag = GradBag()
+        with deferred(bag, dout.device):
+            g, finish = power_encoder_bwd(bag, ctx.saved, dout.contiguous(), ctx.need_dx)
+        finish()
+        dx = None
+        if ctx.need_dx:
+            Bx, C, T = ctx.x_shape
+            dx = _empty((Bx, C, T), _F32, dout)
+            _hip.call("mm_unpack_ntc_f32", g, dx, Bx, C, T, g.shape[2])
+        return (None, dx, None) + tuple(bag.result(p) for p in ctx.params)
 
 
 class TransformerBlockFn(_ModuleFn):

@@ -320,26 +320,32 @@ def attention(qkv: torch.Tensor, nhead: int, want_lse: bool, drop_p: float = 0.0
 
 # ------------------------------------------------------------------- stages
 def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=False, drop_p=0.0,
-                drop_first=True, pe=None, pe_drop_p=0.0, want_f32=False, want_bf16=True, need_dgrad=False):
+                drop_first=True, pe=None, pe_drop_p=0.0, want_f32=False, want_bf16=True, need_dgrad=False,
+                save=None):
     """Conv1d -> BatchNorm1d -> act [-> MaxPool(2)] [-> Dropout] on (B, T, Cp) bf16.
 
     eval : one kernel (BN folded into the GEMM epilogue).
     train: GEMM (+bias, per-channel sum/sumsq) -> finalize -> BN/act/pool apply.
+    eval with ``save`` (a backward will follow: frozen BatchNorm, saliency maps): the
+    train-shaped pipeline with the RUNNING statistics and no statistic update.
     Returns (out dict, saved-for-backward dict or None)."""
+    save = training if save is None else save
     k = conv.kernel_size[0]
     pad = conv.padding[0]
     cout = conv.out_channels
     wf, _, cinp, _ = weights.get(conv.weight, need_dgrad)
     assert xb.shape[2] == cinp, (xb.shape, cinp)
     B, T, _ = xb.shape
-    if not training:
+    if not save:
         out4 = bn_fold_eval(bn, conv.bias)
         r = igemm(xb, wf, k, pad, cout, scale=out4[0], shift=out4[1], act=act, pe=pe, pool=pool,
                   out_f32=want_f32, out_bf16=want_bf16)
         return r, None
-    stats = _zeros((REPL, 2, cout), xb)
+    stats = _zeros((REPL, 2, cout), xb) if training else None
     y = igemm(xb, wf, k, pad, cout, shift=conv.bias, stats=stats, out_f32=True, out_bf16=False)["f32"]
-    out4 = bn_finalize_train(bn, stats, B * T)
+    out4 = bn_finalize_train(bn, stats, B * T) if training else bn_fold_eval(bn, None)
+    if not training:
+        drop_p = pe_drop_p = 0.0
     seed = _next_seed() if drop_p > 0 else 0
     seed2 = _next_seed() if pe_drop_p > 0 else 0
     of = _empty((B, T // pool, cout), _F32, xb) if want_f32 else None
@@ -347,7 +353,7 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
     _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, B, T, cout, ACT[act], pool,
               1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2, EP())
     saved = dict(xb=xb, y=y, out4=out4, act=act, pool=pool, drop_p=drop_p, seed=seed,
-                 drop2=(float(pe_drop_p), seed2), drop_first=drop_first, conv=conv, bn=bn)
+                 drop2=(float(pe_drop_p), seed2), drop_first=drop_first, conv=conv, bn=bn, train=training)
     return {"f32": of, "bf16": ob, "pre": None}, saved
 
 
@@ -385,17 +391,18 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
 
 
 def pooled_head_fwd(x: torch.Tensor, lin, *, act="gelu", training=False, drop_p=0.0,
-                    need_dgrad=False):
+                    need_dgrad=False, save=None):
     """mean over L of fp32 (B, L, d) -> Linear -> act [-> dropout]: fp32 (B, out)."""
     B, L, D = x.shape
+    save = training if save is None else save
     pooled = _empty((B, D), _BF, x)
     _hip.call("mm_meanpool_fwd", x, None, pooled, B, L, D)
-    seed = _next_seed() if (training and drop_p > 0) else 0
+    p = drop_p if training else 0.0
+    seed = _next_seed() if p > 0 else 0
     r = linear_rows(pooled, lin.weight, lin.bias, act=act, out_f32=True, out_bf16=False,
-                    out_pre=training, drop_p=drop_p if training else 0.0, seed=seed,
-                    need_dgrad=need_dgrad)
-    saved = dict(pooled=pooled, z=r["pre"], seed=seed, drop_p=drop_p, B=B, L=L, D=D, lin=lin,
-                 act=act) if training else None
+                    out_pre=save, drop_p=p, seed=seed, need_dgrad=need_dgrad)
+    saved = dict(pooled=pooled, z=r["pre"], seed=seed, drop_p=p, B=B, L=L, D=D, lin=lin,
+                 act=act) if save else None
     return r["f32"], saved
 
 
@@ -408,38 +415,51 @@ def pe_table(pos_encoder, L: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------ EEG encoders
-def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool):
-    """EnhancedERPEncoder forward; returns (features fp32 (B, H), saved list)."""
+def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool):
+    """shared tail of both EEG encoders: transformer stack -> mean pool -> Linear -> GELU"""
+    blocks = []
+    for blk in m.transformer_layers:
+        h, s = transformer_block_fwd(h, blk, training, need_dgrad, save=save)
+        blocks.append(s)
+    out, s = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=m.drop_p, need_dgrad=need_dgrad,
+                             save=save)
+    return out, blocks, s, h
+
+
+def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None):
+    """EnhancedERPEncoder forward; returns (features fp32 (B, H), saved list).
+    ``save`` (default = training): keep what a backward needs (eval + save = frozen BatchNorm)."""
     cl = m.conv_layers
+    save = training if save is None else save
     p = m.drop_p if training else 0.0
     xb = pack_nct(x)
     saved = []
-    r, s = conv_bn_act(xb, cl[0], cl[1], training=training, drop_p=p, need_dgrad=need_dgrad)
+    r, s = conv_bn_act(xb, cl[0], cl[1], training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
     r, s = conv_bn_act(r["bf16"], cl[4], cl[5], pool=2, training=training, drop_p=p,
-                       drop_first=False, need_dgrad=need_dgrad)
+                       drop_first=False, need_dgrad=need_dgrad, save=save)
     saved.append(s)
     L = r["bf16"].shape[1]
     r, s = conv_bn_act(r["bf16"], cl[9], cl[10], training=training, drop_p=p,
                        pe=pe_table(m.pos_encoder, L), pe_drop_p=(m.pos_encoder.dropout.p if training else 0.0),
-                       want_f32=True, want_bf16=False, need_dgrad=need_dgrad)
+                       want_f32=True, want_bf16=False, need_dgrad=need_dgrad, save=save)
     saved.append(s)
-    h = r["f32"]
-    blocks = []
-    for blk in m.transformer_layers:
-        h, s = transformer_block_fwd(h, blk, training, need_dgrad)
-        blocks.append(s)
-    out, s = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad)
+    out, blocks, s, h = _encoder_tail_impl(m, r["f32"], training, need_dgrad, save)
     return out, dict(convs=saved, blocks=blocks, head=s, x_shape=tuple(x.shape), tokens=h)
 
 
 def erp_encoder_forward(m, x: torch.Tensor) -> torch.Tensor:
     _need_gpu(x)
-    if m.training or (torch.is_grad_enabled() and x.requires_grad):
+    if m.training or _wants_grad(m, x):
         from .autograd import ErpEncoderFn
         return ErpEncoderFn.run(m, x)
     with torch.no_grad():
         return _erp_forward_impl(m, x.float(), False, False)[0]
+
+
+def _wants_grad(m, x) -> bool:
+    """a backward may follow: autograd is on and the input or a parameter asks for a gradient"""
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in m.parameters()))
 
 
 def add_positional(x, pe, drop_p, training):
@@ -846,19 +866,76 @@ def stft_front_end(x: torch.Tensor, n_ffts, hop: int) -> torch.Tensor:
 
 
 def stft_power_encoder_forward(m, x):
-    """MultiScaleSTFTPowerEncoder: STFT power front-end -> EnhancedPowerEncoder."""
+    """MultiScaleSTFTPowerEncoder: STFT power front-end -> EnhancedPowerEncoder.
+    The front-end has no parameters; gradients stop at the spectra (no d/d raw-EEG)."""
     _need_gpu(x)
-    _eval_only("MultiScaleSTFTPowerEncoder", m.training)
+    enc = m.encoder
+    if enc.training or _wants_grad(enc, x.detach()):
+        if x.requires_grad:
+            raise NotImplementedError("MultiScaleSTFTPowerEncoder: no gradient w.r.t. the raw EEG input is built")
+        from .autograd import PowerEncoderFn
+        with torch.no_grad():
+            spec = stft_front_end(x, m.n_ffts, m.hop)
+        return PowerEncoderFn.run(enc, spec, packed=True)
     with torch.no_grad():
-        return _power_forward_ntc(m.encoder, stft_front_end(x, m.n_ffts, m.hop))
+        return _power_forward_ntc(enc, stft_front_end(x, m.n_ffts, m.hop))
 
 
 def power_encoder_forward(m, x):
     """EnhancedPowerEncoder (enhanced_models_v4.py:258-285)."""
     _need_gpu(x)
-    _eval_only("EnhancedPowerEncoder", m.training)
+    if m.training or _wants_grad(m, x):
+        from .autograd import PowerEncoderFn
+        return PowerEncoderFn.run(m, x)
     with torch.no_grad():
         return _power_forward_ntc(m, pack_nct(x.float()))
+
+
+class _Merged:
+    """attribute bag standing in for an nn.Conv1d / nn.BatchNorm1d built from several modules"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _power_merged_train(m):
+    """the three conv scales as ONE Conv1d(C -> 192, k=7, p=3) + BatchNorm1d(192) whose tensors are
+    fresh leaves (requires_grad as the parts'), so the generic conv/BN forward+backward applies;
+    autograd.power_encoder_bwd slices their gradients back into the six real parameters."""
+    seqs = (m.conv_scale1, m.conv_scale2, m.conv_scale3)
+    F = torch.nn.functional
+    cat = lambda ts: torch.cat([t.detach() for t in ts], dim=0).contiguous()    # noqa: E731
+    w = cat([F.pad(s[0].weight.detach(), ((7 - s[0].kernel_size[0]) // 2,) * 2) for s in seqs])
+    conv = _Merged(weight=w.requires_grad_(any(s[0].weight.requires_grad for s in seqs)),
+                   bias=cat([s[0].bias for s in seqs]).requires_grad_(any(s[0].bias.requires_grad for s in seqs)),
+                   kernel_size=(7,), padding=(3,), in_channels=seqs[0][0].in_channels, out_channels=192)
+    bn = _Merged(weight=cat([s[1].weight for s in seqs]).requires_grad_(any(s[1].weight.requires_grad for s in seqs)),
+                 bias=cat([s[1].bias for s in seqs]).requires_grad_(any(s[1].bias.requires_grad for s in seqs)),
+                 running_mean=cat([s[1].running_mean for s in seqs]), running_var=cat([s[1].running_var for s in seqs]),
+                 num_batches_tracked=None, num_features=192, eps=seqs[0][1].eps, momentum=seqs[0][1].momentum)
+    assert all(s[1].eps == bn.eps and s[1].momentum == bn.momentum for s in seqs)
+    return conv, bn, seqs
+
+
+def _power_forward_impl(m, xb: torch.Tensor, training: bool, need_dgrad: bool, save=None):
+    """EnhancedPowerEncoder on packed (B, T, Cp) bf16 input, train / frozen-BN forms."""
+    save = training if save is None else save
+    conv, bn, seqs = _power_merged_train(m)
+    r, s0 = conv_bn_act(xb, conv, bn, training=training, need_dgrad=need_dgrad, save=save)
+    if training:                                  # running statistics live in the three real modules
+        with torch.no_grad():
+            for i, sq in enumerate(seqs):
+                sq[1].running_mean.copy_(bn.running_mean[64 * i:64 * i + 64])
+                sq[1].running_var.copy_(bn.running_var[64 * i:64 * i + 64])
+                if sq[1].num_batches_tracked is not None:
+                    sq[1].num_batches_tracked.add_(1)
+    T = xb.shape[1]
+    p = m.drop_p if training else 0.0
+    r, s1 = conv_bn_act(r["bf16"], m.fusion[0], m.fusion[1], training=training, drop_p=p,
+                        pe=pe_table(m.pos_encoder, T), pe_drop_p=(m.pos_encoder.dropout.p if training else 0.0),
+                        want_f32=True, want_bf16=False, need_dgrad=True, save=save)
+    out, blocks, sh, h = _encoder_tail_impl(m, r["f32"], training, True, save)
+    return out, dict(convs=[s0, s1], blocks=blocks, head=sh, merged=(conv, bn, seqs), tokens=h)
 
 
 def _power_forward_ntc(m, xb):
