@@ -76,6 +76,24 @@ def conv1d_wgrad_case(B, T, Cin, Cout, k):
     print(f"wgrad1d B={B} T={T} Cin={Cin} Cout={Cout} k={k}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
 
 
+def conv3d_dims_case(B, D, H, W, Cin, Cout):
+    """layer-2-shaped forward at arbitrary volume dims (BASELINE config #4: 64x64x48 input -> 32x32x24 here)"""
+    x = torch.randn(B, D, H, W, Cin, device="cuda").to(BF)
+    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
+    wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
+    of = torch.empty(B, D, H, W, Cout, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
+    b = torch.randn(Cout, device="cuda")
+
+    def fn():
+        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, b, stats, of, None)
+    us = graph_time(fn, n=10)
+    fl = 2.0 * B * D * H * W * Cin * Cout * 27
+    print(f"conv3d B={B} {D}x{H}x{W} Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s "
+          f"({fl / us / 1e6 / 2500:.3f} of 2.5 PF; graph-replayed)")
+
+
 def conv3d_case(B, S, Cin, Cout, wgrad=True):
     x = torch.randn(B, S, S, S, Cin, device="cuda").to(BF)
     w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
@@ -186,6 +204,11 @@ def main():
         return
     if "tl" in flt:
         timeline_case()
+        return
+    if "c4" in flt:                 # full-resolution fMRI (64x64x48): layer 2 runs at 32x32x24
+        for B in (4, 8, 32):
+            conv3d_dims_case(B, 32, 32, 24, 32, 64)
+        conv3d_dims_case(32, 16, 16, 16, 32, 64)
         return
     if "abl" in flt:
         for f in (0, 1, 2, 3):
