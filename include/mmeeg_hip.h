@@ -251,6 +251,16 @@ int mm_softmax2_concat(const float* a, const float* c, const float* pa, const fl
 int mm_learned_fusion(const float* f0, const float* f1, const float* f2, const float* dyn,
                       const float* logits, const float* temperature, float* fused, float* weights, int B,
                       int H, int M, hipStream_t stream);
+/* nn.MultiheadAttention core for ONE query token and K <= 4 key/value tokens per sample: the
+ * modality-level cross attention of the V4 classifiers (crossmodal_v4_enhancements.py:366-372 K = 3,
+ * :448-456 K = 2).  p_j = in_proj(token_j) fp32 [B][3E] = [q | k | v]; the query is token 0's q.
+ * backward == 0: ctx [B][E] (+ head-averaged attw [B][K], nullable);  backward == 1: dp_j [B][3E] from
+ * dctx.  Attention-probability dropout by counter hash, recomputed in backward. */
+int mm_attn_1xk(const float* p0, const float* p1, const float* p2, const float* p3, int K, const float* dctx,
+                float* ctx, float* attw, float* dp0, float* dp1, float* dp2, float* dp3, int B, int E,
+                int nhead, float drop_p, uint32_t seed, const uint32_t* seed_epoch, int backward,
+                hipStream_t stream);
+int mm_add_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 /* bridge cross-attention core, 1 query x 2 keys (bridge_utils.py:75-82) */
 int mm_attn_1x2(const float* proj_e, const float* proj_f, float* ctx, float* attw, int B, int E, int nhead,
                 hipStream_t stream);

@@ -44,7 +44,10 @@ class BridgeTrainer(nn.Module):
         self._cap = None
         self._weight_list = None                      # recorded by the first manual step
         self.stamps = None                            # int64[16] device buffer when phase stamps are wanted
-        self._side = torch.cuda.Stream()
+        import os
+        # MM_ONE_STREAM=1 (diagnostic): run the fMRI branch on the main stream after the EEG branch
+        self._one_stream = bool(os.environ.get("MM_ONE_STREAM"))
+        self._side_stream = torch.cuda.Stream()
         self.lr, self.weight_decay, self.grad_clip = lr, weight_decay, grad_clip
         self.betas, self.eps = betas, eps
         br = self.head.bridge
@@ -58,6 +61,10 @@ class BridgeTrainer(nn.Module):
         self.bucket = FlatBucket(train_params)
         self.bucket.state[2] = lr
         ops.weights_changed()
+
+    @property
+    def _side(self):
+        return torch.cuda.current_stream() if self._one_stream else self._side_stream
 
     @property
     def world(self):

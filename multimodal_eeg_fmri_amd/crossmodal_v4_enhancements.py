@@ -2,7 +2,8 @@
 
 Class surface of the reference's ``EEG_CODE/crossmodal_v4_enhancements.py``:
 the duplicated encoder family (:29-271, re-exported from
-``enhanced_models_v4``), DropPath :639-658, LabelSmoothingCrossEntropy
+``enhanced_models_v4``), the full V4 classifiers EnhancedTriModalFusionNetV4 :278-388,
+BiDirectionalCrossAttention :403-466, EnhancedSmartFusionNetV4 :473-570, DropPath :639-658, LabelSmoothingCrossEntropy
 :665-677, EnhancedConnEncoder :684-739, HybridFusionModule :746-810,
 LiteERPEncoder/LitePowerEncoder :817-877, EnhancedTriModalFusionNetV4Lite
 :880-948, CosineAnnealingWarmup :1084-1112, EarlyStopping :1115-1143,
@@ -107,6 +108,84 @@ def get_lite_fusion_weights(model):
     if hasattr(model, "get_fusion_weights"):
         return model.get_fusion_weights()
     return getattr(model, "_fusion_weights", None)
+
+
+# ------------------------------------------------- full V4 classifiers
+def _mlp_bn(i, o, dropout):
+    return [nn.Linear(i, o), nn.BatchNorm1d(o), nn.GELU(), nn.Dropout(dropout)]
+
+
+def _v4_head(hidden_dim, num_classes, dropout):
+    return nn.Sequential(*_mlp_bn(hidden_dim, hidden_dim, dropout), *_mlp_bn(hidden_dim, hidden_dim // 2, dropout),
+                         nn.Linear(hidden_dim // 2, num_classes))
+
+
+def _flagged(logits, weights, fused, return_fusion_weights, return_fused_feats):
+    out = [logits]
+    if return_fusion_weights:
+        out.append(weights)
+    if return_fused_feats:
+        out.append(fused)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+class EnhancedTriModalFusionNetV4(nn.Module):
+    """ERP + Power transformer encoders, MLP connectivity encoder, ERP-queries-all cross attention,
+    learned 3-way fusion, BN-MLP classifier (reference :278-388; same state_dict)."""
+
+    def __init__(self, erp_channels: int, pw_channels: int, conn_features: int,
+                 hidden_dim: int = 128, num_classes: int = 2, dropout: float = 0.3,
+                 num_transformer_layers: int = 2, num_heads: int = 4):
+        super().__init__()
+        self.erp_encoder = EnhancedERPEncoder(erp_channels, hidden_dim, num_transformer_layers, num_heads, dropout)
+        self.pw_encoder = EnhancedPowerEncoder(pw_channels, hidden_dim, num_transformer_layers, num_heads, dropout)
+        self.conn_encoder = nn.Sequential(*_mlp_bn(conn_features, 256, dropout), *_mlp_bn(256, hidden_dim, dropout))
+        self.cross_attn = nn.MultiheadAttention(hidden_dim, num_heads=num_heads, dropout=dropout, batch_first=True)
+        self.fusion = LearnedFusionModule(num_modalities=3, hidden_dim=hidden_dim, use_temperature=True)
+        self.classifier = _v4_head(hidden_dim, num_classes, dropout)
+        self.drop_p = dropout
+
+    def forward(self, erp, pw, conn, return_fusion_weights: bool = False, return_fused_feats: bool = False):
+        logits, weights, fused = ops.trimodal_v4_forward(self, erp, pw, conn)
+        return _flagged(logits, weights, fused, return_fusion_weights, return_fused_feats)
+
+
+class BiDirectionalCrossAttention(nn.Module):
+    """each modality attends to [erp, pw]; sigmoid-gated residual + LayerNorm (reference :403-466)."""
+
+    def __init__(self, hidden_dim: int, num_heads: int = 4, dropout: float = 0.3):
+        super().__init__()
+        self.erp_to_pw_attn = nn.MultiheadAttention(hidden_dim, num_heads=num_heads, dropout=dropout, batch_first=True)
+        self.pw_to_erp_attn = nn.MultiheadAttention(hidden_dim, num_heads=num_heads, dropout=dropout, batch_first=True)
+        self.norm_erp = nn.LayerNorm(hidden_dim)
+        self.norm_pw = nn.LayerNorm(hidden_dim)
+        self.erp_gate = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.Sigmoid())
+        self.pw_gate = nn.Sequential(nn.Linear(hidden_dim * 2, hidden_dim), nn.Sigmoid())
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, erp_feat, pw_feat):
+        return ops.bidirectional_cross_attention_forward(self, erp_feat, pw_feat)
+
+
+class EnhancedSmartFusionNetV4(nn.Module):
+    """bi-modal (ERP + Power) classifier with bi-directional cross attention (reference :473-570)."""
+
+    def __init__(self, erp_channels: int, pw_channels: int, hidden_dim: int = 128, num_classes: int = 2,
+                 dropout: float = 0.4, num_transformer_layers: int = 2, num_heads: int = 4,
+                 use_cross_attention: bool = True):
+        super().__init__()
+        self.use_cross_attention = use_cross_attention
+        self.erp_encoder = EnhancedERPEncoder(erp_channels, hidden_dim, num_transformer_layers, num_heads, dropout)
+        self.pw_encoder = EnhancedPowerEncoder(pw_channels, hidden_dim, num_transformer_layers, num_heads, dropout)
+        if use_cross_attention:
+            self.cross_attention = BiDirectionalCrossAttention(hidden_dim, num_heads=num_heads, dropout=dropout)
+        self.fusion = LearnedFusionModule(num_modalities=2, hidden_dim=hidden_dim, use_temperature=True)
+        self.classifier = _v4_head(hidden_dim, num_classes, dropout)
+        self.drop_p = dropout
+
+    def forward(self, erp, pw, return_fusion_weights: bool = False, return_fused_feats: bool = False):
+        logits, weights, fused = ops.smart_fusion_v4_forward(self, erp, pw)
+        return _flagged(logits, weights, fused, return_fusion_weights, return_fused_feats)
 
 
 # ----------------------------------------------------------------- encoders

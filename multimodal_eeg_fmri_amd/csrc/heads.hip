@@ -518,6 +518,87 @@ __global__ void attn_1x2_fused_kernel(const float* __restrict__ pe, const float*
     }
 }
 
+
+// nn.MultiheadAttention core with ONE query token and K <= 4 key/value tokens per sample (the
+// modality-level cross attention of the V4 classifiers: crossmodal_v4_enhancements.py:366-372 K = 3,
+// :448-456 K = 2).  p[j] = in_proj(token_j) [B][3E] = [q | k | v]; the query is token 0's q.
+// Attention-probability dropout as in the 1x2 kernel (index (b * nhead + h) * K + j).
+struct Attn1xKArgs {
+    const float* p[4]; float* dp[4];
+    const float* dctx; float* ctx; float* attw;
+    int B, E, nhead, K; uint32_t thresh, seed; float inv_keep; const uint32_t* epoch; int backward;
+};
+__global__ __launch_bounds__(256) void attn_1xk_kernel(Attn1xKArgs a) {
+    const uint32_t seed = mm_eff_seed(a.seed, a.epoch);
+    const int b = blockIdx.x, E = a.E, K = a.K;
+    const int dh = E / a.nhead;
+    __shared__ float ps[16][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* q = a.p[0] + (size_t)b * 3 * E;
+    const float isq = rsqrtf((float)dh);
+    for (int h = wave; h < a.nhead; h += (blockDim.x >> 6)) {
+        float s[4], pr[4], keep[4];
+        float m = -INFINITY;
+        for (int j = 0; j < K; ++j) {
+            const float* kj = a.p[j] + (size_t)b * 3 * E + E;
+            float acc = 0.f;
+            for (int d = lane; d < dh; d += 64) acc += q[h * dh + d] * kj[h * dh + d];
+            s[j] = wave_sum(acc) * isq;
+            m = fmaxf(m, s[j]);
+        }
+        float den = 0.f;
+        for (int j = 0; j < K; ++j) { pr[j] = __expf(s[j] - m); den += pr[j]; }
+        for (int j = 0; j < K; ++j) {
+            pr[j] /= den;
+            keep[j] = a.thresh ? dropout_scale(seed, (uint32_t)((b * a.nhead + h) * K + j), a.thresh, a.inv_keep) : 1.f;
+        }
+        if (!a.backward) {
+            for (int d = lane; d < dh; d += 64) {
+                float acc = 0.f;
+                for (int j = 0; j < K; ++j) acc += pr[j] * keep[j] * a.p[j][(size_t)b * 3 * E + 2 * E + h * dh + d];
+                a.ctx[(size_t)b * E + h * dh + d] = acc;
+            }
+            if (lane == 0)
+                for (int j = 0; j < K; ++j) ps[h][j] = pr[j];
+        } else {
+            const float* dc = a.dctx + (size_t)b * E + h * dh;
+            float dp[4], dot = 0.f;
+            for (int j = 0; j < K; ++j) {
+                const float* vj = a.p[j] + (size_t)b * 3 * E + 2 * E + h * dh;
+                float acc = 0.f;
+                for (int d = lane; d < dh; d += 64) acc += dc[d] * vj[d];
+                dp[j] = wave_sum(acc) * keep[j];
+                dot += pr[j] * dp[j];
+            }
+            for (int d = lane; d < dh; d += 64) {
+                const int i = h * dh + d;
+                float dq = 0.f;
+                for (int j = 0; j < K; ++j) {
+                    const float ds = pr[j] * (dp[j] - dot) * isq;
+                    dq += ds * a.p[j][(size_t)b * 3 * E + E + i];
+                    float* o = a.dp[j] + (size_t)b * 3 * E;
+                    if (j > 0) o[i] = 0.f;
+                    o[E + i] = ds * q[i];
+                    o[2 * E + i] = pr[j] * keep[j] * dc[d];
+                }
+                a.dp[0][(size_t)b * 3 * E + i] = dq;
+            }
+        }
+    }
+    if (!a.backward && a.attw) {
+        __syncthreads();
+        if (threadIdx.x < K) {
+            float s = 0.f;
+            for (int h = 0; h < a.nhead; ++h) s += ps[h][threadIdx.x];
+            a.attw[(size_t)b * K + threadIdx.x] = s / a.nhead;
+        }
+    }
+}
+
+__global__ void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
+}
+
 // backward of learned_fusion_kernel.  One wave per row; parameter gradients
 // (logits [M], temperature) are summed over rows with atomics into dlogits / dtemp.
 __global__ void learned_fusion_bwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
@@ -979,6 +1060,31 @@ int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, 
     hipLaunchKernelGGL(stft_power_kernel, dim3(ceil_div(frames, 8), C, B), dim3(256), lds, st, x, (bf16*)out_bf16, out_f32,
                        C, T, nfft, hop, frames, ch_off, ch_total);
     return mm_check_launch("stft_power");
+}
+
+int mm_attn_1xk(const float* p0, const float* p1, const float* p2, const float* p3, int K, const float* dctx,
+                float* ctx, float* attw, float* dp0, float* dp1, float* dp2, float* dp3, int B, int E, int nhead,
+                float drop_p, uint32_t seed, const uint32_t* seed_epoch, int backward, hipStream_t st) {
+    MM_REQUIRE(K >= 1 && K <= 4 && B > 0 && nhead > 0 && nhead <= 16 && E % nhead == 0, "attn_1xk: K=%d nhead=%d E=%d", K, nhead, E);
+    Attn1xKArgs a{};
+    const float* p[4] = {p0, p1, p2, p3};
+    float* dp[4] = {dp0, dp1, dp2, dp3};
+    for (int j = 0; j < K; ++j) {
+        MM_REQUIRE(p[j] && (!backward || dp[j]), "attn_1xk: null token %d", j);
+        a.p[j] = p[j]; a.dp[j] = dp[j];
+    }
+    MM_REQUIRE(backward ? dctx != nullptr : ctx != nullptr, "attn_1xk: outputs");
+    a.dctx = dctx; a.ctx = ctx; a.attw = attw; a.B = B; a.E = E; a.nhead = nhead; a.K = K;
+    a.thresh = thresh_h(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.epoch = seed_epoch; a.backward = backward;
+    hipLaunchKernelGGL(attn_1xk_kernel, dim3(B), dim3(256), 0, st, a);
+    return mm_check_launch("attn_1xk");
+}
+
+int mm_add_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
+    MM_REQUIRE(a && b && out && n > 0, "add_f32: null");
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, a, b, out, (size_t)n);
+    return mm_check_launch("add_f32");
 }
 
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {

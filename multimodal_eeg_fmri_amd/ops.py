@@ -730,6 +730,67 @@ def bridge_forward(m, eeg, fmri):
     return logits, fused, fw, attw.view(B, 1, 2)
 
 
+def _mlp_bn_act(x, lin, bn, act, drop_p, training):
+    """Linear -> BatchNorm1d -> act -> Dropout on fp32 rows (eval: BN folded into the linear)."""
+    if training:
+        from . import small_autograd as sa
+        return sa.linear_bn_act(x, lin, bn, act, drop_p)
+    if torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
+        raise NotImplementedError("backward through an eval-mode BatchNorm1d MLP head is not built; use no_grad or train()")
+    return small_linear(_f32c(x), lin, act=act, bn=bn)[0]
+
+
+def _v4_classifier(cl, fused, p, training):
+    from . import small_autograd as sa
+    h = _mlp_bn_act(fused, cl[0], cl[1], "gelu", p, training)
+    h = _mlp_bn_act(h, cl[4], cl[5], "gelu", p, training)
+    return sa.linear(h, cl[8])
+
+
+def trimodal_v4_forward(m, erp, pw, conn):
+    """EnhancedTriModalFusionNetV4.forward (crossmodal_v4_enhancements.py:338-388)
+    -> (logits, fusion weights (B, 3), fused (B, H))"""
+    _need_gpu(erp, pw, conn)
+    from . import small_autograd as sa
+    tr, p = m.training, m.drop_p
+    e = m.erp_encoder(erp)
+    w = m.pw_encoder(pw)
+    c = conn.reshape(conn.size(0), -1) if conn.dim() > 2 else conn
+    ce = m.conn_encoder
+    c = _mlp_bn_act(c, ce[0], ce[1], "gelu", p, tr)
+    c = _mlp_bn_act(c, ce[4], ce[5], "gelu", p, tr)
+    enh, _ = sa.mha_1xk(m.cross_attn, [e, w, c], tr)
+    fused, weights = learned_fusion(m.fusion, [enh, w, c], tr)
+    return _v4_classifier(m.classifier, fused, p, tr), weights, fused
+
+
+def bidirectional_cross_attention_forward(m, e, w):
+    """BiDirectionalCrossAttention.forward (crossmodal_v4_enhancements.py:436-466)"""
+    _need_gpu(e, w)
+    from . import small_autograd as sa
+    tr = m.training
+    p = m.dropout.p if tr else 0.0
+    ea, _ = sa.mha_1xk(m.erp_to_pw_attn, [e, w], tr)
+    wa, _ = sa.mha_1xk(m.pw_to_erp_attn, [w, e], tr)       # softmax over the same two keys: order is immaterial
+
+    def gated(feat, att, gate, norm):
+        g = sa.linear(torch.cat([_f32c(feat), att], dim=1), gate[0], "sigmoid")
+        upd = sa.ActFn.apply(sa.MulFn.apply(g, att), "none", p)
+        return sa.LayerNormFn.apply(sa.AddFn.apply(feat, upd), norm.weight, norm.bias, norm.eps)
+    return gated(e, ea, m.erp_gate, m.norm_erp), gated(w, wa, m.pw_gate, m.norm_pw)
+
+
+def smart_fusion_v4_forward(m, erp, pw):
+    """EnhancedSmartFusionNetV4.forward (crossmodal_v4_enhancements.py:537-570)"""
+    _need_gpu(erp, pw)
+    e = m.erp_encoder(erp)
+    w = m.pw_encoder(pw)
+    if m.use_cross_attention:
+        e, w = m.cross_attention(e, w)
+    fused, weights = learned_fusion(m.fusion, [e, w], m.training)
+    return _v4_classifier(m.classifier, fused, m.drop_p, m.training), weights, fused
+
+
 def fmri_mlp_forward(seq, x, drop_p, training):
     """Linear-BN-ReLU-Drop x2 (fmri_utils.py:26-35); eval-mode BN is folded."""
     _need_gpu(x)

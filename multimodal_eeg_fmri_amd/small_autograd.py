@@ -274,6 +274,58 @@ class Attn1x2Fn(torch.autograd.Function):
         return dpe, dpf, None, None
 
 
+class Attn1xKFn(torch.autograd.Function):
+    """MultiheadAttention core, one query token x K <= 4 key/value tokens: (nhead, p, *in-projected
+    tokens (B, 3E)) -> (context (B, E), head-averaged weights (B, K))."""
+
+    @staticmethod
+    def forward(ctx, nhead, drop_p, *projs):
+        projs = [_f(p) for p in projs]
+        K = len(projs)
+        B, E3 = projs[0].shape
+        E = E3 // 3
+        seed = ops._next_seed() if drop_p > 0 else 0
+        out = _empty((B, E), _F32, projs[0])
+        attw = _empty((B, K), _F32, projs[0])
+        pads = projs + [None] * (4 - K)
+        _hip.call("mm_attn_1xk", *pads, K, None, out, attw, None, None, None, None, B, E, int(nhead),
+                  float(drop_p), seed, ops.EP(), 0)
+        ctx.save_for_backward(*projs)
+        ctx.meta = (int(nhead), float(drop_p), seed, K, B, E)
+        ctx.mark_non_differentiable(attw)
+        return out, attw
+
+    @staticmethod
+    def backward(ctx, dctx, _dattw):
+        projs = list(ctx.saved_tensors)
+        nhead, p, seed, K, B, E = ctx.meta
+        dps = [torch.empty_like(t) for t in projs]
+        _hip.call("mm_attn_1xk", *(projs + [None] * (4 - K)), K, _f(dctx), None, None, *(dps + [None] * (4 - K)),
+                  B, E, nhead, p, seed, ops.EP(), 1)
+        return (None, None) + tuple(dps)
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f(a), _f(b)
+        out = torch.empty_like(a)
+        _hip.call("mm_add_f32", a, b, out, a.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def mha_1xk(attn, tokens, training: bool):
+    """nn.MultiheadAttention(batch_first) with query = tokens[0] (one token) over keys/values = tokens:
+    -> (output (B, E), head-averaged attention weights (B, K))"""
+    projs = [SmallLinearFn.apply(t, attn.in_proj_weight, attn.in_proj_bias, "none", 0.0) for t in tokens]
+    c, w = Attn1xKFn.apply(attn.num_heads, float(attn.dropout) if training else 0.0, *projs)
+    return linear(c, attn.out_proj), w
+
+
 class LearnedFusionFn(torch.autograd.Function):
     """LearnedFusionModule combine: (dyn (B, M), logits (M), temperature (), f_0..f_{M-1}) -> (fused, w)"""
 

@@ -231,6 +231,36 @@ def main():
     np.savez_compressed(os.path.join(OUT, "a11_bridge_train_grads.npz"), **fx)
     report.append("grads ok")
 
+    # ----------------------------------------- (f).1 full V4 classifiers (eval + train grads)
+    import multimodal_eeg_fmri_amd.crossmodal_v4_enhancements as ours_c
+    for tag, name, args in (("trimodal_v4", "EnhancedTriModalFusionNetV4", (8, 8, 36)),
+                            ("smart_v4", "EnhancedSmartFusionNetV4", (8, 8))):
+        tri = "Tri" in name
+        ref = build(getattr(cv4, name), 31, *args).eval()
+        our = build(getattr(ours_c, name), 31, *args).eval()
+        _same_state(ref, our, "f1 " + name)
+        xs = [seeded_randn(131, 4, 8, 256), seeded_randn(132, 4, 8, 256)] + ([seeded_randn(133, 4, 36)] if tri else [])
+        with torch.no_grad():
+            want = ref(*xs, return_fusion_weights=True, return_fused_feats=True)
+            got = (RF.trimodal_v4 if tri else RF.smart_fusion_v4)(ref.state_dict(), *xs)
+        for nm, w_, g_ in zip(("logits", "weights", "fused"), want, got):
+            _close(g_, w_, f"f1 {name} {nm}", 5e-6)
+        fx = {"seed": 31, "x_seeds": np.array([131, 132, 133]), "cks": checksum(ref),
+              "logits": _np(want[0]), "weights": _np(want[1]), "fused": _np(want[2])}
+        # train mode: constructor dropout 0, the fusion gate's hard-coded Dropout(0.2) off
+        ref = build(getattr(cv4, name), 32, *args, dropout=0.0).train()
+        ref.fusion.gate_net[2].p = 0.0
+        gy = seeded_randn(134, 4, 2)
+        ref(*xs).backward(gy)
+        sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in ref.state_dict().items()}
+        (RF.trimodal_v4 if tri else RF.smart_fusion_v4)(sd, *xs, train=True)[0].backward(gy)
+        for n, pr in ref.named_parameters():
+            _close(sd[n].grad, pr.grad, f"f1 {name} d{n}", 2e-4)
+        fx.update({"train_seed": 32, "gy_seed": 134})
+        fx.update({"t_" + k: v for k, v in grad_summary(ref, head=8).items()})
+        np.savez_compressed(os.path.join(OUT, f"f1_{tag}.npz"), **fx)
+    report.append("f1 V4 classifiers ok")
+
     # ------------------------------------------------------------- (viii) a8
     logits, tgt = seeded_randn(125, 16, 2), (seeded_randn(126, 16) > 0).long()
     ls = cv4.LabelSmoothingCrossEntropy(0.1)(logits, tgt)
@@ -252,6 +282,8 @@ def main():
                       ("EnhancedPowerEncoder", cv4.EnhancedPowerEncoder(64)),
                       ("LearnedFusionModule", cv4.LearnedFusionModule(3, 128)),
                       ("EnhancedTriModalFusionNetV4Lite", cv4.EnhancedTriModalFusionNetV4Lite(8, 8, 459)),
+                      ("EnhancedTriModalFusionNetV4", cv4.EnhancedTriModalFusionNetV4(64, 64, 459)),
+                      ("EnhancedSmartFusionNetV4", cv4.EnhancedSmartFusionNetV4(64, 64)),
                       ("fMRIFusionNet", fm.fMRIFusionNet(100, 200)),
                       ("EEGfMRIBridgeFusionNet", br.EEGfMRIBridgeFusionNet())):
         layout[name] = [[k, list(v.shape)] for k, v in mod.state_dict().items()]

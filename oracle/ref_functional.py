@@ -288,6 +288,56 @@ def bridge_net(sd: SD, eeg, fmri, p: str = "", nhead: int = 4):
     return logits, fused, fw, attw
 
 
+# --------------------------------------------------------------------------
+# full V4 classifiers composed from a3 / a4 / a5
+# (crossmodal_v4_enhancements.py:278-388 tri-modal, :403-466 bi-directional
+# cross attention, :473-570 bi-modal).  Dropout is the identity here (eval, or
+# train with p = 0); ``train`` switches BatchNorm to batch statistics.
+# --------------------------------------------------------------------------
+def _mlp_bn_gelu(sd: SD, p: str, x, i_lin: int, train: bool):
+    return gelu(_bn(sd, f"{p}{i_lin + 1}.", _lin(sd, f"{p}{i_lin}.", x), train))
+
+
+def _v4_classifier(sd: SD, p: str, fused, train: bool):
+    h = _mlp_bn_gelu(sd, p, fused, 0, train)
+    h = _mlp_bn_gelu(sd, p, h, 4, train)
+    return _lin(sd, p + "8.", h)
+
+
+def trimodal_v4(sd: SD, erp, pw, conn, p: str = "", nhead: int = 4, train: bool = False):
+    """-> (logits, fusion weights (B, 3), fused (B, H))"""
+    e = erp_encoder(sd, erp, p + "erp_encoder.", nhead, train)
+    w = power_encoder(sd, pw, p + "pw_encoder.", nhead, train)
+    c = conn.reshape(conn.shape[0], -1)
+    c = _mlp_bn_gelu(sd, p + "conn_encoder.", c, 0, train)
+    c = _mlp_bn_gelu(sd, p + "conn_encoder.", c, 4, train)
+    stack = torch.stack([e, w, c], dim=1)
+    enh, _ = multihead_attention(sd, p + "cross_attn.", e.unsqueeze(1), stack, nhead)
+    fused, weights = learned_fusion(sd, [enh.squeeze(1), w, c], p + "fusion.")
+    return _v4_classifier(sd, p + "classifier.", fused, train), weights, fused
+
+
+def bidirectional_cross_attention(sd: SD, e, w, p: str = "", nhead: int = 4):
+    comb = torch.stack([e, w], dim=1)
+    ea, _ = multihead_attention(sd, p + "erp_to_pw_attn.", e.unsqueeze(1), comb, nhead)
+    wa, _ = multihead_attention(sd, p + "pw_to_erp_attn.", w.unsqueeze(1), comb, nhead)
+    ea, wa = ea.squeeze(1), wa.squeeze(1)
+    ge = torch.sigmoid(_lin(sd, p + "erp_gate.0.", torch.cat([e, ea], dim=1)))
+    gw = torch.sigmoid(_lin(sd, p + "pw_gate.0.", torch.cat([w, wa], dim=1)))
+    return _ln(sd, p + "norm_erp.", e + ge * ea), _ln(sd, p + "norm_pw.", w + gw * wa)
+
+
+def smart_fusion_v4(sd: SD, erp, pw, p: str = "", nhead: int = 4, train: bool = False,
+                    use_cross_attention: bool = True):
+    """-> (logits, fusion weights (B, 2), fused (B, H))"""
+    e = erp_encoder(sd, erp, p + "erp_encoder.", nhead, train)
+    w = power_encoder(sd, pw, p + "pw_encoder.", nhead, train)
+    if use_cross_attention:
+        e, w = bidirectional_cross_attention(sd, e, w, p + "cross_attention.", nhead)
+    fused, weights = learned_fusion(sd, [e, w], p + "fusion.")
+    return _v4_classifier(sd, p + "classifier.", fused, train), weights, fused
+
+
 # ==========================================================================
 # EXTENSIONS named by north_star, absent from the reference
 # ("parity unpinned by reference"; definitions in DESIGN.md)

@@ -58,6 +58,8 @@ def test_state_dict_layout_matches_reference():
           "EnhancedPowerEncoder": lambda: E.EnhancedPowerEncoder(64),
           "LearnedFusionModule": lambda: E.LearnedFusionModule(3, 128),
           "EnhancedTriModalFusionNetV4Lite": lambda: C.EnhancedTriModalFusionNetV4Lite(8, 8, 459),
+          "EnhancedTriModalFusionNetV4": lambda: C.EnhancedTriModalFusionNetV4(64, 64, 459),
+          "EnhancedSmartFusionNetV4": lambda: C.EnhancedSmartFusionNetV4(64, 64),
           "fMRIFusionNet": lambda: Fm.fMRIFusionNet(100, 200),
           "EEGfMRIBridgeFusionNet": lambda: B.EEGfMRIBridgeFusionNet()}
     for name, layout in ref.items():

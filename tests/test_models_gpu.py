@@ -430,3 +430,39 @@ def test_aX3_stft_power_encoder_trains():
         opt.step()
         losses.append(loss.item())
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("tag,name,n_in", [("trimodal_v4", "EnhancedTriModalFusionNetV4", 3),
+                                            ("smart_v4", "EnhancedSmartFusionNetV4", 2)])
+def test_f1_full_v4_classifiers_vs_reference_golden(golden, tag, name, n_in):
+    """EnhancedTriModalFusionNetV4 / EnhancedSmartFusionNetV4 (a3 + a4 encoders, 1xK
+    modality cross attention, learned fusion, BN-MLP head) on the HIP path.
+    eval: logits / fusion weights / fused features vs the reference golden (cosine >= 1 - 1e-4 on the
+    fused features; logits 3e-2 abs: two bf16 encoders feed a 5-layer fp32 head);
+    train (dropout 0): every parameter-gradient norm within 6e-2 of the reference's autograd."""
+    fx = golden(f"f1_{tag}.npz")
+    args = (8, 8, 36) if n_in == 3 else (8, 8)
+    m = build(getattr(Cv, name), int(fx["seed"]), *args).eval()
+    np.testing.assert_allclose(checksum(m), fx["cks"], rtol=1e-6, atol=1e-6)
+    s = [int(v) for v in fx["x_seeds"]]
+    xs = [seeded_randn(s[0], 4, 8, 256), seeded_randn(s[1], 4, 8, 256)] + ([seeded_randn(s[2], 4, 36)] if n_in == 3 else [])
+    with torch.no_grad():
+        logits, weights, fused = m.cuda()(*[x.cuda() for x in xs], return_fusion_weights=True, return_fused_feats=True)
+    assert cos_min(fused.cpu(), torch.as_tensor(fx["fused"])) >= 1 - COS_TOL
+    _close(weights, fx["weights"], 1e-2, 2e-3, "fusion weights")
+    _close(logits, fx["logits"], 3e-2, 3e-2, "logits")
+    mt = build(getattr(Cv, name), int(fx["train_seed"]), *args, dropout=0.0).train().cuda()
+    mt.fusion.gate_net[2].p = 0.0
+    out = mt(*[x.cuda() for x in xs])
+    out.backward(seeded_randn(int(fx["gy_seed"]), 4, 2).cuda())
+    params = dict(mt.named_parameters())
+    bad = []
+    for n, gn in zip((str(v) for v in fx["t_gnames"]), fx["t_gnorms"]):
+        if gn < 1e-4:
+            continue
+        g = params[n].grad
+        assert g is not None, n
+        e = abs(g.double().norm().item() - gn) / gn
+        if e > 6e-2:
+            bad.append((n, e))
+    assert not bad, bad

@@ -177,3 +177,28 @@ def test_extension_restatements_match_torch_leaf_ops():
     assert abs(loss.item() - want.item()) < 1e-6
     p = RF.stft_power(seeded_randn(134, 2, 3, 256), 64, 32)
     assert p.shape == (2, 3 * 33, 9) and bool((p >= 0).all())
+
+
+@pytest.mark.parametrize("tag,name,n_in", [("trimodal_v4", "EnhancedTriModalFusionNetV4", 3),
+                                            ("smart_v4", "EnhancedSmartFusionNetV4", 2)])
+def test_f1_full_v4_classifiers(golden, tag, name, n_in):
+    """the oracle's restatement of the full V4 classifiers against the reference's own
+    outputs (eval) and gradient norms (train, dropout 0)."""
+    fx = golden(f"f1_{tag}.npz")
+    args = (8, 8, 36) if n_in == 3 else (8, 8)
+    m = build(getattr(C, name), int(fx["seed"]), *args).eval()
+    _chk(m, fx)
+    s = [int(v) for v in fx["x_seeds"]]
+    xs = [seeded_randn(s[0], 4, 8, 256), seeded_randn(s[1], 4, 8, 256)] + ([seeded_randn(s[2], 4, 36)] if n_in == 3 else [])
+    fn = RF.trimodal_v4 if n_in == 3 else RF.smart_fusion_v4
+    with torch.no_grad():
+        logits, weights, fused = fn(m.state_dict(), *xs)
+    _eq(logits, fx["logits"], 5e-6); _eq(weights, fx["weights"], 5e-6); _eq(fused, fx["fused"], 5e-6)
+    mt = build(getattr(C, name), int(fx["train_seed"]), *args, dropout=0.0).train()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in mt.state_dict().items()}
+    fn(sd, *xs, train=True)[0].backward(seeded_randn(int(fx["gy_seed"]), 4, 2))
+    for n, gn in zip((str(v) for v in fx["t_gnames"]), fx["t_gnorms"]):
+        if gn < 1e-4:          # biases in front of a train-mode BatchNorm: true gradient 0, rounding noise only
+            continue
+        got = sd[n].grad.double().norm().item()
+        assert abs(got - gn) <= 1e-4 * gn, (n, got, gn)
