@@ -139,6 +139,79 @@ def train_bridge_epoch(model, loader, optimizer, criterion, device, grad_clip=1.
     return total / max(n, 1)
 
 
+class ImprovedTriModalFusionNet(nn.Module):
+    """checkpoint wrapper of the bridge pipeline (_test_bridge.py:118-151): state_dict keys carry the
+    ``model.`` prefix of ``best_trimodal_fold*.pt``; ``return_feats`` -> dict(logits, gates, fused_feats)."""
+
+    def __init__(self, in_pw_dim, in_erp_dim, in_conn_dim, fusion_dim=128, num_classes=2, dropout=0.3,
+                 num_transformer_layers=2, num_heads=4):
+        super().__init__()
+        from .crossmodal_v4_enhancements import EnhancedTriModalFusionNetV4
+        self.model = EnhancedTriModalFusionNetV4(erp_channels=in_erp_dim, pw_channels=in_pw_dim,
+                                                 conn_features=in_conn_dim, hidden_dim=fusion_dim,
+                                                 num_classes=num_classes, dropout=dropout,
+                                                 num_transformer_layers=num_transformer_layers, num_heads=num_heads)
+        self.fusion_weight_history = []
+
+    def forward(self, erp, pw, conn, return_feats=False):
+        if return_feats:
+            logits, gates, fused = self.model(erp, pw, conn, return_fusion_weights=True, return_fused_feats=True)
+            return {"logits": logits, "gates": gates, "fused_feats": fused}
+        return self.model(erp, pw, conn)
+
+
+@torch.no_grad()
+def extract_eeg_features(model, raw_dataset, device, batch_size: int = 64):
+    """{subject: mean fused feature over the subject's EEG samples} from a frozen tri-modal model.
+
+    Same contract as the reference's extract_eeg_features (_test_bridge.py:560-585) - items are
+    ``(eeg_samples, _, _, label, subject)`` with ``eeg_samples`` a list of (erp, pw, conn) arrays - but
+    the samples of ALL subjects run through the GPU in batches of ``batch_size`` instead of one
+    forward per sample; the per-subject mean is a segment mean over the batch outputs."""
+    model.eval()
+    erps, pws, conns, owner, subjects = [], [], [], [], []
+    for idx in range(len(raw_dataset)):
+        eeg_samples, _, _, _, subj = raw_dataset[idx]
+        if not len(eeg_samples):
+            continue
+        subjects.append(subj)
+        for erp_np, pw_np, conn_np in eeg_samples:
+            erps.append(torch.as_tensor(erp_np, dtype=torch.float32))
+            pws.append(torch.as_tensor(pw_np, dtype=torch.float32))
+            conns.append(torch.as_tensor(conn_np, dtype=torch.float32).reshape(-1))
+            owner.append(len(subjects) - 1)
+    if not erps:
+        return {}
+    feats = []
+    for i in range(0, len(erps), batch_size):
+        sl = slice(i, i + batch_size)
+        out = model(erp=torch.stack(erps[sl]).to(device), pw=torch.stack(pws[sl]).to(device),
+                    conn=torch.stack(conns[sl]).to(device), return_feats=True)
+        feats.append(out["fused_feats"].float().cpu())
+    feats = torch.cat(feats, dim=0)
+    own = torch.tensor(owner)
+    sums = torch.zeros(len(subjects), feats.shape[1]).index_add_(0, own, feats)
+    counts = torch.bincount(own, minlength=len(subjects)).clamp_min(1).unsqueeze(1)
+    means = sums / counts
+    return {s: means[i] for i, s in enumerate(subjects)}
+
+
+@torch.no_grad()
+def extract_fmri_features(model, fmri_act, fmri_conn, subject_list, device, batch_size: int = 256):
+    """{subject: fused feature} from a frozen fMRIFusionNet (_test_bridge.py:588-603), batched."""
+    model.eval()
+    subs = [s for s in subject_list if s in fmri_act and s in fmri_conn]
+    features = {}
+    for i in range(0, len(subs), batch_size):
+        chunk = subs[i:i + batch_size]
+        act = torch.stack([fmri_act[s].float() for s in chunk]).to(device)
+        conn = torch.stack([fmri_conn[s].float() for s in chunk]).to(device)
+        _, fused = model(act, conn, return_features=True)
+        fused = fused.float().cpu()
+        features.update({s: fused[j] for j, s in enumerate(chunk)})
+    return features
+
+
 def collate_bridge(batch):
     """(``_test_bridge.py:755-760``) stack features, long labels, subject list."""
     eeg = torch.stack([b[0] for b in batch])

@@ -466,3 +466,34 @@ def test_f1_full_v4_classifiers_vs_reference_golden(golden, tag, name, n_in):
         if e > 6e-2:
             bad.append((n, e))
     assert not bad, bad
+
+
+def test_f2_batched_frozen_feature_extraction_matches_per_sample_loop():
+    """extract_eeg_features / extract_fmri_features run every subject's samples in GPU
+    batches; the result must equal the reference's one-forward-per-sample loop (same kernels, eval-mode
+    BatchNorm: rows are independent) and feed BridgeFeatureDataset."""
+    import multimodal_eeg_fmri_amd.fmri_utils as Fm2
+    torch.manual_seed(3)
+    eeg_model = Bu.ImprovedTriModalFusionNet(8, 8, 36, fusion_dim=128).cuda().eval()
+    assert next(iter(eeg_model.state_dict())).startswith("model.")           # checkpoint key prefix
+    g = torch.Generator().manual_seed(4)
+    raw = []
+    for subj, n in ((11, 3), (12, 1), (15, 4)):
+        samples = [(torch.randn(8, 256, generator=g).numpy(), torch.randn(8, 256, generator=g).numpy(),
+                    torch.randn(9, 4, generator=g).numpy()) for _ in range(n)]
+        raw.append((samples, None, None, subj % 2, subj))
+    got = Bu.extract_eeg_features(eeg_model, raw, "cuda", batch_size=5)
+    assert sorted(got) == [11, 12, 15]
+    with torch.no_grad():
+        for samples, _, _, _, subj in raw:
+            per = [eeg_model(erp=torch.tensor(e)[None].cuda(), pw=torch.tensor(p)[None].cuda(),
+                             conn=torch.tensor(c).reshape(1, -1).cuda(), return_feats=True)["fused_feats"].cpu()
+                   for e, p, c in samples]
+            torch.testing.assert_close(got[subj], torch.cat(per).mean(0), rtol=1e-4, atol=1e-4)
+    fm = Fm2.fMRIFusionNet(20, 30).cuda().eval()
+    act = {s: torch.randn(20, generator=g) for s in (11, 12, 13)}
+    conn = {s: torch.randn(30, generator=g) for s in (11, 12, 15)}
+    ff = Bu.extract_fmri_features(fm, act, conn, [11, 12, 13, 15], "cuda", batch_size=2)
+    assert sorted(ff) == [11, 12] and ff[11].shape == (64,)
+    ds = Bu.BridgeFeatureDataset(got, ff, {11: 1, 12: 0}, [11, 12, 13, 15])
+    assert len(ds) == 2 and ds[0][0].shape == (128,) and ds[0][1].shape == (64,)
