@@ -44,6 +44,7 @@ class BridgeTrainer(nn.Module):
         self._cap = None
         self._weight_list = None                      # recorded by the first manual step
         self.stamps = None                            # int64[16] device buffer when phase stamps are wanted
+        self.force_segments = False                   # rehearsal: run the N > 1 segmented step even at world 1
         import os
         # MM_ONE_STREAM=1 (diagnostic): run the fMRI branch on the main stream after the EEG branch
         self._one_stream = bool(os.environ.get("MM_ONE_STREAM"))
@@ -245,7 +246,7 @@ class BridgeTrainer(nn.Module):
         B = eeg.shape[0]
         N2 = 2 * self.head.bridge.bridge_dim
         c["scal"] = torch.zeros(4, device=dev)
-        if world == 1:
+        if world == 1 and not (self.force_segments and self.group is not None):
             def whole():
                 c["epoch"].add_(1)
                 z, saved = self._seg_forward(c["eeg"], c["fmri"])

@@ -102,3 +102,16 @@ def test_two_rank_data_parallel_step_on_one_gpu():
     for a, b in zip(r["losses"]["graph"], r["losses"]["manual"]):
         assert abs(a - b) <= 5e-3 * abs(b), r
     assert r["losses"]["graph"][-1] < r["losses"]["graph"][0], r
+
+
+def test_segmented_step_through_rccl_with_one_rank():
+    """a-X5: the N > 1 code path (4 hipGraph segments, the three collectives between them) through
+    the real backend ("nccl" == RCCL) at world size 1, in a child process: RCCL initialises, every
+    collective call of the multi-GPU bench is accepted, and the result equals the one-graph step."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_rehearsal.py"), "rccl1"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -62,7 +62,40 @@ def run(world=2, timeout=600):
     return res
 
 
+def run_rccl_world1():
+    """the N > 1 code path (4 graph segments + the three collectives) through the REAL backend
+    ("nccl" == RCCL) with a world of one rank: checks RCCL initialisation and every collective call
+    the multi-GPU bench makes, against the single-graph step on the same data."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+        eeg, fmri = synthetic_pairs(8, 16, 256, (16, 16, 16), seed=1234)
+        res = {}
+        for tag, group, force in (("one graph", None, False), ("segments + RCCL", dist.group.WORLD, True)):
+            torch.manual_seed(0)
+            tr = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-3, group=group).train()
+            tr.force_segments = force
+            ls = [tr.train_step(eeg, fmri)["loss"].item() for _ in range(6)]
+            torch.cuda.synchronize()
+            res[tag] = (ls, tr.bucket.p.detach().cpu().clone(), len(tr._cap["graphs"]))
+        a, b = res["one graph"], res["segments + RCCL"]
+        rel = ((a[1] - b[1]).norm() / a[1].norm()).item()
+        return {"graphs": (a[2], b[2]), "losses": (a[0], b[0]), "param_rel": rel}
+    finally:
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rccl1":
+        r = run_rccl_world1()
+        print(r)
+        assert r["graphs"] == (1, 4), r
+        assert r["param_rel"] < 1e-2, r
+        for x, y in zip(*r["losses"]):
+            assert abs(x - y) <= 5e-3 * abs(y), r
+        sys.exit(0)
     r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 2)
     print(r)
     assert r["same_params_across_ranks"]
