@@ -7,10 +7,14 @@
 //
 // One workgroup owns a TD x 8 x 8 block of output voxels (BM = 64*TD GEMM rows)
 // of one sample.  The (TD+2) x 10 x 10 input halo block is staged ONCE per Cin
-// chunk into LDS as rows of KC channels; every one of the 27 taps then reads
-// its A fragments from that block at a row offset kd*100 + kh*10 + kw, so the
-// im2col matrix only ever exists as LDS addresses.  The weight slice of one kd
-// plane (9 taps) sits beside it and is re-staged three times per chunk.
+// chunk into LDS as rows of KC channels (w-pitch 12 rows); every one of the 27
+// taps then reads its A fragments from that block at a row offset
+// kd*120 + kh*12 + kw, so the im2col matrix only ever exists as LDS addresses.
+// The weight slice of one kd plane (9 taps) sits beside it and is re-staged three
+// times per chunk.  GEMM row -> voxel is (h, w) = (lr >> 3, (lr & 3) + 4 *
+// parity(lr >> 2)) so that every ds_read_b128 lane group ({0-3,12-15,20-27}, ...)
+// reads a 4 x 4 voxel patch: 16 rows that are distinct mod 16 on the pitch of 12,
+// i.e. conflict-free with the 80-byte row stride (see the W-resident kernel below).
 #include "common.h"
 
 namespace {
@@ -18,12 +22,19 @@ namespace {
 constexpr int KC3 = 32;
 constexpr int KPAD3 = 8;
 constexpr int HB = 10;            // halo edge of an 8-wide tile
+constexpr int GWP = 12;           // halo w-pitch in LDS rows (generic kernel)
+constexpr int GDP = HB * GWP;     // halo d-pitch
+
+// GEMM row m (0..63 inside a depth slice) <-> voxel (h, w) of the 8 x 8 tile face
+__device__ __forceinline__ int row_h(int m) { return (m >> 3) & 7; }
+__device__ __forceinline__ int row_w(int m) { return (m & 3) + 4 * (__builtin_popcount((m >> 2) & 7) & 1); }
 
 struct Conv3dArgs {
     const bf16* x; const bf16* w;
     int B, D, H, W, Cin, Cout;
     const float* shift;           // [Cout] bias (nullptr = 0)
     int dbg;                      // ablation switches for tools/kbench.py (0 in production)
+    int kc;                       // generic kernel: channels per LDS chunk (32 or 64), set by launch3d
     float* stats;                 // [2][Cout] sum / sumsq of (acc + shift)   (nullptr)
     float* out_f32;               // [B][D][H][W][Cout]
     bf16* out_bf16;
@@ -46,11 +57,12 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
     const int d0 = (bid % td) * TD; bid /= td;
     const int b = bid;
     const int n0 = blockIdx.y * BN;
-    const int kc = a.Cin < KC3 ? a.Cin : KC3;
+    const int kc = a.kc;
     const int AS = kc + KPAD3;
-    constexpr int HROWS = (TD + 2) * HB * HB;
+    constexpr int HROWS = (TD + 2) * HB * HB;            // rows fetched
+    constexpr int LROWS = (TD + 2) * GDP;                 // rows of the LDS image
     bf16* As = reinterpret_cast<bf16*>(smem);
-    bf16* Ws = As + HROWS * AS;
+    bf16* Ws = As + LROWS * AS;
     const int segs = kc / 8;
 
     f32x16 acc[TM][TN];
@@ -66,34 +78,57 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = (wm * TM + i) * 32 + lr;
-        abase[i] = ((m >> 6) * HB + ((m >> 3) & 7)) * HB + (m & 7);
+        abase[i] = ((m >> 6) * HB + row_h(m)) * GWP + row_w(m);
     }
     const bf16* xb = a.x + (size_t)b * a.D * a.H * a.W * a.Cin;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int SB = 8;                                 // 16-byte chunks per thread per staging batch
 
     for (int c0 = 0; c0 < a.Cin; c0 += kc) {
-        for (int s = tid; s < HROWS * segs; s += 256) {
-            const int r = s / segs, sg = s - r * segs;
-            const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
-            const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                v = *reinterpret_cast<const uint4*>(xb + (((size_t)d * a.H + h) * a.W + w) * a.Cin + c0 + sg * 8);
-            *reinterpret_cast<uint4*>(As + r * AS + sg * 8) = v;
+        // staging in batches: all loads of a batch are in flight before its first LDS write
+        for (int s0 = 0; s0 < HROWS * segs; s0 += 256 * SB) {
+            u32x4 v[SB];
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int s = s0 + q * 256 + tid;
+                const int r = s / segs, sg = s - r * segs;
+                const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
+                const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+                v[q] = u32x4{0u, 0u, 0u, 0u};
+                if (s < HROWS * segs && d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
+                    v[q] = *reinterpret_cast<const u32x4*>(xb + (((size_t)d * a.H + h) * a.W + w) * a.Cin + c0 + sg * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const int s = s0 + q * 256 + tid;
+                const int r = s / segs, sg = s - r * segs;
+                if (s < HROWS * segs)
+                    *reinterpret_cast<u32x4*>(As + ((r / HB) * GWP + r % HB) * AS + sg * 8) = v[q];
+            }
         }
         for (int kd = 0; kd < 3; ++kd) {
             if (kd) __syncthreads();                       // previous plane's reads done
-            for (int s = tid; s < BN * 9 * segs; s += 256) {
-                const int r = s / segs, sg = s - r * segs; // r = n_local * 9 + t9
-                const int nl = r / 9, t9 = r - nl * 9;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (n0 + nl < a.Cout)
-                    v = *reinterpret_cast<const uint4*>(a.w + ((size_t)(n0 + nl) * 27 + kd * 9 + t9) * a.Cin + c0 + sg * 8);
-                *reinterpret_cast<uint4*>(Ws + r * AS + sg * 8) = v;
+            for (int s0 = 0; s0 < BN * 9 * segs; s0 += 256 * SB) {
+                u32x4 v[SB];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const int s = s0 + q * 256 + tid;
+                    const int r = s / segs, sg = s - r * segs; // r = n_local * 9 + t9
+                    const int nl = r / 9, t9 = r - nl * 9;
+                    v[q] = u32x4{0u, 0u, 0u, 0u};
+                    if (s < BN * 9 * segs && n0 + nl < a.Cout)
+                        v[q] = *reinterpret_cast<const u32x4*>(a.w + ((size_t)(n0 + nl) * 27 + kd * 9 + t9) * a.Cin + c0 + sg * 8);
+                }
+#pragma unroll
+                for (int q = 0; q < SB; ++q) {
+                    const int s = s0 + q * 256 + tid;
+                    if (s < BN * 9 * segs) *reinterpret_cast<u32x4*>(Ws + (s / segs) * AS + (s % segs) * 8) = v[q];
+                }
             }
             __syncthreads();
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
-                const int toff = kd * HB * HB + (t9 / 3) * HB + (t9 % 3);
+                const int toff = kd * GDP + (t9 / 3) * GWP + (t9 % 3);
                 for (int ks = 0; ks < kc; ks += 16) {
                     bf16x8 af[TM], bfr[TN];
 #pragma unroll
@@ -131,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int d = d0 + (m >> 6), h = h0 + ((m >> 3) & 7), w = w0 + (m & 7);
+                const int d = d0 + (m >> 6), h = h0 + row_h(m), w = w0 + row_w(m);
                 if (nok && d < a.D && h < a.H && w < a.W) {
                     const float v = acc[i][j][r] + sh;
                     s1 += v; s2 += v * v;
@@ -162,9 +197,13 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
 }
 
 template <int TD, int BN, int WM, int WN>
-int launch3d(const Conv3dArgs& a, hipStream_t st) {
+int launch3d(Conv3dArgs a, hipStream_t st) {
+    // channels per chunk stay at 32: 64-channel chunks halve the re-stagings but the bigger image
+    // costs residency (measured: L3 forward 30 -> 45 us, L2 data gradient 39 -> 78 us)
+    auto lds_for = [](int kc) { return (size_t)((TD + 2) * GDP + BN * 9) * (kc + KPAD3) * sizeof(bf16); };
     const int kc = a.Cin < KC3 ? a.Cin : KC3;
-    const size_t lds = (size_t)((TD + 2) * HB * HB + BN * 9) * (kc + KPAD3) * sizeof(bf16);
+    a.kc = kc;
+    const size_t lds = lds_for(kc);
     if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "conv3d_fwd: LDS %zu", lds);
     auto kern = conv3d_fwd_kernel<TD, BN, WM, WN>;
     if (lds > 64 * 1024)
@@ -834,7 +873,7 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
                   float* stats, float* out_f32, void* out_bf16, hipStream_t st) {
     MM_REQUIRE(x && w && (out_f32 || out_bf16) && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: null/invalid");
     MM_REQUIRE(Cin == 16 || Cin % 32 == 0, "conv3d_fwd: Cin=%d must be 16 or a multiple of 32", Cin);
-    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, g_dbg, stats, out_f32, (bf16*)out_bf16};
+    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, g_dbg, 0, stats, out_f32, (bf16*)out_bf16};
     const long tiles2 = (long)B * ceil_div(D, 2) * ceil_div(H, 8) * ceil_div(W, 8);
     const bool stamp_run = (g_dbg & 512) != 0;                       // out_bf16 is then the stamp buffer
     if (Cin == WR_CIN && Cout == WR_BN && out_f32 && (!out_bf16 || stamp_run) && tiles2 >= 512) return launch3d_wres(a, st);
