@@ -157,12 +157,29 @@ __global__ __launch_bounds__(256) void proj_heads_fwd_kernel(HeadsArgs a) {
     const int N = a.N, K = s.K;
     for (int k = tid; k < K; k += 256) xs[k] = s.x[(size_t)b * K + k];
     __syncthreads();
-    for (int n = wave; n < N; n += 4) {                      // one output per wave pass: W rows read coalesced
+    // T = 256 / N lanes share one output; each issues its float4 loads of the weight row back to
+    // back (a wave-per-output loop waits out one global-load round trip per output: 36 us at N = 128)
+    const int T = N <= 64 ? 4 : (N <= 128 ? 2 : 1);
+    {
+        const int n = tid / T, part = tid % T;
         float acc = 0.f;
-        for (int k = lane; k < K; k += 64) acc += s.W[(size_t)n * K + k] * xs[k];
-        acc = wave_sum(acc);
-        if (lane == 0) v[n] = acc + (s.bias ? s.bias[n] : 0.f);
+        if (n < N) {
+            const float* wr = s.W + (size_t)n * K;
+            if ((K & 3) == 0) {
+#pragma unroll 8
+                for (int k = part * 4; k < K; k += 4 * T) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+                    acc += w4.x * xs[k] + w4.y * xs[k + 1] + w4.z * xs[k + 2] + w4.w * xs[k + 3];
+                }
+            } else {
+                for (int k = part; k < K; k += T) acc += wr[k] * xs[k];
+            }
+        }
+        if (T >= 2) acc += __shfl_xor(acc, 1, 64);
+        if (T >= 4) acc += __shfl_xor(acc, 2, 64);
+        if (n < N && part == 0) v[n] = acc + (s.bias ? s.bias[n] : 0.f);
     }
+    (void)lane; (void)wave;
     __syncthreads();
     const bool on = tid < N;
     const float x1 = on ? v[tid] : 0.f;
