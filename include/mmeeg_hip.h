@@ -88,6 +88,9 @@ int mm_debug_stamp(void* buf, int idx, hipStream_t stream);
  * of {const float* w; void* w_fwd; void* w_dgrad /*nullable*/; int32 Cout, Cin, k, Cinp, Coutp, 0}
  * (48 bytes each), copied into the kernel arguments (capturable in a hipGraph) */
 int mm_prep_many(const void* desc_host, int ndesc, hipStream_t stream);
+/* mm_wgrad_scatter for ndesc workspaces in one launch per 64 descriptors; desc_host = HOST array of
+ * {const float* ws; float* dw; int32 Cout, Cin, taps, Cinp, nrep, 0} (40 bytes each) */
+int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t stream);
 /* ndesc independent replica reductions in one launch per 64 descriptors; desc_host =
  * HOST array of {const float* src; float* dst; int64 K, nrep, rep_stride} (40 bytes
  * each), copied into the kernel arguments (capturable in a hipGraph) */
@@ -111,7 +114,8 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
                   void* out_bf16, float* out_f32, int R, int S, int N, int act, int pool,
                   int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
                   const uint32_t* seed_epoch, hipStream_t stream);
-/* drop2 = the PositionalEncoding dropout applied AFTER the table add (:55) */
+/* drop2 = the PositionalEncoding dropout applied AFTER the table add (:55)  * mm_bn_act_bwd_apply: sums = [sums_nrep][2][N] as written by mm_bn_act_bwd_reduce (sums_nrep = 32:
+ * the kernel adds the replicas up itself) or an already compacted [2][N] (sums_nrep = 1). */
 int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16,
                          const float* dout_f32, float* sums_out, int R, int S, int N, int act,
                          int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p,
@@ -119,7 +123,7 @@ int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf1
 int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16,
                         const float* dout_f32, const float* sums, void* dy, float* dy_f32, int R,
                         int S, int N, int act, int pool, int drop_first, float drop_p, uint32_t seed,
-                        float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, int train, hipStream_t stream);
+                        float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t stream);
 
 /* ---- LayerNorm (nn.LayerNorm, enhanced_models_v4.py:80-81; bridge_utils.py:36,42,62) */
 int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16,

@@ -31,6 +31,15 @@ def _reduce_into(dst, src, K, stride, offset=0, nrep=REPL):
         _hip.call("mm_reduce_replicas", src.data_ptr() + 4 * offset, dst, K, nrep, stride)
 
 
+def _scatter_into(dw, ws, cout, cin, taps, cinp, nrep):
+    """dw[n][c][tap] += sum_rep ws[rep][n][tap][c]   (deferred to GradBag.flush when a bag is active)"""
+    bag = _BAG["cur"]
+    if bag is not None:
+        bag.defer_scatter(ws, dw, cout, cin, taps, cinp, nrep)
+    else:
+        _hip.call("mm_wgrad_scatter", ws, dw, cout, cin, taps, cinp, nrep)
+
+
 class deferred:
     """context: parameter-gradient replica reductions issued inside are collected
     in ``bag`` and executed as one mm_reduce_many launch on exit."""
@@ -67,10 +76,10 @@ def _compact(rep_buf, K):
     return out
 
 
-def _bn_param_grads(bag, bn, sums_c, N):
-    """sums_c = [sum dz (dbeta) | sum dz*xhat (dgamma)]"""
-    _reduce_into(bag.target(bn.bias), sums_c, N, N, 0, nrep=1)
-    _reduce_into(bag.target(bn.weight), sums_c, N, N, N, nrep=1)
+def _bn_param_grads(bag, bn, sums, N, nrep=1):
+    """sums = [nrep][sum dz (dbeta) | sum dz*xhat (dgamma)]"""
+    _reduce_into(bag.target(bn.bias), sums, N, 2 * N, 0, nrep=nrep)
+    _reduce_into(bag.target(bn.weight), sums, N, 2 * N, N, nrep=nrep)
 
 
 # ------------------------------------------------------------ gradient sinks
@@ -81,18 +90,28 @@ class GradBag:
     def __init__(self):
         self.fresh: Dict[int, torch.Tensor] = {}
         self.pending = []            # (src_ptr, dst_ptr, K, nrep, stride)
+        self.scatters = []           # (ws_ptr, dw_ptr, Cout, Cin, taps, Cinp, nrep)
         self._keep = []
 
     def defer(self, src_ptr: int, dst: torch.Tensor, K: int, nrep: int, stride: int, keep=None):
         self.pending.append((src_ptr, dst.data_ptr(), K, nrep, stride))
         self._keep.append((dst, keep))
 
+    def defer_scatter(self, ws: torch.Tensor, dw: torch.Tensor, cout, cin, taps, cinp, nrep):
+        self.scatters.append((ws.data_ptr(), dw.data_ptr(), cout, cin, taps, cinp, nrep))
+        self._keep.append((dw, ws))
+
     def flush(self, device):
+        import ctypes
+        import struct
+        if self.scatters:
+            raw = b"".join(struct.pack("<QQiiiiii", *d, 0) for d in self.scatters)
+            host = ctypes.create_string_buffer(raw, len(raw))
+            _hip.call("mm_scatter_many", ctypes.addressof(host), len(self.scatters))
+            self.scatters = []
         if not self.pending:
             return
-        import struct
         raw = b"".join(struct.pack("<QQqqq", *d) for d in self.pending)
-        import ctypes
         host = ctypes.create_string_buffer(raw, len(raw))      # descriptors travel as kernel arguments
         _hip.call("mm_reduce_many", ctypes.addressof(host), len(self.pending))
         self.pending = []
@@ -162,10 +181,11 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     args = (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]),
             float(d2[0]), int(d2[1]), ops.EP())
     _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
-    sc = _compact(sums, 2 * N)
     dy = _empty((B, T, N), _BF, y)
-    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sc, dy, None, *args, 1 if s.get("train", True) else 0)
-    _bn_param_grads(bag, bn, sc, N)
+    # the apply pass sums the 32 replicas itself (no compaction launch between the two passes)
+    _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sums, dy, None, *args,
+              1 if s.get("train", True) else 0, REPL)
+    _bn_param_grads(bag, bn, sums, N, nrep=REPL)
     k, pad = conv.kernel_size[0], conv.padding[0]
     cin = conv.in_channels
     dw = bag.target(conv.weight)
@@ -179,7 +199,7 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
             ws = _zeros((WREP, N, k, cinp_x), y)               # replicated, channel-contiguous atomics
             _hip.call("mm_conv1d_wgrad", dy, xb, ws, dbr, B, T, cinp_x, N, k, pad, cinp_x,
                       k * cinp_x, 1, cinp_x, WREP, N * k * cinp_x)
-            _hip.call("mm_wgrad_scatter", ws, dw, N, cin, k, cinp_x, WREP)
+            _scatter_into(dw, ws, N, cin, k, cinp_x, WREP)
         if db is not None:
             _reduce_into(db, dbr, N, N)
     if not need_dx:
@@ -403,7 +423,7 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
         args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
         sc = _compact(sums, 2 * N)
-        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sc, dy, None, *args, 1)
+        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sc, dy, None, *args, 1, 1)
     _bn_param_grads(bag, bn, sc, N)
     cin = conv.in_channels
     dw = bag.target(conv.weight)
@@ -414,7 +434,7 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
         ws = _zeros((WREP, N, 27, cinp_x), y)                  # replicated, channel-contiguous atomics
         _hip.call("mm_conv3d_wgrad", dy, xv, ws, dbr, B, D, H, W, cinp_x, N, cinp_x,
                   27 * cinp_x, 1, cinp_x, WREP, N * 27 * cinp_x)
-        _hip.call("mm_wgrad_scatter", ws, dw, N, cin, 27, cinp_x, WREP)
+        _scatter_into(dw, ws, N, cin, 27, cinp_x, WREP)
         if db is not None:
             _reduce_into(db, dbr, N, N)
     if not need_dx:

@@ -123,6 +123,7 @@ struct BnBwdArgs {
     uint32_t thresh, seed; float inv_keep, inv_count;
     uint32_t thresh2, seed2; float inv_keep2;
     const uint32_t* epoch;
+    int sums_nrep;               // apply: sums is [sums_nrep][2][N]; the block reduces the replicas itself
 };
 
 // computes dz for the (up to) two inputs of one pooled output element
@@ -166,12 +167,30 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     const size_t nrows = (size_t)a.R * So;
     float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     float scs[4], shs[4], mus[4], rss[4], c0[4], c1[4];
+    __shared__ float csum[APPLY ? 2048 : 1];           // sum dz | sum dz*xhat per channel (N <= 1024)
+    if (APPLY && a.train) {
+        // replica reduction in the prologue: a separate 5 us compaction launch sat between the two passes
+        for (int i = threadIdx.x; i < 2 * a.N; i += 256) {
+            float s = 0.f;
+            if (a.sums_nrep == MM_REPL) {              // all 32 loads in flight at once, not a dependent chain
+                float v[MM_REPL];
+#pragma unroll
+                for (int r = 0; r < MM_REPL; ++r) v[r] = a.sums[(size_t)r * 2 * a.N + i];
+#pragma unroll
+                for (int r = 0; r < MM_REPL; ++r) s += v[r];
+            } else {
+                for (int r = 0; r < a.sums_nrep; ++r) s += a.sums[(size_t)r * 2 * a.N + i];
+            }
+            csum[i] = s * a.inv_count;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         scs[q] = a.scale[n4 + q]; shs[q] = a.shift[n4 + q];
         mus[q] = a.mean ? a.mean[n4 + q] : 0.f; rss[q] = a.rstd ? a.rstd[n4 + q] : 1.f;
-        c0[q] = (APPLY && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;       // compact [2][N] sums
-        c1[q] = (APPLY && a.train) ? a.sums[a.N + n4 + q] * a.inv_count : 0.f;
+        c0[q] = (APPLY && a.train) ? csum[n4 + q] : 0.f;
+        c1[q] = (APPLY && a.train) ? csum[a.N + n4 + q] : 0.f;
     }
     if (active)
         for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
@@ -552,8 +571,9 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
 static int bn_bwd_common(bool apply, const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
                          const float* sums_in, float* sums_out, void* dy, float* dy_f32, int R, int S, int N, int act,
                          int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
-                         const uint32_t* seed_epoch, int train, hipStream_t st) {
+                         const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t st) {
     MM_REQUIRE(y && out4 && (dout_bf16 || dout_f32), "bn_act_bwd: null");
+    MM_REQUIRE(sums_nrep >= 1 && sums_nrep <= 64, "bn_act_bwd: sums_nrep");
     MM_REQUIRE(N % 4 == 0 && N <= 1024 && (N / 4) <= 256, "bn_act_bwd: N");
     BnBwdArgs a;
     a.y = y; a.scale = out4; a.shift = out4 + N; a.mean = out4 + 2 * N; a.rstd = out4 + 3 * N;
@@ -564,6 +584,7 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
     a.inv_count = 1.f / ((float)R * (float)S);
     a.thresh2 = thresh_of(drop2_p); a.seed2 = seed2; a.inv_keep2 = drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f;
     a.epoch = seed_epoch;
+    a.sums_nrep = sums_nrep;
     const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
     const size_t rows = (size_t)R * (S / pool);
     int grid = (int)((rows + rpb - 1) / rpb);
@@ -578,16 +599,16 @@ int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf1
                          uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(sums_out, "bn_act_bwd_reduce: null sums");
     return bn_bwd_common(false, y, out4, dout_bf16, dout_f32, nullptr, sums_out, nullptr, nullptr, R, S, N, act,
-                         pool, drop_first, drop_p, seed, drop2_p, seed2, seed_epoch, 1, st);
+                         pool, drop_first, drop_p, seed, drop2_p, seed2, seed_epoch, 1, 1, st);
 }
 
 int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
                         const float* sums, void* dy, float* dy_f32, int R, int S, int N, int act, int pool,
                         int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
-                        const uint32_t* seed_epoch, int train, hipStream_t st) {
+                        const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t st) {
     MM_REQUIRE((dy || dy_f32) && (!train || sums), "bn_act_bwd_apply: null");
     return bn_bwd_common(true, y, out4, dout_bf16, dout_f32, sums, nullptr, dy, dy_f32, R, S, N, act, pool,
-                         drop_first, drop_p, seed, drop2_p, seed2, seed_epoch, train, st);
+                         drop_first, drop_p, seed, drop2_p, seed2, seed_epoch, train, sums_nrep, st);
 }
 
 #define LN_DISPATCH(D, CALL)                                   \

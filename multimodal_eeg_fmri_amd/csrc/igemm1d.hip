@@ -470,6 +470,24 @@ __global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __rest
     }
 }
 
+// every conv weight-gradient workspace of a backward pass in one launch (blockIdx.y = tensor)
+struct ScatterDesc { const float* ws; float* dw; int Cout, Cin, taps, Cinp, nrep, pad_; };
+constexpr int SM_MAX = 64;
+struct ScatterTable { ScatterDesc d[SM_MAX]; };
+__global__ void scatter_many_kernel(ScatterTable tab) {
+    const ScatterDesc d = tab.d[blockIdx.y];
+    const size_t total = (size_t)d.Cout * d.Cin * d.taps;
+    const size_t rstride = (size_t)d.Cout * d.taps * d.Cinp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % d.taps);
+        const int c = (int)((i / d.taps) % d.Cin);
+        const int n = (int)(i / ((size_t)d.taps * d.Cin));
+        float s = 0.f;
+        for (int r = 0; r < d.nrep; ++r) s += d.ws[r * rstride + ((size_t)n * d.taps + tap) * d.Cinp + c];
+        d.dw[i] += s;
+    }
+}
+
 // dst[k] += sum_rep src[rep][k]
 // one replica per lane (32 lanes per output), one shuffle reduction: a single
 // load round trip instead of a 32-deep dependent chain
@@ -653,6 +671,23 @@ int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, in
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(grid), dim3(256), 0, st, ws, dw, Cout, Cin, taps, Cinp, nrep);
     return mm_check_launch("wgrad_scatter");
+}
+
+int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t st) {
+    MM_REQUIRE(desc_host && ndesc > 0, "scatter_many: bad args");
+    const ScatterDesc* src = (const ScatterDesc*)desc_host;
+    for (int base = 0; base < ndesc; base += SM_MAX) {
+        ScatterTable tab;
+        const int n = ndesc - base < SM_MAX ? ndesc - base : SM_MAX;
+        for (int i = 0; i < n; ++i) {
+            const ScatterDesc& d = src[base + i];
+            MM_REQUIRE(d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.Cinp >= d.Cin && d.nrep >= 1,
+                       "scatter_many: descriptor %d", base + i);
+            tab.d[i] = d;
+        }
+        hipLaunchKernelGGL(scatter_many_kernel, dim3(96, n), dim3(256), 0, st, tab);
+    }
+    return mm_check_launch("scatter_many");
 }
 
 }  // extern "C"

@@ -77,7 +77,7 @@ class BNRowsActFn(torch.autograd.Function):
         _hip.call("mm_bn_act_bwd_reduce", x, out4, None, dy, sums, *args)
         sc = _compact(sums, 2 * N)
         dx = _empty((B, N), _F32, x)
-        _hip.call("mm_bn_act_bwd_apply", x, out4, None, dy, sc, None, dx, *args, 1)
+        _hip.call("mm_bn_act_bwd_apply", x, out4, None, dy, sc, None, dx, *args, 1, 1)
         bag = GradBag()
         gg, gb = bag.target(bn.weight), bag.target(bn.bias)
         if gb is not None:

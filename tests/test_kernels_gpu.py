@@ -221,8 +221,11 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     torch.testing.assert_close(sums.sum(0)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(sums.sum(0)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums.sum(0).contiguous(), dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1)
+    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums.sum(0).contiguous(), dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
+    dy2 = torch.empty_like(dy)                      # same, the kernel summing the 32 replicas itself
+    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy2, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1, 32)
+    torch.testing.assert_close(dy2.float(), dy.float(), rtol=1e-2, atol=1e-3)
 
 
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
