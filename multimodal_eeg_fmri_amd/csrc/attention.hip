@@ -39,6 +39,14 @@ __device__ __forceinline__ float attn_keep(uint32_t seed, int bh, int q, int key
     return x >= thresh ? inv_keep : 0.f;
 }
 
+// v_exp_f32 as is: arguments are <= 0 here and a result below 2^-126 may flush to zero (softmax
+// weights); exp2f() wraps the instruction in a compare / two selects / add / ldexp for denormal
+// results, i.e. 6 extra VALU instructions per score in loops that are VALU-bound.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// DROP: attention-probability dropout compiled in (no per-score branch); FULL: L is a multiple of
+// the key and query chunk sizes, so no score needs a validity mask (3 VALU instructions each)
+template <bool DROP, bool FULL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int L, int H, float scale_log2,
                                                        uint32_t dthresh, uint32_t dseed, float dinv,
@@ -111,19 +119,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                sacc[r] = key < kn ? sacc[r] * scale_log2 : -INFINITY;
+                sacc[r] = (FULL || key < kn) ? sacc[r] * scale_log2 : -INFINITY;
                 mx = fmaxf(mx, sacc[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f(m_run - m_new);      // m_run = -inf first time -> 0
+            const float alpha = fast_exp2(m_run - m_new);  // m_run = -inf first time -> 0
             float ps = 0.f;
             bf16x8 pf[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = exp2f(sacc[r] - m_new);
+                float p = fast_exp2(sacc[r] - m_new);
                 ps += p;
-                if (dthresh) p *= attn_keep(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv);
+                if (DROP) p *= attn_keep(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv);
                 pf[r >> 3][r & 7] = (bf16)p;
             }
             l_run = l_run * alpha + ps;
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 // In both, the first product is oriented so that its accumulator tile is the
 // B operand of the following products (rows = reduction index).
 // ---------------------------------------------------------------------------
+template <bool DROP, bool FULL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16* __restrict__ dqkv, float* __restrict__ delta,
@@ -247,9 +256,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float p = key < kn ? exp2f(sacc[r] * scale_log2 - lse2) : 0.f;
+                const float p = (FULL || key < kn) ? fast_exp2(sacc[r] * scale_log2 - lse2) : 0.f;
                 float dpr = dp[r];
-                if (dthresh) dpr *= attn_keep(dseed, b * H + h, q, k0 + key, L, dthresh, dinv);
+                if (DROP) dpr *= attn_keep(dseed, b * H + h, q, k0 + key, L, dthresh, dinv);
                 dsf[r >> 3][r & 7] = (bf16)(p * (dpr - dl));
             }
 #pragma unroll
@@ -272,6 +281,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 constexpr int QCH = 128;                 // queries staged per chunk in the dK/dV pass
 constexpr int QS = QCH + 8;              // transposed row stride
 
+template <bool DROP, bool FULL>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16* __restrict__ dqkv, int L, int H, float scale,
@@ -361,8 +371,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float p = kok ? exp2f(sacc[r] * scale_log2 - Ls[qi]) : 0.f;
-                const float keep = dthresh ? attn_keep(dseed, b * H + h, q0 + qi, key, L, dthresh, dinv) : 1.f;
+                const float p = (FULL || kok) ? fast_exp2(sacc[r] * scale_log2 - Ls[qi]) : 0.f;
+                const float keep = DROP ? attn_keep(dseed, b * H + h, q0 + qi, key, L, dthresh, dinv) : 1.f;
                 pf[r >> 3][r & 7] = (bf16)(p * keep);
                 dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] * keep - Dl[qi]));
             }
@@ -400,7 +410,10 @@ int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int
     MM_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0, "attn_fwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_fwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
+    const bool full = L % KCH == 0;
+    auto kern = drop_p > 0.f ? (full ? attn_fwd_kernel<true, true> : attn_fwd_kernel<true, false>)
+                             : (full ? attn_fwd_kernel<false, true> : attn_fwd_kernel<false, false>);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
                        scale * 1.4426950408889634f, attn_thresh(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
                        seed_epoch);
     return mm_check_launch("attn_fwd");
@@ -414,11 +427,16 @@ int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
     MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_bwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)out,
+    const bool full = L % KCH == 0 && L % QCH == 0;
+    auto kdq = dth ? (full ? attn_bwd_dq_kernel<true, true> : attn_bwd_dq_kernel<true, false>)
+                   : (full ? attn_bwd_dq_kernel<false, true> : attn_bwd_dq_kernel<false, false>);
+    auto kdkv = dth ? (full ? attn_bwd_dkv_kernel<true, true> : attn_bwd_dkv_kernel<true, false>)
+                    : (full ? attn_bwd_dkv_kernel<false, true> : attn_bwd_dkv_kernel<false, false>);
+    hipLaunchKernelGGL(kdq, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)out,
                        (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv, seed_epoch);
     int rc = mm_check_launch("attn_bwd_dq");
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
+    hipLaunchKernelGGL(kdkv, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
                        delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv, seed_epoch);
     return mm_check_launch("attn_bwd_dkv");
 }
