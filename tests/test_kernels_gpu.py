@@ -314,12 +314,13 @@ def test_pool3d_bn_act_train_fwd_bwd():
 
 
 
-def test_attention_dropout_is_consistent_between_fwd_and_bwd():
+@pytest.mark.parametrize("L", [64, 256])      # 256: the full-tile specialisation (L % 256 == 0) of all three kernels
+def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     """attention-probability dropout: forward equals softmax(S) * mask / keep @ V for the
     kernel's own hash mask, and backward differentiates exactly that function
     (checked with a finite-difference directional derivative in fp64 on the CPU)."""
     hip = _hip()
-    B, L, H, p, seed = 1, 64, 2, 0.3, 1234
+    B, H, p, seed = 1, 2, 0.3, 1234
     E = H * 32
     g = torch.Generator().manual_seed(3)
     qkv = _bf(torch.randn(B, L, 3 * E, generator=g) * 0.5)
