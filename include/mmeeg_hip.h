@@ -199,6 +199,16 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
                  const void* dout, const float* sums, float* stats, void* out, float* dw_tapmajor,
                  float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
                  const uint32_t* seed_epoch, hipStream_t stream);
+/* Training backward of the same layer in ONE recompute pass (replaces modes 2 + 3): BatchNorm's
+ * backward is linear in the two sums S1 = sum dz, S2 = sum dz * xhat, so
+ *   dW = scale * (A1 - (S1/M) * T - (S2/M) * A3),  A1 = x^T dz, A3 = x^T xhat, T[tap] = sum_v x[v + tap].
+ * Zeroed fp32 workspaces (32 replicas each): sums_out [32][2][32] (also the BatchNorm parameter
+ * gradients: dbeta = S1, dgamma = S2), a1 / a3 [32][27][32], tapsum [32][32].  dw (PyTorch layout
+ * [32][1][3][3][3]) and dbias are ADDED to (dbias only when train == 0; it is identically 0 otherwise). */
+int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
+                     float* sums_out, float* a1, float* a3, float* tapsum, float* dw, float* dbias, int B, int D,
+                     int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                     hipStream_t stream);
 /* dst[c][r] += sum_rep src[rep][r][c] */
 int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t stream);
 

@@ -450,21 +450,19 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
     """backward of ops.conv3d_l1_bn_act (no input gradient: the volume is data)."""
     conv, bn, x = s["conv"], s["bn"], s["x"]
     B, _, D, H, W = x.shape
+    # one recompute pass: S1/S2, A1 = x^T dz, A3 = x^T xhat; BatchNorm's backward is linear in S1, S2
     sums = _zeros((REPL, 2, 32), x)
-    _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
-              B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
-    ws = _zeros((REPL, 27, 32), x)
-    db = bag.target(conv.bias)
-    dbr = _zeros((REPL, 32), x) if db is not None else None
-    sc = _compact(sums, 64)
-    _hip.call("mm_conv3d_l1", 3, x, s["wimg"], conv.bias, s["out4"], dout, sc, None, None, ws,
-              dbr, B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
-    _bn_param_grads(bag, bn, sc, 32)
-    if db is not None:
-        _reduce_into(db, dbr, 32, 32)
+    a1 = _zeros((REPL, 27, 32), x)
+    a3 = _zeros((REPL, 27, 32), x)
+    tapsum = _zeros((REPL, 32), x)
     dw = bag.target(conv.weight)
-    if dw is not None:
-        _hip.call("mm_transpose_add", ws, dw, 27, 32, REPL)
+    if dw is None:                                   # frozen conv weight: the sums alone (BatchNorm gradients)
+        _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
+                  B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
+    else:
+        _hip.call("mm_conv3d_l1_bwd", x, s["wimg"], conv.bias, s["out4"], dout, sums, a1, a3, tapsum, dw,
+                  bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
+    _bn_param_grads(bag, bn, sums, 32, nrep=REPL)
 
 
 def volume_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor):

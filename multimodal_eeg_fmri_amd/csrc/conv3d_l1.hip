@@ -11,6 +11,12 @@
 //   mode 3  bwd apply    : dy = BN'(dz) for every voxel, dW[tap][n] += x^T dy,
 //                          dbias += sum dy     (second MFMA: the dy accumulator
 //                          tile is the B operand, the im2col gather the A operand)
+//   mode 4  bwd, one pass: BN' is linear in the two sums of mode 2, so the weight gradient is
+//                          dW = sc (A1 - c0 S - c1 A3) with A1 = x^T dz, A3 = x^T xhat,
+//                          S[tap] = sum_v x[v + tap] (l1_tapsum_kernel), c0 = S1/M, c1 = S2/M.
+//                          One recompute of the convolution yields S1, S2, A1 and A3 (the two
+//                          products share their gathered A fragments); l1_combine_kernel finishes.
+//                          Replaces modes 2 + 3 (two recomputes) in training.
 // One wave owns a 2 x 8 x 8 block of conv outputs (= 1 x 4 x 4 pooled voxels) x
 // 32 channels: all 8 members of every pooling window sit in the same lane.
 // GELU is evaluated once per window when max(z) >= 0 (GELU is monotone on
@@ -33,7 +39,8 @@ struct L1Args {
     const float* sums;     // [2][32]                           (mode 3)
     float* stats;          // mode 0: [2][32];  mode 2: sums_out
     bf16* out;             // mode 1
-    float* dw;             // mode 3: [27][32] (tap-major, channel-contiguous atomics)
+    float* dw;             // mode 3: [27][32] (tap-major, channel-contiguous atomics); mode 4: A1
+    float* dw3;            // mode 4: A3, same layout
     float* dbias;          // mode 3
     int B, D, H, W, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
@@ -74,10 +81,10 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
         sc = a.out4[lr]; sh = a.out4[32 + lr]; mu = a.out4[64 + lr]; rs = a.out4[96 + lr];
         if (MODE == 3 && a.train) { c0 = a.sums[lr] * a.inv_count; c1 = a.sums[32 + lr] * a.inv_count; }   // compact sums
     }
-    float acc1 = 0.f, acc2 = 0.f;          // per-lane channel sums (modes 0, 2) / dbias (mode 3)
-    f32x16 dwacc;                          // mode 3: D[tap][n]
+    float acc1 = 0.f, acc2 = 0.f;          // per-lane channel sums (modes 0, 2, 4) / dbias (mode 3)
+    f32x16 dwacc, dwacc3;                  // modes 3, 4: D[tap][n]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { dwacc[r] = 0.f; dwacc3[r] = 0.f; }
     const int my_tap_off = tap_off(lr);    // mode 3: A row = tap lr
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -131,7 +138,8 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
             continue;
         }
         // ---- pooled windows: (ip, ra, rb) -> regs {r0, r0+1, r0+4, r0+5} of tiles ip and ip+2
-        bf16x8 dyf[4][2];                                   // mode 3: dy fragments per tile / k-step
+        bf16x8 dyf[4][2];                                   // mode 3: dy fragments per tile / k-step (mode 4: dz)
+        bf16x8 xhf[4][2];                                   // mode 4: xhat fragments
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
@@ -176,10 +184,20 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
                         for (int j = 1; j < 8; ++j)
                             if (j == jmax) { zs = z[j]; ys = y[j]; }
                         const float dzs = g * gelu_erf_grad(zs);
-                        if (MODE == 2) {
+                        if (MODE == 2 || MODE == 4) {
                             acc1 += dzs;
                             acc2 += dzs * (ys - mu) * rs;
-                        } else {
+                        }
+                        if (MODE == 4) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                                const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
+                                const bool in = d < a.D && h < a.H && w < a.W;
+                                dyf[ti][r >> 3][r & 7] = (bf16)((in && j == jmax) ? dzs : 0.f);
+                                xhf[ti][r >> 3][r & 7] = (bf16)(in ? (y[j] - mu) * rs : 0.f);
+                            }
+                        } else if (MODE == 3) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
                         }
                     }
                 }
-        if (MODE == 3) {
+        if (MODE == 3 || MODE == 4) {
             // dW[tap][n] += sum_v xcol[tap][v] * dy[v][n]: A row = tap lr, k-th element of
             // half lh is voxel row 16 s + 8 (j >> 2) + 4 lh + (j & 3) of tile ti
 #pragma unroll
@@ -208,11 +226,12 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
                         fr.u[j] = halo[vb + my_tap_off];
                     }
                     dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, dyf[ti][s], dwacc, 0, 0, 0);
+                    if (MODE == 4) dwacc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, xhf[ti][s], dwacc3, 0, 0, 0);
                 }
         }
     }
     // ---------------------------------------------------------------- reductions
-    if (MODE == 0 || MODE == 2 || MODE == 3) {
+    if (MODE == 0 || MODE >= 2) {
         acc1 += __shfl_xor(acc1, 32, 64);
         acc2 += __shfl_xor(acc2, 32, 64);
         __syncthreads();
@@ -231,18 +250,72 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
             if (tid < 32) atomicAdd(&a.stats[rep * 64 + 32 + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
         }
     }
-    if (MODE == 3) {
-        for (int i = tid; i < 27 * 32; i += 256) (&wred[0][0])[i] = 0.f;
-        __syncthreads();
+    if (MODE == 3 || MODE == 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tap = (r & 3) + 8 * (r >> 2) + 4 * lh;      // D row
-            if (tap < 27) atomicAdd(&wred[tap][lr], dwacc[r]);
+        for (int pass = 0; pass < (MODE == 4 ? 2 : 1); ++pass) {
+            __syncthreads();
+            for (int i = tid; i < 27 * 32; i += 256) (&wred[0][0])[i] = 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tap = (r & 3) + 8 * (r >> 2) + 4 * lh;      // D row
+                if (tap < 27) atomicAdd(&wred[tap][lr], pass ? dwacc3[r] : dwacc[r]);
+            }
+            __syncthreads();
+            float* dwr = (pass ? a.dw3 : a.dw) + (size_t)(blockIdx.x % MM_REPL) * 27 * 32;
+            for (int i = tid; i < 27 * 32; i += 256) atomicAdd(&dwr[i], (&wred[0][0])[i]);
         }
-        __syncthreads();
-        float* dwr = a.dw + (size_t)(blockIdx.x % MM_REPL) * 27 * 32;
-        for (int i = tid; i < 27 * 32; i += 256) atomicAdd(&dwr[i], (&wred[0][0])[i]);
     }
+}
+
+// S[tap] = sum over output voxels v of x~[v + tap - 1] (zero padded, bf16-rounded as the conv sees it):
+// input voxel u feeds tap (kd, kh, kw) iff u - (k - 1) is inside the volume
+__global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict__ x, float* __restrict__ out /* [REPL][32] */,
+                                                        int B, int D, int H, int W) {
+    const size_t n = (size_t)B * D * H * W;
+    float s[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) s[t] = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H), d = (int)((i / ((size_t)W * H)) % D);
+        const float v = (float)(bf16)x[i];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int vd = d - t / 9 + 1, vh = h - (t / 3) % 3 + 1, vw = w - t % 3 + 1;
+            if (vd >= 0 && vd < D && vh >= 0 && vh < H && vw >= 0 && vw < W) s[t] += v;
+        }
+    }
+    __shared__ float red[32];
+    if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const float v = wave_sum(s[t]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[t], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) atomicAdd(&out[(blockIdx.x % MM_REPL) * 32 + threadIdx.x], red[threadIdx.x]);
+}
+
+// dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1   (all inputs replicated x MM_REPL)
+__global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __restrict__ a3, const float* __restrict__ tapsum,
+                                  const float* __restrict__ sums, const float* __restrict__ out4, float* __restrict__ dw,
+                                  float* __restrict__ dbias, float inv_count, int train) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 32 * 27) return;
+    const int n = i / 27, tap = i % 27;
+    float A1 = 0.f, A3 = 0.f, St = 0.f, s0 = 0.f, s1 = 0.f;
+    for (int r = 0; r < MM_REPL; ++r) {
+        A1 += a1[(size_t)r * 864 + tap * 32 + n];
+        A3 += a3[(size_t)r * 864 + tap * 32 + n];
+        St += tapsum[r * 32 + tap];
+        s0 += sums[r * 64 + n];
+        s1 += sums[r * 64 + 32 + n];
+    }
+    const float sc = out4[n];
+    const float c0 = train ? s0 * inv_count : 0.f, c1 = train ? s1 * inv_count : 0.f;
+    dw[i] += sc * (A1 - c0 * St - c1 * A3);
+    if (tap == 0 && dbias && !train) dbias[n] += sc * s0;      // train: sum dy == 0 identically
 }
 
 // dst[c][r] += sum_rep src[rep][r][c]
@@ -268,7 +341,7 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
                  hipStream_t st) {
     MM_REQUIRE(x && wimg && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1: null/invalid");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1: D,H,W must be even (MaxPool3d(2))");
-    MM_REQUIRE(mode >= 0 && mode <= 3, "conv3d_l1: mode");
+    MM_REQUIRE(mode >= 0 && mode <= 3, "conv3d_l1: mode");  /* mode 4 has its own entry point */
     MM_REQUIRE(mode == 0 ? stats != nullptr : out4 != nullptr, "conv3d_l1: stats/out4");
     MM_REQUIRE(mode != 1 || out, "conv3d_l1: out");
     MM_REQUIRE(mode < 2 || dout, "conv3d_l1: dout");
@@ -276,7 +349,7 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     MM_REQUIRE(mode != 3 || (dw_tapmajor && (!train || sums)), "conv3d_l1: dw/sums");
     L1Args a;
     a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = sums;
-    a.stats = stats; a.out = (bf16*)out; a.dw = dw_tapmajor; a.dbias = dbias;
+    a.stats = stats; a.out = (bf16*)out; a.dw = dw_tapmajor; a.dw3 = nullptr; a.dbias = dbias;
     a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
     a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)B * D * H * W);
@@ -290,6 +363,26 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
         default: hipLaunchKernelGGL(conv3d_l1_kernel<3>, dim3(grid), dim3(256), 0, st, a); break;
     }
     return mm_check_launch("conv3d_l1");
+}
+
+int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
+                     float* sums_out, float* a1, float* a3, float* tapsum, float* dw, float* dbias, int B, int D, int H,
+                     int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(x && wimg && out4 && dout && sums_out && a1 && a3 && tapsum && dw && B > 0, "conv3d_l1_bwd: null/invalid");
+    MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_bwd: D,H,W must be even (MaxPool3d(2))");
+    L1Args a;
+    a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = nullptr;
+    a.stats = sums_out; a.out = nullptr; a.dw = a1; a.dw3 = a3; a.dbias = nullptr;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
+    a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.inv_count = 1.f / ((float)B * D * H * W);
+    a.epoch = seed_epoch;
+    const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
+    hipLaunchKernelGGL(l1_tapsum_kernel, dim3(512), dim3(256), 0, st, x, tapsum, B, D, H, W);
+    hipLaunchKernelGGL(conv3d_l1_kernel<4>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
+                       dbias, a.inv_count, train);
+    return mm_check_launch("conv3d_l1_bwd");
 }
 
 int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t st) {

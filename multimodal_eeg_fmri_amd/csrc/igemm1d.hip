@@ -458,15 +458,15 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
 // dw[n][c][tap] += sum_rep ws[rep][n][tap][c]   (replicated contiguous-atomics workspace -> PyTorch layout)
 __global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps,
                                      int Cinp, int nrep) {
-    const size_t total = (size_t)Cout * Cin * taps;
     const size_t rstride = (size_t)Cout * taps * Cinp;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % taps);
-        const int c = (int)((i / taps) % Cin);
-        const int n = (int)(i / ((size_t)taps * Cin));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rstride; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cinp);
+        if (c >= Cin) continue;
+        const int tap = (int)((i / Cinp) % taps);
+        const int n = (int)(i / ((size_t)Cinp * taps));
         float s = 0.f;
-        for (int r = 0; r < nrep; ++r) s += ws[r * rstride + ((size_t)n * taps + tap) * Cinp + c];
-        dw[i] += s;
+        for (int r = 0; r < nrep; ++r) s += ws[r * rstride + i];       // coalesced along c
+        dw[((size_t)n * Cin + c) * taps + tap] += s;
     }
 }
 
@@ -476,15 +476,25 @@ constexpr int SM_MAX = 64;
 struct ScatterTable { ScatterDesc d[SM_MAX]; };
 __global__ void scatter_many_kernel(ScatterTable tab) {
     const ScatterDesc d = tab.d[blockIdx.y];
-    const size_t total = (size_t)d.Cout * d.Cin * d.taps;
+    // walk the workspace in ITS order (channel-contiguous: the nrep replica reads coalesce) and
+    // scatter one strided write per element, not nrep strided reads
     const size_t rstride = (size_t)d.Cout * d.taps * d.Cinp;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % d.taps);
-        const int c = (int)((i / d.taps) % d.Cin);
-        const int n = (int)(i / ((size_t)d.taps * d.Cin));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rstride; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d.Cinp);
+        if (c >= d.Cin) continue;
+        const int tap = (int)((i / d.Cinp) % d.taps);
+        const int n = (int)(i / ((size_t)d.Cinp * d.taps));
         float s = 0.f;
-        for (int r = 0; r < d.nrep; ++r) s += d.ws[r * rstride + ((size_t)n * d.taps + tap) * d.Cinp + c];
-        d.dw[i] += s;
+        if (d.nrep == 8) {                                  // independent loads, not an 8-deep latency chain
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = d.ws[r * rstride + i];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += v[r];
+        } else {
+            for (int r = 0; r < d.nrep; ++r) s += d.ws[r * rstride + i];
+        }
+        d.dw[((size_t)n * d.Cin + c) * d.taps + tap] += s;
     }
 }
 
@@ -685,7 +695,7 @@ int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t st) {
                        "scatter_many: descriptor %d", base + i);
             tab.d[i] = d;
         }
-        hipLaunchKernelGGL(scatter_many_kernel, dim3(96, n), dim3(256), 0, st, tab);
+        hipLaunchKernelGGL(scatter_many_kernel, dim3(256, n), dim3(256), 0, st, tab);
     }
     return mm_check_launch("scatter_many");
 }
