@@ -54,7 +54,7 @@ __device__ __forceinline__ int tap_off(int tap) {          // halo offset of tap
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
+__global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // two waves per SIMD: <= 256 registers
     a.seed = mm_eff_seed(a.seed, a.epoch);
     __shared__ __attribute__((aligned(16))) unsigned short halo[HSZ];
     __shared__ float red[4][32];
@@ -138,10 +138,13 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
             continue;
         }
         // ---- pooled windows: (ip, ra, rb) -> regs {r0, r0+1, r0+4, r0+5} of tiles ip and ip+2
-        bf16x8 dyf[4][2];                                   // mode 3: dy fragments per tile / k-step (mode 4: dz)
-        bf16x8 xhf[4][2];                                   // mode 4: xhat fragments
+        // dy (mode 3) / dz and xhat (mode 4) fragments of the two conv tiles ip, ip + 2 that one pass of
+        // the ip loop completes; their weight-gradient MFMAs run at the end of that pass, so only two
+        // tiles' fragments are ever live (all four: 316 VGPRs in mode 4 = one wave per SIMD)
+        bf16x8 dyf[2][2];
+        bf16x8 xhf[2][2];
 #pragma unroll
-        for (int ip = 0; ip < 2; ++ip)
+        for (int ip = 0; ip < 2; ++ip) {
 #pragma unroll
             for (int ra = 0; ra < 2; ++ra)
 #pragma unroll
@@ -194,8 +197,8 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
                                 const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
                                 const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
                                 const bool in = d < a.D && h < a.H && w < a.W;
-                                dyf[ti][r >> 3][r & 7] = (bf16)((in && j == jmax) ? dzs : 0.f);
-                                xhf[ti][r >> 3][r & 7] = (bf16)(in ? (y[j] - mu) * rs : 0.f);
+                                dyf[ti >> 1][r >> 3][r & 7] = (bf16)((in && j == jmax) ? dzs : 0.f);
+                                xhf[ti >> 1][r >> 3][r & 7] = (bf16)(in ? (y[j] - mu) * rs : 0.f);
                             }
                         } else if (MODE == 3) {
 #pragma unroll
@@ -206,28 +209,30 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
                                 const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
                                 if (!(d < a.D && h < a.H && w < a.W)) dy = 0.f;
                                 acc1 += dy;
-                                dyf[ti][r >> 3][r & 7] = (bf16)dy;
+                                dyf[ti >> 1][r >> 3][r & 7] = (bf16)dy;
                             }
                         }
                     }
                 }
-        if (MODE == 3 || MODE == 4) {
-            // dW[tap][n] += sum_v xcol[tap][v] * dy[v][n]: A row = tap lr, k-th element of
-            // half lh is voxel row 16 s + 8 (j >> 2) + 4 lh + (j & 3) of tile ti
+            if (MODE == 3 || MODE == 4) {
+                // dW[tap][n] += sum_v xcol[tap][v] * dy[v][n]: A row = tap lr, k-th element of
+                // half lh is voxel row 16 s + 8 (j >> 2) + 4 lh + (j & 3) of tile ti
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti)
+                for (int tq = 0; tq < 2; ++tq)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    union { unsigned short u[8]; bf16x8 v; } fr;
+                    for (int s = 0; s < 2; ++s) {
+                        const int ti = ip + 2 * tq;
+                        union { unsigned short u[8]; bf16x8 v; } fr;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int m = 32 * ti + 16 * s + 8 * (j >> 2) + 4 * lh + (j & 3);
-                        const int vb = ((m >> 6) * 10 + ((m >> 3) & 7)) * HP + (m & 7) + wbase;
-                        fr.u[j] = halo[vb + my_tap_off];
+                        for (int j = 0; j < 8; ++j) {
+                            const int m = 32 * ti + 16 * s + 8 * (j >> 2) + 4 * lh + (j & 3);
+                            const int vb = ((m >> 6) * 10 + ((m >> 3) & 7)) * HP + (m & 7) + wbase;
+                            fr.u[j] = halo[vb + my_tap_off];
+                        }
+                        dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, dyf[tq][s], dwacc, 0, 0, 0);
+                        if (MODE == 4) dwacc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, xhf[tq][s], dwacc3, 0, 0, 0);
                     }
-                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, dyf[ti][s], dwacc, 0, 0, 0);
-                    if (MODE == 4) dwacc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, xhf[ti][s], dwacc3, 0, 0, 0);
-                }
+            }
         }
     }
     // ---------------------------------------------------------------- reductions
@@ -269,20 +274,31 @@ __global__ __launch_bounds__(256) void conv3d_l1_kernel(L1Args a) {
 }
 
 // S[tap] = sum over output voxels v of x~[v + tap - 1] (zero padded, bf16-rounded as the conv sees it):
-// input voxel u feeds tap (kd, kh, kw) iff u - (k - 1) is inside the volume
+// input voxel u = (d, h, w) feeds tap (kd, kh, kw) iff u - (k - 1) is inside the volume, i.e. the
+// indicator factorises per axis.  One thread owns one (b, d, h) row: three row sums (all w, all but
+// the last, all but the first) and nine conditional adds of them - 27 adds per ROW, not per voxel.
 __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict__ x, float* __restrict__ out /* [REPL][32] */,
                                                         int B, int D, int H, int W) {
-    const size_t n = (size_t)B * D * H * W;
+    const size_t nrows = (size_t)B * D * H;
     float s[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) s[t] = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W), h = (int)((i / W) % H), d = (int)((i / ((size_t)W * H)) % D);
-        const float v = (float)(bf16)x[i];
+    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(row % H), d = (int)((row / H) % D);
+        const float* xr = x + row * W;
+        float all = 0.f;
+        for (int w = 0; w < W; ++w) all += (float)(bf16)xr[w];
+        const float rw[3] = {all - (float)(bf16)xr[W - 1], all, all - (float)(bf16)xr[0]};   // kw = 0, 1, 2
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const int vd = d - t / 9 + 1, vh = h - (t / 3) % 3 + 1, vw = w - t % 3 + 1;
-            if (vd >= 0 && vd < D && vh >= 0 && vh < H && vw >= 0 && vw < W) s[t] += v;
+        for (int kd = 0; kd < 3; ++kd) {
+            const bool okd = (kd == 0) ? d <= D - 2 : (kd == 2 ? d >= 1 : true);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const bool okh = (kh == 0) ? h <= H - 2 : (kh == 2 ? h >= 1 : true);
+                if (okd && okh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) s[(kd * 3 + kh) * 3 + kw] += rw[kw];
+            }
         }
     }
     __shared__ float red[32];
@@ -378,7 +394,8 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
     a.inv_count = 1.f / ((float)B * D * H * W);
     a.epoch = seed_epoch;
     const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
-    hipLaunchKernelGGL(l1_tapsum_kernel, dim3(512), dim3(256), 0, st, x, tapsum, B, D, H, W);
+    hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0, st,
+                       x, tapsum, B, D, H, W);
     hipLaunchKernelGGL(conv3d_l1_kernel<4>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
     hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
                        dbias, a.inv_count, train);
