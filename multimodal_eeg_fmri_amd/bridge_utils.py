@@ -212,6 +212,60 @@ def extract_fmri_features(model, fmri_act, fmri_conn, subject_list, device, batc
     return features
 
 
+def _one_hot_of(logits, target_class):
+    if target_class is None:
+        target_class = logits.argmax(dim=1)
+    return torch.zeros_like(logits).scatter_(1, target_class.view(-1, 1), 1.0), target_class
+
+
+class BridgeGradientSaliency:
+    """|d logit_target / d input| for both modalities (bridge_utils.py:158-183 of the reference):
+    eval-mode forward and backward run in the HIP kernels (ops.bridge_forward's differentiable form)."""
+
+    def __init__(self, model, device):
+        self.model, self.device = model, device
+
+    def compute(self, eeg_feats, fmri_feats, target_class=None):
+        self.model.eval()
+        eeg = eeg_feats.clone().detach().to(self.device).requires_grad_(True)
+        fmri = fmri_feats.clone().detach().to(self.device).requires_grad_(True)
+        logits = self.model(eeg, fmri)
+        one_hot, _ = _one_hot_of(logits.detach(), target_class if target_class is None else target_class.to(self.device))
+        self.model.zero_grad()
+        logits.backward(gradient=one_hot)
+        return {"eeg": eeg.grad.abs().cpu().numpy(), "fmri": fmri.grad.abs().cpu().numpy()}
+
+
+class BridgeIntegratedGradients:
+    """Integrated gradients from the zero baseline (reference :189-229).  The reference runs its
+    ``n_steps`` interpolation points one forward/backward at a time; here they are ONE batch of
+    ``n_steps * B`` rows through the same kernels (the bridge has no batch statistics, rows are
+    independent), i.e. one launch sequence instead of fifty."""
+
+    def __init__(self, model, device, n_steps=50):
+        self.model, self.device, self.n_steps = model, device, n_steps
+
+    def compute(self, eeg_feats, fmri_feats, target_class=None):
+        self.model.eval()
+        eeg = eeg_feats.detach().to(self.device).float()
+        fmri = fmri_feats.detach().to(self.device).float()
+        B = eeg.shape[0]
+        if target_class is None:                      # the reference fixes the class at alpha = 0 (its first step)
+            with torch.no_grad():
+                target_class = self.model(torch.zeros_like(eeg), torch.zeros_like(fmri)).argmax(dim=1)
+        target_class = target_class.to(self.device)
+        alphas = torch.linspace(0.0, 1.0, self.n_steps, device=self.device).view(-1, 1, 1)
+        e = (alphas * eeg.unsqueeze(0)).reshape(self.n_steps * B, -1).requires_grad_(True)
+        f = (alphas * fmri.unsqueeze(0)).reshape(self.n_steps * B, -1).requires_grad_(True)
+        logits = self.model(e, f)
+        one_hot, _ = _one_hot_of(logits.detach(), target_class.repeat(self.n_steps))
+        self.model.zero_grad()
+        logits.backward(gradient=one_hot)
+        ge = e.grad.view(self.n_steps, B, -1).mean(dim=0)
+        gf = f.grad.view(self.n_steps, B, -1).mean(dim=0)
+        return {"eeg": (eeg * ge).abs().cpu().numpy(), "fmri": (fmri * gf).abs().cpu().numpy()}
+
+
 def collate_bridge(batch):
     """(``_test_bridge.py:755-760``) stack features, long labels, subject list."""
     eeg = torch.stack([b[0] for b in batch])

@@ -671,12 +671,13 @@ def _eval_only(what: str, training: bool):
             "see DESIGN.md 'next'); call .eval() and torch.no_grad()")
 
 
-def learned_fusion(m, feats: List[torch.Tensor], training: bool):
-    """LearnedFusionModule.forward -> (fused (B, H), weights (B, M))."""
+def learned_fusion(m, feats: List[torch.Tensor], training: bool, autograd: bool = False):
+    """LearnedFusionModule.forward -> (fused (B, H), weights (B, M)).  ``autograd``: differentiable
+    composition even in eval mode (its gate dropout is then off)."""
     _need_gpu(*feats)
-    if training:
+    if training or autograd:
         from . import small_autograd as sa
-        g = sa.linear(torch.cat(list(feats), dim=1), m.gate_net[0], "gelu", m.gate_net[2].p)
+        g = sa.linear(torch.cat(list(feats), dim=1), m.gate_net[0], "gelu", m.gate_net[2].p if training else 0.0)
         dyn = sa.linear(g, m.gate_net[3])
         return sa.LearnedFusionFn.apply(dyn, m.fusion_logits, m.temperature, *feats)
     M = len(feats)
@@ -694,17 +695,21 @@ def learned_fusion(m, feats: List[torch.Tensor], training: bool):
 def bridge_forward(m, eeg, fmri):
     """EEGfMRIBridgeFusionNet.forward -> (logits, fused, fusion_w (B,2), attn_w (B,1,2))."""
     _need_gpu(eeg, fmri)
-    if m.training:
+    # eval mode with a backward to follow (gradient saliency / integrated gradients,
+    # bridge_utils.py:158-229): the autograd composition with every dropout off - the bridge has
+    # LayerNorms only, so that IS the eval forward
+    wants = torch.is_grad_enabled() and (eeg.requires_grad or fmri.requires_grad)
+    if m.training or wants:
         from . import small_autograd as sa
-        p = m.drop_p
+        p = m.drop_p if m.training else 0.0
         ca = m.cross_attn
         ep = sa.proj_head(eeg, m.eeg_proj, p)
         fp = sa.proj_head(fmri, m.fmri_proj, p)
         pe = sa.SmallLinearFn.apply(ep, ca.in_proj_weight, ca.in_proj_bias, "none", 0.0)
         pf = sa.SmallLinearFn.apply(fp, ca.in_proj_weight, ca.in_proj_bias, "none", 0.0)
-        ctx, attw = sa.Attn1x2Fn.apply(pe, pf, m.num_heads, float(ca.dropout))
+        ctx, attw = sa.Attn1x2Fn.apply(pe, pf, m.num_heads, float(ca.dropout) if m.training else 0.0)
         att = sa.linear(ctx, ca.out_proj)
-        fused, fw = learned_fusion(m.fusion, [att, fp], True)
+        fused, fw = learned_fusion(m.fusion, [att, fp], m.training, autograd=True)
         c = m.classifier
         h = sa.ActFn.apply(sa.LayerNormFn.apply(sa.linear(fused, c[0]), c[1].weight, c[1].bias, c[1].eps), "relu", p)
         return sa.linear(h, c[4]), fused, fw, attw.view(-1, 1, 2)

