@@ -94,15 +94,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
         const int d0 = (q % td) * 2; q /= td;
         const int b = q;
         __syncthreads();
-        for (int i = tid; i < HROWS1 * 34; i += 256) {
-            const int hw = i % 34, hr = i / 34;
-            const int hd = hr / 10, hh = hr % 10;
-            const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-            float v = 0.f;
-            if (d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                v = a.x[(((size_t)b * a.D + d) * a.H + h) * a.W + w];
-            const bf16 hv = (bf16)v;
-            halo[hr * HP + hw] = *reinterpret_cast<const unsigned short*>(&hv);
+        {   // all loads of the halo are in flight before the first LDS write (a load -> store loop
+            // pays one global round trip per pass: six per tile)
+            constexpr int NH = (HROWS1 * 34 + 255) / 256;
+            float hv[NH];
+#pragma unroll
+            for (int q = 0; q < NH; ++q) {
+                const int i = tid + q * 256;
+                const int hw = i % 34, hr = i / 34;
+                const int hd = hr / 10, hh = hr % 10;
+                const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+                hv[q] = 0.f;
+                if (i < HROWS1 * 34 && d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
+                    hv[q] = a.x[(((size_t)b * a.D + d) * a.H + h) * a.W + w];
+            }
+#pragma unroll
+            for (int q = 0; q < NH; ++q) {
+                const int i = tid + q * 256;
+                const bf16 hb = (bf16)hv[q];
+                if (i < HROWS1 * 34) halo[(i / 34) * HP + i % 34] = *reinterpret_cast<const unsigned short*>(&hb);
+            }
         }
         __syncthreads();
         const int wbase = 8 * wave;                         // this wave's w-block inside the tile

@@ -622,10 +622,12 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
     a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
     a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.pad = pad; a.Cin_real = Cin_real;
     a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride;
-    // aim for ~384 workgroups: split each batch item's T into chunks of whole 64-row tiles
+    // split each batch item's T into chunks of whole 64-row tiles
     const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
     const int tilesT = ceil_div(T, WG_MK);
-    int want_chunks = ceil_div(384, tiles * B);
+    // every workgroup ends with 64 x 64 x taps fp32 atomics: for the k > 1 convs few, long workgroups
+    // win (sweep on the three EEG convs: 32 / 30 / 20 us at 384 workgroups, 16 / 19 / 13 us at ~100)
+    int want_chunks = ceil_div(taps > 1 ? 112 : 384, tiles * B);
     if (want_chunks < 1) want_chunks = 1;
     if (want_chunks > tilesT) want_chunks = tilesT;
     a.rows_per_wg = ceil_div(tilesT, want_chunks) * WG_MK;
