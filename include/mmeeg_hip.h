@@ -318,12 +318,14 @@ int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t
  * = 8 + 1024 floats): [0] step count, [1] sum of squared grads of the last step, [2] lr,
  * [3] clip coefficient of the last step, [4] grad norm of the last step, [8..) per-block
  * partial sums written by mm_sumsq and added in a fixed order by mm_adamw_clip (no float
- * atomics: ranks holding the same all-reduced gradient stay bit-identical). */
+ * atomics: ranks holding the same all-reduced gradient stay bit-identical).
+ * zero_grad != 0: g is cleared after use (the next step's zero_grad()); seed_epoch (nullable): the
+ * device dropout-epoch word is incremented for the next step. */
 #define MM_OPT_STATE_FLOATS 1032
 int mm_sumsq(const float* g, float* state, int64_t n, hipStream_t stream);
-int mm_adamw_clip(float* p, const float* g, float* m, float* v, float* state, int64_t n, float beta1,
+int mm_adamw_clip(float* p, float* g, float* m, float* v, float* state, int64_t n, float beta1,
                   float beta2, float eps, float weight_decay, float max_norm, float grad_scale,
-                  hipStream_t stream);
+                  int zero_grad, uint32_t* seed_epoch, hipStream_t stream);
 
 #ifdef __cplusplus
 }

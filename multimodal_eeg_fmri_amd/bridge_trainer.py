@@ -43,6 +43,7 @@ class BridgeTrainer(nn.Module):
         self.mode = mode
         self._cap = None
         self._weight_list = None                      # recorded by the first manual step
+        self._arena_need = None                       # floats of scratch one step uses (None: clear all)
         self.stamps = None                            # int64[16] device buffer when phase stamps are wanted
         self.force_segments = False                   # rehearsal: run the N > 1 segmented step even at world 1
         import os
@@ -126,8 +127,9 @@ class BridgeTrainer(nn.Module):
 
     def _seg_forward(self, eeg, fmri):
         self._stamp(0)
-        ops.arena.begin(eeg.device)
-        self.bucket.g.zero_()
+        # one memset of what the step's accumulators actually use (high-water mark of the first
+        # step + slack); the gradient bucket is cleared by the previous step's AdamW kernel
+        ops.arena.begin(eeg.device, clear=self._arena_need)
         if self._weight_list is not None:
             ops.weights.prepare_all(self._weight_list)   # every bf16 weight image of the step, one launch
         self._stamp(1)
@@ -183,8 +185,10 @@ class BridgeTrainer(nn.Module):
         b = self.bucket
         _hip.call("mm_sumsq", b.g, b.state, b.n)
         _hip.call("mm_adamw_clip", b.p, b.g, b.m, b.v, b.state, b.n, self.betas[0], self.betas[1],
-                  self.eps, self.weight_decay, self.grad_clip, 1.0 / self.world)
+                  self.eps, self.weight_decay, self.grad_clip, 1.0 / self.world, 1, ops.EP())
         ops.weights_changed()
+        if self._arena_need is None:
+            self._arena_need = (ops.arena.high * 5 // 4 + 4095) // 4096 * 4096
         ops.arena.end()
         self._stamp(12)
 
@@ -248,7 +252,6 @@ class BridgeTrainer(nn.Module):
         c["scal"] = torch.zeros(4, device=dev)
         if world == 1 and not (self.force_segments and self.group is not None):
             def whole():
-                c["epoch"].add_(1)
                 z, saved = self._seg_forward(c["eeg"], c["fmri"])
                 c["dz_all"] = torch.empty_like(z)
                 self._seg_loss(z, z, c["scal"], c["dz_all"])
@@ -257,7 +260,6 @@ class BridgeTrainer(nn.Module):
             record(whole)
         else:
             def seg1():
-                c["epoch"].add_(1)
                 c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"])
             record(seg1)
             c["z_all"] = torch.empty(world * B, N2, device=dev)
@@ -288,6 +290,11 @@ class BridgeTrainer(nn.Module):
             dp.allreduce_sum_(self.bucket.g, self.group)
             g[3].replay()
         return {"loss": c["scal"][0], "top1_e2f": c["scal"][1], "top1_f2e": c["scal"][2]}
+
+    def input_buffers(self):
+        """the static (eeg, fmri) tensors the captured step reads, or None before the first graph step:
+        a loader that writes the next batch straight into them saves the two device copies per step"""
+        return None if self._cap is None else (self._cap["eeg"], self._cap["fmri"])
 
     @torch.no_grad()
     def evaluate(self, eeg, fmri):

@@ -366,9 +366,9 @@ __device__ inline float sumsq_total(const float* __restrict__ state) {
     return (tot[0] + tot[1]) + (tot[2] + tot[3]);
 }
 
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, const float* __restrict__ state, size_t n, float beta1,
-                             float beta2, float eps, float wd, float max_norm, float grad_scale) {
+                             float beta2, float eps, float wd, float max_norm, float grad_scale, int zero_grad) {
     const float step = state[0] + 1.f;
     const float lr = state[2];
     const float gn = sqrtf(sumsq_total(state)) * grad_scale;
@@ -383,12 +383,14 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         pi -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        if (zero_grad) g[i] = 0.f;                 // the next step's zero_grad(), for free
     }
 }
 
-__global__ void adamw_finish_kernel(float* __restrict__ state, float max_norm, float grad_scale) {
+__global__ void adamw_finish_kernel(float* __restrict__ state, float max_norm, float grad_scale, uint32_t* epoch) {
     const float ss = sumsq_total(state);
     if (threadIdx.x != 0) return;
+    if (epoch) epoch[0] += 1;                      // dropout epoch word of the NEXT step (hipGraph replays)
     const float gn = sqrtf(ss) * grad_scale;
     state[3] = (max_norm > 0.f) ? fminf(1.f, max_norm / (gn + 1e-6f)) : 1.f;
     state[4] = gn;
@@ -975,12 +977,13 @@ int mm_sumsq(const float* g, float* state, int64_t n, hipStream_t st) {
     return mm_check_launch("sumsq");
 }
 
-int mm_adamw_clip(float* p, const float* g, float* m, float* v, float* state, int64_t n, float beta1, float beta2,
-                  float eps, float weight_decay, float max_norm, float grad_scale, hipStream_t st) {
+int mm_adamw_clip(float* p, float* g, float* m, float* v, float* state, int64_t n, float beta1, float beta2,
+                  float eps, float weight_decay, float max_norm, float grad_scale, int zero_grad, uint32_t* seed_epoch,
+                  hipStream_t st) {
     MM_REQUIRE(p && g && m && v && state && n > 0, "adamw_clip: null");
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, p, g, m, v, state, (size_t)n, beta1,
-                       beta2, eps, weight_decay, max_norm, grad_scale);
-    hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(256), 0, st, state, max_norm, grad_scale);
+                       beta2, eps, weight_decay, max_norm, grad_scale, zero_grad);
+    hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(256), 0, st, state, max_norm, grad_scale, seed_epoch);
     return mm_check_launch("adamw_clip");
 }
 

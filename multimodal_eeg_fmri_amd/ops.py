@@ -59,11 +59,16 @@ class _Arena:
         self.buf = None
         self.off = 0
         self.active = False
+        self.cleared = 0
+        self.high = 0                     # largest offset any step has reached
 
-    def begin(self, device, nfloats: int = 6 << 20):
+    def begin(self, device, nfloats: int = 6 << 20, clear: Optional[int] = None):
+        """``clear``: zero only the first ``clear`` floats (a caller that knows its step's high-water
+        mark; slices beyond it fall back to torch.zeros)."""
         if self.buf is None or self.buf.device != device or self.buf.numel() < nfloats:
             self.buf = torch.empty(nfloats, dtype=_F32, device=device)
-        self.buf.zero_()
+        self.cleared = self.buf.numel() if clear is None else min(int(clear), self.buf.numel())
+        self.buf[:self.cleared].zero_()
         self.off = 0
         self.active = True
 
@@ -74,10 +79,11 @@ class _Arena:
         n = 1
         for d in shape:
             n *= int(d)
-        if not self.active or self.buf.device != device or self.off + n > self.buf.numel():
+        if not self.active or self.buf.device != device or self.off + n > self.cleared:
             return None
         out = self.buf[self.off:self.off + n].view(shape)
         self.off += (n + 63) // 64 * 64
+        self.high = max(self.high, self.off)
         return out
 
 

@@ -66,7 +66,7 @@ class FusedAdamW:
         b.state[2] = float(self.param_groups[0]["lr"])
         _hip.call("mm_sumsq", b.g, b.state, b.n)
         _hip.call("mm_adamw_clip", b.p, b.g, b.m, b.v, b.state, b.n, self.betas[0], self.betas[1],
-                  self.eps, self.weight_decay, float(self.max_grad_norm), 1.0)
+                  self.eps, self.weight_decay, float(self.max_grad_norm), 1.0, 0, None)
         ops.weights_changed()
 
     @property
