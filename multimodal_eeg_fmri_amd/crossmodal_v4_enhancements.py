@@ -7,7 +7,7 @@ BiDirectionalCrossAttention :403-466, EnhancedSmartFusionNetV4 :473-570, DropPat
 :665-677, EnhancedConnEncoder :684-739, HybridFusionModule :746-810,
 LiteERPEncoder/LitePowerEncoder :817-877, EnhancedTriModalFusionNetV4Lite
 :880-948, CosineAnnealingWarmup :1084-1112, EarlyStopping :1115-1143,
-get_lite_fusion_weights :1146-1152.  Leaf ``torch.nn`` modules are parameter
+get_lite_fusion_weights :1146-1152, BalancedTriModalDataset :955-1077.  Leaf ``torch.nn`` modules are parameter
 containers (identical ``state_dict``); arithmetic is in the HIP library.
 """
 from __future__ import annotations
@@ -186,6 +186,58 @@ class EnhancedSmartFusionNetV4(nn.Module):
     def forward(self, erp, pw, return_fusion_weights: bool = False, return_fused_feats: bool = False):
         logits, weights, fused = ops.smart_fusion_v4_forward(self, erp, pw)
         return _flagged(logits, weights, fused, return_fusion_weights, return_fused_feats)
+
+
+# ------------------------------------------------------------- data layer
+class BalancedTriModalDataset(torch.utils.data.Dataset):
+    """one (erp, pw, conn, label, subject) sample per subject present in all three modalities and in
+    ``label_dict`` (reference :955-1077).  Feature dicts are keyed by subject or by a tuple whose
+    first element is the subject; values are tensors / arrays or (feature, metadata) pairs.  Every
+    entry is flattened and the subject's entries are reduced with ``agg_method`` ('mean', 'max',
+    anything else = first entry)."""
+
+    def __init__(self, erp_features: dict, pw_features: dict, conn_features: dict, label_dict: dict,
+                 transform=None, agg_method: str = "mean"):
+        self.transform, self.agg_method = transform, agg_method
+        per_modality = [self._aggregate_by_subject(d, agg_method) for d in (erp_features, pw_features, conn_features)]
+        common = set(per_modality[0]) & set(per_modality[1]) & set(per_modality[2])
+        print(f"BalancedTriModalDataset: Found {len(common)} common subjects")
+        print("  ERP subjects: %d, PW subjects: %d, CONN subjects: %d" % tuple(len(m) for m in per_modality))
+        self.samples = [{"erp": per_modality[0][s], "pw": per_modality[1][s], "conn": per_modality[2][s],
+                         "label": label_dict[s], "subject": s}
+                        for s in sorted(common) if s in label_dict]
+        print(f"BalancedTriModalDataset: Created {len(self.samples)} balanced samples")
+
+    @staticmethod
+    def _subject_of(key):
+        return key[0] if isinstance(key, tuple) else key
+
+    def _extract_subjects(self, features_dict):
+        return {self._subject_of(k) for k in features_dict}
+
+    def _aggregate_by_subject(self, features_dict, method="mean"):
+        import numpy as np
+        rows = {}
+        for key, value in features_dict.items():
+            feat = value[0] if isinstance(value, tuple) else value
+            feat = feat.numpy() if isinstance(feat, torch.Tensor) else np.asarray(feat)
+            rows.setdefault(self._subject_of(key), []).append(feat.reshape(-1))
+        out = {}
+        for subj, feats in rows.items():
+            stacked = np.stack(feats, axis=0)
+            agg = stacked.mean(axis=0) if method == "mean" else stacked.max(axis=0) if method == "max" else stacked[0]
+            out[subj] = torch.tensor(agg, dtype=torch.float32)
+        return out
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, idx):
+        s = self.samples[idx]
+        erp, pw = s["erp"], s["pw"]
+        if self.transform:
+            erp, pw = self.transform(erp), self.transform(pw)
+        return erp, pw, s["conn"], s["label"], s["subject"]
 
 
 # ----------------------------------------------------------------- encoders

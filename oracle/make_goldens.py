@@ -261,6 +261,27 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"f1_{tag}.npz"), **fx)
     report.append("f1 V4 classifiers ok")
 
+    # --------------------------------------------- (f).3 BalancedTriModalDataset aggregation
+    def _feature_dicts():
+        erp = {(s_, b_): (seeded_randn(200 + 10 * s_ + b_, 4, 6), {"band": b_}) for s_ in (1, 2, 3, 5) for b_ in range(3)}
+        pw = {(s_, b_): seeded_randn(300 + 10 * s_ + b_, 4, 6).numpy() for s_ in (1, 2, 3, 4) for b_ in range(2)}
+        conn = {s_: seeded_randn(400 + s_, 5, 5) for s_ in (1, 2, 3, 5, 6)}
+        labels = {1: 0, 2: 1, 3: 1, 4: 0, 6: 1}
+        return erp, pw, conn, labels
+    fx = {}
+    for method in ("mean", "max", "first"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref_ds = cv4.BalancedTriModalDataset(*_feature_dicts(), agg_method=method)
+            our_ds = ours_c.BalancedTriModalDataset(*_feature_dicts(), agg_method=method)
+        assert len(ref_ds) == len(our_ds) == 3
+        for i in range(len(ref_ds)):
+            a, b = ref_ds[i], our_ds[i]
+            assert a[3:] == b[3:] and all(torch.equal(x, y) for x, y in zip(a[:3], b[:3])), (method, i)
+            fx[f"{method}_{i}_erp"], fx[f"{method}_{i}_pw"], fx[f"{method}_{i}_conn"] = _np(a[0]), _np(a[1]), _np(a[2])
+            fx[f"{method}_{i}_meta"] = np.array([a[3], a[4]])
+    np.savez_compressed(os.path.join(OUT, "f3_balanced_dataset.npz"), **fx)
+    report.append("f3 BalancedTriModalDataset ok")
+
     # ------------------------------------------------------------- (viii) a8
     logits, tgt = seeded_randn(125, 16, 2), (seeded_randn(126, 16) > 0).long()
     ls = cv4.LabelSmoothingCrossEntropy(0.1)(logits, tgt)

@@ -110,3 +110,29 @@ def test_lite_wrapper_and_collate_surface():
     assert R.vec_upper_triangle(m).tolist() == [1, 2, 3, 6, 7, 11]
     z = R.normalize_modality(np.array([1.0, 2.0, 3.0]))
     assert abs(z.mean()) < 1e-9
+
+
+def test_f3_balanced_trimodal_dataset_matches_reference_golden():
+    """per-subject aggregation of BalancedTriModalDataset (tuple keys, (feature, metadata)
+    values, numpy / tensor entries, mean / max / first) against the reference's own output."""
+    import contextlib, io
+    import numpy as np
+    from oracle.fixtures import seeded_randn
+    fx = np.load(os.path.join(GOLDEN, "f3_balanced_dataset.npz"))
+    erp = {(s, b): (seeded_randn(200 + 10 * s + b, 4, 6), {"band": b}) for s in (1, 2, 3, 5) for b in range(3)}
+    pw = {(s, b): seeded_randn(300 + 10 * s + b, 4, 6).numpy() for s in (1, 2, 3, 4) for b in range(2)}
+    conn = {s: seeded_randn(400 + s, 5, 5) for s in (1, 2, 3, 5, 6)}
+    labels = {1: 0, 2: 1, 3: 1, 4: 0, 6: 1}
+    for method in ("mean", "max", "first"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds = C.BalancedTriModalDataset(erp, pw, conn, labels, agg_method=method)
+        assert len(ds) == 3
+        for i in range(3):
+            e, p, c, lab, subj = ds[i]
+            np.testing.assert_array_equal(e.numpy(), fx[f"{method}_{i}_erp"])
+            np.testing.assert_array_equal(p.numpy(), fx[f"{method}_{i}_pw"])
+            np.testing.assert_array_equal(c.numpy(), fx[f"{method}_{i}_conn"])
+            assert [lab, subj] == list(fx[f"{method}_{i}_meta"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = C.BalancedTriModalDataset(erp, pw, conn, labels, transform=lambda t: t * 2)
+    assert torch.equal(ds[0][0], torch.as_tensor(fx["mean_0_erp"]) * 2) and torch.equal(ds[0][2], torch.as_tensor(fx["mean_0_conn"]))
