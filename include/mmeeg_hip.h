@@ -73,10 +73,17 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
                   const void* gradz, int gradz_act, hipStream_t stream);
 /* dW[n][c][tap] (fp32, strides sn/sc/stap in elements) += sum_{b,t} dY[b,t,n]*X[b,t+tap-pad,c];
  * optional dbias[n] += sum dY.  Replaces the weight/bias gradients autograd
- * derives for the layers above (loss.backward(), run_training_lite.py:486). */
+ * derives for the layers above (loss.backward(), run_training_lite.py:486).
+ * slot_mode = 0: fp32 atomics into replica (workgroup % nrep) of dw.
+ * slot_mode = 1: dw is a workspace of nrep >= mm_conv1d_wgrad_slots(...) slots of rep_stride floats;
+ * workgroup row-chunk x stores (no atomics, no zeroing needed) its partial dW into slot x; the caller
+ * sums the slots (mm_wgrad_scatter / mm_scatter_many with nrep = slots).  A launch's 10^6 same-tile
+ * atomics were the whole cost of the Linear weight gradients. */
 int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin,
                     int Cout, int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap,
-                    int nrep, int64_t rep_stride, hipStream_t stream);
+                    int nrep, int64_t rep_stride, int slot_mode, hipStream_t stream);
+/* *slots_host (HOST int) = number of slots a slot-mode launch with these dimensions writes */
+int mm_conv1d_wgrad_slots(int B, int T, int Cin, int Cout, int taps, int* slots_host, hipStream_t stream);
 /* dw[n][c][tap] += ws[n][tap][c]: conv weight gradients are accumulated by the
  * wgrad kernels in a channel-contiguous workspace (contiguous fp32 atomics run
  * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */

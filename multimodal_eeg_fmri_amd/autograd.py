@@ -40,6 +40,26 @@ def _scatter_into(dw, ws, cout, cin, taps, cinp, nrep):
         _hip.call("mm_wgrad_scatter", ws, dw, cout, cin, taps, cinp, nrep)
 
 
+_SLOTS = {}
+
+
+def _wgrad_slots(dy, x, dw, dbr, B, T, cinp, N, k, pad, cin):
+    """conv / linear weight gradient without atomics: every row-chunk workgroup stores its partial
+    dW[n][tap][c] into its own slot of a workspace; the (deferred, batched) scatter sums the slots
+    into the parameter layout."""
+    import ctypes
+    key = (B, T, cinp, N, k)
+    slots = _SLOTS.get(key)
+    if slots is None:
+        out = ctypes.c_int(0)
+        _hip.call("mm_conv1d_wgrad_slots", B, T, cinp, N, k, ctypes.addressof(out))
+        slots = _SLOTS[key] = int(out.value)
+    ws = _empty((slots, N, k, cinp), _F32, dy)                   # every element has exactly one writer: no memset
+    _hip.call("mm_conv1d_wgrad", dy, x, ws, dbr, B, T, cinp, N, k, pad, cinp, k * cinp, 1, cinp,
+              slots, N * k * cinp, 1)
+    _scatter_into(dw, ws, N, cin, k, cinp, slots)
+
+
 class deferred:
     """context: parameter-gradient replica reductions issued inside are collected
     in ``bag`` and executed as one mm_reduce_many launch on exit."""
@@ -153,7 +173,7 @@ def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *,
     db = bag.target(bias)
     dbr = _zeros((REPL, N), dy) if db is not None else None
     if dw is not None:
-        _hip.call("mm_conv1d_wgrad", dy, x, dw, dbr, 1, M, Kp, N, 1, 0, K, K, 1, 0, 1, 0)
+        _wgrad_slots(dy, x, dw, dbr, 1, M, Kp, N, 1, 0, K)
     elif db is not None:
         _hip.call("mm_colsum", dy, None, dbr, M, N)
     if db is not None:
@@ -193,13 +213,7 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
         cinp_x = xb.shape[2]
         db = bag.target(conv.bias)
         dbr = _zeros((REPL, N), y) if db is not None else None
-        if k == 1:
-            _hip.call("mm_conv1d_wgrad", dy, xb, dw, dbr, B, T, cinp_x, N, 1, 0, cin, cin, 1, 0, 1, 0)
-        else:
-            ws = _zeros((WREP, N, k, cinp_x), y)               # replicated, channel-contiguous atomics
-            _hip.call("mm_conv1d_wgrad", dy, xb, ws, dbr, B, T, cinp_x, N, k, pad, cinp_x,
-                      k * cinp_x, 1, cinp_x, WREP, N * k * cinp_x)
-            _scatter_into(dw, ws, N, cin, k, cinp_x, WREP)
+        _wgrad_slots(dy, xb, dw, dbr, B, T, cinp_x, N, k, pad, cin)
         if db is not None:
             _reduce_into(db, dbr, N, N)
     if not need_dx:

@@ -170,11 +170,13 @@ class BridgeTrainer(nn.Module):
             self._stamp(8)
             with torch.cuda.stream(self._side):
                 self._stamp(9)
-                volume_encoder_bwd(bag, sv_f, dff)
+                bag_f = GradBag()                    # the fMRI branch flushes its own reductions on ITS stream,
+                with deferred(bag_f, dz.device):     # hidden beside the rest of the EEG backward
+                    volume_encoder_bwd(bag_f, sv_f, dff)
                 self._stamp(10)
             main.wait_stream(self._side)
         self._stamp(11)
-        self._bags = getattr(self, "_bags", [])[-3:] + [bag]   # keep descriptor tables alive for graph replays
+        self._bags = getattr(self, "_bags", [])[-6:] + [bag, bag_f]   # keep descriptor tables alive for graph replays
 
     def _seg_optimizer(self):
         b = self.bucket

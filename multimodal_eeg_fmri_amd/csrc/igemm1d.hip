@@ -365,6 +365,7 @@ struct WgradArgs {
     const bf16* dy; const bf16* x; float* dw; float* dbias;
     int B, T, Cin, Cout, pad, Cin_real, rows_per_wg, nrep;
     long sn, sc, stap, rep_stride;
+    int slot_mode;            // 1: workgroup x stores its partial tile into slot blockIdx.x (no atomics)
 };
 
 template <int TAPS>
@@ -438,14 +439,18 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
     }
     // D[i = n][j = c]: lane owns column c, rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int c = c0 + wc * 32 + (lane & 31);
-    float* dwr = a.dw + (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
+    float* dwr = a.dw + (size_t)(a.slot_mode ? blockIdx.x : blockIdx.x % a.nrep) * a.rep_stride;
     if (c < a.Cin_real) {
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < a.Cout) atomicAdd(dwr + n * a.sn + c * a.sc + tp * a.stap, acc[tp][r]);
+                if (n < a.Cout) {
+                    float* o = dwr + n * a.sn + c * a.sc + tp * a.stap;
+                    if (a.slot_mode) *o = acc[tp][r];          // this (slot, tile) element has one writer
+                    else atomicAdd(o, acc[tp][r]);
+                }
             }
     }
     if (a.dbias && blockIdx.z == 0 && wc == 0) {
@@ -465,7 +470,15 @@ __global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __rest
         const int tap = (int)((i / Cinp) % taps);
         const int n = (int)(i / ((size_t)Cinp * taps));
         float s = 0.f;
-        for (int r = 0; r < nrep; ++r) s += ws[r * rstride + i];       // coalesced along c
+        int r = 0;
+        for (; r + 8 <= nrep; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ws[(r + q) * rstride + i];      // coalesced along c
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; r < nrep; ++r) s += ws[r * rstride + i];
         dw[((size_t)n * Cin + c) * taps + tap] += s;
     }
 }
@@ -485,15 +498,15 @@ __global__ void scatter_many_kernel(ScatterTable tab) {
         const int tap = (int)((i / d.Cinp) % d.taps);
         const int n = (int)(i / ((size_t)d.Cinp * d.taps));
         float s = 0.f;
-        if (d.nrep == 8) {                                  // independent loads, not an 8-deep latency chain
+        int r = 0;
+        for (; r + 8 <= d.nrep; r += 8) {                   // eight independent loads at a time, not a latency chain
             float v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = d.ws[r * rstride + i];
+            for (int q = 0; q < 8; ++q) v[q] = d.ws[(r + q) * rstride + i];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) s += v[r];
-        } else {
-            for (int r = 0; r < d.nrep; ++r) s += d.ws[r * rstride + i];
+            for (int q = 0; q < 8; ++q) s += v[q];
         }
+        for (; r < d.nrep; ++r) s += d.ws[r * rstride + i];
         d.dw[((size_t)n * d.Cin + c) * d.taps + tap] += s;
     }
 }
@@ -611,26 +624,38 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
 #undef MM_FWD
 }
 
+// rows of T per workgroup.  Atomic mode: every workgroup ends with 64 x 64 x taps fp32 atomics, so for
+// the k > 1 convs few, long workgroups win (sweep on the three EEG convs: 32 / 30 / 20 us at 384
+// workgroups, 16 / 19 / 13 us at ~100).  Slot mode has no atomics: parallelism alone decides.
+static int wgrad_rows_per_wg(int B, int T, int Cin, int Cout, int taps, int slot_mode) {
+    const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
+    const int tilesT = ceil_div(T, WG_MK);
+    int want_chunks = ceil_div((taps > 1 && !slot_mode) ? 112 : 384, tiles * B);
+    if (want_chunks < 1) want_chunks = 1;
+    if (want_chunks > tilesT) want_chunks = tilesT;
+    return ceil_div(tilesT, want_chunks) * WG_MK;
+}
+
+int mm_conv1d_wgrad_slots(int B, int T, int Cin, int Cout, int taps, int* slots_host, hipStream_t) {
+    MM_REQUIRE(slots_host && B > 0 && T > 0 && Cin > 0 && Cout > 0, "conv1d_wgrad_slots: bad args");
+    *slots_host = B * ceil_div(T, wgrad_rows_per_wg(B, T, Cin, Cout, taps, 1));
+    return 0;
+}
+
 int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin, int Cout,
                     int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep,
-                    int64_t rep_stride, hipStream_t st) {
+                    int64_t rep_stride, int slot_mode, hipStream_t st) {
     MM_REQUIRE(dy && x && dw && B > 0 && T > 0, "conv1d_wgrad: null/invalid");
-    MM_REQUIRE(nrep >= 1 && nrep <= 64, "conv1d_wgrad: nrep");
+    MM_REQUIRE(nrep >= 1 && (slot_mode || nrep <= 64), "conv1d_wgrad: nrep");
     MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "conv1d_wgrad: Cin=%d Cout=%d must be multiples of 8", Cin, Cout);
     MM_REQUIRE(Cin_real > 0 && Cin_real <= Cin, "conv1d_wgrad: Cin_real");
     WgradArgs a;
     a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
     a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.pad = pad; a.Cin_real = Cin_real;
-    a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride;
-    // split each batch item's T into chunks of whole 64-row tiles
-    const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
-    const int tilesT = ceil_div(T, WG_MK);
-    // every workgroup ends with 64 x 64 x taps fp32 atomics: for the k > 1 convs few, long workgroups
-    // win (sweep on the three EEG convs: 32 / 30 / 20 us at 384 workgroups, 16 / 19 / 13 us at ~100)
-    int want_chunks = ceil_div(taps > 1 ? 112 : 384, tiles * B);
-    if (want_chunks < 1) want_chunks = 1;
-    if (want_chunks > tilesT) want_chunks = tilesT;
-    a.rows_per_wg = ceil_div(tilesT, want_chunks) * WG_MK;
+    a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride; a.slot_mode = slot_mode;
+    a.rows_per_wg = wgrad_rows_per_wg(B, T, Cin, Cout, taps, slot_mode);
+    MM_REQUIRE(!slot_mode || nrep >= B * ceil_div(T, a.rows_per_wg),
+               "conv1d_wgrad: slot mode needs %d slots (mm_conv1d_wgrad_slots), got %d", B * ceil_div(T, a.rows_per_wg), nrep);
     switch (taps) {
         case 1: return launch_wgrad<1>(a, st);
         case 3: return launch_wgrad<3>(a, st);

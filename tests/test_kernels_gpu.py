@@ -132,10 +132,21 @@ def test_conv1d_wgrad_matches_autograd(B, C, T, Cout, k):
     dyg = dy.transpose(1, 2).contiguous().cuda().to(torch.bfloat16)
     dw = torch.zeros(2, Cout, C, k, device="cuda")
     db = torch.zeros(32, Cout, device="cuda")
-    hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1, 2, Cout * C * k)
+    hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1, 2, Cout * C * k, 0)
     dw, db = dw.sum(0), db.sum(0)
     torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
+    # slot mode: one slot per row-chunk workgroup, plain stores into UNINITIALISED memory, summed by the scatter
+    import ctypes
+    n = ctypes.c_int(0)
+    hip.call("mm_conv1d_wgrad_slots", B, T, cp, Cout, k, ctypes.addressof(n))
+    slots = n.value
+    assert slots >= 1
+    ws = torch.full((slots, Cout, k, cp), float("nan"), device="cuda")
+    hip.call("mm_conv1d_wgrad", dyg, xg, ws, None, B, T, cp, Cout, k, k // 2, cp, k * cp, 1, cp, slots, Cout * k * cp, 1)
+    dw2 = torch.zeros(Cout, C, k, device="cuda")
+    hip.call("mm_wgrad_scatter", ws, dw2, Cout, C, k, cp, slots)
+    torch.testing.assert_close(dw2.cpu(), w.grad, rtol=2e-3, atol=2e-2)
 
 
 def test_conv1d_dgrad_via_forward_kernel():

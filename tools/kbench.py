@@ -70,7 +70,7 @@ def conv1d_wgrad_case(B, T, Cin, Cout, k):
     db = torch.zeros(32, Cout, device="cuda")
 
     def fn():
-        _hip.call("mm_conv1d_wgrad", dy, x, ws, db, B, T, Cin, Cout, k, k // 2, Cin, k * Cin, 1, Cin, 8, Cout * k * Cin)
+        _hip.call("mm_conv1d_wgrad", dy, x, ws, db, B, T, Cin, Cout, k, k // 2, Cin, k * Cin, 1, Cin, 8, Cout * k * Cin, 0)
     us = timeit(fn)
     fl = 2.0 * B * T * Cin * Cout * k
     print(f"wgrad1d B={B} T={T} Cin={Cin} Cout={Cout} k={k}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
