@@ -179,7 +179,9 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
                   const float* shift, float* stats, float* out_f32, void* out_bf16, hipStream_t stream);
 int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W,
                     int Cin, int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep,
-                    int64_t rep_stride, hipStream_t stream);
+                    int64_t rep_stride, int slot_mode, hipStream_t stream);
+/* slot_mode as in mm_conv1d_wgrad; *slots_host (HOST int) = slots a slot-mode launch writes */
+int mm_conv3d_wgrad_slots(int B, int D, int H, int W, int Cin, int Cout, int* slots_host, hipStream_t stream);
 /* y fp32 [B][D][H][W][N] -> act(BN(y)) -> MaxPool3d(2) -> dropout -> bf16 [B][D/2][H/2][W/2][N].
  * Training also keeps, per pooled element, the winner's pre-BN value (ysel fp32) and its index in
  * the 2x2x2 window (arg, one byte: 4 d + 2 h + w); both null in eval.  The reduction of the

@@ -445,10 +445,17 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
         cinp_x = xv.shape[4]
         db = bag.target(conv.bias)
         dbr = _zeros((REPL, N), y) if db is not None else None
-        ws = _zeros((WREP, N, 27, cinp_x), y)                  # replicated, channel-contiguous atomics
+        import ctypes
+        key = ("3d", B, D, H, W, cinp_x, N)
+        slots = _SLOTS.get(key)
+        if slots is None:
+            out = ctypes.c_int(0)
+            _hip.call("mm_conv3d_wgrad_slots", B, D, H, W, cinp_x, N, ctypes.addressof(out))
+            slots = _SLOTS[key] = int(out.value)
+        ws = _empty((slots, N, 27, cinp_x), _F32, y)           # one writer per element: no atomics, no memset
         _hip.call("mm_conv3d_wgrad", dy, xv, ws, dbr, B, D, H, W, cinp_x, N, cinp_x,
-                  27 * cinp_x, 1, cinp_x, WREP, N * 27 * cinp_x)
-        _scatter_into(dw, ws, N, cin, 27, cinp_x, WREP)
+                  27 * cinp_x, 1, cinp_x, slots, N * 27 * cinp_x, 1)
+        _scatter_into(dw, ws, N, cin, 27, cinp_x, slots)
         if db is not None:
             _reduce_into(db, dbr, N, N)
     if not need_dx:

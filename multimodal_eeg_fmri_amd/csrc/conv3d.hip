@@ -558,6 +558,7 @@ struct Wgrad3dArgs {
     const bf16* dy; const bf16* x; float* dw; float* dbias;
     int B, D, H, W, Cin, Cout, Cin_real, tiles_per_wg, nrep;
     long sn, sc, stap, rep_stride;
+    int slot_mode;            // 1: tile-chunk x stores its partial dW into slot blockIdx.x (no atomics)
 };
 
 __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
@@ -646,14 +647,18 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
         }
     }
     const int c = c0 + wc * 32 + (lane & 31);
-    float* dwr = a.dw + (size_t)(blockIdx.x % a.nrep) * a.rep_stride;
+    float* dwr = a.dw + (size_t)(a.slot_mode ? blockIdx.x : blockIdx.x % a.nrep) * a.rep_stride;
     if (c < a.Cin_real) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < a.Cout) atomicAdd(dwr + n * a.sn + c * a.sc + (kd * 9 + t9) * a.stap, acc[t9][r]);
+                if (n < a.Cout) {
+                    float* o = dwr + n * a.sn + c * a.sc + (kd * 9 + t9) * a.stap;
+                    if (a.slot_mode) *o = acc[t9][r];
+                    else atomicAdd(o, acc[t9][r]);
+                }
             }
     }
     if (a.dbias && kd == 0 && cblk == 0 && wc == 0) {
@@ -907,27 +912,40 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
     return launch3d<1, 64, 2, 2>(a, st);
 }
 
-int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W, int Cin,
-                    int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep, int64_t rep_stride,
-                    hipStream_t st) {
-    MM_REQUIRE(dy && x && dw && B > 0, "conv3d_wgrad: null/invalid");
-    MM_REQUIRE(nrep >= 1 && nrep <= 64, "conv3d_wgrad: nrep");
-    MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cin_real <= Cin, "conv3d_wgrad: channels");
-    Wgrad3dArgs a;
-    a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
-    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cin_real = Cin_real;
-    a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride;
+// tiles per workgroup.  Atomic mode: every workgroup ends with 64 x 64 x 9 fp32 atomics, so few, long
+// workgroups win once the tile loop is software-pipelined: >= 12 tiles each, at most ~384 workgroups
+// (sweep: L2 54.7 us at 384, L3 35.5 us at 128-160; 64 / 56 us before).  Slot mode keeps the same plan.
+static int wgrad3d_tiles_per_wg(int B, int D, int H, int W, int Cin, int Cout) {
     const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
     const int par = ceil_div(Cout, 64) * 3 * ceil_div(Cin, 64);
-    // every workgroup ends with 64 x 64 x 9 fp32 atomics, so few, long workgroups win once the tile
-    // loop is software-pipelined: >= 12 tiles each, at most ~384 workgroups (measured sweep:
-    // L2 54.7 us at 384, L3 35.5 us at 128-160; 64 / 56 us before)
     int chunks = ceil_div(384, par);
     if (chunks > tiles_total / 12) chunks = tiles_total / 12;
     if (chunks > tiles_total) chunks = tiles_total;
     if (chunks < 1) chunks = 1;
-    a.tiles_per_wg = ceil_div(tiles_total, chunks);
+    return ceil_div(tiles_total, chunks);
+}
+
+int mm_conv3d_wgrad_slots(int B, int D, int H, int W, int Cin, int Cout, int* slots_host, hipStream_t) {
+    MM_REQUIRE(slots_host && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_wgrad_slots: bad args");
+    const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
+    *slots_host = ceil_div(tiles_total, wgrad3d_tiles_per_wg(B, D, H, W, Cin, Cout));
+    return 0;
+}
+
+int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W, int Cin,
+                    int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep, int64_t rep_stride,
+                    int slot_mode, hipStream_t st) {
+    MM_REQUIRE(dy && x && dw && B > 0, "conv3d_wgrad: null/invalid");
+    MM_REQUIRE(nrep >= 1 && (slot_mode || nrep <= 64), "conv3d_wgrad: nrep");
+    MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cin_real <= Cin, "conv3d_wgrad: channels");
+    Wgrad3dArgs a;
+    a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cin_real = Cin_real;
+    a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride; a.slot_mode = slot_mode;
+    const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
+    a.tiles_per_wg = wgrad3d_tiles_per_wg(B, D, H, W, Cin, Cout);
     dim3 grid(ceil_div(tiles_total, a.tiles_per_wg), ceil_div(Cout, 64), 3 * ceil_div(Cin, 64));
+    MM_REQUIRE(!slot_mode || nrep >= (int)grid.x, "conv3d_wgrad: slot mode needs %d slots, got %d", (int)grid.x, nrep);
     hipLaunchKernelGGL(conv3d_wgrad_kernel, grid, dim3(256), 0, st, a);
     return mm_check_launch("conv3d_wgrad");
 }

@@ -267,10 +267,19 @@ def test_conv3d_fwd_wgrad_dgrad(B, Cin, Cout, D, H, W):
     dyg = _vol_cl(dy)
     dw = torch.zeros(3, Cout, Cin, 27, device="cuda")
     db = torch.zeros(32, Cout, device="cuda")
-    hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1, 3, Cout * Cin * 27)
+    hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1, 3, Cout * Cin * 27, 0)
     dw, db = dw.sum(0), db.sum(0)
     torch.testing.assert_close(dw.cpu().view_as(w), w.grad, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
+    # slot mode: plain stores into NaN-filled per-chunk slots, summed by the scatter
+    import ctypes
+    n = ctypes.c_int(0)
+    hip.call("mm_conv3d_wgrad_slots", B, D, H, W, Cin, Cout, ctypes.addressof(n))
+    ws = torch.full((n.value, Cout, 27, Cin), float("nan"), device="cuda")
+    hip.call("mm_conv3d_wgrad", dyg, xg, ws, None, B, D, H, W, Cin, Cout, Cin, 27 * Cin, 1, Cin, n.value, Cout * 27 * Cin, 1)
+    dw2 = torch.zeros(Cout, Cin, 27, device="cuda")
+    hip.call("mm_wgrad_scatter", ws, dw2, Cout, Cin, 27, Cin, n.value)
+    torch.testing.assert_close(dw2.cpu().view_as(w), w.grad, rtol=2e-3, atol=2e-2)
     dx = torch.empty(B, D, H, W, Cin, device="cuda")
     hip.call("mm_conv3d_fwd", dyg, wd, B, D, H, W, Cout, Cin, None, None, dx, None)
     torch.testing.assert_close(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1), rtol=1e-3, atol=2e-3)

@@ -114,7 +114,7 @@ def conv3d_case(B, S, Cin, Cout, wgrad=True):
     ws = torch.zeros(8, Cout, 27, Cin, device="cuda")
 
     def fn2():
-        _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin, 8, Cout * 27 * Cin)
+        _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin, 8, Cout * 27 * Cin, 0)
     us = timeit(fn2)
     print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
 
