@@ -148,6 +148,21 @@ def timeline_case(B=32, S=16, Cin=32, Cout=64):
     print(f"  s_memtime ticks per us over the kernel: {mhz:.0f}")
 
 
+def attn_case(B=32, L=512, H=4, p=0.1):
+    E = H * 32
+    qkv = (torch.randn(B, L, 3 * E, device="cuda") * 0.5).to(BF)
+    out = torch.empty(B, L, E, dtype=BF, device="cuda")
+    lse = torch.empty(B, H, L, device="cuda")
+    dout = torch.randn(B, L, E, device="cuda").to(BF)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, L, device="cuda")
+    sc = 1 / math.sqrt(32)
+    f = timeit(lambda: _hip.call("mm_attn_fwd", qkv, out, lse, B, L, H, 32, sc, p, 77, None))
+    b = timeit(lambda: _hip.call("mm_attn_bwd", qkv, out, dout, lse, dqkv, delta, B, L, H, 32, sc, p, 77, None))
+    fl = 4.0 * B * H * L * L * 32
+    print(f"attention B={B} L={L} H={H} p={p}: fwd {f:6.1f} us ({fl / f / 1e6:6.1f} TF/s)   bwd (dq + dkv) {b:6.1f} us")
+
+
 def floor_case():
     x = torch.zeros(64, device="cuda")
     y = torch.zeros(64, dtype=BF, device="cuda")
@@ -201,6 +216,10 @@ def main():
         conv1d_wgrad_case(1, M, 128, 512, 1)
     if "pmc3d" in flt:
         conv3d_case(32, 16, 32, 64, wgrad=False)
+        return
+    if "attn" in flt:
+        for p_ in (0.0, 0.1, 0.3):
+            attn_case(p=p_)
         return
     if "tl" in flt:
         timeline_case()
