@@ -121,6 +121,13 @@ class GradBag:
         self.scatters.append((ws.data_ptr(), dw.data_ptr(), cout, cin, taps, cinp, nrep))
         self._keep.append((dw, ws))
 
+    def hand_over(self) -> "GradBag":
+        """move everything deferred so far into a new bag (to be flushed elsewhere, e.g. on another stream)"""
+        other = GradBag()
+        other.pending, other.scatters, other._keep = self.pending, self.scatters, self._keep
+        self.pending, self.scatters, self._keep = [], [], []
+        return other
+
     def flush(self, device):
         import ctypes
         import struct
@@ -290,8 +297,10 @@ class _ModuleFn(torch.autograd.Function):
         return (None, dx) + tuple(bag.result(p) for p in params)
 
 
-def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = False):
-    """backward of ops._erp_forward_impl (train mode); dout fp32 (B, H)."""
+def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = False, after_blocks=None):
+    """backward of ops._erp_forward_impl (train mode); dout fp32 (B, H).  ``after_blocks()`` is called
+    once the transformer stack's backward has been issued (a trainer hands the reductions collected
+    so far to another stream there)."""
     d = pooled_head_bwd(bag, sv["head"], dout)
     B, L, D = d.shape
     d = d.view(B * L, D)
@@ -300,6 +309,8 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     for i in range(len(blocks) - 1, -1, -1):
         below = (blocks[i - 1]["p"], blocks[i - 1]["seeds"][2]) if i > 0 else None
         d, dy2 = transformer_block_bwd(bag, blocks[i], d, dy2=dy2, emit_for=below)
+    if after_blocks is not None:
+        after_blocks()
     c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
     g = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D))
     g = conv_bn_act_bwd(bag, c2, dout_bf16=g)

@@ -166,7 +166,16 @@ class BridgeTrainer(nn.Module):
             self._stamp(7)
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
-            erp_encoder_bwd(bag, sv_e, dfe)          # longer chain first (see _seg_forward)
+            # the transformer stack's weight-gradient slot sums and parameter reductions (~50 MB of
+            # reads) do not wait for the end of the chain: they are handed to the side stream, which
+            # is idle once the fMRI branch is done
+            handed = {}
+
+            def split():
+                handed["bag"] = bag.hand_over()
+                handed["ev"] = torch.cuda.Event()
+                handed["ev"].record()
+            erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split)          # longer chain first (see _seg_forward)
             self._stamp(8)
             with torch.cuda.stream(self._side):
                 self._stamp(9)
@@ -174,9 +183,11 @@ class BridgeTrainer(nn.Module):
                 with deferred(bag_f, dz.device):     # hidden beside the rest of the EEG backward
                     volume_encoder_bwd(bag_f, sv_f, dff)
                 self._stamp(10)
+                self._side.wait_event(handed["ev"])
+                handed["bag"].flush(dz.device)
             main.wait_stream(self._side)
         self._stamp(11)
-        self._bags = getattr(self, "_bags", [])[-6:] + [bag, bag_f]   # keep descriptor tables alive for graph replays
+        self._bags = getattr(self, "_bags", [])[-9:] + [bag, bag_f, handed["bag"]]   # keep descriptor tables alive
 
     def _seg_optimizer(self):
         b = self.bucket
