@@ -120,12 +120,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank per GPU (RCCL).  MM_DIST_BACKEND=gloo is the one-GPU rehearsal of the N > 1 code path:
+    # several ranks then share a device (LOCAL_RANK modulo the device count) and exchange over gloo.
+    backend = os.environ.get("MM_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 

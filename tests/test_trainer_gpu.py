@@ -115,3 +115,23 @@ def test_segmented_step_through_rccl_with_one_rank():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_rehearsal.py"), "rccl1"],
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per
+    process), except that both ranks share this GPU and exchange over gloo (MM_DIST_BACKEND): the
+    N > 1 timing / reduction / JSON path must run and report whole-job throughput."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 64 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
