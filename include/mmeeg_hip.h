@@ -303,6 +303,11 @@ int mm_softmax2_concat_bwd(const float* dout, const float* a, const float* c, co
 /* nn.CrossEntropyLoss(weight=class_weight) (_test_bridge.py:858; run_fmri_v11.py): loss_out[0] += loss */
 int mm_weighted_ce(const float* logits, const void* target_i64, const float* class_weight, float* loss_out,
                    float* dlogits, int B, int C, hipStream_t stream);
+/* FocalLoss (CrossModal_EEG_scr.ipynb cell 20; FlexibleTrainer(use_focal_loss=True), cell 23):
+ * fl_b = alpha (1 - exp(-ce_b))^gamma ce_b.  loss_out[0] += scale * sum_b fl_b (zeroed by the caller),
+ * per_sample[b] = fl_b (nullable), dlogits = d fl_b / d logits without the reduction's factor (nullable) */
+int mm_focal_loss(const float* logits, const void* target_i64, float* loss_out, float* per_sample,
+                  float* dlogits, int B, int C, float alpha, float gamma, float scale, hipStream_t stream);
 /* HybridFusionModule gate + mix + conn boost (crossmodal_v4_enhancements.py:787-797) */
 int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float* conn, float* comb,
                  float* gate, int B, int H, float boost, hipStream_t stream);

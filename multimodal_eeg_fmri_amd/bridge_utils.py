@@ -125,14 +125,20 @@ class WeightedCrossEntropy(nn.Module):
 
 
 def train_bridge_epoch(model, loader, optimizer, criterion, device, grad_clip=1.0):
-    """one epoch of the reference bridge loop (_test_bridge.py:775-788); ``optimizer`` is a
-    ``multimodal_eeg_fmri_amd.optim.FusedAdamW`` (its step already clips to ``max_grad_norm``)."""
+    """one epoch of the reference bridge loop (_test_bridge.py:775-788).  With a
+    ``multimodal_eeg_fmri_amd.optim.FusedAdamW`` the clip is part of its step; any other optimizer gets
+    ``clip_grad_norm_`` here as in the reference."""
+    from .optim import FusedAdamW
     model.train()
     total, n = 0.0, 0
     for eeg, fmri, labels, _ in loader:
         optimizer.zero_grad()
         loss = criterion(model(eeg.to(device), fmri.to(device)), labels.to(device))
         loss.backward()
+        if isinstance(optimizer, FusedAdamW):
+            optimizer.max_grad_norm = float(grad_clip)
+        elif grad_clip > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
         optimizer.step()
         total += loss.item()
         n += 1
@@ -158,6 +164,18 @@ class ImprovedTriModalFusionNet(nn.Module):
             logits, gates, fused = self.model(erp, pw, conn, return_fusion_weights=True, return_fused_feats=True)
             return {"logits": logits, "gates": gates, "fused_feats": fused}
         return self.model(erp, pw, conn)
+
+    def get_fusion_weights(self):
+        from .crossmodal_v4_enhancements import get_fusion_weights_from_model
+        return get_fusion_weights_from_model(self.model)
+
+    def track_fusion_weights(self):
+        w = self.get_fusion_weights()
+        if w:
+            self.fusion_weight_history.append(w)
+
+    def get_weight_history(self):
+        return self.fusion_weight_history
 
 
 @torch.no_grad()
@@ -272,3 +290,98 @@ def collate_bridge(batch):
     fmri = torch.stack([b[1] for b in batch])
     labels = torch.tensor([b[2] for b in batch], dtype=torch.long)
     return eeg, fmri, labels, [b[3] for b in batch]
+
+
+@torch.no_grad()
+def evaluate_bridge(model, loader, device):
+    """(``_test_bridge.py:791-820``) -> (metrics, targets, probs, subjects)."""
+    import numpy as np
+    from .fmri_utils import classification_metrics
+    model.eval()
+    preds, targets, probs, subjects = [], [], [], []
+    for eeg, fmri, labels, subj in loader:
+        logits = model(eeg.to(device), fmri.to(device)).float()
+        probs.append(torch.softmax(logits, dim=1).cpu().numpy())
+        preds.append(logits.argmax(dim=1).cpu().numpy())
+        targets.append(labels.numpy())
+        subjects.extend(subj)
+    preds, targets, probs = np.concatenate(preds), np.concatenate(targets), np.concatenate(probs)
+    return classification_metrics(targets, preds, probs, 2), targets, probs, subjects
+
+
+def balanced_class_weights(labels):
+    """sklearn's ``compute_class_weight('balanced')``: n / (n_classes * count_c) for the classes present."""
+    import numpy as np
+    labels = np.asarray(labels)
+    classes, counts = np.unique(labels, return_counts=True)
+    return torch.tensor(len(labels) / (len(classes) * counts), dtype=torch.float32)
+
+
+def run_bridge_loocv(dataset, eeg_dim=128, fmri_dim=64, bridge_dim=128, num_classes=2, dropout=0.3,
+                     lr=1e-4, weight_decay=1e-4, batch_size=8, num_epochs=100, patience=15, grad_clip=1.0,
+                     device=None, xai=True, ig_steps=50, seed=None):
+    """Leave-one-subject-out protocol of the bridge pipeline (``_test_bridge.py:826-970``): per fold a
+    fresh ``EEGfMRIBridgeFusionNet``, balanced class weights from the training labels, AdamW +
+    ReduceLROnPlateau(0.5, 5) on the epoch's training loss, best-training-loss state restored after
+    ``patience`` epochs without improvement, then the held-out subject is scored and (``xai``) explained
+    with gradient saliency and integrated gradients - all forward/backward passes on the HIP kernels.
+
+    Returns a dict: ``predictions`` [(subject, true, pred, prob_class1)], ``fusion_weights`` [per-fold
+    dict], ``fused_features`` {subject: (bridge_dim,)}, ``saliency`` / ``integrated_gradients``
+    {subject: {'eeg','fmri'}}, ``attn_fusion`` {subject: {...}}, ``metrics``."""
+    import copy
+    import numpy as np
+    from torch.utils.data import DataLoader, Subset
+    from .crossmodal_eeg_scr import _PlateauLR
+    from .fmri_utils import classification_metrics
+    from .optim import FusedAdamW
+    device = device or torch.device("cuda")
+    labels = np.array([s["label"] for s in dataset.samples])
+    n = len(dataset)
+    gen = torch.Generator().manual_seed(seed) if seed is not None else None
+    res = {"predictions": [], "fusion_weights": [], "fused_features": {}, "saliency": {},
+           "integrated_gradients": {}, "attn_fusion": {}}
+    for held in range(n):
+        train_idx = [i for i in range(n) if i != held]
+        subject = dataset.samples[held]["subject"]
+        loader = DataLoader(Subset(dataset, train_idx), batch_size=batch_size, shuffle=True,
+                            collate_fn=collate_bridge, generator=gen)
+        if seed is not None:
+            torch.manual_seed(seed + held)
+        model = EEGfMRIBridgeFusionNet(eeg_dim, fmri_dim, bridge_dim, num_classes, dropout=dropout).to(device)
+        criterion = WeightedCrossEntropy(balanced_class_weights(labels[train_idx])).to(device)
+        opt = FusedAdamW(model.parameters(), lr=lr, weight_decay=weight_decay)
+        sched = _PlateauLR(opt, factor=0.5, patience=5)
+        best, best_state, bad = float("inf"), None, 0
+        for _ in range(num_epochs):
+            loss = train_bridge_epoch(model, loader, opt, criterion, device, grad_clip)
+            sched.step(loss)
+            if loss < best:
+                best, best_state, bad = loss, copy.deepcopy(model.state_dict()), 0
+            else:
+                bad += 1
+            if bad >= patience:
+                break
+        if best_state:
+            model.load_state_dict(best_state)
+            ops.weights_changed()
+        model.eval()
+        eeg_t, fmri_t, label_t, _ = collate_bridge([dataset[held]])
+        with torch.no_grad():
+            logits, fused, fw, aw = model(eeg_t.to(device), fmri_t.to(device), return_features=True, return_weights=True)
+        probs = torch.softmax(logits.float(), dim=1)
+        res["predictions"].append((subject, int(label_t[0]), int(logits.argmax(dim=1)), float(probs[0, 1])))
+        res["fused_features"][subject] = fused.squeeze(0).float().cpu()
+        res["fusion_weights"].append(model.get_fusion_weights())
+        res["attn_fusion"][subject] = {"label": int(label_t[0]), "prediction": int(logits.argmax(dim=1)),
+                                       "fusion_weights": fw.squeeze(0).float().cpu().numpy(),
+                                       "attn_weights": aw.squeeze(0).float().cpu().numpy()}
+        if xai:
+            res["saliency"][subject] = {k: v[0] for k, v in BridgeGradientSaliency(model, device).compute(eeg_t, fmri_t).items()}
+            res["integrated_gradients"][subject] = {
+                k: v[0] for k, v in BridgeIntegratedGradients(model, device, ig_steps).compute(eeg_t, fmri_t).items()}
+    t = np.array([p[1] for p in res["predictions"]])
+    pr = np.array([p[2] for p in res["predictions"]])
+    p1 = np.array([p[3] for p in res["predictions"]])
+    res["metrics"] = classification_metrics(t, pr, np.stack([1 - p1, p1], axis=1), 2)
+    return res

@@ -110,6 +110,25 @@ def get_lite_fusion_weights(model):
     return getattr(model, "_fusion_weights", None)
 
 
+def get_fusion_weights_from_model(model):
+    """{'temperature', 'erp_weight', 'pw_weight'[, 'conn_weight']} of a model with a LearnedFusionModule
+    at ``.fusion`` (reference :577-602); None otherwise."""
+    fusion = getattr(model, "fusion", None)
+    if fusion is None or not hasattr(fusion, "fusion_logits"):
+        return None
+    with torch.no_grad():
+        temp = fusion.temperature
+        w = torch.softmax(fusion.fusion_logits / temp, dim=0).tolist()
+    result = {"temperature": temp.detach().item()}
+    if len(w) in (2, 3):
+        result.update(zip(("erp_weight", "pw_weight", "conn_weight"), w))
+    return result
+
+
+def count_parameters(model: nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
 # ------------------------------------------------- full V4 classifiers (SURVEY 8(f).1)
 def _mlp_bn(i, o, dropout):
     return [nn.Linear(i, o), nn.BatchNorm1d(o), nn.GELU(), nn.Dropout(dropout)]

@@ -728,6 +728,43 @@ __global__ void weighted_ce_kernel(const float* __restrict__ logits, const long 
     }
 }
 
+// FocalLoss (CrossModal_EEG_scr.ipynb cell 20): ce_b = lse(z_b) - z_b[t_b]; pt = exp(-ce);
+// fl_b = alpha (1 - pt)^gamma ce.  out[0] += scale * sum_b fl_b; per_sample[b] = fl_b (optional);
+// dlogits[b][c] = d fl_b / d z_bc (un-reduced; the caller applies the reduction's factor).
+__global__ void focal_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                  float* __restrict__ out, float* __restrict__ per_sample,
+                                  float* __restrict__ dlogits, int B, int C, float alpha, float gamma, float scale) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* z = logits + (size_t)b * C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(z[c] - m);
+        const int t = (int)target[b];
+        const float ce = m + __logf(se) - z[t];
+        const float pt = __expf(-ce), q = fmaxf(1.f - pt, 0.f);
+        const float qg = (gamma == 0.f) ? 1.f : powf(q, gamma);
+        const float fl = alpha * qg * ce;
+        if (per_sample) per_sample[b] = fl;
+        acc += fl;
+        if (dlogits) {
+            const float qg1 = (gamma == 0.f || q <= 0.f) ? 0.f : gamma * powf(q, gamma - 1.f) * pt * ce;
+            const float dce = alpha * (qg + qg1);
+            for (int c = 0; c < C; ++c)
+                dlogits[(size_t)b * C + c] = dce * (__expf(z[c] - m) / se - (c == t ? 1.f : 0.f));
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += scale * red[0];
+}
+
 // HybridFusionModule mix (crossmodal_v4_enhancements.py:787-797):
 // gate = softmax(g[b][0:2]); comb[b] = [ gate0*erp + gate1*pw | conn * boost ]
 __global__ void gate2_mix_kernel(const float* __restrict__ g, const float* __restrict__ erp, const float* __restrict__ pw,
@@ -1045,6 +1082,14 @@ int mm_weighted_ce(const float* logits, const void* target_i64, const float* cla
     hipLaunchKernelGGL(weighted_ce_kernel, dim3(1), dim3(256), 0, st, logits, (const long long*)target_i64, class_weight,
                        loss_out, dlogits, B, C);
     return mm_check_launch("weighted_ce");
+}
+
+int mm_focal_loss(const float* logits, const void* target_i64, float* loss_out, float* per_sample, float* dlogits,
+                  int B, int C, float alpha, float gamma, float scale, hipStream_t st) {
+    MM_REQUIRE(logits && target_i64 && loss_out && B > 0 && C > 0, "focal_loss: bad args");
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, st, logits, (const long long*)target_i64, loss_out,
+                       per_sample, dlogits, B, C, alpha, gamma, scale);
+    return mm_check_launch("focal_loss");
 }
 
 int mm_gate2_mix(const float* g, const float* erp, const float* pw, const float* conn, float* comb, float* gate, int B,

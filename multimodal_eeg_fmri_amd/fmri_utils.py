@@ -11,10 +11,14 @@
 """
 from __future__ import annotations
 
+import logging
+
 import torch
 import torch.nn as nn
 
 from . import ops
+
+logger = logging.getLogger(__name__)
 
 
 def _mlp(in_dim, hidden_dim, dropout):
@@ -93,3 +97,192 @@ class fMRIVolumeEncoder3D(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return ops.volume_encoder_forward(self, x)
+
+
+# ---------------------------------------------------------------------------
+# host side of the tabular fMRI pipeline: dataset, collate, the epoch
+# loops and the CSV loaders.  Same names, arguments and return values as the reference; the model
+# calls inside the loops run on the HIP kernels.
+# ---------------------------------------------------------------------------
+
+class fMRIDataset(torch.utils.data.Dataset):
+    """subjects present in all three dicts, ascending (``run_fmri_v11.py:216-257``); item =
+    ``(activation, connectivity, class_label, reg_label, subject)``, ``reg_label`` 0.0 when absent."""
+
+    def __init__(self, activation_features, connectivity_features, class_labels, reg_labels=None, transform=None):
+        self.transform = transform
+        common = set(activation_features) & set(connectivity_features) & set(class_labels)
+        self.samples = [{"activation": activation_features[s], "connectivity": connectivity_features[s],
+                         "class_label": class_labels[s],
+                         "reg_label": reg_labels[s] if reg_labels and s in reg_labels else 0.0,
+                         "subject": s} for s in sorted(common)]
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, idx):
+        s = self.samples[idx]
+        act, conn = s["activation"], s["connectivity"]
+        if self.transform:
+            act, conn = self.transform(act), self.transform(conn)
+        return act, conn, s["class_label"], s["reg_label"], s["subject"]
+
+
+def collate_fmri(batch):
+    """(``run_fmri_v11.py:259-266``)"""
+    return (torch.stack([b[0] for b in batch]), torch.stack([b[1] for b in batch]),
+            torch.tensor([b[2] for b in batch], dtype=torch.long),
+            torch.tensor([b[3] for b in batch], dtype=torch.float32), [b[4] for b in batch])
+
+
+def train_epoch(model, train_loader, optimizer, criterion, device, task="classification", grad_clip=1.0):
+    """one epoch of ``run_fmri_v11.py:430-449``.  With a ``FusedAdamW`` the clip is part of its step
+    (``max_grad_norm``); with any other optimizer ``clip_grad_norm_`` runs here as in the reference."""
+    from .optim import FusedAdamW
+    model.train()
+    total = 0.0
+    for activation, connectivity, class_labels, reg_labels, _ in train_loader:
+        labels = (class_labels if task == "classification" else reg_labels).to(device)
+        optimizer.zero_grad()
+        loss = criterion(model(activation.to(device), connectivity.to(device)), labels)
+        loss.backward()
+        if isinstance(optimizer, FusedAdamW):
+            optimizer.max_grad_norm = float(grad_clip)
+        elif grad_clip > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+        optimizer.step()
+        total += loss.item()
+    return total / len(train_loader)
+
+
+def classification_metrics(targets, preds, probs=None, num_classes=2):
+    """Accuracy / weighted F1, precision, recall (+ AUC for two classes; 0.5 when undefined) - the
+    metric dict of ``run_fmri_v11.py:482-493`` and ``_test_bridge.py:810-819``."""
+    from sklearn.metrics import accuracy_score, f1_score, precision_score, recall_score, roc_auc_score
+    m = {"Accuracy": accuracy_score(targets, preds),
+         "F1": f1_score(targets, preds, average="weighted", zero_division=0),
+         "Precision": precision_score(targets, preds, average="weighted", zero_division=0),
+         "Recall": recall_score(targets, preds, average="weighted", zero_division=0)}
+    if probs is not None and num_classes == 2:
+        try:
+            m["AUC"] = roc_auc_score(targets, probs[:, 1])
+        except Exception:
+            m["AUC"] = 0.5
+    return m
+
+
+@torch.no_grad()
+def evaluate(model, data_loader, device, task="classification", num_classes=2):
+    """(``run_fmri_v11.py:452-504``) -> (metrics, targets, probs) or, for regression, (metrics, targets, preds)."""
+    import numpy as np
+    model.eval()
+    preds, targets, probs = [], [], []
+    for activation, connectivity, class_labels, reg_labels, _ in data_loader:
+        out = model(activation.to(device), connectivity.to(device)).float()
+        if task == "classification":
+            probs.append(torch.softmax(out, dim=1).cpu().numpy())
+            preds.append(out.argmax(dim=1).cpu().numpy())
+            targets.append(class_labels.numpy())
+        else:
+            preds.append(out.reshape(-1).cpu().numpy())
+            targets.append(reg_labels.numpy())
+    preds, targets = np.concatenate(preds), np.concatenate(targets)
+    if task == "classification":
+        probs = np.concatenate(probs)
+        return classification_metrics(targets, preds, probs, num_classes), targets, probs
+    from sklearn.metrics import mean_absolute_error, mean_squared_error, r2_score
+    mse = mean_squared_error(targets, preds)
+    return ({"MSE": mse, "RMSE": float(np.sqrt(mse)), "MAE": mean_absolute_error(targets, preds),
+             "R2": r2_score(targets, preds)}, targets, preds)
+
+
+def _read_numeric_csv(path):
+    import numpy as np
+    import pandas as pd
+    df = pd.read_csv(path)
+    if "Subject" in df.columns:
+        df = df.drop("Subject", axis=1)
+    return np.nan_to_num(df.values.astype(np.float32), nan=0.0)
+
+
+def load_activation_features(data_dir, subject_list, activation_types, agg_method="both"):
+    """{subject: tensor}: per activation type, column-wise mean / std / [mean, std] over the rows of
+    ``sub-N/subject_N_activation_<type>.csv``, concatenated over types (``fmri_utils.py:115-160``)."""
+    import numpy as np
+    from pathlib import Path
+    features = {}
+    for subj in subject_list:
+        parts = []
+        for act_type in activation_types:
+            path = Path(data_dir) / f"sub-{subj}" / f"subject_{subj}_activation_{act_type}.csv"
+            if not path.exists():
+                continue
+            try:
+                data = _read_numeric_csv(path)
+                if agg_method not in ("mean", "std", "both"):
+                    raise ValueError(f"Unknown agg method: {agg_method}")
+                stats = {"mean": [data.mean(axis=0)], "std": [data.std(axis=0)],
+                         "both": [data.mean(axis=0), data.std(axis=0)]}[agg_method]
+                parts.append(np.concatenate(stats))
+            except Exception as e:  # unreadable file or unknown method: warning + skip, as the reference does
+                logger.warning("Error loading %s: %s", path, e)
+        if parts:
+            features[subj] = torch.tensor(np.concatenate(parts), dtype=torch.float32)
+    logger.info("fMRI activation features: %d/%d subjects", len(features), len(subject_list))
+    return features
+
+
+def load_connectivity_features(data_dir, subject_list, connectivity_types):
+    """{subject: tensor}: flattened ``sub-N/subject_N_fdr_PPI_Connectivity_<type>.csv`` matrices,
+    concatenated over types (``fmri_utils.py:163-201``)."""
+    import numpy as np
+    from pathlib import Path
+    features = {}
+    for subj in subject_list:
+        parts = []
+        for conn_type in connectivity_types:
+            path = Path(data_dir) / f"sub-{subj}" / f"subject_{subj}_fdr_PPI_Connectivity_{conn_type}.csv"
+            if not path.exists():
+                continue
+            try:
+                parts.append(_read_numeric_csv(path).flatten())
+            except Exception as e:
+                logger.warning("Error loading %s: %s", path, e)
+        if parts:
+            features[subj] = torch.tensor(np.concatenate(parts), dtype=torch.float32)
+    logger.info("fMRI connectivity features: %d/%d subjects", len(features), len(subject_list))
+    return features
+
+
+_SUBJECT_COLS = ("Subject", "subject", "SubjectID", "ID", "id")
+_LABEL_COLS = ("Label", "label", "Outcome", "outcome", "Class", "class", "Group", "group")
+
+
+def load_fmri_labels(label_path, subject_list):
+    """{subject: 0/1} from the first of labels.csv / outcomes.csv / subjects_labels.csv /
+    ../labels.csv that exists; string labels good/positive/yes/1 -> 1 (``fmri_utils.py:204-244``).
+    With no label file the reference falls back to random dummy labels; so does this."""
+    import numpy as np
+    import pandas as pd
+    from pathlib import Path
+    label_path = Path(label_path)
+    candidates = [label_path / "labels.csv", label_path / "outcomes.csv",
+                  label_path / "subjects_labels.csv", label_path.parent / "labels.csv"]
+    label_file = next((p for p in candidates if p.exists()), None)
+    if label_file is None:
+        logger.warning("No fMRI label file found. Using dummy labels.")
+        return {s: int(np.random.randint(0, 2)) for s in subject_list}
+    df = pd.read_csv(label_file)
+    subj_col = next((c for c in _SUBJECT_COLS if c in df.columns), None)
+    label_col = next((c for c in _LABEL_COLS if c in df.columns), None)
+    if not subj_col or not label_col:
+        raise ValueError(f"Cannot identify columns in {label_file}: {df.columns.tolist()}")
+    wanted = set(subject_list)
+    labels = {}
+    for subj, label in zip(df[subj_col], df[label_col]):
+        if int(subj) not in wanted:
+            continue
+        if isinstance(label, str):
+            label = 1 if label.lower() in ("good", "positive", "yes", "1") else 0
+        labels[int(subj)] = int(label)
+    return labels

@@ -1033,6 +1033,13 @@ def weighted_cross_entropy(logits, target, weight=None):
     return sa.WeightedCEFn.apply(logits, target, w)
 
 
+def focal_loss(logits, target, alpha=0.25, gamma=2.0, reduction="mean"):
+    """FocalLoss of the EEG notebook (CrossModal_EEG_scr.ipynb cell 20) on the HIP path."""
+    _need_gpu(logits, target)
+    from . import small_autograd as sa
+    return sa.FocalLossFn.apply(logits, target, float(alpha), float(gamma), reduction)
+
+
 def drop_path(x, drop_prob):
     raise NotImplementedError("DropPath is unused on the reference hot path (crossmodal_v4_enhancements.py:639-658)")
 

@@ -52,7 +52,8 @@ class FusedAdamW:
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
                  max_grad_norm: float = 0.0):
-        self.bucket = FlatBucket(list(params))
+        self._all = list(params)                  # torch's state_dict numbers EVERY param of the group
+        self.bucket = FlatBucket(self._all)
         self.param_groups = [{"lr": lr, "params": self.bucket.params}]
         self.betas, self.eps, self.weight_decay, self.max_grad_norm = betas, eps, weight_decay, max_grad_norm
         ops.weights_changed()
@@ -68,6 +69,50 @@ class FusedAdamW:
         _hip.call("mm_adamw_clip", b.p, b.g, b.m, b.v, b.state, b.n, self.betas[0], self.betas[1],
                   self.eps, self.weight_decay, float(self.max_grad_norm), 1.0, 0, None)
         ops.weights_changed()
+
+    # -- checkpoint drop-in: the dict layout of torch.optim.AdamW.state_dict(), so a
+    # FlexibleTrainer checkpoint (EEG notebook cell 23: 'optimizer_state_dict') moves both ways.
+    def _slices(self):
+        off = 0
+        index = {id(p): i for i, p in enumerate(self._all)}
+        for p in self.bucket.params:
+            k = p.numel()
+            yield index[id(p)], p, slice(off, off + k)
+            off += k
+
+    def state_dict(self):
+        b = self.bucket
+        step = float(b.state[0].item())
+        state = {i: {"step": torch.tensor(step), "exp_avg": b.m[sl].view(p.shape).clone(),
+                     "exp_avg_sq": b.v[sl].view(p.shape).clone()} for i, p, sl in self._slices()}
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True,
+                 "params": list(range(len(self._all)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        if len(group["params"]) != len(self._all):
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of "
+                             "optimizer's group")
+        if group.get("amsgrad"):
+            raise ValueError("FusedAdamW has no amsgrad state")
+        b = self.bucket
+        self.param_groups[0]["lr"] = group["lr"]
+        self.betas, self.eps, self.weight_decay = tuple(group["betas"]), group["eps"], group["weight_decay"]
+        steps = set()
+        b.m.zero_(); b.v.zero_()
+        for i, p, sl in self._slices():
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            b.m[sl].copy_(st["exp_avg"].reshape(-1))
+            b.v[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(float(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("FusedAdamW keeps one step counter; the loaded per-parameter steps differ")
+        b.state[0] = steps.pop() if steps else 0.0
 
     @property
     def last_grad_norm(self) -> float:

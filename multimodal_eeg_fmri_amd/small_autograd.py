@@ -403,6 +403,31 @@ class WeightedCEFn(torch.autograd.Function):
         return dl * g, None, None
 
 
+class FocalLossFn(torch.autograd.Function):
+    """FocalLoss(alpha, gamma, reduction) of the EEG notebook (cell 20) in one launch (``mm_focal_loss``)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, alpha, gamma, reduction):
+        logits = _f(logits)
+        B, C = logits.shape
+        out = _zeros((1,), logits)
+        per = _empty((B,), _F32, logits) if reduction == "none" else None
+        dl = _empty((B, C), _F32, logits)
+        scale = 1.0 / B if reduction == "mean" else 1.0
+        _hip.call("mm_focal_loss", logits, target.contiguous(), out, per, dl, B, C, float(alpha), float(gamma), scale)
+        ctx.save_for_backward(dl)
+        ctx.factor = scale
+        ctx.reduction = reduction
+        return per if reduction == "none" else out.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        if ctx.reduction == "none":
+            return dl * g.reshape(-1, 1), None, None, None, None
+        return dl * (g * ctx.factor), None, None, None, None
+
+
 def proj_head(x, seq, drop_p):
     """Linear -> LayerNorm -> GELU -> Dropout (bridge_utils.py:34-45)"""
     return ActFn.apply(LayerNormFn.apply(linear(x, seq[0]), seq[1].weight, seq[1].bias, seq[1].eps), "gelu", float(drop_p))

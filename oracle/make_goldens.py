@@ -282,6 +282,129 @@ def main():
     np.savez_compressed(os.path.join(OUT, "f3_balanced_dataset.npz"), **fx)
     report.append("f3 BalancedTriModalDataset ok")
 
+    # --------------------------------------------- (f).3 on-disk loaders (CSV / MATLAB-v5 trees)
+    import json as _json
+    import tempfile
+    import types
+    import pandas as pd
+    from scipy.io import savemat
+    import multimodal_eeg_fmri_amd.eeg_data_utils as ours_ed
+    rng = np.random.default_rng(7)
+
+    def _nan(a, frac=0.1):
+        a = a.astype(np.float32)
+        a[rng.random(a.shape) < frac] = np.nan
+        return a
+    csv_files, mat_files = {}, {}
+    for subj in (1, 2, 3):
+        for t in ("faces", "tools"):
+            if subj == 3 and t == "tools":
+                continue                                   # a missing activation type
+            df = pd.DataFrame(_nan(rng.standard_normal((5, 6))), columns=[f"roi{i}" for i in range(6)])
+            if subj != 2:
+                df.insert(0, "Subject", subj)
+            csv_files[f"fmri/sub-{subj}/subject_{subj}_activation_{t}.csv"] = df.to_csv(index=False)
+        df = pd.DataFrame(_nan(rng.standard_normal((4, 4))), columns=[f"r{i}" for i in range(4)])
+        csv_files[f"fmri/sub-{subj}/subject_{subj}_fdr_PPI_Connectivity_rest.csv"] = df.to_csv(index=False)
+    csv_files["fmri/labels/outcomes.csv"] = "ID,Outcome,extra\n1,good,a\n2,Bad,b\n3,YES,c\n9,good,d\n"
+    csv_files["eeg/labels/medical_score.csv"] = ("Subject,Postoperative evaluation\nsub01,1\nsub02,3\nsub03,\n"
+                                                 "sub04,2\nsub05,4\n")
+    mat_files["eeg/conn/conn_Alpha_open_sub01.mat"] = _nan(rng.standard_normal((5, 5)))
+    mat_files["eeg/conn/conn_beta_close_sub02.mat"] = _nan(rng.standard_normal((5, 5)))     # band-key fallback name
+    mat_files["eeg/pw/powspctrm_alpha_1_Hz_sub01.mat"] = _nan(rng.standard_normal((8, 3)))
+    mat_files["eeg/pw/powspctrm_beta_2_Hz_sub02.mat"] = _nan(rng.standard_normal((8, 3)))
+    mat_files["eeg/erp/ERP_sub01_alpha_1_Hz_avg.mat"] = _nan(rng.standard_normal((8, 20)))
+    mat_files["eeg/erp/ERP_sub02_beta_2_Hz.mat"] = _nan(rng.standard_normal((8, 20)))
+    if "h5py" not in sys.modules:
+        # h5py is not installed here; the reference module imports it at the top.  An EMPTY module object
+        # lets the import succeed; every h5py.* use then raises and the reference takes its own
+        # scipy.loadmat fallback branch (eeg_data_utils.py:168-180).  Its HDF5 branch stays unpinned.
+        sys.modules["h5py"] = types.ModuleType("h5py")
+    with contextlib.redirect_stdout(io.StringIO()):
+        import EEG_CODE.eeg_data_utils as ed
+    with tempfile.TemporaryDirectory() as tmp:
+        for rel, text in csv_files.items():
+            os.makedirs(os.path.dirname(os.path.join(tmp, rel)), exist_ok=True)
+            with open(os.path.join(tmp, rel), "w") as fh:
+                fh.write(text)
+        for rel, arr in mat_files.items():
+            os.makedirs(os.path.dirname(os.path.join(tmp, rel)), exist_ok=True)
+            savemat(os.path.join(tmp, rel), {"data": arr})
+        subs = [1, 2, 3, 5]
+        expected = {}
+
+        def _cmp(name, ref_d, our_d):
+            assert list(ref_d.keys()) == list(our_d.keys()), (name, list(ref_d), list(our_d))
+            for k in ref_d:
+                a, b = np.asarray(ref_d[k]), np.asarray(our_d[k])
+                assert a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), (name, k)
+                expected[f"{name}|{_json.dumps(k)}"] = a
+        f = os.path.join(tmp, "fmri")
+        for agg in ("mean", "std", "both"):
+            _cmp(f"act_{agg}", fm.load_activation_features(f, subs, ["faces", "tools"], agg),
+                 ours_f.load_activation_features(f, subs, ["faces", "tools"], agg))
+        assert fm.load_activation_features(f, subs, ["faces"], "median") == \
+            ours_f.load_activation_features(f, subs, ["faces"], "median") == {}
+        _cmp("conn", fm.load_connectivity_features(f, subs, ["rest", "task"]),
+             ours_f.load_connectivity_features(f, subs, ["rest", "task"]))
+        lr_, lo_ = fm.load_fmri_labels(os.path.join(f, "labels"), subs), ours_f.load_fmri_labels(os.path.join(f, "labels"), subs)
+        assert lr_ == lo_ == {1: 1, 2: 0, 3: 1}
+        e = os.path.join(tmp, "eeg")
+        for binary in (True, False):
+            a, b = ed.load_eeg_labels(os.path.join(e, "labels"), binary), ours_ed.load_eeg_labels(os.path.join(e, "labels"), binary)
+            assert a == b, (a, b)
+            expected[f"eeg_labels_{int(binary)}"] = np.array(sorted(a.items()), dtype=np.float64)
+        bands = {"alpha": "Alpha", "beta": "Beta"}
+        _cmp("eeg_conn", ed.load_eeg_conn_features(os.path.join(e, "conn"), subs, bands, ["open", "close"]),
+             ours_ed.load_eeg_conn_features(os.path.join(e, "conn"), subs, bands, ["open", "close"]))
+        _cmp("eeg_pw", ed.load_eeg_pw_features(os.path.join(e, "pw"), subs, ["alpha", "beta"], ["1_Hz", "2_Hz"]),
+             ours_ed.load_eeg_pw_features(os.path.join(e, "pw"), subs, ["alpha", "beta"], ["1_Hz", "2_Hz"]))
+        _cmp("eeg_erp", ed.load_eeg_erp_features(os.path.join(e, "erp"), subs, ["alpha", "beta"], ["1_Hz", "2_Hz"]),
+             ours_ed.load_eeg_erp_features(os.path.join(e, "erp"), subs, ["alpha", "beta"], ["1_Hz", "2_Hz"]))
+    fx = {"csv_paths": np.array(list(csv_files)), "csv_texts": np.array(list(csv_files.values())),
+          "mat_paths": np.array(list(mat_files)), "expected_keys": np.array(list(expected))}
+    for i, arr in enumerate(mat_files.values()):
+        fx[f"mat_{i}"] = arr
+    for i, arr in enumerate(expected.values()):
+        fx[f"exp_{i}"] = arr
+    np.savez_compressed(os.path.join(OUT, "f3_loaders.npz"), **fx)
+    report.append(f"f3 loaders ok ({len(expected)} entries; reference HDF5 branch unpinned: h5py absent)")
+
+    # ------------------- (f).1/(f).3 notebook classes: PerFoldNormalizer, FocalLoss, collate_trimodal
+    nb = _json.load(open(os.path.join(REF, "EEG_CODE", "CrossModal_EEG_scr.ipynb")))
+    ns = {"np": np, "torch": torch, "nn": torch.nn, "F": torch.nn.functional}
+    for cell in (19, 20, 24):                        # the notebook is not a module: run the three cells
+        with contextlib.redirect_stdout(io.StringIO()):
+            exec("".join(nb["cells"][cell]["source"]), ns)
+    import multimodal_eeg_fmri_amd.crossmodal_eeg_scr as ours_nb
+    data = {(s_, b_, 0): rng.standard_normal((3, 4)).astype(np.float32) * (1 + s_) for s_ in (1, 2, 3, 4) for b_ in range(2)}
+    subj_arr, train_idx = np.array([1, 2, 3, 4]), np.array([0, 2, 3])
+    with contextlib.redirect_stdout(io.StringIO()):
+        rn, on = ns["PerFoldNormalizer"](), ours_nb.PerFoldNormalizer()
+        rn.fit_on_indices(data, train_idx, subj_arr); on.fit_on_indices(data, train_idx, subj_arr)
+    assert rn.stats["mean"] == on.stats["mean"] and rn.stats["std"] == on.stats["std"]
+    rt, ot = rn.transform(data), on.transform(data)
+    assert all(np.array_equal(rt[k], ot[k]) for k in rt)
+    fx = {"norm_keys": np.array(list(data)), "norm_vals": np.stack(list(data.values())), "norm_train_idx": train_idx,
+          "norm_subjects": subj_arr, "norm_mean": np.array(rn.stats["mean"]), "norm_std": np.array(rn.stats["std"]),
+          "norm_out": np.stack(list(rt.values()))}
+    logits, tgt = seeded_randn(127, 16, 3) * 2.0, torch.randint(0, 3, (16,), generator=torch.Generator().manual_seed(128))
+    fx["focal_logits"], fx["focal_target"] = _np(logits), tgt.numpy()
+    for alpha, gamma in ((0.25, 2.0), (1.0, 0.0), (0.5, 1.5)):
+        for red in ("mean", "sum", "none"):
+            z = logits.clone().requires_grad_(True)
+            loss = ns["FocalLoss"](alpha, gamma, red)(z, tgt)
+            (loss.sum() * 1.0).backward()
+            fx[f"focal_{alpha}_{gamma}_{red}"], fx[f"focal_{alpha}_{gamma}_{red}_grad"] = _np(loss), _np(z.grad)
+    batch5 = [(seeded_randn(130 + i, 20, 4), seeded_randn(140 + i, 3, 12), seeded_randn(150 + i, 7), i, i % 2) for i in range(3)]
+    batch4 = [b[:2] + b[3:] for b in batch5]
+    for b_ in (batch5, batch4):
+        r_, o_ = ns["collate_trimodal"](b_), ours_nb.collate_trimodal(b_)
+        assert all((x is None and y is None) or torch.equal(x, y) for x, y in zip(r_, o_))
+    fx["collate_erp_shape"] = np.array(ns["collate_trimodal"](batch5)[0].shape)
+    np.savez_compressed(os.path.join(OUT, "f3_notebook_classes.npz"), **fx)
+    report.append("f3 PerFoldNormalizer / FocalLoss / collate_trimodal ok")
+
     # ------------------------------------------------------------- (viii) a8
     logits, tgt = seeded_randn(125, 16, 2), (seeded_randn(126, 16) > 0).long()
     ls = cv4.LabelSmoothingCrossEntropy(0.1)(logits, tgt)

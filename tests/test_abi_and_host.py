@@ -136,3 +136,116 @@ def test_f3_balanced_trimodal_dataset_matches_reference_golden():
     with contextlib.redirect_stdout(io.StringIO()):
         ds = C.BalancedTriModalDataset(erp, pw, conn, labels, transform=lambda t: t * 2)
     assert torch.equal(ds[0][0], torch.as_tensor(fx["mean_0_erp"]) * 2) and torch.equal(ds[0][2], torch.as_tensor(fx["mean_0_conn"]))
+
+
+def _rebuild_tree(fx, root):
+    from scipy.io import savemat
+    for rel, text in zip(fx["csv_paths"], fx["csv_texts"]):
+        path = os.path.join(root, str(rel))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            fh.write(str(text))
+    for i, rel in enumerate(fx["mat_paths"]):
+        path = os.path.join(root, str(rel))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        savemat(path, {"data": fx[f"mat_{i}"]})
+
+
+def test_f3_csv_and_mat_loaders_match_reference_golden(golden, tmp_path):
+    """the fMRI CSV loaders and the EEG .mat/CSV loaders return exactly (bit-equal, same
+    keys in the same order) what the reference's loaders returned for the same synthetic tree
+    (oracle/make_goldens.py wrote the tree and ran both).  The tree holds NaNs, a 'Subject' column in
+    some files, a missing activation type, a subject without a directory, the band-key fallback name."""
+    import multimodal_eeg_fmri_amd.eeg_data_utils as Ed
+    fx = golden("f3_loaders.npz")
+    _rebuild_tree(fx, str(tmp_path))
+    subs = [1, 2, 3, 5]
+    f, e = str(tmp_path / "fmri"), str(tmp_path / "eeg")
+    got = {}
+
+    def put(name, d):
+        for k, v in d.items():
+            got[f"{name}|{json.dumps(k)}"] = np.asarray(v)
+    for agg in ("mean", "std", "both"):
+        put(f"act_{agg}", Fm.load_activation_features(f, subs, ["faces", "tools"], agg))
+    assert Fm.load_activation_features(f, subs, ["faces"], "median") == {}     # the reference warns and skips
+    put("conn", Fm.load_connectivity_features(f, subs, ["rest", "task"]))
+    assert Fm.load_fmri_labels(os.path.join(f, "labels"), subs) == {1: 1, 2: 0, 3: 1}
+    for binary in (True, False):
+        lab = Ed.load_eeg_labels(os.path.join(e, "labels"), binary)
+        got[f"eeg_labels_{int(binary)}"] = np.array(sorted(lab.items()), dtype=np.float64)
+    bands = {"alpha": "Alpha", "beta": "Beta"}
+    put("eeg_conn", Ed.load_eeg_conn_features(os.path.join(e, "conn"), subs, bands, ["open", "close"]))
+    put("eeg_pw", Ed.load_eeg_pw_features(os.path.join(e, "pw"), subs, ["alpha", "beta"], ["1_Hz", "2_Hz"]))
+    put("eeg_erp", Ed.load_eeg_erp_features(os.path.join(e, "erp"), subs, ["alpha", "beta"], ["1_Hz", "2_Hz"]))
+    keys = [str(k) for k in fx["expected_keys"]]
+    assert list(got) == keys
+    for i, k in enumerate(keys):
+        exp = fx[f"exp_{i}"]
+        assert got[k].shape == exp.shape and got[k].dtype == exp.dtype and np.array_equal(got[k], exp), k
+    with pytest.raises(FileNotFoundError):
+        Ed.load_eeg_labels(str(tmp_path / "nowhere"))
+    with pytest.raises(ValueError):
+        (tmp_path / "bad").mkdir()
+        (tmp_path / "bad" / "labels.csv").write_text("who,what\n1,2\n")
+        Fm.load_fmri_labels(str(tmp_path / "bad"), subs)
+
+
+def test_f3_per_fold_normalizer_and_collate_match_reference_golden(golden):
+    import multimodal_eeg_fmri_amd.crossmodal_eeg_scr as Nb
+    fx = golden("f3_notebook_classes.npz")
+    data = {tuple(int(v) for v in k): a for k, a in zip(fx["norm_keys"], fx["norm_vals"])}
+    n = Nb.PerFoldNormalizer()
+    n.fit_on_indices(data, fx["norm_train_idx"], fx["norm_subjects"])
+    assert n.stats["mean"] == fx["norm_mean"] and n.stats["std"] == fx["norm_std"]
+    out = n.transform(data)
+    assert np.array_equal(np.stack(list(out.values())), fx["norm_out"])
+    batch = [(torch.randn(20, 4), torch.randn(3, 12), torch.randn(7), i, i % 2) for i in range(3)]
+    erp, pw, conn, subj, y = Nb.collate_trimodal(batch)
+    assert list(erp.shape) == list(fx["collate_erp_shape"]) == [3, 4, 20] and pw.shape == (3, 3, 12)
+    assert conn.shape == (3, 7) and subj.dtype == y.dtype == torch.long
+    assert Nb.collate_trimodal([b[:2] + b[3:] for b in batch])[2] is None
+    with pytest.raises(ValueError):
+        Nb.collate_trimodal([b[:3] for b in batch])
+
+
+def test_a10_fmri_dataset_collate_and_metrics():
+    act = {s: torch.full((4,), float(s)) for s in (3, 1, 2, 7)}
+    conn = {s: torch.full((6,), float(s)) for s in (1, 2, 3)}
+    ds = Fm.fMRIDataset(act, conn, {1: 0, 2: 1, 3: 1, 9: 0}, reg_labels={2: 0.5}, transform=lambda t: t * 2)
+    assert [s["subject"] for s in ds.samples] == [1, 2, 3] and len(ds) == 3
+    a, c, y, r, subj = Fm.collate_fmri([ds[i] for i in range(3)])
+    assert a.shape == (3, 4) and c.shape == (3, 6) and a[2, 0] == 6.0
+    assert y.tolist() == [0, 1, 1] and r.tolist() == [0.0, 0.5, 0.0] and subj == [1, 2, 3]
+    m = Fm.classification_metrics(np.array([0, 1, 1, 0]), np.array([0, 1, 0, 0]),
+                                  np.array([[.9, .1], [.2, .8], [.6, .4], [.7, .3]]))
+    assert m["Accuracy"] == 0.75 and m["AUC"] == 1.0 and set(m) == {"Accuracy", "F1", "Precision", "Recall", "AUC"}
+    w = B.balanced_class_weights([0, 0, 0, 1])
+    assert torch.allclose(w, torch.tensor([4 / 6, 4 / 2]))
+
+
+def test_fused_adamw_state_dict_is_torch_adamw_layout():
+    """checkpoint drop-in (FlexibleTrainer.save_checkpoint, EEG notebook cell 23): torch.optim.AdamW loads
+    the FusedAdamW state_dict and the other way round."""
+    from multimodal_eeg_fmri_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    net[0].bias.requires_grad_(False)
+    fused = FusedAdamW(net.parameters(), lr=3e-4, weight_decay=0.02, betas=(0.8, 0.95))
+    fused.bucket.m.copy_(torch.arange(fused.bucket.n, dtype=torch.float32))
+    fused.bucket.v.fill_(2.0)
+    fused.bucket.state[0] = 7.0
+    sd = fused.state_dict()
+    ref = torch.optim.AdamW(net.parameters())
+    assert set(sd["param_groups"][0]) == set(ref.state_dict()["param_groups"][0])
+    ref.load_state_dict(sd)
+    g = ref.param_groups[0]
+    assert g["lr"] == 3e-4 and g["weight_decay"] == 0.02 and tuple(g["betas"]) == (0.8, 0.95)
+    assert 1 not in ref.state_dict()["state"]                     # the frozen bias carries no state
+    st = ref.state[net[1].weight]
+    assert float(st["step"]) == 7.0 and torch.equal(st["exp_avg_sq"], torch.full((2, 3), 2.0))
+    assert torch.equal(ref.state[net[0].weight]["exp_avg"], torch.arange(12.0).view(3, 4))
+    fused2 = FusedAdamW(net.parameters())
+    fused2.load_state_dict(ref.state_dict())
+    assert torch.equal(fused2.bucket.m, fused.bucket.m) and torch.equal(fused2.bucket.v, fused.bucket.v)
+    assert fused2.bucket.state[0] == 7.0 and fused2.param_groups[0]["lr"] == 3e-4 and fused2.betas == (0.8, 0.95)

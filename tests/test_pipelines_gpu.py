@@ -1,0 +1,191 @@
+"""GPU: the callers either side of the hot path on the HIP kernels -
+the reference's epoch loops, the LOOCV bridge protocol, FlexibleTrainer and its checkpoint container,
+FocalLoss against the reference's values (tests/golden/f3_notebook_classes.npz)."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader
+
+from oracle.fixtures import build, seeded_randn
+
+import multimodal_eeg_fmri_amd.bridge_utils as Bu
+import multimodal_eeg_fmri_amd.crossmodal_eeg_scr as Nb
+import multimodal_eeg_fmri_amd.fmri_utils as Fm
+from multimodal_eeg_fmri_amd.optim import FusedAdamW
+
+pytestmark = pytest.mark.gpu
+
+
+def test_focal_loss_vs_reference_golden(golden):
+    """values and input gradients of the notebook's FocalLoss for three (alpha, gamma) pairs and all three
+    reductions; fp32 kernel vs fp32 reference: 2e-5 relative."""
+    fx = golden("f3_notebook_classes.npz")
+    logits, tgt = torch.as_tensor(fx["focal_logits"]).cuda(), torch.as_tensor(fx["focal_target"]).cuda()
+    for alpha, gamma in ((0.25, 2.0), (1.0, 0.0), (0.5, 1.5)):
+        for red in ("mean", "sum", "none"):
+            z = logits.clone().requires_grad_(True)
+            loss = Nb.FocalLoss(alpha, gamma, red)(z, tgt)
+            loss.sum().backward()
+            key = f"focal_{alpha}_{gamma}_{red}"
+            torch.testing.assert_close(loss.detach().cpu(), torch.as_tensor(fx[key]), rtol=2e-5, atol=1e-6)
+            torch.testing.assert_close(z.grad.cpu(), torch.as_tensor(fx[key + "_grad"]), rtol=2e-5, atol=1e-6)
+
+
+def test_fused_adamw_checkpoint_continues_like_torch_adamw():
+    """three fused steps, state exported in torch's layout, then one more step on each side with the same
+    gradient: parameters agree to 1e-6 (same update rule, same moments, same step count)."""
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 8), torch.nn.Linear(8, 4)).cuda()
+    opt = FusedAdamW(net.parameters(), lr=1e-2, weight_decay=0.05)
+    grads = [[torch.randn_like(p) for p in net.parameters()] for _ in range(4)]
+    for step in range(3):
+        opt.zero_grad()
+        for p, g in zip(net.parameters(), grads[step]):
+            p.grad = g.clone()
+        opt.step()
+    twin = torch.nn.Sequential(torch.nn.Linear(16, 8), torch.nn.Linear(8, 4)).cuda()
+    twin.load_state_dict(net.state_dict())
+    ref = torch.optim.AdamW(twin.parameters())
+    ref.load_state_dict(opt.state_dict())
+    opt.zero_grad()
+    for p, q, g in zip(net.parameters(), twin.parameters(), grads[3]):
+        p.grad, q.grad = g.clone(), g.clone()
+    opt.step()
+    ref.step()
+    for p, q in zip(net.parameters(), twin.parameters()):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-6, atol=1e-6)
+
+
+def _separable_fmri(n, da, dc, seed):
+    g = torch.Generator().manual_seed(seed)
+    y = torch.arange(n) % 2
+    act = torch.randn(n, da, generator=g) + (y.float() * 2 - 1).unsqueeze(1) * 0.8
+    conn = torch.randn(n, dc, generator=g) + (y.float() * 2 - 1).unsqueeze(1) * 0.4
+    return ({i: act[i] for i in range(n)}, {i: conn[i] for i in range(n)}, {i: int(y[i]) for i in range(n)})
+
+
+def test_a10_fmri_train_epoch_and_evaluate():
+    """reference loop shape (run_fmri_v11.py:430-504): the loss falls and the held-in accuracy rises on
+    linearly separable synthetic subjects; the regression task returns the four regression metrics."""
+    act, conn, lab = _separable_fmri(64, 40, 60, 5)
+    ds = Fm.fMRIDataset(act, conn, lab, reg_labels={i: float(lab[i]) * 2 - 1 for i in lab})
+    loader = DataLoader(ds, batch_size=16, shuffle=True, collate_fn=Fm.collate_fmri,
+                        generator=torch.Generator().manual_seed(0))
+    dev = torch.device("cuda")
+    model = build(Fm.fMRIFusionNet, 81, 40, 60, dropout=0.1).cuda()
+    opt = FusedAdamW(model.parameters(), lr=2e-3, weight_decay=1e-4)
+    crit = Bu.WeightedCrossEntropy().cuda()
+    losses = [Fm.train_epoch(model, loader, opt, crit, dev, "classification", grad_clip=1.0) for _ in range(12)]
+    assert losses[-1] < 0.5 * losses[0], losses
+    assert opt.max_grad_norm == 1.0
+    metrics, targets, probs = Fm.evaluate(model, loader, dev, "classification", 2)
+    assert metrics["Accuracy"] >= 0.95 and metrics["AUC"] >= 0.98 and probs.shape == (64, 2) and targets.shape == (64,)
+    reg = build(Fm.fMRIFusionNet, 82, 40, 60, dropout=0.0, task="regression").cuda()
+    ropt = FusedAdamW(reg.parameters(), lr=2e-3)
+
+    class MSE(torch.nn.Module):
+        def forward(self, out, y):
+            return ((out.float() - y) ** 2).mean()
+    r0 = Fm.train_epoch(reg, loader, ropt, MSE(), dev, "regression")
+    for _ in range(10):
+        r1 = Fm.train_epoch(reg, loader, ropt, MSE(), dev, "regression")
+    assert r1 < r0
+    m, t, p = Fm.evaluate(reg, loader, dev, "regression")
+    assert set(m) == {"MSE", "RMSE", "MAE", "R2"} and p.shape == t.shape == (64,)
+
+
+def test_f1_bridge_loocv_protocol():
+    """_test_bridge.py:826-970 on 12 synthetic subjects whose class shifts both feature vectors: every
+    fold trains a fresh bridge on the HIP path, the held-out predictions beat chance clearly, and every
+    per-subject artefact of the reference loop is produced with the reference's shapes."""
+    g = torch.Generator().manual_seed(11)
+    n = 12
+    y = torch.arange(n) % 2
+    shift = (y.float() * 2 - 1).unsqueeze(1)
+    eeg = torch.randn(n, 128, generator=g) * 0.5 + shift * 0.7
+    fmri = torch.randn(n, 64, generator=g) * 0.5 + shift * 0.7
+    subs = list(range(101, 101 + n))
+    ds = Bu.BridgeFeatureDataset({s: eeg[i] for i, s in enumerate(subs)}, {s: fmri[i] for i, s in enumerate(subs)},
+                                 {s: int(y[i]) for i, s in enumerate(subs)}, subs)
+    res = Bu.run_bridge_loocv(ds, lr=2e-3, num_epochs=12, patience=6, batch_size=8, dropout=0.1, ig_steps=16, seed=0)
+    assert [p[0] for p in res["predictions"]] == subs
+    assert res["metrics"]["Accuracy"] >= 0.9 and res["metrics"]["AUC"] >= 0.9, res["metrics"]
+    assert len(res["fusion_weights"]) == n and set(res["fusion_weights"][0]) == {"eeg_weight", "fmri_weight", "temperature"}
+    s0 = subs[0]
+    assert res["fused_features"][s0].shape == (128,)
+    assert res["saliency"][s0]["eeg"].shape == (128,) and res["saliency"][s0]["fmri"].shape == (64,)
+    assert res["integrated_gradients"][s0]["eeg"].shape == (128,) and np.isfinite(res["integrated_gradients"][s0]["fmri"]).all()
+    af = res["attn_fusion"][s0]
+    assert af["fusion_weights"].shape == (2,) and af["attn_weights"].shape == (1, 2) and abs(af["fusion_weights"].sum() - 1) < 1e-4
+    # evaluate_bridge: same metric dict through the loader interface
+    model = build(Bu.EEGfMRIBridgeFusionNet, 5).cuda()
+    loader = DataLoader(ds, batch_size=5, collate_fn=Bu.collate_bridge)
+    m, t, p, ss = Bu.evaluate_bridge(model, loader, torch.device("cuda"))
+    assert ss == subs and p.shape == (n, 2) and set(m) == {"Accuracy", "F1", "Precision", "Recall", "AUC"}
+
+
+def _trimodal_batches(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    y = torch.arange(n) % 2
+    s = (y.float() * 2 - 1)
+    erp = torch.randn(n, 8, 256, generator=g) + s.view(-1, 1, 1) * 0.5
+    pw = torch.randn(n, 8, 256, generator=g) + s.view(-1, 1, 1) * 0.5
+    conn = torch.randn(n, 36, generator=g) + s.view(-1, 1) * 0.5
+    # samples arrive time-major (T, C) as in the notebook's datasets: collate_trimodal / _unpack_batch flip them
+    return [(erp[i].t().contiguous(), pw[i].t().contiguous(), conn[i], i, int(y[i])) for i in range(n)]
+
+
+@pytest.mark.parametrize("focal", [False, True])
+def test_f1_flexible_trainer_trains_and_checkpoints(tmp_path, focal):
+    """FlexibleTrainer (EEG notebook cell 23) around ImprovedTriModalFusionNet: the training loss falls,
+    evaluate() returns the notebook's 6-tuple, and the checkpoint has the notebook's container keys, loads
+    into a fresh trainer (same logits afterwards) and its optimizer part loads into torch.optim.AdamW."""
+    samples = _trimodal_batches(32, 21)
+    loader = DataLoader(samples, batch_size=8, shuffle=True, collate_fn=Nb.collate_trimodal,
+                        generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(1)
+    model = Nb.ImprovedTriModalFusionNet(in_pw_dim=8, in_erp_dim=8, in_conn_dim=36, dropout=0.1)
+    tr = Nb.FlexibleTrainer(model, lr=1e-3, weight_decay=1e-4, modality="trimodal", use_focal_loss=focal,
+                            class_weights=None if focal else torch.tensor([1.0, 1.5]))
+    losses = []
+    for _ in range(6):
+        losses.append(tr.train_one_epoch(loader, grad_clip=1.0))
+        tr.scheduler.step(losses[-1])
+        tr.track_fusion_weights()
+    assert losses[-1] < losses[0], losses
+    assert set(tr.fusion_weights_history[-1]) == {"temperature", "erp_weight", "pw_weight", "conn_weight"}
+    metrics, targets, probs, feats, gates, subj = tr.evaluate(loader, 2)
+    assert set(metrics) == {"Accuracy", "F1", "Precision", "Recall"} and probs.shape == (32, 2)
+    assert sum(f.shape[0] for f in feats) == 32 and feats[0].shape[1] == 128 and gates[0].shape[1] == 3
+    assert sorted(int(s) for s in subj) == list(range(32))
+    path = str(tmp_path / "best_trimodal_fold1.pt")
+    tr.save_checkpoint(path, epoch=6, metrics=metrics)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "metrics"}
+    assert all(k.startswith("model.") for k in ck["model_state_dict"])
+    model2 = Nb.ImprovedTriModalFusionNet(in_pw_dim=8, in_erp_dim=8, in_conn_dim=36, dropout=0.1)
+    tr2 = Nb.FlexibleTrainer(model2, modality="trimodal")
+    epoch, m2 = tr2.load_checkpoint(path)
+    assert epoch == 6 and m2 == metrics and tr2.opt.param_groups[0]["lr"] == tr.opt.param_groups[0]["lr"]
+    assert torch.equal(tr2.opt.bucket.m, tr.opt.bucket.m) and tr2.opt.bucket.state[0] == tr.opt.bucket.state[0]
+    erp, pw, conn, _, _ = Nb.collate_trimodal(samples[:8])
+    model.eval(); model2.eval()
+    with torch.no_grad():
+        a = model(erp.cuda(), pw.cuda(), conn.cuda())
+        b = model2(erp.cuda(), pw.cuda(), conn.cuda())
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
+    torch.optim.AdamW(model2.parameters()).load_state_dict(ck["optimizer_state_dict"])
+
+
+def test_f1_flexible_trainer_two_modality_wrapper():
+    """ImprovedSmartFusionNet + modality='fusion' with 4-tuple batches (no connectivity input)."""
+    samples = [s[:2] + s[3:] for s in _trimodal_batches(16, 22)]
+    loader = DataLoader(samples, batch_size=8, collate_fn=Nb.collate_trimodal)
+    torch.manual_seed(2)
+    tr = Nb.FlexibleTrainer(Nb.ImprovedSmartFusionNet(in_pw_dim=8, in_erp_dim=8, dropout=0.1), lr=1e-3, modality="fusion")
+    l0 = tr.train_one_epoch(loader)
+    for _ in range(4):
+        l1 = tr.train_one_epoch(loader)
+    assert l1 < l0
+    metrics, _, probs, feats, gates, _ = tr.evaluate(loader, 2)
+    assert probs.shape == (16, 2) and gates[0].shape[1] == 2 and set(tr.get_fusion_weights()) == {"temperature", "erp_weight", "pw_weight"}
