@@ -324,6 +324,10 @@ int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out,
 int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, int T, int nfft, int hop,
                   int ch_off, int ch_total, hipStream_t stream);
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
+/* drop_path / DropPath (crossmodal_v4_enhancements.py:639-658): out[b][...] = x[b][...] * keep_b / (1 - p),
+ * keep_b from the counter hash of (seed, b); calling it on the upstream gradient is the backward */
+int mm_drop_path(const float* x, float* out, int64_t B, int64_t inner, float drop_p, uint32_t seed,
+                 const uint32_t* seed_epoch, hipStream_t stream);
 /* AdaptiveAvgPool1d(1) of the Lite encoders on bf16 [R][S][N] */
 int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t stream);
 

@@ -887,6 +887,16 @@ __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restr
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
 }
 
+// drop_path / stochastic depth (crossmodal_v4_enhancements.py:639-650): sample b is kept with
+// probability 1 - p and scaled by 1 / (1 - p); the mask depends on (seed, b) only, so the same
+// launch on the upstream gradient is the backward.
+__global__ void drop_path_kernel(const float* __restrict__ x, float* __restrict__ o, size_t n, size_t inner,
+                                 uint32_t thresh, float inv_keep, uint32_t base, const uint32_t* __restrict__ epoch) {
+    const uint32_t seed = mm_eff_seed(base, epoch);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        o[i] = x[i] * dropout_scale(seed, (uint32_t)(i / inner), thresh, inv_keep);
+}
+
 // mean over S of bf16 [R][S][N] -> fp32 [R][N]   (AdaptiveAvgPool1d(1) of the Lite encoders)
 __global__ void meanpool_bf16_kernel(const bf16* __restrict__ x, float* __restrict__ out, int S, int N) {
     const int r = blockIdx.x;
@@ -1156,6 +1166,15 @@ int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_
     MM_REQUIRE(a && b && out && n > 0, "mul_f32: null");
     hipLaunchKernelGGL(mul_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, a, b, out, (size_t)n);
     return mm_check_launch("mul_f32");
+}
+
+int mm_drop_path(const float* x, float* out, int64_t B, int64_t inner, float drop_p, uint32_t seed,
+                 const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(x && out && B > 0 && inner > 0 && drop_p >= 0.f && drop_p < 1.f, "drop_path: bad args");
+    const uint32_t thresh = (uint32_t)fminf(drop_p * 4294967296.f, 4294967295.f);
+    hipLaunchKernelGGL(drop_path_kernel, dim3(grid_h((size_t)(B * inner))), dim3(256), 0, st, x, out, (size_t)(B * inner),
+                       (size_t)inner, thresh, 1.f / (1.f - drop_p), seed, seed_epoch);
+    return mm_check_launch("drop_path");
 }
 
 int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t st) {

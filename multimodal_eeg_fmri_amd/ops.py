@@ -1041,7 +1041,10 @@ def focal_loss(logits, target, alpha=0.25, gamma=2.0, reduction="mean"):
 
 
 def drop_path(x, drop_prob):
-    raise NotImplementedError("DropPath is unused on the reference hot path (crossmodal_v4_enhancements.py:639-658)")
+    """training-mode stochastic depth (crossmodal_v4_enhancements.py:639-650) in one launch"""
+    _need_gpu(x)
+    from . import small_autograd as sa
+    return sa.DropPathFn.apply(x, float(drop_prob))
 
 
 def smoothed_cross_entropy(pred, target, smoothing):

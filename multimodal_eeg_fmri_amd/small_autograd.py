@@ -403,6 +403,29 @@ class WeightedCEFn(torch.autograd.Function):
         return dl * g, None, None
 
 
+class DropPathFn(torch.autograd.Function):
+    """per-sample stochastic depth; forward and backward are the same masked scale (``mm_drop_path``)."""
+
+    @staticmethod
+    def forward(ctx, x, drop_p):
+        x = _f(x)
+        seed = ops._next_seed()
+        y = torch.empty_like(x)
+        B = x.shape[0]
+        _hip.call("mm_drop_path", x, y, B, x.numel() // B, drop_p, seed, ops.EP())
+        ctx.meta = (drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        drop_p, seed = ctx.meta
+        g = _f(g)
+        out = torch.empty_like(g)
+        B = g.shape[0]
+        _hip.call("mm_drop_path", g, out, B, g.numel() // B, drop_p, seed, ops.EP())
+        return out, None
+
+
 class FocalLossFn(torch.autograd.Function):
     """FocalLoss(alpha, gamma, reduction) of the EEG notebook (cell 20) in one launch (``mm_focal_loss``)."""
 

@@ -189,3 +189,25 @@ def test_f1_flexible_trainer_two_modality_wrapper():
     assert l1 < l0
     metrics, _, probs, feats, gates, _ = tr.evaluate(loader, 2)
     assert probs.shape == (16, 2) and gates[0].shape[1] == 2 and set(tr.get_fusion_weights()) == {"temperature", "erp_weight", "pw_weight"}
+
+
+def test_a8_drop_path_per_sample_mask_and_backward():
+    """drop_path (crossmodal_v4_enhancements.py:639-650): every sample is either zeroed or scaled by
+    1/(1-p) as a whole, the keep rate is 1-p within sampling noise, the backward applies the same mask,
+    eval / p = 0 is the identity."""
+    import multimodal_eeg_fmri_amd.crossmodal_v4_enhancements as Cv
+    x = torch.randn(4096, 3, 5, device="cuda").abs() + 0.1
+    assert Cv.drop_path(x, 0.3, training=False) is x and Cv.drop_path(x, 0.0, training=True) is x
+    xin = x.clone().requires_grad_(True)
+    layer = Cv.DropPath(0.3).train()
+    y = layer(xin)
+    ratio = (y / x).flatten(1)
+    kept = ratio[:, 0] > 0
+    assert torch.all((ratio - ratio[:, :1]).abs() < 1e-6)
+    torch.testing.assert_close(ratio[kept], torch.full_like(ratio[kept], 1 / 0.7), rtol=1e-6, atol=1e-6)
+    assert abs(kept.float().mean().item() - 0.7) < 0.03
+    y.backward(torch.ones_like(y))
+    torch.testing.assert_close(xin.grad, ratio.view_as(x), rtol=1e-6, atol=1e-6)
+    y2 = layer(xin.detach())
+    assert not torch.equal(y2 > 0, y > 0)                   # a fresh mask per call
+    assert layer.eval()(x) is x
