@@ -63,9 +63,48 @@ def cpu_baseline(pairs: int, steps: int = 2):
     for _ in range(steps):
         step()
     dt = (time.perf_counter() - t0) / steps
+    torch.set_num_threads(1)                  # "also report 1-thread for reference"
+    t0 = time.perf_counter()
+    step()
+    dt1 = time.perf_counter() - t0
+    torch.set_num_threads(cores)
+    c1 = cpu_baseline_c1_lite()
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"{steps} timed + 1 warm-up full training steps of {pairs} pairs "
-                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step"}
+                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step",
+            "one_thread": {"value": pairs / dt1, "unit": "pairs/s", "sample": f"1 step, {dt1:.1f} s"},
+            "c1_lite": c1}
+
+
+def cpu_baseline_c1_lite(steps: int = 20):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): B=8, 8 ch x 256 ERP + power, 459
+    connectivity features through the V4-Lite classifier; oracle training step (label-smoothed CE,
+    clip 1.0, AdamW lr 5e-5 wd 0.01 as run_training_lite.py:465-488) on the host cores."""
+    from oracle import ref_functional as RF
+    import multimodal_eeg_fmri_amd.crossmodal_v4_enhancements as Cv
+    torch.manual_seed(0)
+    m = Cv.EnhancedTriModalFusionNetV4Lite(8, 8, 459, dropout=0.0)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    leaves = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(leaves, lr=5e-5, weight_decay=0.01)
+    g = torch.Generator().manual_seed(1234)
+    erp, pw, conn = torch.randn(8, 8, 256, generator=g), torch.randn(8, 8, 256, generator=g), torch.randn(8, 459, generator=g)
+    y = torch.arange(8) % 2
+
+    def step():
+        opt.zero_grad()
+        loss = RF.label_smoothing_ce(RF.trimodal_lite(sd, erp, pw, conn, train=True)[0], y, 0.1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in leaves if p.grad is not None], 1.0)
+        opt.step()
+    for _ in range(2):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 8 / dt, "unit": "samples/s", "sample": f"{steps} timed + 2 warm-up V4-Lite training steps of 8 "
+            f"samples, fp32 torch CPU oracle, {dt * 1e3:.1f} ms/step"}
 
 
 def fit_and_retrieve(steps: int, lr: float = 3e-4, dropout: float = 0.1, held_out_batches: int = 8):
@@ -106,8 +145,8 @@ def fit_and_retrieve(steps: int, lr: float = 3e-4, dropout: float = 0.1, held_ou
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.3)
     ap.add_argument("--profile", action="store_true", help="skip the post-region event-timing steps (for rocprofv3 runs)")
