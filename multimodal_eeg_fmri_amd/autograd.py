@@ -55,8 +55,14 @@ def _wgrad_slots(dy, x, dw, dbr, B, T, cinp, N, k, pad, cin):
         _hip.call("mm_conv1d_wgrad_slots", B, T, cinp, N, k, ctypes.addressof(out))
         slots = _SLOTS[key] = int(out.value)
     ws = _empty((slots, N, k, cinp), _F32, dy)                   # every element has exactly one writer: no memset
-    _hip.call("mm_conv1d_wgrad", dy, x, ws, dbr, B, T, cinp, N, k, pad, cinp, k * cinp, 1, cinp,
-              slots, N * k * cinp, 1)
+    bag = _BAG["cur"]
+    if bag is not None and k == 1:
+        # a Linear's weight gradient feeds nothing but the final slot sum: collect it; the bag issues
+        # all of them as ONE launch when it is flushed (possibly on another stream, off the chain)
+        bag.defer_wgrad(dy, x, ws, dbr, B, T, cinp, N, slots)
+    else:
+        _hip.call("mm_conv1d_wgrad", dy, x, ws, dbr, B, T, cinp, N, k, pad, cinp, k * cinp, 1, cinp,
+                  slots, N * k * cinp, 1)
     _scatter_into(dw, ws, N, cin, k, cinp, slots)
 
 
@@ -111,6 +117,7 @@ class GradBag:
         self.fresh: Dict[int, torch.Tensor] = {}
         self.pending = []            # (src_ptr, dst_ptr, K, nrep, stride)
         self.scatters = []           # (ws_ptr, dw_ptr, Cout, Cin, taps, Cinp, nrep)
+        self.wgrads = []             # (dy_ptr, x_ptr, ws_ptr, dbias_ptr, B, T, Cin, Cout, Cin_real, nslots)
         self._keep = []
 
     def defer(self, src_ptr: int, dst: torch.Tensor, K: int, nrep: int, stride: int, keep=None):
@@ -121,16 +128,26 @@ class GradBag:
         self.scatters.append((ws.data_ptr(), dw.data_ptr(), cout, cin, taps, cinp, nrep))
         self._keep.append((dw, ws))
 
+    def defer_wgrad(self, dy, x, ws, dbr, B, T, cinp, N, slots):
+        self.wgrads.append((dy.data_ptr(), x.data_ptr(), ws.data_ptr(), dbr.data_ptr() if dbr is not None else 0,
+                            B, T, cinp, N, cinp, slots))
+        self._keep.append((dy, x, ws, dbr))
+
     def hand_over(self) -> "GradBag":
         """move everything deferred so far into a new bag (to be flushed elsewhere, e.g. on another stream)"""
         other = GradBag()
-        other.pending, other.scatters, other._keep = self.pending, self.scatters, self._keep
-        self.pending, self.scatters, self._keep = [], [], []
+        other.pending, other.scatters, other.wgrads, other._keep = self.pending, self.scatters, self.wgrads, self._keep
+        self.pending, self.scatters, self.wgrads, self._keep = [], [], [], []
         return other
 
     def flush(self, device):
         import ctypes
         import struct
+        if self.wgrads:                                  # first: the slot sums and bias reductions below read them
+            raw = b"".join(struct.pack("<QQQQiiiiiiii", *d, 0, 0) for d in self.wgrads)
+            host = ctypes.create_string_buffer(raw, len(raw))
+            _hip.call("mm_conv1d_wgrad_many", ctypes.addressof(host), len(self.wgrads))
+            self.wgrads = []
         if self.scatters:
             raw = b"".join(struct.pack("<QQiiiiii", *d, 0) for d in self.scatters)
             host = ctypes.create_string_buffer(raw, len(raw))

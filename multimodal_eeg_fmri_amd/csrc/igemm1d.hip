@@ -369,16 +369,16 @@ struct WgradArgs {
 };
 
 template <int TAPS>
-__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz) {
     __shared__ __attribute__((aligned(16))) bf16 Ys[WG_MK * WG_LD];
     __shared__ __attribute__((aligned(16))) bf16 Xs[(WG_MK + TAPS - 1) * WG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
     const int chunksT = (a.T + a.rows_per_wg - 1) / a.rows_per_wg;
-    const int b = blockIdx.x / chunksT;
-    const int tbeg = (blockIdx.x % chunksT) * a.rows_per_wg;
+    const int b = bx / chunksT;
+    const int tbeg = (bx % chunksT) * a.rows_per_wg;
     const int tend = min(a.T, tbeg + a.rows_per_wg);
-    const int n0 = blockIdx.y * 64, c0 = blockIdx.z * 64;
+    const int n0 = by * 64, c0 = bz * 64;
     const bf16* dyb = a.dy + (size_t)b * a.T * a.Cout;
     const bf16* xb = a.x + (size_t)b * a.T * a.Cin;
 
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int kk = 0; kk < WG_MK; kk += 16) {
             const bf16x8 af = tr_frag(Ys, kk, wn * 32, lane);
-            if (a.dbias && blockIdx.z == 0 && wc == 0)
+            if (a.dbias && bz == 0 && wc == 0)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bsum += (float)af[j];
 #pragma unroll
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
     }
     // D[i = n][j = c]: lane owns column c, rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int c = c0 + wc * 32 + (lane & 31);
-    float* dwr = a.dw + (size_t)(a.slot_mode ? blockIdx.x : blockIdx.x % a.nrep) * a.rep_stride;
+    float* dwr = a.dw + (size_t)(a.slot_mode ? bx : bx % a.nrep) * a.rep_stride;
     if (c < a.Cin_real) {
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
@@ -453,11 +453,29 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
                 }
             }
     }
-    if (a.dbias && blockIdx.z == 0 && wc == 0) {
+    if (a.dbias && bz == 0 && wc == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         const int n = n0 + wn * 32 + (lane & 31);
-        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(blockIdx.x % MM_REPL) * a.Cout + n, bsum);
+        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(bx % MM_REPL) * a.Cout + n, bsum);
     }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
+    conv1d_wgrad_body<TAPS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// several independent Linear (taps = 1) weight gradients in ONE launch: workgroup id -> (problem,
+// its own 3-D block index).  The transformer blocks' eight weight-gradient GEMMs have nothing waiting
+// on them but the final slot sum, so a trainer collects them and issues them once, off the chain.
+constexpr int WM_MAX = 12;
+struct WgradTable { WgradArgs a[WM_MAX]; int first[WM_MAX + 1]; int gx[WM_MAX], gy[WM_MAX]; int n; };
+__global__ __launch_bounds__(256) void conv1d_wgrad_many_kernel(WgradTable tab) {
+    int p = 0;
+    while (p + 1 < tab.n && (int)blockIdx.x >= tab.first[p + 1]) ++p;
+    const int local = blockIdx.x - tab.first[p];
+    const int gx = tab.gx[p], gy = tab.gy[p];
+    conv1d_wgrad_body<1>(tab.a[p], local % gx, (local / gx) % gy, local / (gx * gy));
 }
 
 // dw[n][c][tap] += sum_rep ws[rep][n][tap][c]   (replicated contiguous-atomics workspace -> PyTorch layout)
@@ -663,6 +681,40 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
         case 7: return launch_wgrad<7>(a, st);
         default: return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_wgrad: taps=%d (1,3,5,7)", taps);
     }
+}
+
+// desc (host, 64 bytes each): {dy, x, dw(workspace), dbias (nullable)} pointers, then int B, T, Cin, Cout,
+// Cin_real, nslots, 2 x pad.  Linear layers only (taps 1, pad 0), slot mode, workspace layout [slot][n][c].
+struct WgradManyDesc { const void* dy; const void* x; float* dw; float* dbias; int B, T, Cin, Cout, Cin_real, nslots, p0, p1; };
+int mm_conv1d_wgrad_many(const void* desc_host, int n, hipStream_t st) {
+    MM_REQUIRE(desc_host && n > 0, "conv1d_wgrad_many: bad args");
+    const WgradManyDesc* d = (const WgradManyDesc*)desc_host;
+    for (int base = 0; base < n; base += WM_MAX) {
+        WgradTable tab;
+        tab.n = (n - base < WM_MAX) ? n - base : WM_MAX;
+        int total = 0;
+        for (int i = 0; i < tab.n; ++i) {
+            const WgradManyDesc& q = d[base + i];
+            MM_REQUIRE(q.dy && q.x && q.dw && q.B > 0 && q.T > 0, "conv1d_wgrad_many: null/invalid");
+            MM_REQUIRE(q.Cin % 8 == 0 && q.Cout % 8 == 0 && q.Cin_real > 0 && q.Cin_real <= q.Cin,
+                       "conv1d_wgrad_many: Cin=%d Cout=%d", q.Cin, q.Cout);
+            WgradArgs& a = tab.a[i];
+            a.dy = (const bf16*)q.dy; a.x = (const bf16*)q.x; a.dw = q.dw; a.dbias = q.dbias;
+            a.B = q.B; a.T = q.T; a.Cin = q.Cin; a.Cout = q.Cout; a.pad = 0; a.Cin_real = q.Cin_real;
+            a.sn = q.Cin; a.sc = 1; a.stap = q.Cin; a.nrep = q.nslots; a.rep_stride = (long)q.Cout * q.Cin; a.slot_mode = 1;
+            a.rows_per_wg = wgrad_rows_per_wg(q.B, q.T, q.Cin, q.Cout, 1, 1);
+            const int chunks = q.B * ceil_div(q.T, a.rows_per_wg);
+            MM_REQUIRE(q.nslots >= chunks, "conv1d_wgrad_many: needs %d slots (mm_conv1d_wgrad_slots), got %d", chunks, q.nslots);
+            tab.first[i] = total;
+            tab.gx[i] = chunks; tab.gy[i] = ceil_div(q.Cout, 64);
+            total += chunks * tab.gy[i] * ceil_div(q.Cin, 64);
+        }
+        tab.first[tab.n] = total;
+        hipLaunchKernelGGL(conv1d_wgrad_many_kernel, dim3(total), dim3(256), 0, st, tab);
+        const int rc = mm_check_launch("conv1d_wgrad_many");
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // many independent replica reductions in one launch: desc[i] = {src, dst, K, nrep, stride}

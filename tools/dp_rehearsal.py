@@ -92,7 +92,41 @@ def run_rccl_world1():
         dist.destroy_process_group()
 
 
+def time_rccl_world1(steps=200):
+    """cost of the N > 1 execution shape at full C2 size, measurable on one GPU: the single-graph step
+    against four graph segments with the three RCCL calls between them (world of one rank, so the
+    collectives move no data - what is timed is segmentation + collective launch overhead)."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+        eeg, fmri = synthetic_pairs(32, 64, 1024, (32, 32, 32), seed=1234)
+        out = {}
+        for tag, group, force in (("one graph", None, False), ("segments + RCCL", dist.group.WORLD, True)):
+            torch.manual_seed(0)
+            tr = BridgeTrainer(eeg_channels=64, dropout=0.3, group=group).train()
+            tr.force_segments = force
+            for _ in range(20):
+                tr.train_step(eeg, fmri)
+            e, f = tr.input_buffers()
+            e.copy_(eeg); f.copy_(fmri)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.train_step(e, f)
+            torch.cuda.synchronize()
+            out[tag] = (time.perf_counter() - t0) / steps * 1e3
+        return out
+    finally:
+        dist.destroy_process_group()
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rccl1time":
+        print({k: f"{v:.3f} ms/step" for k, v in time_rccl_world1().items()})
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rccl1":
         r = run_rccl_world1()
         print(r)
