@@ -146,6 +146,13 @@ int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, c
                      const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
                      int M, int D, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                      hipStream_t stream);
+/* TemporalTransformerBlock backward (enhanced_models_v4.py:86-105, autograd of norm1/norm2 feeding
+ * self_attn.in_proj / linear1): data gradient of that Linear and the LayerNorm-128 backward in one launch.
+ * dy (M, K) bf16; w = the Linear's data-gradient weight image (mm_prep_conv_weight's w_dgrad: 128 x K);
+ * x / stat / gamma / dres / dx / dx_bf16 / dgb_repl / dropout arguments exactly as mm_layernorm_bwd. */
+int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                           const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
+                           float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,

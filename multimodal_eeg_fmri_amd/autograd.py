@@ -247,6 +247,24 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"]
 
 
+def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, drop_p, seed):
+    """backward of ``Linear(LayerNorm(x))``: weight / bias gradients of the Linear (``h`` = LN(x) bf16 is its
+    input), then d x = LN_backward(dy W) + dres.  Width 128 with M % 32 == 0 (the transformer blocks) runs
+    the data-gradient GEMM with the LayerNorm backward as its epilogue; anything else takes two launches."""
+    weight, bias = (lin.weight, lin.bias) if lin is not None else wb
+    M, D = x.shape
+    if D == 128 and M % 32 == 0:
+        linear_bwd(bag, dy, h, weight, bias, need_dx=False)
+        _, wd, cinp, coutp = ops.weights.get(weight, True)
+        if coutp != dy.shape[1] or cinp != D:
+            raise _hip.HipLibraryError(f"linear_ln_bwd: dY width {dy.shape[1]} / LN width {D} != weight image {coutp} x {cinp}")
+        _hip.call("mm_linear_dgrad_ln_bwd", dy, wd, M, coutp, x, stat, ln.weight, dres, dx, dx_bf16, dgb,
+                  drop_p, seed, ops.EP())
+        return
+    dh = linear_bwd(bag, dy, h, weight, bias)
+    _hip.call("mm_layernorm_bwd", dh, None, x, stat, ln.weight, dres, dx, dx_bf16, dgb, M, D, drop_p, seed, ops.EP())
+
+
 def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, emit_for=None):
     """dx2 fp32 (M, D) -> (dx0 fp32 (M, D), bf16(dx0 * mask) or None).
 
@@ -264,12 +282,11 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     if dy2 is None:
         dy2 = _mask_cast(g_f32=dx2, drop_p=p, seed=s3)
     dz = linear_bwd(bag, dy2, s["g"], blk.linear2.weight, blk.linear2.bias, below=(s["z"], blk._act, p, s2))
-    dh2 = linear_bwd(bag, dz, s["h2"], blk.linear1.weight, blk.linear1.bias)
     dx1 = _empty((M, D), _F32, dx2)
     dyo = _empty((M, D), _BF, dx2)                      # bf16(dx1 * mask1): out-proj backward operand
     dgb = _zeros((REPL, 2, D), dx2)
-    _hip.call("mm_layernorm_bwd", dh2, None, s["x1"], s["st2"], blk.norm2.weight, dx2, dx1, dyo, dgb, M, D,
-              float(p), int(s1), ops.EP())
+    _linear_ln_bwd(bag, dz, s["h2"], blk.linear1, None, s["x1"], s["st2"], blk.norm2, dx2, dx1, dyo, dgb,
+                   float(p), int(s1))
     _ln_param_grads(bag, blk.norm2, dgb, D)
     # attention output projection:  x1 = x0 + drop(o Wo^T + bo)
     do = linear_bwd(bag, dyo, s["o"].view(M, D), at.out_proj.weight, at.out_proj.bias)
@@ -279,13 +296,12 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     pa, sa = s.get("attn_drop", (0.0, 0))
     _hip.call("mm_attn_bwd", s["qkv"], s["o"], do, s["lse"], dqkv, delta, B, L, blk.nhead, dh, float(dh) ** -0.5,
               float(pa), int(sa), ops.EP())
-    dh1 = linear_bwd(bag, dqkv.view(M, 3 * D), s["h1"], at.in_proj_weight, at.in_proj_bias)
     dx0 = _empty((M, D), _F32, dx2)
     emit = _empty((M, D), _BF, dx2) if emit_for is not None else None
     ep, es = emit_for if emit_for is not None else (0.0, 0)
     dgb = _zeros((REPL, 2, D), dx2)
-    _hip.call("mm_layernorm_bwd", dh1, None, s["x"], s["st1"], blk.norm1.weight, dx1, dx0, emit, dgb, M, D,
-              float(ep), int(es), ops.EP())
+    _linear_ln_bwd(bag, dqkv.view(M, 3 * D), s["h1"], None, (at.in_proj_weight, at.in_proj_bias), s["x"], s["st1"],
+                   blk.norm1, dx1, dx0, emit, dgb, float(ep), int(es))
     _ln_param_grads(bag, blk.norm1, dgb, D)
     return dx0, emit
 

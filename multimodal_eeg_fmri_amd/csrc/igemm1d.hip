@@ -36,6 +36,13 @@ struct EpiArgs {
     const uint32_t* drop_epoch;
     const bf16* gradz;        // backward fusion: v *= act'(gradz[idx]) (nullptr = off)
     int gradz_act;
+    // LayerNorm-128 backward fused behind a data-gradient GEMM (ln_x != nullptr): the tile rows are
+    // d(LN output); residual = gradient of the skip path; out_f32 / out_bf16 = d(LN input) (bf16 copy
+    // carries the consumer's dropout mask); ln_dgb = [REPL][2][128] {dgamma, dbeta} replicas
+    const float* ln_x;
+    const float* ln_stat;     // [M][2] mean, rstd
+    const float* ln_gamma;
+    float* ln_dgb;
 };
 
 struct ConvArgs {
@@ -127,6 +134,71 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
                 atomicAdd(&rep[n0 + i], sstat[i]);
                 atomicAdd(&rep[N + n0 + i], sstat[BN + i]);
             }
+    }
+}
+
+// dgrad GEMM -> LayerNorm backward in one pass (N == BN == 128, T % BM == 0: checked on the host).
+// 32 lanes own one row (4 columns each): the two row means are 5-step half-wave shuffles; every
+// thread keeps its 4 columns' dgamma / dbeta partial sums over the rows it walks.
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
+                                                float* sstat) {
+    static_assert(BN == 128, "LayerNorm-128 epilogue");
+    constexpr int LDC = BN + 4;
+    const int cg = tid & 31, rr = tid >> 5;
+    const float4 gg = *reinterpret_cast<const float4*>(e.ln_gamma + cg * 4);
+    const float gam[4] = {gg.x, gg.y, gg.z, gg.w};
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.shift) {
+        const float4 s4 = *reinterpret_cast<const float4*>(e.shift + cg * 4);
+        sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+    }
+    const uint32_t dseed = e.drop_thresh ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
+    float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int row = rr; row < BM; row += 8) {
+        const size_t m = (size_t)b * T + t0 + row;
+        const size_t base = m * 128 + cg * 4;
+        const float4 a4 = *reinterpret_cast<const float4*>(Cs + row * LDC + cg * 4);
+        const float4 xv = *reinterpret_cast<const float4*>(e.ln_x + base);
+        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e.residual) rv = *reinterpret_cast<const float4*>(e.residual + base);
+        const float2 st = *reinterpret_cast<const float2*>(e.ln_stat + 2 * m);
+        const float dyv[4] = {a4.x + sh[0], a4.y + sh[1], a4.z + sh[2], a4.w + sh[3]};
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
+        float xh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xh[c] = (xs[c] - st.x) * st.y;
+            const float gh = dyv[c] * gam[c];
+            s1 += gh; s2 += gh * xh[c];
+            ag[c] += dyv[c] * xh[c]; ab[c] += dyv[c];
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 *= (1.f / 128.f); s2 *= (1.f / 128.f);
+        float o4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o4[c] = st.y * (dyv[c] * gam[c] - s1 - xh[c] * s2) + rs[c];
+        if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + base) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        if (e.out_bf16) {
+            bf16x4 ob;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                ob[c] = (bf16)(e.drop_thresh ? o4[c] * dropout_scale(dseed, (uint32_t)(base + c), e.drop_thresh, e.drop_inv_keep)
+                                             : o4[c]);
+            *reinterpret_cast<bf16x4*>(e.out_bf16 + base) = ob;
+        }
+    }
+    if (e.ln_dgb) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            atomicAdd(&sstat[cg * 4 + c], ag[c]);
+            atomicAdd(&sstat[BN + cg * 4 + c], ab[c]);
+        }
+        __syncthreads();
+        float* rep = e.ln_dgb + (size_t)(blockIdx.x % MM_REPL) * 256;
+        atomicAdd(&rep[tid], sstat[tid]);                       // 256 threads: [dgamma 128 | dbeta 128]
     }
 }
 
@@ -237,9 +309,15 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
                 const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 Cs[row * LDC + (wn * TN + j) * 32 + lr] = acc[i][j][r];
             }
-    if (a.e.stats)
+    if (a.e.stats || a.e.ln_dgb)
         for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
     __syncthreads();
+    if constexpr (BM == 32 && BN == 128) {
+        if (a.e.ln_x) {
+            epilogue_ln_bwd<BM, BN>(Cs, a.e, tid, b, t0, a.T, sstat);
+            return;
+        }
+    }
     epilogue_rows<BM, BN>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
 }
 
@@ -624,6 +702,7 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.drop_epoch = seed_epoch;
     a.e.gradz = (const bf16*)gradz; a.e.gradz_act = gradz_act;
     a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    a.e.ln_x = nullptr; a.e.ln_stat = nullptr; a.e.ln_gamma = nullptr; a.e.ln_dgb = nullptr;
     // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
     // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS
     const int kct = (taps == 1 && Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : (Cin % 32 == 0 ? 32 : 16));
@@ -640,6 +719,36 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     if ((long)B * ceil_div(T, 64) * ceil_div(Cout, 128) <= 512) { MM_FWD(32, 128, 1, 4) }
     MM_FWD(64, 128, 2, 2)
 #undef MM_FWD
+}
+
+// dx = LayerNorm128_backward(dy @ W^T) + dres in one launch: the data-gradient GEMM of the Linear that
+// consumed LN(x) (dy (M, K) bf16, w = that Linear's dgrad image (128 rows of K)) with the LayerNorm
+// backward as its epilogue.  Same results as mm_conv1d_fwd followed by mm_layernorm_bwd, except that the
+// d(LN output) rows stay fp32 instead of a bf16 round trip.
+int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                           const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
+                           float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(dy && w && x && stat && gamma && (dx || dx_bf16), "linear_dgrad_ln_bwd: null");
+    MM_REQUIRE(M > 0 && M % 32 == 0 && K > 0 && K % 16 == 0, "linear_dgrad_ln_bwd: M=%d (multiple of 32) K=%d (multiple of 16)", M, K);
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_dgrad_ln_bwd: drop_p");
+    ConvArgs a;
+    a.x = (const bf16*)dy; a.w = (const bf16*)w;
+    a.B = 1; a.T = M; a.Cin = K; a.Cout = 128; a.taps = 1; a.pad = 0;
+    a.e.scale = nullptr; a.e.shift = nullptr; a.e.residual = dres; a.e.pe = nullptr; a.e.stats = nullptr;
+    a.e.out_f32 = dx; a.e.out_bf16 = (bf16*)dx_bf16; a.e.out_pre = nullptr;
+    a.e.act = 0; a.e.pool = 1;
+    a.e.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    a.e.drop_seed = seed; a.e.drop_epoch = seed_epoch;
+    a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    a.e.gradz = nullptr; a.e.gradz_act = 0;
+    a.e.ln_x = x; a.e.ln_stat = stat; a.e.ln_gamma = gamma; a.e.ln_dgb = dgb_repl;
+    const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
+    switch (kct) {
+        case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);
+        case 32: return launch_fwd<32, 128, 1, 4, 32>(a, st);
+        case 64: return launch_fwd<32, 128, 1, 4, 64>(a, st);
+        default: return launch_fwd<32, 128, 1, 4, 128>(a, st);
+    }
 }
 
 // rows of T per workgroup.  Atomic mode: every workgroup ends with 64 x 64 x taps fp32 atomics, so for

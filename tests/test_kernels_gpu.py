@@ -192,6 +192,48 @@ def test_layernorm_fwd_bwd(M, D):
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,K", [(512, 384), (96, 512), (64, 48)])
+def test_linear_dgrad_fused_with_layernorm_backward(M, K):
+    """mm_linear_dgrad_ln_bwd = data gradient of Linear(128 -> K) followed by the LayerNorm-128 backward
+    (+ skip-path gradient), vs torch autograd of Linear(LayerNorm(x)) in fp32 with the same bf16-rounded
+    operands: dx 2e-3 (bf16 MFMA operands, fp32 accumulate), dgamma / dbeta 2e-3 relative to their scale."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, 128, generator=g) * 2 + 0.5
+    gam = 0.5 + torch.rand(128, generator=g)
+    bet = torch.randn(128, generator=g)
+    w = _bf(torch.randn(K, 128, generator=g) * 0.1)
+    dy = _bf(torch.randn(M, K, generator=g))
+    dres = torch.randn(M, 128, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    (F.layer_norm(xr, (128,), gr, br, 1e-5) @ w.t()).backward(dy)
+    out = torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")
+    stat = torch.empty(M, 2, device="cuda")
+    hip.call("mm_layernorm_fwd", x.cuda(), gam.cuda(), bet.cuda(), out, None, stat, M, 128, 1e-5)
+    _, wd = _prep_w(hip, w.view(K, 128, 1), 128, K)
+    dx = torch.empty(M, 128, device="cuda")
+    dxb = torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")
+    dgb = torch.zeros(32, 2, 128, device="cuda")
+    hip.call("mm_linear_dgrad_ln_bwd", dy.cuda().to(torch.bfloat16), wd, M, K, x.cuda(), stat, gam.cuda(), dres.cuda(),
+             dx, dxb, dgb, 0.0, 0, None)
+    torch.testing.assert_close(dx.cpu(), xr.grad + dres, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(dxb.float().cpu(), dx.cpu(), rtol=1e-2, atol=1e-2)
+    dg, db = dgb.sum(0)[0].cpu(), dgb.sum(0)[1].cpu()
+    torch.testing.assert_close(dg, gr.grad, rtol=2e-3, atol=2e-3 * gr.grad.abs().max().item())
+    torch.testing.assert_close(db, br.grad, rtol=2e-3, atol=2e-3 * br.grad.abs().max().item())
+    # dropout on the bf16 copy only: kept elements are dx / (1 - p), the fp32 output is untouched
+    dx2 = torch.empty_like(dx)
+    hip.call("mm_linear_dgrad_ln_bwd", dy.cuda().to(torch.bfloat16), wd, M, K, x.cuda(), stat, gam.cuda(), dres.cuda(),
+             dx2, dxb, None, 0.25, 77, None)
+    assert torch.equal(dx2, dx)
+    kept = dxb.float() != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.03
+    torch.testing.assert_close(dxb.float()[kept], (dx / 0.75)[kept], rtol=1e-2, atol=1e-2)
+    with pytest.raises(Exception):
+        hip.call("mm_linear_dgrad_ln_bwd", dy.cuda().to(torch.bfloat16), wd, M - 1, K, x.cuda(), stat, gam.cuda(),
+                 None, dx, None, None, 0.0, 0, None)
+
+
 @pytest.mark.parametrize("pool", [1, 2])
 @pytest.mark.parametrize("N", [128, 48])
 def test_bn_act_pool_train_fwd_bwd(pool, N):
