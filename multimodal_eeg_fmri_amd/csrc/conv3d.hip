@@ -831,17 +831,19 @@ __global__ __launch_bounds__(256) void pool3_bwd_reduce_kernel(Pool3Args a) {
             }
         }
     }
-    __shared__ float red[2][1024];
-    for (int i = threadIdx.x; i < 2 * a.N; i += 256) (&red[0][0])[i < a.N ? i : 1024 + i - a.N] = 0.f;
-    __syncthreads();
-    if (active)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { atomicAdd(&red[0][n4 + c], s0[c]); atomicAdd(&red[1][n4 + c], s1[c]); }
+    // plain stores + column walk (LDS float atomics with rows_per_blk-way same-address conflicts are slow)
+    __shared__ __attribute__((aligned(16))) float part[2048];        // [rows_per_blk][2][N]
+    if (active) {
+        float* dst = part + (size_t)ri * 2 * a.N + n4;
+        *reinterpret_cast<float4*>(dst) = make_float4(s0[0], s0[1], s0[2], s0[3]);
+        *reinterpret_cast<float4*>(dst + a.N) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    }
     __syncthreads();
     float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
-    for (int i = threadIdx.x; i < a.N; i += 256) {
-        atomicAdd(&rep[i], red[0][i]);
-        atomicAdd(&rep[a.N + i], red[1][i]);
+    for (int i = threadIdx.x; i < 2 * a.N; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rows_per_blk; ++r) s += part[r * 2 * a.N + i];
+        atomicAdd(&rep[i], s);
     }
 }
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
     a.seed = mm_eff_seed(a.seed, a.epoch);
     __shared__ __attribute__((aligned(16))) unsigned short halo[HSZ];
     __shared__ float red[4][32];
-    __shared__ float wred[27][32];
+    __shared__ float wred[4][27][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int tw = (a.W + 31) / 32, th = (a.H + 7) / 8, td = a.D / 2;
@@ -270,16 +270,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
 #pragma unroll
         for (int pass = 0; pass < (MODE == 4 ? 2 : 1); ++pass) {
             __syncthreads();
-            for (int i = tid; i < 27 * 32; i += 256) (&wred[0][0])[i] = 0.f;
-            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; ++r) {                            // every wave parks its tile: no LDS atomics
                 const int tap = (r & 3) + 8 * (r >> 2) + 4 * lh;      // D row
-                if (tap < 27) atomicAdd(&wred[tap][lr], pass ? dwacc3[r] : dwacc[r]);
+                if (tap < 27) wred[wave][tap][lr] = pass ? dwacc3[r] : dwacc[r];
             }
             __syncthreads();
             float* dwr = (pass ? a.dw3 : a.dw) + (size_t)(blockIdx.x % MM_REPL) * 27 * 32;
-            for (int i = tid; i < 27 * 32; i += 256) atomicAdd(&dwr[i], (&wred[0][0])[i]);
+            for (int i = tid; i < 27 * 32; i += 256)
+                atomicAdd(&dwr[i], ((&wred[0][0][0])[i] + (&wred[1][0][0])[i]) + ((&wred[2][0][0])[i] + (&wred[3][0][0])[i]));
         }
     }
 }

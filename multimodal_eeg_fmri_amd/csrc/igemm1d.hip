@@ -121,19 +121,24 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
         }
     }
     if (e.stats) {
-        if (nok)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                atomicAdd(&sstat[cg * 4 + c], s1[c]);
-                atomicAdd(&sstat[BN + cg * 4 + c], s2[c]);
-            }
+        // block reduction of the per-thread column sums: plain stores into the (now dead) C tile, then a
+        // column walk.  LDS float atomics with RPP-way same-address conflicts cost ~2 us per workgroup.
+        __syncthreads();                                   // every thread is done reading Cs
+        float* part = const_cast<float*>(Cs);              // [RPP][2][BN]  (RPP * 2 * BN = 2048 floats <= BM * LDC)
+        static_assert(RPP * 2 * BN <= BM * LDC, "partials fit the C tile");
+        *reinterpret_cast<float4*>(part + (rr * 2 + 0) * BN + cg * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *reinterpret_cast<float4*>(part + (rr * 2 + 1) * BN + cg * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
         __syncthreads();
         float* rep = e.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * N;
-        for (int i = tid; i < BN; i += 256)
-            if (n0 + i < N) {
-                atomicAdd(&rep[n0 + i], sstat[i]);
-                atomicAdd(&rep[N + n0 + i], sstat[BN + i]);
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, col = i % BN;
+            if (n0 + col < N) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) s += part[(r * 2 + which) * BN + col];
+                atomicAdd(&rep[which * N + n0 + col], s);
             }
+        }
     }
 }
 
@@ -191,14 +196,16 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
         }
     }
     if (e.ln_dgb) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            atomicAdd(&sstat[cg * 4 + c], ag[c]);
-            atomicAdd(&sstat[BN + cg * 4 + c], ab[c]);
-        }
+        __syncthreads();                                   // every thread is done reading Cs
+        float* part = const_cast<float*>(Cs);              // [8 row groups][dgamma 128 | dbeta 128]
+        static_assert(8 * 256 <= BM * LDC, "partials fit the C tile");
+        *reinterpret_cast<float4*>(part + rr * 256 + cg * 4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+        *reinterpret_cast<float4*>(part + rr * 256 + 128 + cg * 4) = make_float4(ab[0], ab[1], ab[2], ab[3]);
         __syncthreads();
-        float* rep = e.ln_dgb + (size_t)(blockIdx.x % MM_REPL) * 256;
-        atomicAdd(&rep[tid], sstat[tid]);                       // 256 threads: [dgamma 128 | dbeta 128]
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += part[r * 256 + tid];
+        atomicAdd(&e.ln_dgb[(size_t)(blockIdx.x % MM_REPL) * 256 + tid], s);
     }
 }
 

@@ -195,6 +195,25 @@ def graph_time(fn, n=20):
     return timeit(g.replay, iters=5) / n
 
 
+def bn_bwd_case(R, S, N, pool, f32_dout):
+    """the two BatchNorm+act backward passes at an EEG conv layer's shape (graph-replayed launches)"""
+    y = torch.randn(R, S, N, device="cuda")
+    out4 = torch.stack([torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda") * 0.1,
+                        torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")]).contiguous()
+    So = S // pool
+    dout = torch.randn(R, So, N, device="cuda")
+    db = None if f32_dout else dout.to(BF)
+    df = dout if f32_dout else None
+    sums = torch.zeros(32, 2, N, device="cuda")
+    dy = torch.empty(R, S, N, dtype=BF, device="cuda")
+    args = (R, S, N, ops.ACT["gelu"], pool, 0, 0.3, 1234, 0.0, 0, None)
+    red = graph_time(lambda: _hip.call("mm_bn_act_bwd_reduce", y, out4, db, df, sums, *args))
+    app = graph_time(lambda: _hip.call("mm_bn_act_bwd_apply", y, out4, db, df, sums, dy, None, *args, 1, 32))
+    mb = (y.numel() * 4 + dout.numel() * (4 if f32_dout else 2)) / 1e6
+    print(f"bn_bwd R={R} S={S} N={N} pool={pool} dout={'f32' if f32_dout else 'bf16'}: reduce {red:6.1f} us "
+          f"({mb / red:5.2f} TB/s of {mb:.1f} MB)  apply {app:6.1f} us")
+
+
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     if "floor" in flt:
@@ -214,6 +233,11 @@ def main():
         conv1d_wgrad_case(32, 1024, 64, 128, 5)
         conv1d_wgrad_case(32, 512, 128, 128, 3)
         conv1d_wgrad_case(1, M, 128, 512, 1)
+    if "bn" in flt:
+        bn_bwd_case(32, 512, 128, 1, True)
+        bn_bwd_case(32, 1024, 128, 2, False)
+        bn_bwd_case(32, 1024, 64, 1, False)
+        return
     if "pmc3d" in flt:
         conv3d_case(32, 16, 32, 64, wgrad=False)
         return
