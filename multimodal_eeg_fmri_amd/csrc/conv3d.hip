@@ -150,11 +150,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
         __syncthreads();
     }
 
-    float* sstat = reinterpret_cast<float*>(smem);
-    if (a.stats) {
-        for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
-        __syncthreads();
-    }
+    float* sstat = reinterpret_cast<float*>(smem);            // [WM][2][BN] per-wave-row partial sums (plain stores)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + lr;
@@ -180,19 +176,23 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
             s2 += __shfl_xor(s2, 32, 64);
             if (lh == 0) {
                 const int nl = (wn * TN + j) * 32 + lr;
-                atomicAdd(&sstat[nl], s1);
-                atomicAdd(&sstat[BN + nl], s2);
+                sstat[(wm * 2 + 0) * BN + nl] = s1;
+                sstat[(wm * 2 + 1) * BN + nl] = s2;
             }
         }
     }
     if (a.stats) {
         __syncthreads();
         float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * a.Cout;
-        for (int i = tid; i < BN; i += 256)
-            if (n0 + i < a.Cout) {
-                atomicAdd(&rep[n0 + i], sstat[i]);
-                atomicAdd(&rep[a.Cout + n0 + i], sstat[BN + i]);
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, col = i % BN;
+            if (n0 + col < a.Cout) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) t += sstat[(w * 2 + which) * BN + col];
+                atomicAdd(&rep[which * a.Cout + n0 + col], t);
             }
+        }
     }
 }
 
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Wl = reinterpret_cast<bf16*>(smem);                       // [64*27][32]
     bf16* Hl = Wl + WR_BN * 27 * WR_CIN;                             // [720][32]
-    float* sstat = reinterpret_cast<float*>(Hl + WR_LROWS * WR_CIN); // [2][64]
+    float* sstat = reinterpret_cast<float*>(Hl + WR_LROWS * WR_CIN); // [4 waves][2][64] partial BatchNorm sums
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: keeps tile addressing in SGPRs
     const int lr = lane & 31, lh = lane >> 5;
@@ -275,8 +275,6 @@ __global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
 #define WR_STAMP(idx) do { if ((a.dbg & 512) && tid == 0 && (idx) < 16) stamps[idx] = wall_clock64(); } while (0)
     WR_STAMP(0);
     if ((a.dbg & 512) && tid == 0) stamps[12] = clock64();          // shader-clock counter, for the MHz estimate
-    if (a.stats)
-        for (int i = tid; i < 2 * WR_BN; i += 256) sstat[i] = 0.f;
 
     auto coords = [&](int tile) {
         WrTile t;
@@ -503,15 +501,17 @@ __global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
             st1[j] += __shfl_xor(st1[j], 32);
             st2[j] += __shfl_xor(st2[j], 32);
         }
-        if (lh == 0) {
-            atomicAdd(&sstat[lr], st1[0]);
-            atomicAdd(&sstat[32 + lr], st1[1]);
-            atomicAdd(&sstat[WR_BN + lr], st2[0]);
-            atomicAdd(&sstat[WR_BN + 32 + lr], st2[1]);
+        if (lh == 0) {                                   // every wave parks its column sums: no LDS atomics
+            float* mine = sstat + wave * 2 * WR_BN;
+            mine[lr] = st1[0];
+            mine[32 + lr] = st1[1];
+            mine[WR_BN + lr] = st2[0];
+            mine[WR_BN + 32 + lr] = st2[1];
         }
         __syncthreads();
         float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * WR_BN;
-        if (tid < 2 * WR_BN) atomicAdd(&rep[tid], sstat[tid]);
+        if (tid < 2 * WR_BN)
+            atomicAdd(&rep[tid], (sstat[tid] + sstat[2 * WR_BN + tid]) + (sstat[4 * WR_BN + tid] + sstat[6 * WR_BN + tid]));
     }
     WR_STAMP(15);
     if ((a.dbg & 512) && tid == 0) stamps[13] = clock64();
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
 }
 
 int launch3d_wres(const Conv3dArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)(WR_BN * 27 + WR_LROWS) * WR_CIN * sizeof(bf16) + 2 * WR_BN * sizeof(float);
+    constexpr size_t lds = (size_t)(WR_BN * 27 + WR_LROWS) * WR_CIN * sizeof(bf16) + 4 * 2 * WR_BN * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = conv3d_fwd_wres_kernel;
     static bool attr_set = false;
