@@ -149,10 +149,13 @@ class BridgeTrainer(nn.Module):
         self._stamp(5)
         return z, (sv_e, sv_f, sv_h)
 
-    def _seg_loss(self, z, z_all, scal, dz_all):
+    def _seg_loss(self, z, z_all, scal, dz_all, zero=True):
+        """``zero=False``: ``scal`` / ``dz_all`` are slices of the step's scratch arena, already cleared by
+        its one memset (the world-1 step: two fill launches fewer on the critical chain)."""
         B, N2 = z.shape
-        scal.zero_()
-        dz_all.zero_()
+        if zero:
+            scal.zero_()
+            dz_all.zero_()
         ls = self.head.logit_scale.detach().reshape(1)
         _hip.call("mm_clip_loss", z, z_all, ls, scal, dz_all, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
         self._stamp(6)
@@ -160,8 +163,9 @@ class BridgeTrainer(nn.Module):
     def _seg_backward(self, saved, dz, scal):
         sv_e, sv_f, sv_h = saved
         bag = GradBag()
-        self.head.logit_scale._mm_grad.add_(scal[3])
         with deferred(bag, dz.device):           # ONE batched reduction after both branches joined
+            # d loss / d logit_scale (scal[3]) rides in the same batched reduction launch
+            bag.defer(scal.data_ptr() + 12, self.head.logit_scale._mm_grad.view(1), 1, 1, 1, keep=scal)
             dfe, dff = contrastive_embed_bwd(bag, sv_h, dz)
             self._stamp(7)
             main = torch.cuda.current_stream()
@@ -218,9 +222,13 @@ class BridgeTrainer(nn.Module):
     def _step_manual_body(self, eeg, fmri):
         z, saved = self._seg_forward(eeg, fmri)
         z_all = dp.gather_embeddings(z, self.group)
-        scal = torch.empty(4, device=z.device)
-        dz_all = torch.empty_like(z_all)
-        self._seg_loss(z, z_all, scal, dz_all)
+        if self.world == 1:
+            scal, dz_all = ops._zeros((4,), z), ops._zeros(tuple(z_all.shape), z)
+            self._seg_loss(z, z_all, scal, dz_all, zero=False)
+        else:
+            scal = torch.empty(4, device=z.device)
+            dz_all = torch.empty_like(z_all)
+            self._seg_loss(z, z_all, scal, dz_all)
         dz = dp.scatter_column_grads(dz_all, self.group)
         self._seg_backward(saved, dz, scal)
         self._seg_optimizer()
@@ -266,8 +274,8 @@ class BridgeTrainer(nn.Module):
         if world == 1 and not (self.force_segments and self.group is not None):
             def whole():
                 z, saved = self._seg_forward(c["eeg"], c["fmri"])
-                c["dz_all"] = torch.empty_like(z)
-                self._seg_loss(z, z, c["scal"], c["dz_all"])
+                c["scal"], c["dz_all"] = ops._zeros((4,), z), ops._zeros(tuple(z.shape), z)   # arena: no fills
+                self._seg_loss(z, z, c["scal"], c["dz_all"], zero=False)
                 self._seg_backward(saved, c["dz_all"], c["scal"])
                 self._seg_adamw()
             record(whole)
