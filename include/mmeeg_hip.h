@@ -224,11 +224,14 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
  *   dW = scale * (A1 - (S1/M) * T - (S2/M) * A3),  A1 = x^T dz, A3 = x^T xhat, T[tap] = sum_v x[v + tap].
  * Zeroed fp32 workspaces (32 replicas each): sums_out [32][2][32] (also the BatchNorm parameter
  * gradients: dbeta = S1, dgamma = S2), a1 / a3 [32][27][32], tapsum [32][32].  dw (PyTorch layout
- * [32][1][3][3][3]) and dbias are ADDED to (dbias only when train == 0; it is identically 0 otherwise). */
+ * [32][1][3][3][3]) and dbias are ADDED to (dbias only when train == 0; it is identically 0 otherwise).
+ * T depends on the input volume alone: mm_conv3d_l1_tapsum may fill it earlier (e.g. during the forward pass,
+ * off the backward chain) and the backward is then called with tapsum_ready = 1. */
+int mm_conv3d_l1_tapsum(const float* x, float* tapsum, int B, int D, int H, int W, hipStream_t stream);
 int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
-                     float* sums_out, float* a1, float* a3, float* tapsum, float* dw, float* dbias, int B, int D,
-                     int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
-                     hipStream_t stream);
+                     float* sums_out, float* a1, float* a3, float* tapsum, int tapsum_ready, float* dw,
+                     float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
+                     const uint32_t* seed_epoch, hipStream_t stream);
 /* dst[c][r] += sum_rep src[rep][r][c] */
 int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t stream);
 

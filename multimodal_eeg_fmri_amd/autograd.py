@@ -60,6 +60,10 @@ def _wgrad_slots(dy, x, dw, dbr, B, T, cinp, N, k, pad, cin):
         # a Linear's weight gradient feeds nothing but the final slot sum: collect it; the bag issues
         # all of them as ONE launch when it is flushed (possibly on another stream, off the chain)
         bag.defer_wgrad(dy, x, ws, dbr, B, T, cinp, N, slots)
+    elif bag is not None and bag.defer_conv_wgrads:
+        # k > 1 convs: same idea, one launch each at flush time (a trainer hands them to an idle stream)
+        bag.calls.append(("mm_conv1d_wgrad", (dy, x, ws, dbr, B, T, cinp, N, k, pad, cinp, k * cinp, 1, cinp,
+                                              slots, N * k * cinp, 1)))
     else:
         _hip.call("mm_conv1d_wgrad", dy, x, ws, dbr, B, T, cinp, N, k, pad, cinp, k * cinp, 1, cinp,
                   slots, N * k * cinp, 1)
@@ -118,6 +122,8 @@ class GradBag:
         self.pending = []            # (src_ptr, dst_ptr, K, nrep, stride)
         self.scatters = []           # (ws_ptr, dw_ptr, Cout, Cin, taps, Cinp, nrep)
         self.wgrads = []             # (dy_ptr, x_ptr, ws_ptr, dbias_ptr, B, T, Cin, Cout, Cin_real, nslots)
+        self.calls = []              # (entry point, args): launches postponed to flush time
+        self.defer_conv_wgrads = False
         self._keep = []
 
     def defer(self, src_ptr: int, dst: torch.Tensor, K: int, nrep: int, stride: int, keep=None):
@@ -137,13 +143,18 @@ class GradBag:
         """move everything deferred so far into a new bag (to be flushed elsewhere, e.g. on another stream)"""
         other = GradBag()
         other.pending, other.scatters, other.wgrads, other._keep = self.pending, self.scatters, self.wgrads, self._keep
-        self.pending, self.scatters, self.wgrads, self._keep = [], [], [], []
+        other.calls = self.calls
+        self.pending, self.scatters, self.wgrads, self.calls, self._keep = [], [], [], [], []
         return other
 
     def flush(self, device):
         import ctypes
         import struct
-        if self.wgrads:                                  # first: the slot sums and bias reductions below read them
+        for name, args in self.calls:                    # first: the slot sums and bias reductions below read them
+            _hip.call(name, *args)
+        self._keep.append(self.calls)
+        self.calls = []
+        if self.wgrads:
             raw = b"".join(struct.pack("<QQQQiiiiiiii", *d, 0, 0) for d in self.wgrads)
             host = ctypes.create_string_buffer(raw, len(raw))
             _hip.call("mm_conv1d_wgrad_many", ctypes.addressof(host), len(self.wgrads))
@@ -330,10 +341,11 @@ class _ModuleFn(torch.autograd.Function):
         return (None, dx) + tuple(bag.result(p) for p in params)
 
 
-def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = False, after_blocks=None):
+def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = False, after_blocks=None,
+                    after_conv2=None):
     """backward of ops._erp_forward_impl (train mode); dout fp32 (B, H).  ``after_blocks()`` is called
-    once the transformer stack's backward has been issued (a trainer hands the reductions collected
-    so far to another stream there)."""
+    once the transformer stack's backward has been issued, ``after_conv2()`` once the second conv block's
+    has (a trainer hands the reductions / weight gradients collected so far to another stream there)."""
     d = pooled_head_bwd(bag, sv["head"], dout)
     B, L, D = d.shape
     d = d.view(B * L, D)
@@ -347,6 +359,8 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
     g = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D))
     g = conv_bn_act_bwd(bag, c2, dout_bf16=g)
+    if after_conv2 is not None:
+        after_conv2()
     g = conv_bn_act_bwd(bag, c1, dout_bf16=g, need_dx=need_dx)
     if not need_dx:
         return None
@@ -519,14 +533,17 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
     sums = _zeros((REPL, 2, 32), x)
     a1 = _zeros((REPL, 27, 32), x)
     a3 = _zeros((REPL, 27, 32), x)
-    tapsum = _zeros((REPL, 32), x)
+    tapsum = s.get("tapsum")                         # filled during the forward pass when the tape asked for it
+    ready = tapsum is not None
+    if not ready:
+        tapsum = _zeros((REPL, 32), x)
     dw = bag.target(conv.weight)
     if dw is None:                                   # frozen conv weight: the sums alone (BatchNorm gradients)
         _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
                   B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
     else:
-        _hip.call("mm_conv3d_l1_bwd", x, s["wimg"], conv.bias, s["out4"], dout, sums, a1, a3, tapsum, dw,
-                  bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
+        _hip.call("mm_conv3d_l1_bwd", x, s["wimg"], conv.bias, s["out4"], dout, sums, a1, a3, tapsum, 1 if ready else 0,
+                  dw, bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
     _bn_param_grads(bag, bn, sums, 32, nrep=REPL)
 
 

@@ -173,13 +173,21 @@ class BridgeTrainer(nn.Module):
             # the transformer stack's weight-gradient slot sums and parameter reductions (~50 MB of
             # reads) do not wait for the end of the chain: they are handed to the side stream, which
             # is idle once the fMRI branch is done
-            handed = {}
+            handed = []
 
             def split():
-                handed["bag"] = bag.hand_over()
-                handed["ev"] = torch.cuda.Event()
-                handed["ev"].record()
-            erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split)          # longer chain first (see _seg_forward)
+                ev = torch.cuda.Event()
+                handed.append((bag.hand_over(), ev))
+                ev.record()
+            # second hand-over: the weight gradients of conv blocks 3 and 2 (k = 3, 5) leave the chain too;
+            # block 1's (the last kernel of the chain) stays, and its slot sum runs on this stream BEFORE
+            # the join below instead of after it
+            def split_convs():
+                split()
+                bag.defer_conv_wgrads = False
+            bag.defer_conv_wgrads = True
+            erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split, after_conv2=split_convs)   # longer chain first (see _seg_forward)
+            bag.flush(dz.device)
             self._stamp(8)
             with torch.cuda.stream(self._side):
                 self._stamp(9)
@@ -187,11 +195,12 @@ class BridgeTrainer(nn.Module):
                 with deferred(bag_f, dz.device):     # hidden beside the rest of the EEG backward
                     volume_encoder_bwd(bag_f, sv_f, dff)
                 self._stamp(10)
-                self._side.wait_event(handed["ev"])
-                handed["bag"].flush(dz.device)
+                for hb, ev in handed:
+                    self._side.wait_event(ev)
+                    hb.flush(dz.device)
             main.wait_stream(self._side)
         self._stamp(11)
-        self._bags = getattr(self, "_bags", [])[-9:] + [bag, bag_f, handed["bag"]]   # keep descriptor tables alive
+        self._bags = getattr(self, "_bags", [])[-12:] + [bag, bag_f] + [hb for hb, _ in handed]   # keep descriptor tables alive
 
     def _seg_optimizer(self):
         b = self.bucket

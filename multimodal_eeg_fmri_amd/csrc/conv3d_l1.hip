@@ -327,17 +327,19 @@ __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict_
 __global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __restrict__ a3, const float* __restrict__ tapsum,
                                   const float* __restrict__ sums, const float* __restrict__ out4, float* __restrict__ dw,
                                   float* __restrict__ dbias, float inv_count, int train) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one output per 32 lanes, one replica per lane: a single load round trip + shuffle sums
+    // (the serial 32-replica loop was five dependent-latency chains: 11 us on 4 workgroups)
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, r = threadIdx.x & 31;
     if (i >= 32 * 27) return;
     const int n = i / 27, tap = i % 27;
-    float A1 = 0.f, A3 = 0.f, St = 0.f, s0 = 0.f, s1 = 0.f;
-    for (int r = 0; r < MM_REPL; ++r) {
-        A1 += a1[(size_t)r * 864 + tap * 32 + n];
-        A3 += a3[(size_t)r * 864 + tap * 32 + n];
-        St += tapsum[r * 32 + tap];
-        s0 += sums[r * 64 + n];
-        s1 += sums[r * 64 + 32 + n];
+    float A1 = a1[(size_t)r * 864 + tap * 32 + n], A3 = a3[(size_t)r * 864 + tap * 32 + n];
+    float St = tapsum[r * 32 + tap], s0 = sums[r * 64 + n], s1 = sums[r * 64 + 32 + n];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        A1 += __shfl_xor(A1, o, 64); A3 += __shfl_xor(A3, o, 64); St += __shfl_xor(St, o, 64);
+        s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64);
     }
+    if (r) return;
     const float sc = out4[n];
     const float c0 = train ? s0 * inv_count : 0.f, c1 = train ? s1 * inv_count : 0.f;
     dw[i] += sc * (A1 - c0 * St - c1 * A3);
@@ -391,9 +393,17 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     return mm_check_launch("conv3d_l1");
 }
 
+int mm_conv3d_l1_tapsum(const float* x, float* tapsum, int B, int D, int H, int W, hipStream_t st) {
+    MM_REQUIRE(x && tapsum && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_tapsum: null/invalid");
+    hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0, st,
+                       x, tapsum, B, D, H, W);
+    return mm_check_launch("conv3d_l1_tapsum");
+}
+
 int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
-                     float* sums_out, float* a1, float* a3, float* tapsum, float* dw, float* dbias, int B, int D, int H,
-                     int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+                     float* sums_out, float* a1, float* a3, float* tapsum, int tapsum_ready, float* dw, float* dbias, int B,
+                     int D, int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                     hipStream_t st) {
     MM_REQUIRE(x && wimg && out4 && dout && sums_out && a1 && a3 && tapsum && dw && B > 0, "conv3d_l1_bwd: null/invalid");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_bwd: D,H,W must be even (MaxPool3d(2))");
     L1Args a;
@@ -404,10 +414,11 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
     a.inv_count = 1.f / ((float)B * D * H * W);
     a.epoch = seed_epoch;
     const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
-    hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0, st,
-                       x, tapsum, B, D, H, W);
+    if (!tapsum_ready)
+        hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0,
+                           st, x, tapsum, B, D, H, W);
     hipLaunchKernelGGL(conv3d_l1_kernel<4>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
+    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 32, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
                        dbias, a.inv_count, train);
     return mm_check_launch("conv3d_l1_bwd");
 }

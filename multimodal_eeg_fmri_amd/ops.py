@@ -581,6 +581,11 @@ def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool):
     h, s = conv3d_bn_act(h, cl[10], cl[11], pool=False, training=training, drop_p=p, need_dgrad=need_dgrad)
     saved.append(s)
     out, hs = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad)
+    if saved[0] is not None and saved[0].get("l1") and cl[0].weight.requires_grad:
+        # per-tap input sums of the layer-1 weight gradient depend on the volume alone: taken here, where the
+        # fMRI stream has slack, instead of at the head of the layer-1 backward
+        saved[0]["tapsum"] = _zeros((REPL, 32), x)
+        _hip.call("mm_conv3d_l1_tapsum", x, saved[0]["tapsum"], B, D, H, W)
     return out, dict(convs=saved, head=hs)
 
 
