@@ -338,6 +338,24 @@ int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out,
 int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, int T, int nfft, int hop,
                   int ch_off, int ch_total, hipStream_t stream);
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
+/* Encoder tail (enhanced_models_v4.py:161-167, 186-191: mean over time -> output_proj = Linear -> GELU ->
+ * Dropout).  mm_linear_fwd_meanpool is the last transformer block's linear2 (+ dropout + residual, fp32 rows
+ * out_f32 (M, N)) that also accumulates the mean over each group of rows_per_group rows (one EEG epoch's
+ * tokens) into the ZEROED pool_out (M / rows_per_group, N).  mm_pooled_head_fwd applies the head to the
+ * pooled rows in fp32 (W is the nn.Linear weight (N, D)); z_pre_bf16 / pooled_bf16 (nullable) are what the
+ * backward and the weight-gradient GEMM need.  mm_pooled_head_bwd: dz = dout * dropout mask * act'(z) (bf16 copy
+ * dz_bf16 for the weight gradient), d pooled = dz W, and dx[b][l][:] = d pooled / L for every token; dx_bf16
+ * (nullable) = the same rows times the consumer's dropout mask (emit_drop_p, emit_seed; element index as in
+ * mm_act_bwd). */
+int mm_linear_fwd_meanpool(const void* x, const void* w, int M, int K, int N, const float* bias, const float* residual,
+                           float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, float* pool_out,
+                           int rows_per_group, hipStream_t stream);
+int mm_pooled_head_fwd(const float* pooled, const float* W, const float* bias, float* out, void* z_pre_bf16,
+                       void* pooled_bf16, int B, int D, int N, int act, float drop_p, uint32_t seed,
+                       const uint32_t* seed_epoch, hipStream_t stream);
+int mm_pooled_head_bwd(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* dx,
+                       void* dx_bf16, int B, int L, int D, int N, int act, float drop_p, uint32_t seed,
+                       float emit_drop_p, uint32_t emit_seed, const uint32_t* seed_epoch, hipStream_t stream);
 /* drop_path / DropPath (crossmodal_v4_enhancements.py:639-658): out[b][...] = x[b][...] * keep_b / (1 - p),
  * keep_b from the counter hash of (seed, b); calling it on the upstream gradient is the backward */
 int mm_drop_path(const float* x, float* out, int64_t B, int64_t inner, float drop_p, uint32_t seed,

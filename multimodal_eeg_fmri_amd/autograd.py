@@ -317,9 +317,24 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     return dx0, emit
 
 
-def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor) -> torch.Tensor:
-    """dout fp32 (B, H) -> d tokens fp32 (B, L, D)"""
+def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor, emit_for=None):
+    """dout fp32 (B, H) -> d tokens fp32 (B, L, D); with ``emit_for`` = (p, seed) of the consumer also its
+    dropout-masked bf16 copy, returned as a pair (fused head only, else None)."""
     lin = s["lin"]
+    if s.get("fused"):
+        B, L, D = s["B"], s["L"], s["D"]
+        N = lin.weight.shape[0]
+        dout = dout.contiguous()
+        dz = _empty((B, N), _BF, dout)
+        dx = _empty((B, L, D), _F32, dout)
+        emit = _empty((B, L, D), _BF, dout) if emit_for is not None else None
+        ep, es = emit_for if emit_for is not None else (0.0, 0)
+        _hip.call("mm_pooled_head_bwd", dout, s["z"], lin.weight, dz, dx, emit, B, L, D, N, ACT[s["act"]],
+                  float(s["drop_p"]), int(s["seed"]), float(ep), int(es), ops.EP())
+        linear_bwd(bag, dz, s["pooled"], lin.weight, lin.bias, need_dx=False)
+        return (dx, emit) if emit_for is not None else dx
+    if emit_for is not None:
+        return pooled_head_bwd(bag, s, dout), None
     dz = _mask_cast(g_f32=dout.contiguous(), z=s["z"], act=s["act"], drop_p=s["drop_p"], seed=s["seed"])
     dpool = linear_bwd(bag, dz, s["pooled"], lin.weight, lin.bias, dx_f32=True)
     B, L, D = s["B"], s["L"], s["D"]
@@ -346,11 +361,16 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     """backward of ops._erp_forward_impl (train mode); dout fp32 (B, H).  ``after_blocks()`` is called
     once the transformer stack's backward has been issued, ``after_conv2()`` once the second conv block's
     has (a trainer hands the reductions / weight gradients collected so far to another stream there)."""
-    d = pooled_head_bwd(bag, sv["head"], dout)
-    B, L, D = d.shape
-    d = d.view(B * L, D)
     blocks = sv["blocks"]
     dy2 = None
+    if blocks:                                       # the head's backward also writes the top block's masked operand
+        d, dy2 = pooled_head_bwd(bag, sv["head"], dout, emit_for=(blocks[-1]["p"], blocks[-1]["seeds"][2]))
+    else:
+        d = pooled_head_bwd(bag, sv["head"], dout)
+    B, L, D = d.shape
+    d = d.view(B * L, D)
+    if dy2 is not None:
+        dy2 = dy2.view(B * L, D)
     for i in range(len(blocks) - 1, -1, -1):
         below = (blocks[i - 1]["p"], blocks[i - 1]["seeds"][2]) if i > 0 else None
         d, dy2 = transformer_block_bwd(bag, blocks[i], d, dy2=dy2, emit_for=below)

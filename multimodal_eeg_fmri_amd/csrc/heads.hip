@@ -887,6 +887,95 @@ __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restr
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
 }
 
+// ---------------------------------------------------------------------------
+// Encoder output head on the pooled token (enhanced_models_v4.py:161-167, 188-191): Linear(D -> N) ->
+// act -> Dropout on pooled[b] (the mean over time arrives already reduced), fp32 FMAs, one workgroup
+// per sample.  Backward: dz = dout * mask * act'(z); d pooled = dz W; every token of the sample gets
+// d pooled / L (the mean's gradient), optionally with a second, dropout-masked bf16 copy for the GEMM
+// that consumes it next.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pooled_head_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             bf16* __restrict__ z_pre, bf16* __restrict__ pooled_bf16,
+                                                             int D, int N, int act, uint32_t thresh, float inv_keep,
+                                                             uint32_t seed, const uint32_t* __restrict__ epoch) {
+    __shared__ float xs[1024];
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        const float v = pooled[(size_t)b * D + k];
+        xs[k] = v;
+        if (pooled_bf16) pooled_bf16[(size_t)b * D + k] = (bf16)v;
+    }
+    __syncthreads();
+    seed = mm_eff_seed(seed, epoch);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* wr = W + (size_t)n * D;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < D; k += 16) {                   // four independent float4 loads per round
+            float4 w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const float4*>(wr + k + q * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[q] += w4[q].x * xs[k + q * 4] + w4[q].y * xs[k + q * 4 + 1] + w4[q].z * xs[k + q * 4 + 2] +
+                          w4[q].w * xs[k + q * 4 + 3];
+        }
+        const float z = (acc[0] + acc[1]) + (acc[2] + acc[3]) + (bias ? bias[n] : 0.f);
+        const size_t idx = (size_t)b * N + n;
+        if (z_pre) z_pre[idx] = (bf16)z;
+        float v = apply_act(z, act);
+        if (thresh) v *= dropout_scale(seed, (uint32_t)idx, thresh, inv_keep);
+        out[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pooled_head_bwd_kernel(const float* __restrict__ dout, const bf16* __restrict__ z_pre,
+                                                             const float* __restrict__ W, bf16* __restrict__ dz_bf16,
+                                                             float* __restrict__ dx, bf16* __restrict__ dx_bf16, int L, int D,
+                                                             int N, int rows_per_wg, int act, uint32_t thresh, float inv_keep,
+                                                             uint32_t seed, uint32_t thresh2, float inv_keep2, uint32_t seed2,
+                                                             const uint32_t* __restrict__ epoch) {
+    __shared__ float dz[1024];
+    __shared__ __attribute__((aligned(16))) float dp[1024];
+    const int b = blockIdx.x, l0 = blockIdx.y * rows_per_wg;
+    seed = mm_eff_seed(seed, epoch);
+    seed2 = mm_eff_seed(seed2, epoch);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const size_t idx = (size_t)b * N + n;
+        float g = dout[idx] * act_grad((float)z_pre[idx], act);
+        if (thresh) g *= dropout_scale(seed, (uint32_t)idx, thresh, inv_keep);
+        dz[n] = g;
+        if (blockIdx.y == 0 && dz_bf16) dz_bf16[idx] = (bf16)g;
+    }
+    __syncthreads();
+    const float invL = 1.f / (float)L;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < N; n += 4) {                    // coalesced across k; four independent chains
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += dz[n + q] * W[(size_t)(n + q) * D + k];
+        }
+        dp[k] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * invL;
+    }
+    __syncthreads();
+    const int vec = D / 4;                                  // float4 groups per row
+    const int lend = min(L, l0 + rows_per_wg);
+    for (int i = threadIdx.x; i < (lend - l0) * vec; i += 256) {
+        const int l = l0 + i / vec, k4 = (i % vec) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(dp + k4);
+        const size_t base = ((size_t)b * L + l) * D + k4;
+        if (dx) *reinterpret_cast<float4*>(dx + base) = v;
+        if (dx_bf16) {
+            const float vs[4] = {v.x, v.y, v.z, v.w};
+            bf16x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                o[c] = (bf16)(thresh2 ? vs[c] * dropout_scale(seed2, (uint32_t)(base + c), thresh2, inv_keep2) : vs[c]);
+            *reinterpret_cast<bf16x4*>(dx_bf16 + base) = o;
+        }
+    }
+}
+
 // drop_path / stochastic depth (crossmodal_v4_enhancements.py:639-650): sample b is kept with
 // probability 1 - p and scaled by 1 / (1 - p); the mask depends on (seed, b) only, so the same
 // launch on the upstream gradient is the backward.
@@ -1166,6 +1255,33 @@ int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_
     MM_REQUIRE(a && b && out && n > 0, "mul_f32: null");
     hipLaunchKernelGGL(mul_f32_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, a, b, out, (size_t)n);
     return mm_check_launch("mul_f32");
+}
+
+int mm_pooled_head_fwd(const float* pooled, const float* W, const float* bias, float* out, void* z_pre_bf16,
+                       void* pooled_bf16, int B, int D, int N, int act, float drop_p, uint32_t seed,
+                       const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(pooled && W && out && B > 0, "pooled_head_fwd: null");
+    MM_REQUIRE(D > 0 && D <= 1024 && D % 16 == 0 && N > 0, "pooled_head_fwd: D=%d (multiple of 16, <= 1024)", D);
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pooled_head_fwd: drop_p");
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    hipLaunchKernelGGL(pooled_head_fwd_kernel, dim3(B), dim3(256), 0, st, pooled, W, bias, out, (bf16*)z_pre_bf16,
+                       (bf16*)pooled_bf16, D, N, act, thresh, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, seed_epoch);
+    return mm_check_launch("pooled_head_fwd");
+}
+
+int mm_pooled_head_bwd(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* dx, void* dx_bf16,
+                       int B, int L, int D, int N, int act, float drop_p, uint32_t seed, float emit_drop_p,
+                       uint32_t emit_seed, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(dout && z_pre_bf16 && W && (dx || dx_bf16) && B > 0 && L > 0, "pooled_head_bwd: null");
+    MM_REQUIRE(D > 0 && D <= 1024 && D % 4 == 0 && N > 0 && N <= 1024 && N % 4 == 0, "pooled_head_bwd: D=%d N=%d", D, N);
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f && emit_drop_p >= 0.f && emit_drop_p < 1.f, "pooled_head_bwd: drop_p");
+    const int rows = 32;
+    const uint32_t t1 = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const uint32_t t2 = emit_drop_p > 0.f ? (uint32_t)((double)emit_drop_p * 4294967296.0) : 0u;
+    hipLaunchKernelGGL(pooled_head_bwd_kernel, dim3(B, (L + rows - 1) / rows), dim3(256), 0, st, dout, (const bf16*)z_pre_bf16, W,
+                       (bf16*)dz_bf16, dx, (bf16*)dx_bf16, L, D, N, rows, act, t1, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed,
+                       t2, emit_drop_p > 0.f ? 1.f / (1.f - emit_drop_p) : 1.f, emit_seed, seed_epoch);
+    return mm_check_launch("pooled_head_bwd");
 }
 
 int mm_drop_path(const float* x, float* out, int64_t B, int64_t inner, float drop_p, uint32_t seed,

@@ -43,6 +43,10 @@ struct EpiArgs {
     const float* ln_stat;     // [M][2] mean, rstd
     const float* ln_gamma;
     float* ln_dgb;
+    // mean over groups of pool_rows consecutive output rows, fused: pool_out[row / pool_rows][n] += out * pool_scale
+    float* pool_out;
+    int pool_rows;
+    float pool_scale;
 };
 
 struct ConvArgs {
@@ -70,7 +74,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
         if (e.shift) sh = *reinterpret_cast<const float4*>(e.shift + n);
     }
     const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, pp[4] = {0, 0, 0, 0};
     const uint32_t dseed = e.drop_thresh ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
     const int To = T / e.pool;
     const int step = e.pool;                   // rows consumed per item
@@ -112,6 +116,8 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
             }
         }
         if (!any) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pp[c] += o[c];
         const int t = t0 + r0;
         const size_t oi = ((size_t)b * To + t / step) * N + n;
         if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
@@ -119,6 +125,22 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
             bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
             *reinterpret_cast<bf16x4*>(e.out_bf16 + oi) = ov;
         }
+    }
+    if (e.pool_out) {
+        // fused mean over rows (all rows of this tile belong to one group: pool_rows % BM == 0, host-checked)
+        __syncthreads();
+        float* part = const_cast<float*>(Cs);              // [RPP][BN]
+        *reinterpret_cast<float4*>(part + rr * BN + cg * 4) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        __syncthreads();
+        const size_t grp = ((size_t)b * T + t0) / e.pool_rows;
+        for (int i = tid; i < BN; i += 256)
+            if (n0 + i < N) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < RPP; ++r) s += part[r * BN + i];
+                atomicAdd(&e.pool_out[grp * N + n0 + i], s * e.pool_scale);
+            }
+        if (e.stats) __syncthreads();
     }
     if (e.stats) {
         // block reduction of the per-thread column sums: plain stores into the (now dead) C tile, then a
@@ -685,6 +707,10 @@ int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) {
     return mm_check_launch("prep_many");
 }
 
+// mm_linear_fwd_meanpool passes its extra epilogue request to mm_conv1d_fwd through this (per host thread)
+struct PoolReq { float* out; int rows; };
+static thread_local PoolReq g_pool = {nullptr, 0};
+
 // Generic forward implicit GEMM.  See include/mmeeg_hip.h for the contract.
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual, const float* pe,
@@ -710,6 +736,7 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.gradz = (const bf16*)gradz; a.e.gradz_act = gradz_act;
     a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
     a.e.ln_x = nullptr; a.e.ln_stat = nullptr; a.e.ln_gamma = nullptr; a.e.ln_dgb = nullptr;
+    a.e.pool_out = g_pool.out; a.e.pool_rows = g_pool.rows; a.e.pool_scale = g_pool.rows ? 1.f / (float)g_pool.rows : 0.f;
     // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
     // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS
     const int kct = (taps == 1 && Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : (Cin % 32 == 0 ? 32 : 16));
@@ -726,6 +753,20 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     if ((long)B * ceil_div(T, 64) * ceil_div(Cout, 128) <= 512) { MM_FWD(32, 128, 1, 4) }
     MM_FWD(64, 128, 2, 2)
 #undef MM_FWD
+}
+
+// y = dropout(x W^T + b) + residual (fp32 rows) AND pool_out[g][n] += mean over the rows_per_group rows of
+// group g of y - the last transformer block's second FFN Linear followed by the encoder's mean over time.
+int mm_linear_fwd_meanpool(const void* x, const void* w, int M, int K, int N, const float* bias, const float* residual,
+                           float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, float* pool_out,
+                           int rows_per_group, hipStream_t st) {
+    MM_REQUIRE(pool_out && out_f32 && rows_per_group > 0 && rows_per_group % 64 == 0 && M % rows_per_group == 0,
+               "linear_fwd_meanpool: rows_per_group=%d must be a multiple of 64 dividing M=%d", rows_per_group, M);
+    g_pool.out = pool_out; g_pool.rows = rows_per_group;
+    const int rc = mm_conv1d_fwd(x, w, 1, M, K, N, 1, 0, nullptr, bias, 0, residual, nullptr, 1, nullptr, out_f32, nullptr,
+                                 nullptr, drop_p, seed, seed_epoch, nullptr, 0, st);
+    g_pool.out = nullptr; g_pool.rows = 0;
+    return rc;
 }
 
 // dx = LayerNorm128_backward(dy @ W^T) + dres in one launch: the data-gradient GEMM of the Linear that
@@ -749,6 +790,7 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
     a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
     a.e.gradz = nullptr; a.e.gradz_act = 0;
     a.e.ln_x = x; a.e.ln_stat = stat; a.e.ln_gamma = gamma; a.e.ln_dgb = dgb_repl;
+    a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
     const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
     switch (kct) {
         case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);

@@ -364,9 +364,11 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
 
 
 def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False,
-                          save: Optional[bool] = None):
+                          save: Optional[bool] = None, pool_out: Optional[torch.Tensor] = None):
     """x fp32 (B, L, d) -> fp32 (B, L, d); returns (out, saved).  ``training``
-    switches dropout on; ``save`` (default = training) keeps what backward needs."""
+    switches dropout on; ``save`` (default = training) keeps what backward needs.
+    ``pool_out`` (zeroed fp32 (B, d)): the second FFN Linear also accumulates the mean over time of
+    the block's output there (the encoder's pooling step, fused into that GEMM's epilogue)."""
     B, L, D = x.shape
     M = B * L
     save = training if save is None else save
@@ -387,8 +389,14 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
     f1 = linear_rows(h2, blk.linear1.weight, blk.linear1.bias, act=blk._act, out_pre=save,
                      drop_p=p, seed=s2, need_dgrad=need_dgrad)
     s3 = _next_seed() if p > 0 else 0
-    x2o = linear_rows(f1["bf16"], blk.linear2.weight, blk.linear2.bias, residual=x1, out_f32=True,
-                      out_bf16=False, drop_p=p, seed=s3, need_dgrad=need_dgrad)["f32"]
+    if pool_out is None:
+        x2o = linear_rows(f1["bf16"], blk.linear2.weight, blk.linear2.bias, residual=x1, out_f32=True,
+                          out_bf16=False, drop_p=p, seed=s3, need_dgrad=need_dgrad)["f32"]
+    else:
+        wf, _, cinp, _ = weights.get(blk.linear2.weight, need_dgrad)
+        x2o = _empty((M, D), _F32, x)
+        _hip.call("mm_linear_fwd_meanpool", f1["bf16"], wf, M, cinp, D, blk.linear2.bias, x1, x2o, float(p), int(s3),
+                  EP(), pool_out, L)
     saved = None
     if save:
         saved = dict(x=x2, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2,
@@ -397,14 +405,27 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
 
 
 def pooled_head_fwd(x: torch.Tensor, lin, *, act="gelu", training=False, drop_p=0.0,
-                    need_dgrad=False, save=None):
-    """mean over L of fp32 (B, L, d) -> Linear -> act [-> dropout]: fp32 (B, out)."""
+                    need_dgrad=False, save=None, pooled_f32=None):
+    """mean over L of fp32 (B, L, d) -> Linear -> act [-> dropout]: fp32 (B, out).
+    ``pooled_f32``: the mean, when the producer of ``x`` already accumulated it (transformer_block_fwd)."""
     B, L, D = x.shape
     save = training if save is None else save
-    pooled = _empty((B, D), _BF, x)
-    _hip.call("mm_meanpool_fwd", x, None, pooled, B, L, D)
     p = drop_p if training else 0.0
     seed = _next_seed() if p > 0 else 0
+    if D % 16 == 0 and D <= 1024:                    # fp32 head kernel: one small launch instead of a 1-workgroup GEMM
+        if pooled_f32 is None:
+            pooled_f32 = _empty((B, D), _F32, x)
+            _hip.call("mm_meanpool_fwd", x, pooled_f32, None, B, L, D)
+        N = lin.weight.shape[0]
+        out = _empty((B, N), _F32, x)
+        z = _empty((B, N), _BF, x) if save else None
+        pooled = _empty((B, D), _BF, x) if save else None
+        _hip.call("mm_pooled_head_fwd", pooled_f32, lin.weight, lin.bias, out, z, pooled, B, D, N, ACT[act], float(p),
+                  int(seed), EP())
+        saved = dict(pooled=pooled, z=z, seed=seed, drop_p=p, B=B, L=L, D=D, lin=lin, act=act, fused=True) if save else None
+        return out, saved
+    pooled = _empty((B, D), _BF, x)
+    _hip.call("mm_meanpool_fwd", x, None, pooled, B, L, D)
     r = linear_rows(pooled, lin.weight, lin.bias, act=act, out_f32=True, out_bf16=False,
                     out_pre=save, drop_p=p, seed=seed, need_dgrad=need_dgrad)
     saved = dict(pooled=pooled, z=r["pre"], seed=seed, drop_p=p, B=B, L=L, D=D, lin=lin,
@@ -424,11 +445,15 @@ def pe_table(pos_encoder, L: int) -> torch.Tensor:
 def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool):
     """shared tail of both EEG encoders: transformer stack -> mean pool -> Linear -> GELU"""
     blocks = []
-    for blk in m.transformer_layers:
-        h, s = transformer_block_fwd(h, blk, training, need_dgrad, save=save)
+    B, L, D = h.shape
+    nblk = len(m.transformer_layers)
+    pooled = _zeros((B, D), h) if nblk and L % 64 == 0 and D % 16 == 0 and D <= 1024 else None
+    for i, blk in enumerate(m.transformer_layers):
+        h, s = transformer_block_fwd(h, blk, training, need_dgrad, save=save,
+                                     pool_out=pooled if i == nblk - 1 else None)
         blocks.append(s)
     out, s = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=m.drop_p, need_dgrad=need_dgrad,
-                             save=save)
+                             save=save, pooled_f32=pooled)
     return out, blocks, s, h
 
 

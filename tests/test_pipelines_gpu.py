@@ -173,7 +173,7 @@ def test_f1_flexible_trainer_trains_and_checkpoints(tmp_path, focal):
     with torch.no_grad():
         a = model(erp.cuda(), pw.cuda(), conn.cuda())
         b = model2(erp.cuda(), pw.cuda(), conn.cuda())
-    torch.testing.assert_close(a, b, rtol=0, atol=0)
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)      # the fused mean over time sums with float atomics
     torch.optim.AdamW(model2.parameters()).load_state_dict(ck["optimizer_state_dict"])
 
 
