@@ -192,6 +192,99 @@ def test_layernorm_fwd_bwd(M, D):
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-3)
 
 
+def test_grouped_linear_wgrads_equal_separate_launches():
+    """mm_conv1d_wgrad_many (one launch, workgroup id -> problem) writes bit-identical slot workspaces and bias
+    partials to one mm_conv1d_wgrad(slot_mode=1) launch per problem; 14 problems also exercise the split into
+    two tables of 12."""
+    import ctypes
+    import struct
+    hip = _hip()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(512, 128, 384), (512, 512, 128), (96, 128, 128), (32, 128, 64)] + [(64, 48, 32)] * 10
+    keep, descs, ref = [], [], []
+    for M, cin, cout in shapes:
+        dy = torch.randn(M, cout, generator=g).cuda().to(torch.bfloat16)
+        x = torch.randn(M, cin, generator=g).cuda().to(torch.bfloat16)
+        n = ctypes.c_int(0)
+        hip.call("mm_conv1d_wgrad_slots", 1, M, cin, cout, 1, ctypes.addressof(n))
+        slots = n.value
+        ws_a = torch.full((slots, cout, cin), float("nan"), device="cuda")
+        ws_b = torch.full((slots, cout, cin), float("nan"), device="cuda")
+        db_a, db_b = torch.zeros(32, cout, device="cuda"), torch.zeros(32, cout, device="cuda")
+        hip.call("mm_conv1d_wgrad", dy, x, ws_a, db_a, 1, M, cin, cout, 1, 0, cin, cin, 1, cin, slots, cout * cin, 1)
+        descs.append(struct.pack("<QQQQiiiiiiii", dy.data_ptr(), x.data_ptr(), ws_b.data_ptr(), db_b.data_ptr(),
+                                 1, M, cin, cout, cin, slots, 0, 0))
+        keep.append((dy, x))
+        ref.append((ws_a, ws_b, db_a, db_b, dy, x))
+    raw = b"".join(descs)
+    host = ctypes.create_string_buffer(raw, len(raw))
+    hip.call("mm_conv1d_wgrad_many", ctypes.addressof(host), len(shapes))
+    torch.cuda.synchronize()
+    for ws_a, ws_b, db_a, db_b, dy, x in ref:
+        assert torch.equal(ws_a, ws_b) and not torch.isnan(ws_b).any()
+        torch.testing.assert_close(db_a.sum(0), db_b.sum(0), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(ws_b.sum(0), dy.float().t() @ x.float(), rtol=2e-3, atol=2e-2)
+    bad = struct.pack("<QQQQiiiiiiii", keep[0][0].data_ptr(), keep[0][1].data_ptr(), ref[0][1].data_ptr(), 0,
+                      1, 512, 128, 384, 128, 1, 0, 0)                      # one slot is not enough
+    hb = ctypes.create_string_buffer(bad, len(bad))
+    with pytest.raises(Exception):
+        hip.call("mm_conv1d_wgrad_many", ctypes.addressof(hb), 1)
+
+
+def test_linear_with_fused_mean_over_time_and_pooled_head():
+    """encoder tail: mm_linear_fwd_meanpool == mm_conv1d_fwd's rows + their per-group mean (fp32 atomics:
+    1e-5); mm_pooled_head_fwd / _bwd vs torch autograd of mean -> Linear -> GELU in fp32 (1e-5 / 1e-4; the saved
+    pre-activation is bf16, so the backward's GELU' sees a rounded z: 1e-2 on d tokens)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(9)
+    B, L, D, K, N = 4, 128, 128, 512, 96
+    x = _bf(torch.randn(B * L, K, generator=g))
+    w = _bf(torch.randn(D, K, generator=g) / math.sqrt(K))
+    bias, res = torch.randn(D, generator=g), torch.randn(B * L, D, generator=g)
+    wf, _ = _prep_w(hip, w.view(D, K, 1), K)
+    xb = x.cuda().to(torch.bfloat16)
+    out_a = torch.empty(B * L, D, device="cuda")
+    out_b = torch.empty(B * L, D, device="cuda")
+    pooled = torch.zeros(B, D, device="cuda")
+    hip.call("mm_conv1d_fwd", xb, wf, 1, B * L, K, D, 1, 0, None, bias.cuda(), 0, res.cuda(), None, 1, None, out_a,
+             None, None, 0.0, 0, None, None, 0)
+    hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, D, bias.cuda(), res.cuda(), out_b, 0.0, 0, None, pooled, L)
+    assert torch.equal(out_a, out_b)
+    torch.testing.assert_close(out_b.cpu(), x @ w.t() + bias + res, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(pooled, out_b.view(B, L, D).mean(1), rtol=1e-5, atol=1e-5)
+    with pytest.raises(Exception):
+        hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, D, None, None, out_b, 0.0, 0, None, pooled, 96)
+    # head forward / backward
+    W = torch.randn(N, D, generator=g) / math.sqrt(D)
+    hb = torch.randn(N, generator=g)
+    tok = out_b.cpu().view(B, L, D).clone().requires_grad_(True)
+    Wr, br = W.clone().requires_grad_(True), hb.clone().requires_grad_(True)
+    y = F.gelu(tok.mean(1) @ Wr.t() + br)
+    dout = torch.randn(B, N, generator=g)
+    y.backward(dout)
+    out = torch.empty(B, N, device="cuda")
+    z = torch.empty(B, N, dtype=torch.bfloat16, device="cuda")
+    pb = torch.empty(B, D, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_pooled_head_fwd", pooled, W.cuda(), hb.cuda(), out, z, pb, B, D, N, 1, 0.0, 0, None)
+    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(pb.float(), pooled, rtol=1e-2, atol=1e-2)
+    dz = torch.empty(B, N, dtype=torch.bfloat16, device="cuda")
+    dx = torch.empty(B, L, D, device="cuda")
+    dxb = torch.empty(B, L, D, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_pooled_head_bwd", dout.cuda(), z, W.cuda(), dz, dx, dxb, B, L, D, N, 1, 0.0, 0, 0.0, 0, None)
+    torch.testing.assert_close(dx.cpu(), tok.grad, rtol=1e-2, atol=1e-2 * tok.grad.abs().max().item())
+    torch.testing.assert_close(dxb.float(), dx, rtol=1e-2, atol=1e-6)
+    torch.testing.assert_close(dz.float().cpu().t() @ pb.float().cpu(), Wr.grad, rtol=2e-2, atol=2e-2 * Wr.grad.abs().max().item())
+    # dropout on the head output and on the emitted operand: same masks as mm_act_f32 / mm_act_bwd would draw
+    hip.call("mm_pooled_head_bwd", dout.cuda(), z, W.cuda(), None, dx, dxb, B, L, D, N, 1, 0.0, 0, 0.4, 123, None)
+    kept = dxb.float() != 0
+    assert abs(kept.float().mean().item() - 0.6) < 0.02
+    torch.testing.assert_close(dxb.float()[kept], (dx / 0.6)[kept], rtol=1e-2, atol=1e-6)
+    ref_mask = torch.empty(B * L * D, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_act_bwd", torch.ones(B * L * D, device="cuda"), None, None, ref_mask, B * L * D, 0, 0.4, 123, None)
+    assert torch.equal(ref_mask.view(B, L, D) != 0, kept | (dx == 0))
+
+
 @pytest.mark.parametrize("M,K", [(512, 384), (96, 512), (64, 48)])
 def test_linear_dgrad_fused_with_layernorm_backward(M, K):
     """mm_linear_dgrad_ln_bwd = data gradient of Linear(128 -> K) followed by the LayerNorm-128 backward
