@@ -214,6 +214,52 @@ def bn_bwd_case(R, S, N, pool, f32_dout):
           f"({mb / red:5.2f} TB/s of {mb:.1f} MB)  apply {app:6.1f} us")
 
 
+def split_case():
+    """does running two half-batch chains on two streams beat one full-batch chain?  (linear + attention)"""
+    import math as _m
+
+    def mk(M):
+        B = M // 512
+        x = torch.randn(M, 128, device="cuda").to(BF)
+        w = torch.randn(384, 128, device="cuda") / _m.sqrt(128)
+        wf = torch.empty(384, 1, 128, dtype=BF, device="cuda")
+        _hip.call("mm_prep_conv_weight", w.view(384, 128, 1).contiguous(), wf, None, 384, 128, 1, 128, 0)
+        qkv = torch.empty(M, 384, dtype=BF, device="cuda")
+        o = torch.empty(M, 128, dtype=BF, device="cuda")
+        lse = torch.empty(B, 4, 512, device="cuda")
+        w2 = torch.randn(128, 128, device="cuda") / _m.sqrt(128)
+        wf2 = torch.empty(128, 1, 128, dtype=BF, device="cuda")
+        _hip.call("mm_prep_conv_weight", w2.view(128, 128, 1).contiguous(), wf2, None, 128, 128, 1, 128, 0)
+        res = torch.randn(M, 128, device="cuda")
+        out = torch.empty(M, 128, device="cuda")
+
+        def chain():
+            for _ in range(4):
+                _hip.call("mm_conv1d_fwd", x, wf, 1, M, 128, 384, 1, 0, None, None, 0, None, None, 1, None, None, qkv, None, 0.0, 0, None, None, 0)
+                _hip.call("mm_attn_fwd", qkv, o, lse, B, 512, 4, 32, 1.0 / _m.sqrt(32), 0.1, 5, None)
+                _hip.call("mm_conv1d_fwd", o, wf2, 1, M, 128, 128, 1, 0, None, None, 0, res, None, 1, None, out, None, None, 0.1, 7, None, None, 0)
+        return chain
+    full = mk(16384)
+    h1, h2 = mk(8192), mk(8192)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def two():
+        cur = torch.cuda.current_stream()
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            h1()
+        with torch.cuda.stream(s2):
+            h2()
+        cur.wait_stream(s1); cur.wait_stream(s2)
+    for name, fn in (("one stream, B=32", full), ("one stream, B=16 twice", lambda: (h1(), h2())), ("two streams, B=16 each", two)):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        print(f"{name:28s} {timeit(g.replay, iters=10):8.1f} us  (4 x [QKV linear, attention fwd, out-proj])")
+
+
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     if "floor" in flt:
@@ -233,6 +279,9 @@ def main():
         conv1d_wgrad_case(32, 1024, 64, 128, 5)
         conv1d_wgrad_case(32, 512, 128, 128, 3)
         conv1d_wgrad_case(1, M, 128, 512, 1)
+    if "split" in flt:
+        split_case()
+        return
     if "bn" in flt:
         bn_bwd_case(32, 512, 128, 1, True)
         bn_bwd_case(32, 1024, 128, 2, False)
