@@ -340,16 +340,23 @@ int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, 
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 /* Encoder tail (enhanced_models_v4.py:161-167, 186-191: mean over time -> output_proj = Linear -> GELU ->
  * Dropout).  mm_linear_fwd_meanpool is the last transformer block's linear2 (+ dropout + residual, fp32 rows
- * out_f32 (M, N)) that also accumulates the mean over each group of rows_per_group rows (one EEG epoch's
- * tokens) into the ZEROED pool_out (M / rows_per_group, N).  mm_pooled_head_fwd applies the head to the
+ * out_f32 (M, 128)) that also accumulates the mean over each group of rows_per_group rows (one EEG epoch's
+ * tokens) into the ZEROED pool_out (M / rows_per_group, 128).  mm_pooled_head_fwd applies the head to the
  * pooled rows in fp32 (W is the nn.Linear weight (N, D)); z_pre_bf16 / pooled_bf16 (nullable) are what the
  * backward and the weight-gradient GEMM need.  mm_pooled_head_bwd: dz = dout * dropout mask * act'(z) (bf16 copy
  * dz_bf16 for the weight gradient), d pooled = dz W, and dx[b][l][:] = d pooled / L for every token; dx_bf16
  * (nullable) = the same rows times the consumer's dropout mask (emit_drop_p, emit_seed; element index as in
  * mm_act_bwd). */
-int mm_linear_fwd_meanpool(const void* x, const void* w, int M, int K, int N, const float* bias, const float* residual,
+int mm_linear_fwd_meanpool(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
                            float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, float* pool_out,
                            int rows_per_group, hipStream_t stream);
+/* TemporalTransformerBlock forward (enhanced_models_v4.py:86-105): a sub-layer's closing Linear (attention
+ * out_proj or linear2; width 128) + dropout + residual, fp32 rows out_f32 (M, 128), with the NEXT sub-layer's
+ * pre-norm fused: ln_out_bf16 = LayerNorm(out rows; gamma, beta, eps) and ln_stat [M][2] = mean, rstd (nullable),
+ * i.e. mm_conv1d_fwd followed by mm_layernorm_fwd without re-reading the rows. */
+int mm_linear_fwd_ln(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
+                     float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* ln_gamma,
+                     const float* ln_beta, float ln_eps, void* ln_out_bf16, float* ln_stat, hipStream_t stream);
 int mm_pooled_head_fwd(const float* pooled, const float* W, const float* bias, float* out, void* z_pre_bf16,
                        void* pooled_bf16, int B, int D, int N, int act, float drop_p, uint32_t seed,
                        const uint32_t* seed_epoch, hipStream_t stream);

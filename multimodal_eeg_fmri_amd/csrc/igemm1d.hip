@@ -47,6 +47,13 @@ struct EpiArgs {
     float* pool_out;
     int pool_rows;
     float pool_scale;
+    // LayerNorm-128 of every finished output row (the NEXT sub-layer's pre-norm), fused: lnf_out bf16 rows,
+    // lnf_stat [M][2] mean / rstd (nullable)
+    bf16* lnf_out;
+    float* lnf_stat;
+    const float* lnf_gamma;
+    const float* lnf_beta;
+    float lnf_eps;
 };
 
 struct ConvArgs {
@@ -120,6 +127,28 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
         for (int c = 0; c < 4; ++c) pp[c] += o[c];
         const int t = t0 + r0;
         const size_t oi = ((size_t)b * To + t / step) * N + n;
+        if constexpr (BN == 128) {
+            if (e.lnf_out) {                       // host guarantees N == 128, pool == 1: 32 lanes hold this row
+                float sm = (o[0] + o[1]) + (o[2] + o[3]);
+#pragma unroll
+                for (int k = 16; k > 0; k >>= 1) sm += __shfl_xor(sm, k, 64);
+                const float mean = sm * (1.f / 128.f);
+                const float d0 = o[0] - mean, d1 = o[1] - mean, d2 = o[2] - mean, d3 = o[3] - mean;
+                float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+                for (int k = 16; k > 0; k >>= 1) sq += __shfl_xor(sq, k, 64);
+                const float rstd = rsqrtf(sq * (1.f / 128.f) + e.lnf_eps);
+                const float4 g4 = *reinterpret_cast<const float4*>(e.lnf_gamma + n);
+                const float4 b4 = *reinterpret_cast<const float4*>(e.lnf_beta + n);
+                bf16x4 hv = {(bf16)(d0 * rstd * g4.x + b4.x), (bf16)(d1 * rstd * g4.y + b4.y),
+                             (bf16)(d2 * rstd * g4.z + b4.z), (bf16)(d3 * rstd * g4.w + b4.w)};
+                *reinterpret_cast<bf16x4*>(e.lnf_out + oi) = hv;
+                if (e.lnf_stat && cg == 0) {
+                    const size_t m = (size_t)b * To + t;
+                    e.lnf_stat[2 * m] = mean; e.lnf_stat[2 * m + 1] = rstd;
+                }
+            }
+        }
         if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
         if (e.out_bf16) {
             bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
@@ -707,10 +736,6 @@ int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) {
     return mm_check_launch("prep_many");
 }
 
-// mm_linear_fwd_meanpool passes its extra epilogue request to mm_conv1d_fwd through this (per host thread)
-struct PoolReq { float* out; int rows; };
-static thread_local PoolReq g_pool = {nullptr, 0};
-
 // Generic forward implicit GEMM.  See include/mmeeg_hip.h for the contract.
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual, const float* pe,
@@ -736,7 +761,8 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.gradz = (const bf16*)gradz; a.e.gradz_act = gradz_act;
     a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
     a.e.ln_x = nullptr; a.e.ln_stat = nullptr; a.e.ln_gamma = nullptr; a.e.ln_dgb = nullptr;
-    a.e.pool_out = g_pool.out; a.e.pool_rows = g_pool.rows; a.e.pool_scale = g_pool.rows ? 1.f / (float)g_pool.rows : 0.f;
+    a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
+    a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
     // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
     // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS
     const int kct = (taps == 1 && Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : (Cin % 32 == 0 ? 32 : 16));
@@ -755,18 +781,55 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
 #undef MM_FWD
 }
 
-// y = dropout(x W^T + b) + residual (fp32 rows) AND pool_out[g][n] += mean over the rows_per_group rows of
-// group g of y - the last transformer block's second FFN Linear followed by the encoder's mean over time.
-int mm_linear_fwd_meanpool(const void* x, const void* w, int M, int K, int N, const float* bias, const float* residual,
+// y = dropout(x W^T + b) + residual, fp32 rows of width 128 (a transformer sub-layer's output), with up to two
+// fused consumers of the finished rows: the mean over each group of rows_per_group rows (the encoder's pooling
+// step, pool_out zeroed by the caller) and LayerNorm-128 (the next sub-layer's pre-norm: bf16 rows + mean/rstd).
+static int linear128_fwd(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
+                         float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, float* pool_out,
+                         int rows_per_group, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out,
+                         float* ln_stat, hipStream_t st) {
+    MM_REQUIRE(x && w && out_f32 && M > 0 && M % 32 == 0 && K > 0 && K % 16 == 0, "linear128_fwd: M=%d (x32) K=%d (x16)", M, K);
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear128_fwd: drop_p");
+    MM_REQUIRE(!pool_out || (rows_per_group > 0 && rows_per_group % 32 == 0 && M % rows_per_group == 0),
+               "linear128_fwd: rows_per_group=%d must be a multiple of 32 dividing M=%d", rows_per_group, M);
+    MM_REQUIRE(!ln_out || (ln_gamma && ln_beta), "linear128_fwd: LayerNorm parameters");
+    ConvArgs a;
+    a.x = (const bf16*)x; a.w = (const bf16*)w;
+    a.B = 1; a.T = M; a.Cin = K; a.Cout = 128; a.taps = 1; a.pad = 0;
+    a.e.scale = nullptr; a.e.shift = bias; a.e.residual = residual; a.e.pe = nullptr; a.e.stats = nullptr;
+    a.e.out_f32 = out_f32; a.e.out_bf16 = nullptr; a.e.out_pre = nullptr;
+    a.e.act = 0; a.e.pool = 1;
+    a.e.drop_thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    a.e.drop_seed = seed; a.e.drop_epoch = seed_epoch;
+    a.e.drop_inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    a.e.gradz = nullptr; a.e.gradz_act = 0;
+    a.e.ln_x = nullptr; a.e.ln_stat = nullptr; a.e.ln_gamma = nullptr; a.e.ln_dgb = nullptr;
+    a.e.pool_out = pool_out; a.e.pool_rows = pool_out ? rows_per_group : 0;
+    a.e.pool_scale = pool_out ? 1.f / (float)rows_per_group : 0.f;
+    a.e.lnf_out = (bf16*)ln_out; a.e.lnf_stat = ln_stat; a.e.lnf_gamma = ln_gamma; a.e.lnf_beta = ln_beta; a.e.lnf_eps = ln_eps;
+    const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
+    switch (kct) {
+        case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);
+        case 32: return launch_fwd<32, 128, 1, 4, 32>(a, st);
+        case 64: return launch_fwd<32, 128, 1, 4, 64>(a, st);
+        default: return launch_fwd<32, 128, 1, 4, 128>(a, st);
+    }
+}
+
+int mm_linear_fwd_meanpool(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
                            float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, float* pool_out,
                            int rows_per_group, hipStream_t st) {
-    MM_REQUIRE(pool_out && out_f32 && rows_per_group > 0 && rows_per_group % 64 == 0 && M % rows_per_group == 0,
-               "linear_fwd_meanpool: rows_per_group=%d must be a multiple of 64 dividing M=%d", rows_per_group, M);
-    g_pool.out = pool_out; g_pool.rows = rows_per_group;
-    const int rc = mm_conv1d_fwd(x, w, 1, M, K, N, 1, 0, nullptr, bias, 0, residual, nullptr, 1, nullptr, out_f32, nullptr,
-                                 nullptr, drop_p, seed, seed_epoch, nullptr, 0, st);
-    g_pool.out = nullptr; g_pool.rows = 0;
-    return rc;
+    MM_REQUIRE(pool_out, "linear_fwd_meanpool: null pool_out");
+    return linear128_fwd(x, w, M, K, bias, residual, out_f32, drop_p, seed, seed_epoch, pool_out, rows_per_group, nullptr,
+                         nullptr, 0.f, nullptr, nullptr, st);
+}
+
+int mm_linear_fwd_ln(const void* x, const void* w, int M, int K, const float* bias, const float* residual, float* out_f32,
+                     float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* ln_gamma, const float* ln_beta,
+                     float ln_eps, void* ln_out_bf16, float* ln_stat, hipStream_t st) {
+    MM_REQUIRE(ln_out_bf16, "linear_fwd_ln: null ln_out");
+    return linear128_fwd(x, w, M, K, bias, residual, out_f32, drop_p, seed, seed_epoch, nullptr, 0, ln_gamma, ln_beta, ln_eps,
+                         ln_out_bf16, ln_stat, st);
 }
 
 // dx = LayerNorm128_backward(dy @ W^T) + dres in one launch: the data-gradient GEMM of the Linear that
@@ -791,6 +854,7 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
     a.e.gradz = nullptr; a.e.gradz_act = 0;
     a.e.ln_x = x; a.e.ln_stat = stat; a.e.ln_gamma = gamma; a.e.ln_dgb = dgb_repl;
     a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
+    a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
     const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
     switch (kct) {
         case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);

@@ -364,43 +364,67 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
 
 
 def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False,
-                          save: Optional[bool] = None, pool_out: Optional[torch.Tensor] = None):
+                          save: Optional[bool] = None, pool_out: Optional[torch.Tensor] = None,
+                          prenorm=None, next_norm=None):
     """x fp32 (B, L, d) -> fp32 (B, L, d); returns (out, saved).  ``training``
     switches dropout on; ``save`` (default = training) keeps what backward needs.
     ``pool_out`` (zeroed fp32 (B, d)): the second FFN Linear also accumulates the mean over time of
-    the block's output there (the encoder's pooling step, fused into that GEMM's epilogue)."""
+    the block's output there (the encoder's pooling step, fused into that GEMM's epilogue).
+    Width 128: every LayerNorm but the stack's first is computed in the epilogue of the GEMM that produces
+    its input (``prenorm`` = (norm1(x) bf16, stats) handed in by the block below, ``next_norm`` = the next
+    block's norm1, whose output is then returned in ``saved['next_prenorm']`` / as third result)."""
     B, L, D = x.shape
     M = B * L
     save = training if save is None else save
     p = blk.dropout.p if training else 0.0
     x2 = x.view(M, D)
-    h1, st1 = layernorm(x2, blk.norm1, save)
+    fuse_ln = D == 128 and M % 32 == 0
+    h1, st1 = prenorm if prenorm is not None else layernorm(x2, blk.norm1, save)
     qkv = linear_rows(h1, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias,
                       need_dgrad=need_dgrad)["bf16"]
     pa = float(blk.self_attn.dropout) if training else 0.0      # attention-probability dropout
     sa = _next_seed() if pa > 0 else 0
     o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save, pa, sa)
     s1 = _next_seed() if p > 0 else 0
-    x1 = linear_rows(o.view(M, D), blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias,
-                     residual=x2, out_f32=True, out_bf16=False, drop_p=p, seed=s1,
-                     need_dgrad=need_dgrad)["f32"]
-    h2, st2 = layernorm(x1, blk.norm2, save)
+    if fuse_ln:
+        wf, _, cinp, _ = weights.get(blk.self_attn.out_proj.weight, need_dgrad)
+        x1 = _empty((M, D), _F32, x)
+        h2 = _empty((M, D), _BF, x)
+        st2 = _empty((M, 2), _F32, x) if save else None
+        _hip.call("mm_linear_fwd_ln", o.view(M, D), wf, M, cinp, blk.self_attn.out_proj.bias, x2, x1, float(p), int(s1),
+                  EP(), blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), h2, st2)
+    else:
+        x1 = linear_rows(o.view(M, D), blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias,
+                         residual=x2, out_f32=True, out_bf16=False, drop_p=p, seed=s1,
+                         need_dgrad=need_dgrad)["f32"]
+        h2, st2 = layernorm(x1, blk.norm2, save)
     s2 = _next_seed() if p > 0 else 0
     f1 = linear_rows(h2, blk.linear1.weight, blk.linear1.bias, act=blk._act, out_pre=save,
                      drop_p=p, seed=s2, need_dgrad=need_dgrad)
     s3 = _next_seed() if p > 0 else 0
-    if pool_out is None:
-        x2o = linear_rows(f1["bf16"], blk.linear2.weight, blk.linear2.bias, residual=x1, out_f32=True,
-                          out_bf16=False, drop_p=p, seed=s3, need_dgrad=need_dgrad)["f32"]
-    else:
+    nxt = None
+    if pool_out is not None:
         wf, _, cinp, _ = weights.get(blk.linear2.weight, need_dgrad)
         x2o = _empty((M, D), _F32, x)
-        _hip.call("mm_linear_fwd_meanpool", f1["bf16"], wf, M, cinp, D, blk.linear2.bias, x1, x2o, float(p), int(s3),
+        _hip.call("mm_linear_fwd_meanpool", f1["bf16"], wf, M, cinp, blk.linear2.bias, x1, x2o, float(p), int(s3),
                   EP(), pool_out, L)
+    elif next_norm is not None and fuse_ln:
+        wf, _, cinp, _ = weights.get(blk.linear2.weight, need_dgrad)
+        x2o = _empty((M, D), _F32, x)
+        hn = _empty((M, D), _BF, x)
+        stn = _empty((M, 2), _F32, x) if save else None
+        _hip.call("mm_linear_fwd_ln", f1["bf16"], wf, M, cinp, blk.linear2.bias, x1, x2o, float(p), int(s3), EP(),
+                  next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn)
+        nxt = (hn, stn)
+    else:
+        x2o = linear_rows(f1["bf16"], blk.linear2.weight, blk.linear2.bias, residual=x1, out_f32=True,
+                          out_bf16=False, drop_p=p, seed=s3, need_dgrad=need_dgrad)["f32"]
     saved = None
     if save:
         saved = dict(x=x2, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2,
                      z=f1["pre"], g=f1["bf16"], p=p, seeds=(s1, s2, s3), attn_drop=(pa, sa), B=B, L=L, blk=blk)
+    if next_norm is not None:
+        return x2o.view(B, L, D), saved, nxt
     return x2o.view(B, L, D), saved
 
 
@@ -447,10 +471,15 @@ def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool):
     blocks = []
     B, L, D = h.shape
     nblk = len(m.transformer_layers)
-    pooled = _zeros((B, D), h) if nblk and L % 64 == 0 and D % 16 == 0 and D <= 1024 else None
-    for i, blk in enumerate(m.transformer_layers):
-        h, s = transformer_block_fwd(h, blk, training, need_dgrad, save=save,
-                                     pool_out=pooled if i == nblk - 1 else None)
+    pooled = _zeros((B, D), h) if nblk and L % 32 == 0 and D == 128 else None
+    layers = list(m.transformer_layers)
+    prenorm = None
+    for i, blk in enumerate(layers):
+        if i < nblk - 1:                                 # the next block's norm1 rides in this block's last GEMM
+            h, s, prenorm = transformer_block_fwd(h, blk, training, need_dgrad, save=save, prenorm=prenorm,
+                                                  next_norm=layers[i + 1].norm1)
+        else:
+            h, s = transformer_block_fwd(h, blk, training, need_dgrad, save=save, pool_out=pooled, prenorm=prenorm)
         blocks.append(s)
     out, s = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=m.drop_p, need_dgrad=need_dgrad,
                              save=save, pooled_f32=pooled)

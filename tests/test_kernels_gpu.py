@@ -248,12 +248,12 @@ def test_linear_with_fused_mean_over_time_and_pooled_head():
     pooled = torch.zeros(B, D, device="cuda")
     hip.call("mm_conv1d_fwd", xb, wf, 1, B * L, K, D, 1, 0, None, bias.cuda(), 0, res.cuda(), None, 1, None, out_a,
              None, None, 0.0, 0, None, None, 0)
-    hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, D, bias.cuda(), res.cuda(), out_b, 0.0, 0, None, pooled, L)
+    hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, bias.cuda(), res.cuda(), out_b, 0.0, 0, None, pooled, L)
     assert torch.equal(out_a, out_b)
     torch.testing.assert_close(out_b.cpu(), x @ w.t() + bias + res, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(pooled, out_b.view(B, L, D).mean(1), rtol=1e-5, atol=1e-5)
     with pytest.raises(Exception):
-        hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, D, None, None, out_b, 0.0, 0, None, pooled, 96)
+        hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, None, None, out_b, 0.0, 0, None, pooled, 96)
     # head forward / backward
     W = torch.randn(N, D, generator=g) / math.sqrt(D)
     hb = torch.randn(N, generator=g)
@@ -283,6 +283,35 @@ def test_linear_with_fused_mean_over_time_and_pooled_head():
     ref_mask = torch.empty(B * L * D, dtype=torch.bfloat16, device="cuda")
     hip.call("mm_act_bwd", torch.ones(B * L * D, device="cuda"), None, None, ref_mask, B * L * D, 0, 0.4, 123, None)
     assert torch.equal(ref_mask.view(B, L, D) != 0, kept | (dx == 0))
+
+
+@pytest.mark.parametrize("M,K,p", [(512, 128, 0.0), (96, 512, 0.2)])
+def test_linear_with_fused_next_layernorm(M, K, p):
+    """mm_linear_fwd_ln == mm_conv1d_fwd (same rows, bit for bit, same dropout mask) followed by
+    mm_layernorm_fwd on them (bf16 rows equal up to one bf16 ulp, statistics 1e-5)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
+    w = _bf(torch.randn(128, K, generator=g) / math.sqrt(K))
+    bias, res = torch.randn(128, generator=g).cuda(), (torch.randn(M, 128, generator=g) * 2).cuda()
+    gam, bet = (0.5 + torch.rand(128, generator=g)).cuda(), torch.randn(128, generator=g).cuda()
+    wf, _ = _prep_w(hip, w.view(128, K, 1), K)
+    ref = torch.empty(M, 128, device="cuda")
+    hip.call("mm_conv1d_fwd", x, wf, 1, M, K, 128, 1, 0, None, bias, 0, res, None, 1, None, ref, None, None, p, 11, None,
+             None, 0)
+    h_ref = torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")
+    st_ref = torch.empty(M, 2, device="cuda")
+    hip.call("mm_layernorm_fwd", ref, gam, bet, h_ref, None, st_ref, M, 128, 1e-5)
+    out = torch.empty(M, 128, device="cuda")
+    h = torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")
+    st = torch.empty(M, 2, device="cuda")
+    hip.call("mm_linear_fwd_ln", x, wf, M, K, bias, res, out, p, 11, None, gam, bet, 1e-5, h, st)
+    assert torch.equal(out, ref)
+    torch.testing.assert_close(st, st_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(h.float(), h_ref.float(), rtol=8e-3, atol=1e-2)
+    assert (h.float() - h_ref.float()).abs().gt(0).float().mean().item() < 0.02     # a handful of 1-ulp flips at most
+    with pytest.raises(Exception):
+        hip.call("mm_linear_fwd_ln", x, wf, M - 1, K, bias, res, out, p, 11, None, gam, bet, 1e-5, h, st)
 
 
 @pytest.mark.parametrize("M,K", [(512, 384), (96, 512), (64, 48)])
