@@ -86,8 +86,11 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
 int mm_conv1d_wgrad_slots(int B, int T, int Cin, int Cout, int taps, int* slots_host, hipStream_t stream);
 /* several Linear weight gradients (taps 1, slot mode) in one launch: desc_host = n x 64 bytes
  * {dy, x, workspace [nslots][Cout][Cin], dbias replicas (nullable)} pointers + int B, T, Cin, Cout, Cin_real,
- * nslots, 0, 0.  Same arithmetic as n mm_conv1d_wgrad(..., slot_mode = 1) calls. */
+ * nslots (= mm_conv1d_wgrad_many_slots), 0, 0.  Same arithmetic as n mm_conv1d_wgrad(..., slot_mode = 1) calls. */
 int mm_conv1d_wgrad_many(const void* desc_host, int n, hipStream_t stream);
+/* slot count of one problem of such a grouped launch (fewer, longer workgroups per problem than a stand-alone
+ * mm_conv1d_wgrad: the group supplies the parallelism) */
+int mm_conv1d_wgrad_many_slots(int B, int T, int Cin, int Cout, int* slots_host, hipStream_t stream);
 /* dw[n][c][tap] += ws[n][tap][c]: conv weight gradients are accumulated by the
  * wgrad kernels in a channel-contiguous workspace (contiguous fp32 atomics run
  * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */

@@ -48,15 +48,19 @@ def _wgrad_slots(dy, x, dw, dbr, B, T, cinp, N, k, pad, cin):
     dW[n][tap][c] into its own slot of a workspace; the (deferred, batched) scatter sums the slots
     into the parameter layout."""
     import ctypes
-    key = (B, T, cinp, N, k)
+    bag = _BAG["cur"]
+    grouped = bag is not None and k == 1
+    key = (B, T, cinp, N, k, grouped)
     slots = _SLOTS.get(key)
     if slots is None:
         out = ctypes.c_int(0)
-        _hip.call("mm_conv1d_wgrad_slots", B, T, cinp, N, k, ctypes.addressof(out))
+        if grouped:
+            _hip.call("mm_conv1d_wgrad_many_slots", B, T, cinp, N, ctypes.addressof(out))
+        else:
+            _hip.call("mm_conv1d_wgrad_slots", B, T, cinp, N, k, ctypes.addressof(out))
         slots = _SLOTS[key] = int(out.value)
     ws = _empty((slots, N, k, cinp), _F32, dy)                   # every element has exactly one writer: no memset
-    bag = _BAG["cur"]
-    if bag is not None and k == 1:
+    if grouped:
         # a Linear's weight gradient feeds nothing but the final slot sum: collect it; the bag issues
         # all of them as ONE launch when it is flushed (possibly on another stream, off the chain)
         bag.defer_wgrad(dy, x, ws, dbr, B, T, cinp, N, slots)

@@ -876,6 +876,29 @@ static int wgrad_rows_per_wg(int B, int T, int Cin, int Cout, int taps, int slot
     return ceil_div(tilesT, want_chunks) * WG_MK;
 }
 
+// grouped launches (mm_conv1d_wgrad_many) get their parallelism from the number of problems, so each
+// problem is cut into far fewer row chunks: ~64 workgroups per problem instead of 384 (sweep: 384 1.127, 128 1.124,
+// 64 1.120, 32 1.158 ms/step), i.e. 6x less
+// slot memory to write and to sum afterwards
+static int wgrad_many_target() {
+    static const int t = getenv("MM_WGM_TARGET") ? atoi(getenv("MM_WGM_TARGET")) : 64;
+    return t;
+}
+static int wgrad_many_rows_per_wg(int T, int Cin, int Cout) {
+    const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
+    const int tilesT = ceil_div(T, WG_MK);
+    int want_chunks = ceil_div(wgrad_many_target(), tiles);
+    if (want_chunks < 1) want_chunks = 1;
+    if (want_chunks > tilesT) want_chunks = tilesT;
+    return ceil_div(tilesT, want_chunks) * WG_MK;
+}
+
+int mm_conv1d_wgrad_many_slots(int B, int T, int Cin, int Cout, int* slots_host, hipStream_t) {
+    MM_REQUIRE(slots_host && B > 0 && T > 0 && Cin > 0 && Cout > 0, "conv1d_wgrad_many_slots: bad args");
+    *slots_host = B * ceil_div(T, wgrad_many_rows_per_wg(T, Cin, Cout));
+    return 0;
+}
+
 int mm_conv1d_wgrad_slots(int B, int T, int Cin, int Cout, int taps, int* slots_host, hipStream_t) {
     MM_REQUIRE(slots_host && B > 0 && T > 0 && Cin > 0 && Cout > 0, "conv1d_wgrad_slots: bad args");
     *slots_host = B * ceil_div(T, wgrad_rows_per_wg(B, T, Cin, Cout, taps, 1));
@@ -924,9 +947,10 @@ int mm_conv1d_wgrad_many(const void* desc_host, int n, hipStream_t st) {
             a.dy = (const bf16*)q.dy; a.x = (const bf16*)q.x; a.dw = q.dw; a.dbias = q.dbias;
             a.B = q.B; a.T = q.T; a.Cin = q.Cin; a.Cout = q.Cout; a.pad = 0; a.Cin_real = q.Cin_real;
             a.sn = q.Cin; a.sc = 1; a.stap = q.Cin; a.nrep = q.nslots; a.rep_stride = (long)q.Cout * q.Cin; a.slot_mode = 1;
-            a.rows_per_wg = wgrad_rows_per_wg(q.B, q.T, q.Cin, q.Cout, 1, 1);
+            a.rows_per_wg = wgrad_many_rows_per_wg(q.T, q.Cin, q.Cout);
             const int chunks = q.B * ceil_div(q.T, a.rows_per_wg);
-            MM_REQUIRE(q.nslots >= chunks, "conv1d_wgrad_many: needs %d slots (mm_conv1d_wgrad_slots), got %d", chunks, q.nslots);
+            MM_REQUIRE(q.nslots == chunks, "conv1d_wgrad_many: needs exactly %d slots (mm_conv1d_wgrad_many_slots), got %d",
+                       chunks, q.nslots);
             tab.first[i] = total;
             tab.gx[i] = chunks; tab.gy[i] = ceil_div(q.Cout, 64);
             total += chunks * tab.gy[i] * ceil_div(q.Cin, 64);

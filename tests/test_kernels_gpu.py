@@ -193,9 +193,9 @@ def test_layernorm_fwd_bwd(M, D):
 
 
 def test_grouped_linear_wgrads_equal_separate_launches():
-    """mm_conv1d_wgrad_many (one launch, workgroup id -> problem) writes bit-identical slot workspaces and bias
-    partials to one mm_conv1d_wgrad(slot_mode=1) launch per problem; 14 problems also exercise the split into
-    two tables of 12."""
+    """mm_conv1d_wgrad_many (one launch, workgroup id -> problem; fewer, longer row chunks per problem) sums to the
+    same weight gradients and bias partials as one mm_conv1d_wgrad(slot_mode=1) launch per problem; 14 problems
+    also exercise the split into two tables of 12."""
     import ctypes
     import struct
     hip = _hip()
@@ -205,13 +205,15 @@ def test_grouped_linear_wgrads_equal_separate_launches():
     for M, cin, cout in shapes:
         dy = torch.randn(M, cout, generator=g).cuda().to(torch.bfloat16)
         x = torch.randn(M, cin, generator=g).cuda().to(torch.bfloat16)
-        n = ctypes.c_int(0)
-        hip.call("mm_conv1d_wgrad_slots", 1, M, cin, cout, 1, ctypes.addressof(n))
+        n, n1 = ctypes.c_int(0), ctypes.c_int(0)
+        hip.call("mm_conv1d_wgrad_many_slots", 1, M, cin, cout, ctypes.addressof(n))
+        hip.call("mm_conv1d_wgrad_slots", 1, M, cin, cout, 1, ctypes.addressof(n1))
         slots = n.value
-        ws_a = torch.full((slots, cout, cin), float("nan"), device="cuda")
+        assert 1 <= slots <= n1.value
+        ws_a = torch.full((n1.value, cout, cin), float("nan"), device="cuda")
         ws_b = torch.full((slots, cout, cin), float("nan"), device="cuda")
         db_a, db_b = torch.zeros(32, cout, device="cuda"), torch.zeros(32, cout, device="cuda")
-        hip.call("mm_conv1d_wgrad", dy, x, ws_a, db_a, 1, M, cin, cout, 1, 0, cin, cin, 1, cin, slots, cout * cin, 1)
+        hip.call("mm_conv1d_wgrad", dy, x, ws_a, db_a, 1, M, cin, cout, 1, 0, cin, cin, 1, cin, n1.value, cout * cin, 1)
         descs.append(struct.pack("<QQQQiiiiiiii", dy.data_ptr(), x.data_ptr(), ws_b.data_ptr(), db_b.data_ptr(),
                                  1, M, cin, cout, cin, slots, 0, 0))
         keep.append((dy, x))
@@ -221,7 +223,8 @@ def test_grouped_linear_wgrads_equal_separate_launches():
     hip.call("mm_conv1d_wgrad_many", ctypes.addressof(host), len(shapes))
     torch.cuda.synchronize()
     for ws_a, ws_b, db_a, db_b, dy, x in ref:
-        assert torch.equal(ws_a, ws_b) and not torch.isnan(ws_b).any()
+        assert not torch.isnan(ws_b).any()
+        torch.testing.assert_close(ws_a.sum(0), ws_b.sum(0), rtol=1e-4, atol=1e-3)      # other chunking, same sums
         torch.testing.assert_close(db_a.sum(0), db_b.sum(0), rtol=1e-5, atol=1e-4)
         torch.testing.assert_close(ws_b.sum(0), dy.float().t() @ x.float(), rtol=2e-3, atol=2e-2)
     bad = struct.pack("<QQQQiiiiiiii", keep[0][0].data_ptr(), keep[0][1].data_ptr(), ref[0][1].data_ptr(), 0,
