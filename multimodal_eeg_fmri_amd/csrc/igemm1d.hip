@@ -870,7 +870,8 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
 static int wgrad_rows_per_wg(int B, int T, int Cin, int Cout, int taps, int slot_mode) {
     const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
     const int tilesT = ceil_div(T, WG_MK);
-    int want_chunks = ceil_div((taps > 1 && !slot_mode) ? 112 : 384, tiles * B);
+    static const int slot_target = getenv("MM_WG_TARGET") ? atoi(getenv("MM_WG_TARGET")) : 128;   // slot mode, k > 1: 384 1.116, 192 1.107, 128 1.106, 64 1.111 ms/step
+    int want_chunks = ceil_div((taps > 1 && !slot_mode) ? 112 : (taps > 1 ? slot_target : 384), tiles * B);
     if (want_chunks < 1) want_chunks = 1;
     if (want_chunks > tilesT) want_chunks = tilesT;
     return ceil_div(tilesT, want_chunks) * WG_MK;
