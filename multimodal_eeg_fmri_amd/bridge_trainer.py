@@ -231,13 +231,8 @@ class BridgeTrainer(nn.Module):
     def _step_manual_body(self, eeg, fmri):
         z, saved = self._seg_forward(eeg, fmri)
         z_all = dp.gather_embeddings(z, self.group)
-        if self.world == 1:
-            scal, dz_all = ops._zeros((4,), z), ops._zeros(tuple(z_all.shape), z)
-            self._seg_loss(z, z_all, scal, dz_all, zero=False)
-        else:
-            scal = torch.empty(4, device=z.device)
-            dz_all = torch.empty_like(z_all)
-            self._seg_loss(z, z_all, scal, dz_all)
+        scal, dz_all = ops._zeros((4,), z), ops._zeros(tuple(z_all.shape), z)    # cleared arena slices: no fills
+        self._seg_loss(z, z_all, scal, dz_all, zero=False)
         dz = dp.scatter_column_grads(dz_all, self.group)
         self._seg_backward(saved, dz, scal)
         self._seg_optimizer()
@@ -291,11 +286,12 @@ class BridgeTrainer(nn.Module):
         else:
             def seg1():
                 c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"])
+                # loss scalars and the gathered-gradient buffer: slices of the arena this segment has just cleared
+                c["scal"], c["dz_all"] = ops._zeros((4,), c["z"]), ops._zeros((world * B, N2), c["z"])
             record(seg1)
             c["z_all"] = torch.empty(world * B, N2, device=dev)
-            c["dz_all"] = torch.empty(world * B, N2, device=dev)
             c["dz"] = torch.empty(B, N2, device=dev)
-            record(lambda: self._seg_loss(c["z"], c["z_all"], c["scal"], c["dz_all"]))
+            record(lambda: self._seg_loss(c["z"], c["z_all"], c["scal"], c["dz_all"], zero=False))
             record(lambda: self._seg_backward(c["saved"], c["dz"], c["scal"]))
             record(self._seg_adamw)
         c["graphs"] = graphs
