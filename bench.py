@@ -247,7 +247,7 @@ def main():
                                "(3-D conv encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW",
                    "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": global_batch, "parallelism": f"dp{world}",
                    "dropout": args.dropout, "mfma_operands": "bf16", "accumulate": "fp32",
-                   "execution": "hipGraph replay" if world == 1 else "4 hipGraph segments + 3 RCCL collectives"},
+                   "execution": "hipGraph replay" if world == 1 else "3 hipGraph segments + 2 RCCL collectives (all-gather of embeddings, all-reduce of gradients)"},
         "top1_retrieval_acc": {"eeg_to_fmri": ev["top1_e2f"].item(), "fmri_to_eeg": ev["top1_f2e"].item(),
                                "chance": 1.0 / global_batch, "note": "on the training batch after the timed steps",
                                "held_out_after_fit": fit},

@@ -282,6 +282,11 @@ int mm_l2norm_bwd(const float* dz, const float* z, const float* nrm, float* dh, 
  * Extension a-X2: the reference trains a CE classifier (_test_bridge.py:858). */
 int mm_clip_loss(const float* z_local, const float* z_all, const float* logit_scale, float* scal4,
                  float* dz_all, int B, int Bg, int N, int row0, hipStream_t stream);
+/* The same loss without the reduce-scatter: the rank evaluates ALL Bg rows of the gathered batch and keeps
+ * what lands on its own rows, dz_local [B][2N] += d (sum over ranks of their losses) / d z_local - exactly the
+ * block a reduce-scatter-sum of every rank's dz_all would deliver; scal4 counts the local rows only. */
+int mm_clip_loss_own_rows(const float* z_all, const float* logit_scale, float* scal4, float* dz_local, int B,
+                          int Bg, int N, int row0, hipStream_t stream);
 
 /* ---- fused tails of the small models (forward) ------------------------------ */
 /* fMRIFusionNet weighted concat (fmri_utils.py:93-96) */

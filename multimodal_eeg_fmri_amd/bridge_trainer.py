@@ -97,7 +97,7 @@ class BridgeTrainer(nn.Module):
         """zero_grad -> forward -> backward -> (all-reduce) -> clip + AdamW.
 
         ``mode``: "graph" (default) replays the step from hipGraphs captured on
-        first use (one graph at world 1; four segments around the three
+        first use (one graph at world 1; three segments around the two
         collectives otherwise); "manual" runs the same autograd-free tape eagerly;
         "autograd" goes through the public nn.Module / torch.autograd surface."""
         if self.mode == "autograd":
@@ -116,7 +116,7 @@ class BridgeTrainer(nn.Module):
         self._seg_optimizer()
         return {"loss": loss.detach(), "top1_e2f": acc_e, "top1_f2e": acc_f}
 
-    # ---- the four segments of the autograd-free tape -------------------------
+    # ---- the segments of the autograd-free tape ------------------------------
     STAMP_NAMES = ("step start", "weights prepared", "EEG fwd done", "fMRI fwd start", "fMRI fwd done",
                    "heads fwd done", "loss done", "heads bwd done", "EEG bwd done", "fMRI bwd start",
                    "fMRI bwd done", "grad reductions done", "AdamW done")
@@ -149,15 +149,14 @@ class BridgeTrainer(nn.Module):
         self._stamp(5)
         return z, (sv_e, sv_f, sv_h)
 
-    def _seg_loss(self, z, z_all, scal, dz_all, zero=True):
-        """``zero=False``: ``scal`` / ``dz_all`` are slices of the step's scratch arena, already cleared by
-        its one memset (the world-1 step: two fill launches fewer on the critical chain)."""
-        B, N2 = z.shape
-        if zero:
-            scal.zero_()
-            dz_all.zero_()
+    def _seg_loss(self, z_all, scal, dz):
+        """symmetric InfoNCE of this rank's rows against the gathered batch, gradient w.r.t. ITS rows only
+        (``mm_clip_loss_own_rows``: every rank evaluates all rows of the gathered batch, so no reduce-scatter
+        of column gradients is needed).  ``scal`` / ``dz`` are cleared slices of the step's scratch arena."""
+        N2 = z_all.shape[1]
+        B = dz.shape[0]
         ls = self.head.logit_scale.detach().reshape(1)
-        _hip.call("mm_clip_loss", z, z_all, ls, scal, dz_all, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
+        _hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
         self._stamp(6)
 
     def _seg_backward(self, saved, dz, scal):
@@ -231,9 +230,8 @@ class BridgeTrainer(nn.Module):
     def _step_manual_body(self, eeg, fmri):
         z, saved = self._seg_forward(eeg, fmri)
         z_all = dp.gather_embeddings(z, self.group)
-        scal, dz_all = ops._zeros((4,), z), ops._zeros(tuple(z_all.shape), z)    # cleared arena slices: no fills
-        self._seg_loss(z, z_all, scal, dz_all, zero=False)
-        dz = dp.scatter_column_grads(dz_all, self.group)
+        scal, dz = ops._zeros((4,), z), ops._zeros(tuple(z.shape), z)            # cleared arena slices: no fills
+        self._seg_loss(z_all, scal, dz)
         self._seg_backward(saved, dz, scal)
         self._seg_optimizer()
         return {"loss": scal[0], "top1_e2f": scal[1], "top1_f2e": scal[2]}
@@ -278,21 +276,23 @@ class BridgeTrainer(nn.Module):
         if world == 1 and not (self.force_segments and self.group is not None):
             def whole():
                 z, saved = self._seg_forward(c["eeg"], c["fmri"])
-                c["scal"], c["dz_all"] = ops._zeros((4,), z), ops._zeros(tuple(z.shape), z)   # arena: no fills
-                self._seg_loss(z, z, c["scal"], c["dz_all"], zero=False)
-                self._seg_backward(saved, c["dz_all"], c["scal"])
+                c["scal"], c["dz"] = ops._zeros((4,), z), ops._zeros(tuple(z.shape), z)   # arena: no fills
+                self._seg_loss(z, c["scal"], c["dz"])
+                self._seg_backward(saved, c["dz"], c["scal"])
                 self._seg_adamw()
             record(whole)
         else:
             def seg1():
                 c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"])
-                # loss scalars and the gathered-gradient buffer: slices of the arena this segment has just cleared
-                c["scal"], c["dz_all"] = ops._zeros((4,), c["z"]), ops._zeros((world * B, N2), c["z"])
+                # loss scalars and the embedding-gradient buffer: slices of the arena this segment has just cleared
+                c["scal"], c["dz"] = ops._zeros((4,), c["z"]), ops._zeros((B, N2), c["z"])
             record(seg1)
             c["z_all"] = torch.empty(world * B, N2, device=dev)
-            c["dz"] = torch.empty(B, N2, device=dev)
-            record(lambda: self._seg_loss(c["z"], c["z_all"], c["scal"], c["dz_all"], zero=False))
-            record(lambda: self._seg_backward(c["saved"], c["dz"], c["scal"]))
+
+            def seg2():
+                self._seg_loss(c["z_all"], c["scal"], c["dz"])
+                self._seg_backward(c["saved"], c["dz"], c["scal"])
+            record(seg2)
             record(self._seg_adamw)
         c["graphs"] = graphs
         self._cap = c
@@ -308,13 +308,11 @@ class BridgeTrainer(nn.Module):
         if len(g) == 1:
             g[0].replay()
         else:
-            g[0].replay()
+            g[0].replay()                                              # forward
             dp.all_gather_into(c["z_all"], c["z"], self.group)
-            g[1].replay()
-            dp.reduce_scatter_into(c["dz"], c["dz_all"], self.group)
-            g[2].replay()
+            g[1].replay()                                              # loss on the gathered batch + backward
             dp.allreduce_sum_(self.bucket.g, self.group)
-            g[3].replay()
+            g[2].replay()                                              # clip + AdamW
         return {"loss": c["scal"][0], "top1_e2f": c["scal"][1], "top1_f2e": c["scal"][2]}
 
     def input_buffers(self):

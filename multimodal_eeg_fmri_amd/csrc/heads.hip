@@ -251,13 +251,19 @@ __global__ __launch_bounds__(256) void proj_heads_bwd_kernel(HeadsArgs a) {
 //   dze_all[Bg][N], dzf_all[Bg][N] += gradients w.r.t. the GLOBAL embeddings
 //   (row role at row0+i, column role at every j); the host reduce-scatters them.
 // ---------------------------------------------------------------------------
+// OWN = true: the "no reduce-scatter" form.  Every rank runs ALL Bg rows (it holds the gathered embeddings
+// anyway) and keeps only what lands on its own rows [row0, row0 + B): the row-role gradient of its rows and the
+// column-role contributions of every global row to its columns - the sum a reduce-scatter of the dz_all
+// buffers would have delivered.  dz_all is then this rank's [B][2N] block; loss / top-1 / d logit_scale count
+// the local rows only, as before.  z_loc is unused (row i is read from z_all).
+template <bool OWN>
 __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict__ z_loc, const float* __restrict__ z_all,
                                                         const float* __restrict__ logit_scale, float* __restrict__ scal,
                                                         float* __restrict__ dz_all, int B, int Bg, int N, int row0) {
     // packed rows: [ze (N) | zf (N)], leading dimension 2N
     const int LD = 2 * N;
-    const float* ze = z_loc;
-    const float* zf = z_loc + N;
+    const float* ze = OWN ? z_all : z_loc;
+    const float* zf = ze + N;
     const float* ze_all = z_all;
     const float* zf_all = z_all + N;
     float* dze_all = dz_all;
@@ -293,10 +299,11 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
     __syncthreads();
     se = red[0] + red[1] + red[2] + red[3];
     sf = red[4] + red[5] + red[6] + red[7];
-    const int tgt = row0 + i;
+    const int tgt = OWN ? i : row0 + i;
+    const bool mine = !OWN || (i >= row0 && i < row0 + B);      // wave-uniform
     const float ce = Gef[tgt], cf = Gfe[tgt];
     const float invB = 1.f / (float)B;
-    if (tid == 0) {
+    if (tid == 0 && mine) {
         const float le = -(s * (ce - mxe) - __logf(se)), lf = -(s * (cf - mxf) - __logf(sf));
         atomicAdd(&scal[0], 0.5f * (le + lf) * invB);
         atomicAdd(&scal[1], (ce >= mxe ? 1.f : 0.f) * invB);
@@ -314,21 +321,26 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
         Gef[j] = ge; Gfe[j] = gf;
     }
     dsc = wave_sum(dsc);
-    if (lane == 0) atomicAdd(&scal[3], dsc * s);      // d/d logit_scale = s * d/ds
+    if (lane == 0 && mine) atomicAdd(&scal[3], dsc * s);      // d/d logit_scale = s * d/ds
     __syncthreads();
     if (!dze_all) return;
     // row-role gradients:  dze_i += s * sum_j Gef[j] zf_all_j ; dzf_i += s * sum_j Gfe[j] ze_all_j
-    for (int n = tid; n < N; n += 256) {
-        float a = 0.f, c = 0.f;
-        for (int j = 0; j < Bg; ++j) { a += Gef[j] * zf_all[(size_t)j * LD + n]; c += Gfe[j] * ze_all[(size_t)j * LD + n]; }
-        atomicAdd(&dze_all[(size_t)tgt * LD + n], s * a);
-        atomicAdd(&dzf_all[(size_t)tgt * LD + n], s * c);
+    if (mine) {
+        const size_t orow = (size_t)(OWN ? i - row0 : tgt) * LD;
+        for (int n = tid; n < N; n += 256) {
+            float a = 0.f, c = 0.f;
+            for (int j = 0; j < Bg; ++j) { a += Gef[j] * zf_all[(size_t)j * LD + n]; c += Gfe[j] * ze_all[(size_t)j * LD + n]; }
+            atomicAdd(&dze_all[orow + n], s * a);
+            atomicAdd(&dzf_all[orow + n], s * c);
+        }
     }
     // column-role gradients: dzf_all_j += s * Gef[j] ze_i ; dze_all_j += s * Gfe[j] zf_i
-    for (int idx = tid; idx < Bg * N; idx += 256) {
-        const int j = idx / N, n = idx - j * N;
-        atomicAdd(&dzf_all[(size_t)j * LD + n], s * Gef[j] * qe[n]);
-        atomicAdd(&dze_all[(size_t)j * LD + n], s * Gfe[j] * qf[n]);
+    const int j0 = OWN ? row0 : 0, nj = OWN ? B : Bg;
+    for (int idx = tid; idx < nj * N; idx += 256) {
+        const int jl = idx / N, n = idx - jl * N;
+        const int j = j0 + jl;
+        atomicAdd(&dzf_all[(size_t)(OWN ? jl : j) * LD + n], s * Gef[j] * qe[n]);
+        atomicAdd(&dze_all[(size_t)(OWN ? jl : j) * LD + n], s * Gfe[j] * qf[n]);
     }
 }
 
@@ -1102,9 +1114,20 @@ int mm_clip_loss(const float* z_local, const float* z_all, const float* logit_sc
     MM_REQUIRE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg && N > 0, "clip_loss: B=%d Bg=%d row0=%d", B, Bg, row0);
     const size_t lds = (size_t)(2 * N + 2 * Bg + 32) * sizeof(float);
     MM_REQUIRE(lds <= 64 * 1024, "clip_loss: N/Bg too large for LDS");
-    hipLaunchKernelGGL(clip_loss_kernel, dim3(B), dim3(256), lds, st, z_local, z_all, logit_scale, scal4, dz_all, B,
+    hipLaunchKernelGGL(clip_loss_kernel<false>, dim3(B), dim3(256), lds, st, z_local, z_all, logit_scale, scal4, dz_all, B,
                        Bg, N, row0);
     return mm_check_launch("clip_loss");
+}
+
+int mm_clip_loss_own_rows(const float* z_all, const float* logit_scale, float* scal4, float* dz_local, int B, int Bg, int N,
+                          int row0, hipStream_t st) {
+    MM_REQUIRE(z_all && logit_scale && scal4, "clip_loss_own_rows: null");
+    MM_REQUIRE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg && N > 0, "clip_loss_own_rows: B=%d Bg=%d row0=%d", B, Bg, row0);
+    const size_t lds = (size_t)(2 * N + 2 * Bg + 32) * sizeof(float);
+    MM_REQUIRE(lds <= 64 * 1024, "clip_loss_own_rows: N/Bg too large for LDS");
+    hipLaunchKernelGGL(clip_loss_kernel<true>, dim3(Bg), dim3(256), lds, st, nullptr, z_all, logit_scale, scal4, dz_local, B,
+                       Bg, N, row0);
+    return mm_check_launch("clip_loss_own_rows");
 }
 
 int mm_sumsq(const float* g, float* state, int64_t n, hipStream_t st) {

@@ -1,11 +1,14 @@
 """Data-parallel exchange steps of the contrastive bridge (backend-agnostic:
-RCCL on the GPUs, gloo in the CPU tests).  The path has exactly three exchanges
-per step:
+RCCL on the GPUs, gloo in the CPU tests).  SURVEY.md section 8e lists three exchanges per step:
 
   1. all-gather of the packed L2-normalised embeddings  (global negatives)
   2. reduce-scatter (sum) of the gradients w.r.t. the gathered embeddings
   3. all-reduce of the flat fp32 gradient bucket (mean is applied as
      ``grad_scale = 1/world`` inside the fused AdamW kernel)
+
+The trainer's tape (bridge_trainer.py) needs only 1 and 3: every rank evaluates all rows of the gathered
+batch (``mm_clip_loss_own_rows``) and so already holds the sum step 2 would deliver for its own rows.
+Step 2 remains for the public autograd surface (``ops.clip_loss`` with a process group).
 """
 from __future__ import annotations
 

@@ -192,6 +192,43 @@ def test_layernorm_fwd_bwd(M, D):
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-3)
 
 
+def test_clip_loss_own_rows_equals_reduce_scatter_of_all_ranks():
+    """a-X2 / a-X5: mm_clip_loss_own_rows on rank r == the block a reduce-scatter-sum over ranks of
+    mm_clip_loss's dz_all would deliver to rank r (four emulated ranks on one GPU), with identical loss /
+    top-1 / d logit_scale for the local rows; fp32 atomics in a different order: 1e-5."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(21)
+    W, B, N = 4, 16, 128
+    Bg = W * B
+    z_all = torch.cat([F.normalize(torch.randn(Bg, N, generator=g), dim=1),
+                       F.normalize(torch.randn(Bg, N, generator=g), dim=1)], dim=1).cuda().contiguous()
+    ls = torch.tensor([math.log(1 / 0.07)], device="cuda")
+    total = torch.zeros(Bg, 2 * N, device="cuda")
+    scal_old = []
+    for r in range(W):
+        dz_all = torch.zeros(Bg, 2 * N, device="cuda")
+        scal = torch.zeros(4, device="cuda")
+        hip.call("mm_clip_loss", z_all[r * B:(r + 1) * B].contiguous(), z_all, ls, scal, dz_all, B, Bg, N, r * B)
+        total += dz_all
+        scal_old.append(scal)
+    for r in range(W):
+        dz = torch.zeros(B, 2 * N, device="cuda")
+        scal = torch.zeros(4, device="cuda")
+        hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, B, Bg, N, r * B)
+        torch.testing.assert_close(dz, total[r * B:(r + 1) * B], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(scal, scal_old[r], rtol=1e-5, atol=1e-7)
+    # world of one rank: the two entry points are the same computation
+    dz1, dz2 = torch.zeros(B, 2 * N, device="cuda"), torch.zeros(B, 2 * N, device="cuda")
+    s1, s2 = torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda")
+    zl = z_all[:B].contiguous()
+    hip.call("mm_clip_loss", zl, zl, ls, s1, dz1, B, B, N, 0)
+    hip.call("mm_clip_loss_own_rows", zl, ls, s2, dz2, B, B, N, 0)
+    torch.testing.assert_close(dz1, dz2, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(s1, s2, rtol=1e-6, atol=1e-7)
+    with pytest.raises(Exception):
+        hip.call("mm_clip_loss_own_rows", z_all, ls, s2, dz2, B, Bg, N, Bg)
+
+
 def test_grouped_linear_wgrads_equal_separate_launches():
     """mm_conv1d_wgrad_many (one launch, workgroup id -> problem; fewer, longer row chunks per problem) sums to the
     same weight gradients and bias partials as one mm_conv1d_wgrad(slot_mode=1) launch per problem; 14 problems

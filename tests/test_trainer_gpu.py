@@ -91,7 +91,7 @@ def test_graph_mode_draws_new_dropout_masks_each_replay():
 
 def test_two_rank_data_parallel_step_on_one_gpu():
     """a-X5: two ranks share this GPU, exchange steps over gloo (RCCL refuses two
-    ranks per device).  Same code the N>1 bench runs: 4 hipGraph segments + 3
+    ranks per device).  Same code the N>1 bench runs: 3 hipGraph segments + 2
     collectives.  Ranks must end bit-identical; graph replay must equal the eager tape."""
     from tools import dp_rehearsal as mod
     r = mod.run(2)
@@ -105,7 +105,7 @@ def test_two_rank_data_parallel_step_on_one_gpu():
 
 
 def test_segmented_step_through_rccl_with_one_rank():
-    """a-X5: the N > 1 code path (4 hipGraph segments, the three collectives between them) through
+    """a-X5: the N > 1 code path (3 hipGraph segments, the two collectives between them) through
     the real backend ("nccl" == RCCL) at world size 1, in a child process: RCCL initialises, every
     collective call of the multi-GPU bench is accepted, and the result equals the one-graph step."""
     import os

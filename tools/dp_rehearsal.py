@@ -1,6 +1,6 @@
 """Two (or more) ranks of the data-parallel bridge step on ONE GPU, collectives
 over gloo (RCCL refuses two ranks on one device).  Exercises exactly what the
-driver's N>1 bench runs — four hipGraph segments with the three exchange steps
+driver's N>1 bench runs — three hipGraph segments with the two exchange steps
 between them — and checks:
   * every rank ends with bit-identical parameters,
   * graph-segment replay == the same tape run eagerly ("manual") step by step,
@@ -63,7 +63,7 @@ def run(world=2, timeout=600):
 
 
 def run_rccl_world1():
-    """the N > 1 code path (4 graph segments + the three collectives) through the REAL backend
+    """the N > 1 code path (3 graph segments + the two collectives) through the REAL backend
     ("nccl" == RCCL) with a world of one rank: checks RCCL initialisation and every collective call
     the multi-GPU bench makes, against the single-graph step on the same data."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
@@ -94,7 +94,7 @@ def run_rccl_world1():
 
 def time_rccl_world1(steps=200):
     """cost of the N > 1 execution shape at full C2 size, measurable on one GPU: the single-graph step
-    against four graph segments with the three RCCL calls between them (world of one rank, so the
+    against three graph segments with the two RCCL calls between them (world of one rank, so the
     collectives move no data - what is timed is segmentation + collective launch overhead)."""
     import time
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
@@ -130,7 +130,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rccl1":
         r = run_rccl_world1()
         print(r)
-        assert r["graphs"] == (1, 4), r
+        assert r["graphs"] == (1, 3), r
         assert r["param_rel"] < 1e-2, r
         for i, (x, y) in enumerate(zip(*r["losses"])):      # Adam amplifies float-atomic ordering noise step by step
             assert abs(x - y) <= (5e-3 if i < 3 else 3e-2) * abs(y), r
