@@ -106,12 +106,15 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
                     *reinterpret_cast<u32x4*>(As + ((r / HB) * GWP + r % HB) * AS + sg * 8) = v[q];
             }
         }
+        // a weight plane is BN * 9 rows of <= 4 segments: ONE batch of SBW loads per thread (with the halo's
+        // batch size of 8 the 9 chunks of a 64-column plane took two global round trips per plane)
+        constexpr int SBW = (BN * 9 * 4 + 255) / 256;
         for (int kd = 0; kd < 3; ++kd) {
             if (kd) __syncthreads();                       // previous plane's reads done
-            for (int s0 = 0; s0 < BN * 9 * segs; s0 += 256 * SB) {
-                u32x4 v[SB];
+            for (int s0 = 0; s0 < BN * 9 * segs; s0 += 256 * SBW) {
+                u32x4 v[SBW];
 #pragma unroll
-                for (int q = 0; q < SB; ++q) {
+                for (int q = 0; q < SBW; ++q) {
                     const int s = s0 + q * 256 + tid;
                     const int r = s / segs, sg = s - r * segs; // r = n_local * 9 + t9
                     const int nl = r / 9, t9 = r - nl * 9;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
                         v[q] = *reinterpret_cast<const u32x4*>(a.w + ((size_t)(n0 + nl) * 27 + kd * 9 + t9) * a.Cin + c0 + sg * 8);
                 }
 #pragma unroll
-                for (int q = 0; q < SB; ++q) {
+                for (int q = 0; q < SBW; ++q) {
                     const int s = s0 + q * 256 + tid;
                     if (s < BN * 9 * segs) *reinterpret_cast<u32x4*>(Ws + (s / segs) * AS + (s % segs) * 8) = v[q];
                 }
