@@ -294,41 +294,63 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     const int wrows = BN * a.taps;
     const int wvalid = (a.Cout - n0) * a.taps;    // rows >= wvalid are beyond Cout -> zeros
 
-    // staging goes through register batches: all loads of a batch are in flight
-    // before the first LDS write (a load->store loop serialises on load latency)
-    constexpr int NB = 8;
+    // staging goes through register batches: all loads of a batch are in flight before the first LDS
+    // write (a load->store loop serialises on load latency).  The first activation batch and the first
+    // weight batch are issued TOGETHER (one global round trip per K chunk for the Linear layers instead of
+    // two); whatever does not fit (k > 1 convs) follows in further batches.
+    // (only the 32-row Linear tile: at 64 rows the 12 staging registers sets cost the third wave per SIMD)
+    constexpr bool MERGE = BM == 32;
+    constexpr int NA = MERGE ? 2 : 4, NB = 8;
     const bf16* wb = a.w + (size_t)n0 * a.taps * a.Cin;
+    const int nA = arows * SEGS, nW = wrows * SEGS;
+    auto load_a = [&](int s, int c0) {
+        const int r = s / SEGS, sg = s % SEGS;
+        const int t = t0 - a.pad + r;
+        return (s < nA && t >= 0 && t < a.T) ? *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c0 + sg * 8)
+                                             : make_uint4(0, 0, 0, 0);
+    };
+    auto load_w = [&](int s, int c0) {
+        const int r = s / SEGS, sg = s % SEGS;             // r = n_local * taps + tap
+        return (s < nW && r < wvalid) ? *reinterpret_cast<const uint4*>(wb + (size_t)r * a.Cin + c0 + sg * 8)
+                                      : make_uint4(0, 0, 0, 0);
+    };
     for (int c0 = 0; c0 < a.Cin; c0 += KCT) {
         if (c0) __syncthreads();
-        for (int base = 0; base < arows * SEGS; base += NB * 256) {
-            uint4 v[NB];
+        if constexpr (MERGE) {
+            uint4 va[NA], vw[NB];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int s = base + i * 256 + tid;
-                const int r = s / SEGS, sg = s % SEGS;
-                const int t = t0 - a.pad + r;
-                v[i] = (s < arows * SEGS && t >= 0 && t < a.T)
-                           ? *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c0 + sg * 8) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NA; ++i) va[i] = load_a(i * 256 + tid, c0);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) vw[i] = load_w(i * 256 + tid, c0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int s = i * 256 + tid;
+                if (s < nA) *reinterpret_cast<uint4*>(As + (s / SEGS) * AS + (s % SEGS) * 8) = va[i];
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int s = base + i * 256 + tid;
-                if (s < arows * SEGS) *reinterpret_cast<uint4*>(As + (s / SEGS) * AS + (s % SEGS) * 8) = v[i];
+                const int s = i * 256 + tid;
+                if (s < nW) *reinterpret_cast<uint4*>(Ws + (s / SEGS) * AS + (s % SEGS) * 8) = vw[i];
             }
         }
-        for (int base = 0; base < wrows * SEGS; base += NB * 256) {
+        for (int base = MERGE ? NA * 256 : 0; base < nA; base += NA * 256) {
+            uint4 v[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) v[i] = load_a(base + i * 256 + tid, c0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int s = base + i * 256 + tid;
+                if (s < nA) *reinterpret_cast<uint4*>(As + (s / SEGS) * AS + (s % SEGS) * 8) = v[i];
+            }
+        }
+        for (int base = MERGE ? NB * 256 : 0; base < nW; base += NB * 256) {
             uint4 v[NB];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int s = base + i * 256 + tid;
-                const int r = s / SEGS, sg = s % SEGS;         // r = n_local * taps + tap
-                v[i] = (s < wrows * SEGS && r < wvalid)
-                           ? *reinterpret_cast<const uint4*>(wb + (size_t)r * a.Cin + c0 + sg * 8) : make_uint4(0, 0, 0, 0);
-            }
+            for (int i = 0; i < NB; ++i) v[i] = load_w(base + i * 256 + tid, c0);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int s = base + i * 256 + tid;
-                if (s < wrows * SEGS) *reinterpret_cast<uint4*>(Ws + (s / SEGS) * AS + (s % SEGS) * 8) = v[i];
+                if (s < nW) *reinterpret_cast<uint4*>(Ws + (s / SEGS) * AS + (s % SEGS) * 8) = v[i];
             }
         }
         __syncthreads();
