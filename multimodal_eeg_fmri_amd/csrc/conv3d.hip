@@ -84,49 +84,63 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int SB = 8;                                 // 16-byte chunks per thread per staging batch
 
+    // a weight plane is BN * 9 rows of <= 4 segments: ONE batch of SBW loads per thread (with the halo's
+    // batch size of 8 the 9 chunks of a 64-column plane took two global round trips per plane)
+    constexpr int SBW = (BN * 9 * 4 + 255) / 256;
+    auto load_halo = [&](int s, int c0) {
+        const int r = s / segs, sg = s - r * segs;
+        const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
+        const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (s < HROWS * segs && d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
+            v = *reinterpret_cast<const u32x4*>(xb + (((size_t)d * a.H + h) * a.W + w) * a.Cin + c0 + sg * 8);
+        return v;
+    };
+    auto store_halo = [&](int s, const u32x4& v) {
+        const int r = s / segs, sg = s - r * segs;
+        if (s < HROWS * segs) *reinterpret_cast<u32x4*>(As + ((r / HB) * GWP + r % HB) * AS + sg * 8) = v;
+    };
+    auto load_w = [&](int s, int c0, int kd) {
+        const int r = s / segs, sg = s - r * segs;         // r = n_local * 9 + t9
+        const int nl = r / 9, t9 = r - nl * 9;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (s < BN * 9 * segs && n0 + nl < a.Cout)
+            v = *reinterpret_cast<const u32x4*>(a.w + ((size_t)(n0 + nl) * 27 + kd * 9 + t9) * a.Cin + c0 + sg * 8);
+        return v;
+    };
+    auto store_w = [&](int s, const u32x4& v) {
+        if (s < BN * 9 * segs) *reinterpret_cast<u32x4*>(Ws + (s / segs) * AS + (s % segs) * 8) = v;
+    };
+    constexpr bool ONE_HALO_BATCH = HROWS * 4 <= 256 * SB;    // the halo fits one batch: issue it with weight plane 0
     for (int c0 = 0; c0 < a.Cin; c0 += kc) {
         // staging in batches: all loads of a batch are in flight before its first LDS write
-        for (int s0 = 0; s0 < HROWS * segs; s0 += 256 * SB) {
-            u32x4 v[SB];
+        if constexpr (ONE_HALO_BATCH) {
+            u32x4 vh[SB], vw[SBW];
 #pragma unroll
-            for (int q = 0; q < SB; ++q) {
-                const int s = s0 + q * 256 + tid;
-                const int r = s / segs, sg = s - r * segs;
-                const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
-                const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-                v[q] = u32x4{0u, 0u, 0u, 0u};
-                if (s < HROWS * segs && d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                    v[q] = *reinterpret_cast<const u32x4*>(xb + (((size_t)d * a.H + h) * a.W + w) * a.Cin + c0 + sg * 8);
-            }
+            for (int q = 0; q < SB; ++q) vh[q] = load_halo(q * 256 + tid, c0);
 #pragma unroll
-            for (int q = 0; q < SB; ++q) {
-                const int s = s0 + q * 256 + tid;
-                const int r = s / segs, sg = s - r * segs;
-                if (s < HROWS * segs)
-                    *reinterpret_cast<u32x4*>(As + ((r / HB) * GWP + r % HB) * AS + sg * 8) = v[q];
+            for (int q = 0; q < SBW; ++q) vw[q] = load_w(q * 256 + tid, c0, 0);
+#pragma unroll
+            for (int q = 0; q < SB; ++q) store_halo(q * 256 + tid, vh[q]);
+#pragma unroll
+            for (int q = 0; q < SBW; ++q) store_w(q * 256 + tid, vw[q]);
+        } else {
+            for (int s0 = 0; s0 < HROWS * segs; s0 += 256 * SB) {
+                u32x4 v[SB];
+#pragma unroll
+                for (int q = 0; q < SB; ++q) v[q] = load_halo(s0 + q * 256 + tid, c0);
+#pragma unroll
+                for (int q = 0; q < SB; ++q) store_halo(s0 + q * 256 + tid, v[q]);
             }
         }
-        // a weight plane is BN * 9 rows of <= 4 segments: ONE batch of SBW loads per thread (with the halo's
-        // batch size of 8 the 9 chunks of a 64-column plane took two global round trips per plane)
-        constexpr int SBW = (BN * 9 * 4 + 255) / 256;
         for (int kd = 0; kd < 3; ++kd) {
             if (kd) __syncthreads();                       // previous plane's reads done
-            for (int s0 = 0; s0 < BN * 9 * segs; s0 += 256 * SBW) {
+            if (!(ONE_HALO_BATCH && kd == 0)) {
                 u32x4 v[SBW];
 #pragma unroll
-                for (int q = 0; q < SBW; ++q) {
-                    const int s = s0 + q * 256 + tid;
-                    const int r = s / segs, sg = s - r * segs; // r = n_local * 9 + t9
-                    const int nl = r / 9, t9 = r - nl * 9;
-                    v[q] = u32x4{0u, 0u, 0u, 0u};
-                    if (s < BN * 9 * segs && n0 + nl < a.Cout)
-                        v[q] = *reinterpret_cast<const u32x4*>(a.w + ((size_t)(n0 + nl) * 27 + kd * 9 + t9) * a.Cin + c0 + sg * 8);
-                }
+                for (int q = 0; q < SBW; ++q) v[q] = load_w(q * 256 + tid, c0, kd);
 #pragma unroll
-                for (int q = 0; q < SBW; ++q) {
-                    const int s = s0 + q * 256 + tid;
-                    if (s < BN * 9 * segs) *reinterpret_cast<u32x4*>(Ws + (s / segs) * AS + (s % segs) * 8) = v[q];
-                }
+                for (int q = 0; q < SBW; ++q) store_w(q * 256 + tid, v[q]);
             }
             __syncthreads();
 #pragma unroll
