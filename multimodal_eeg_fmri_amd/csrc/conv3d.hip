@@ -133,16 +133,20 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
                 for (int q = 0; q < SB; ++q) store_halo(s0 + q * 256 + tid, v[q]);
             }
         }
+        if constexpr (!ONE_HALO_BATCH) {
+            u32x4 v[SBW];
+#pragma unroll
+            for (int q = 0; q < SBW; ++q) v[q] = load_w(q * 256 + tid, c0, 0);
+#pragma unroll
+            for (int q = 0; q < SBW; ++q) store_w(q * 256 + tid, v[q]);
+        }
         for (int kd = 0; kd < 3; ++kd) {
-            if (kd) __syncthreads();                       // previous plane's reads done
-            if (!(ONE_HALO_BATCH && kd == 0)) {
-                u32x4 v[SBW];
+            __syncthreads();                               // plane kd (and the halo) are in LDS
+            // the NEXT plane's global loads are in flight during this plane's 9 x kc/16 MFMA steps
+            u32x4 vn[SBW];
+            if (kd < 2)
 #pragma unroll
-                for (int q = 0; q < SBW; ++q) v[q] = load_w(q * 256 + tid, c0, kd);
-#pragma unroll
-                for (int q = 0; q < SBW; ++q) store_w(q * 256 + tid, v[q]);
-            }
-            __syncthreads();
+                for (int q = 0; q < SBW; ++q) vn[q] = load_w(q * 256 + tid, c0, kd + 1);
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
                 const int toff = kd * GDP + (t9 / 3) * GWP + (t9 % 3);
@@ -162,6 +166,11 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                 }
+            }
+            if (kd < 2) {
+                __syncthreads();                           // every wave is done reading plane kd
+#pragma unroll
+                for (int q = 0; q < SBW; ++q) store_w(q * 256 + tid, vn[q]);
             }
         }
         __syncthreads();
