@@ -628,12 +628,102 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
 // on them but the final slot sum, so a trainer collects them and issues them once, off the chain.
 constexpr int WM_MAX = 12;
 struct WgradTable { WgradArgs a[WM_MAX]; int first[WM_MAX + 1]; int gx[WM_MAX], gy[WM_MAX]; int n; };
+// Linear (taps = 1) weight gradient on a 128 (n) x 128 (c) workgroup tile: wave (wn, wc) owns 64 x 64 = 2 x 2
+// MFMA tiles, so a k-step is 4 transposed LDS fragment reads for 4 MFMAs (the 64 x 64 tile: 2 for 1) and
+// the operands are fetched from global memory half as often.  Each operand tile lives in LDS as two
+// 64-column halves with the 192-byte row stride tr_frag is laid out for.  Slot mode only.
+__device__ __forceinline__ void linear_wgrad128_body(const WgradArgs& a, const int bx, const int by, const int bz) {
+    __shared__ __attribute__((aligned(16))) bf16 Ys[2][WG_MK * WG_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Xs[2][WG_MK * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int chunksT = (a.T + a.rows_per_wg - 1) / a.rows_per_wg;
+    const int b = bx / chunksT;
+    const int tbeg = (bx % chunksT) * a.rows_per_wg;
+    const int tend = min(a.T, tbeg + a.rows_per_wg);
+    const int n0 = by * 128, c0 = bz * 128;
+    const bf16* dyb = a.dy + (size_t)b * a.T * a.Cout;
+    const bf16* xb = a.x + (size_t)b * a.T * a.Cin;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+
+    constexpr int NREG = WG_MK * 16 / 256;                          // 4 x 16-byte chunks per operand per thread
+    uint4 yv[NREG], xv[NREG];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int s = tid + i * 256, r = s >> 4, sg = s & 15;
+            const int t = t0 + r, n = n0 + sg * 8, c = c0 + sg * 8;
+            yv[i] = (t < tend && n < a.Cout) ? *reinterpret_cast<const uint4*>(dyb + (size_t)t * a.Cout + n) : make_uint4(0, 0, 0, 0);
+            xv[i] = (t < tend && c < a.Cin) ? *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    if (tbeg < tend) fetch(tbeg);
+    for (int t0 = tbeg; t0 < tend; t0 += WG_MK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int s = tid + i * 256, r = s >> 4, sg = s & 15;
+            *reinterpret_cast<uint4*>(Ys[sg >> 3] + r * WG_LD + (sg & 7) * 8) = yv[i];
+            *reinterpret_cast<uint4*>(Xs[sg >> 3] + r * WG_LD + (sg & 7) * 8) = xv[i];
+        }
+        __syncthreads();
+        if (t0 + WG_MK < tend) fetch(t0 + WG_MK);
+#pragma unroll
+        for (int kk = 0; kk < WG_MK; kk += 16) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = tr_frag(Ys[wn], kk, i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = tr_frag(Xs[wc], kk, j * 32, lane);
+            if (a.dbias && bz == 0 && wc == 0)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[i] += (float)af[i][j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[i = n][j = c]: lane owns column c, rows n = (r&3) + 8*(r>>2) + 4*(lane>>5); every (slot, element) has one writer
+    float* dwr = a.dw + (size_t)bx * a.rep_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+        if (c >= a.Cin_real) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < a.Cout) dwr[n * a.sn + c * a.sc] = acc[i][j][r];
+            }
+    }
+    if (a.dbias && bz == 0 && wc == 0)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            const int n = n0 + wn * 64 + i * 32 + (lane & 31);
+            if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(bx % MM_REPL) * a.Cout + n, v);
+        }
+}
+
 __global__ __launch_bounds__(256) void conv1d_wgrad_many_kernel(WgradTable tab) {
     int p = 0;
     while (p + 1 < tab.n && (int)blockIdx.x >= tab.first[p + 1]) ++p;
     const int local = blockIdx.x - tab.first[p];
     const int gx = tab.gx[p], gy = tab.gy[p];
-    conv1d_wgrad_body<1>(tab.a[p], local % gx, (local / gx) % gy, local / (gx * gy));
+    linear_wgrad128_body(tab.a[p], local % gx, (local / gx) % gy, local / (gx * gy));
 }
 
 // dw[n][c][tap] += sum_rep ws[rep][n][tap][c]   (replicated contiguous-atomics workspace -> PyTorch layout)
@@ -908,7 +998,7 @@ static int wgrad_many_target() {
     return t;
 }
 static int wgrad_many_rows_per_wg(int T, int Cin, int Cout) {
-    const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
+    const int tiles = ceil_div(Cout, 128) * ceil_div(Cin, 128);
     const int tilesT = ceil_div(T, WG_MK);
     int want_chunks = ceil_div(wgrad_many_target(), tiles);
     if (want_chunks < 1) want_chunks = 1;
@@ -975,8 +1065,8 @@ int mm_conv1d_wgrad_many(const void* desc_host, int n, hipStream_t st) {
             MM_REQUIRE(q.nslots == chunks, "conv1d_wgrad_many: needs exactly %d slots (mm_conv1d_wgrad_many_slots), got %d",
                        chunks, q.nslots);
             tab.first[i] = total;
-            tab.gx[i] = chunks; tab.gy[i] = ceil_div(q.Cout, 64);
-            total += chunks * tab.gy[i] * ceil_div(q.Cin, 64);
+            tab.gx[i] = chunks; tab.gy[i] = ceil_div(q.Cout, 128);
+            total += chunks * tab.gy[i] * ceil_div(q.Cin, 128);
         }
         tab.first[tab.n] = total;
         hipLaunchKernelGGL(conv1d_wgrad_many_kernel, dim3(total), dim3(256), 0, st, tab);
