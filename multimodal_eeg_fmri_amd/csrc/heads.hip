@@ -278,13 +278,27 @@ __global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict_
     const float s = __expf(logit_scale[0]);
     for (int n = tid; n < N; n += 256) { qe[n] = ze[(size_t)i * LD + n]; qf[n] = zf[(size_t)i * LD + n]; }
     __syncthreads();
-    // raw cosines
+    // raw cosines: 8 lanes per column j (float4 strides over the embedding), so that a batch of 32 columns
+    // keeps all 256 threads busy instead of 32 threads walking 128 elements each
     float mxe = -INFINITY, mxf = -INFINITY;
-    for (int j = tid; j < Bg; j += 256) {
-        float a = 0.f, c = 0.f;
-        for (int n = 0; n < N; ++n) { a += qe[n] * zf_all[(size_t)j * LD + n]; c += qf[n] * ze_all[(size_t)j * LD + n]; }
-        Gef[j] = a; Gfe[j] = c;
-        mxe = fmaxf(mxe, a); mxf = fmaxf(mxf, c);
+    {
+        const int sub = tid & 7;
+        for (int j = tid >> 3; j < Bg; j += 32) {
+            float a = 0.f, c = 0.f;
+            const float* rf = zf_all + (size_t)j * LD;
+            const float* re = ze_all + (size_t)j * LD;
+            for (int n = sub * 4; n + 3 < N; n += 32) {
+                const float4 vf = *reinterpret_cast<const float4*>(rf + n);
+                const float4 ve = *reinterpret_cast<const float4*>(re + n);
+                a += qe[n] * vf.x + qe[n + 1] * vf.y + qe[n + 2] * vf.z + qe[n + 3] * vf.w;
+                c += qf[n] * ve.x + qf[n + 1] * ve.y + qf[n + 2] * ve.z + qf[n + 3] * ve.w;
+            }
+            for (int n = (N & ~31) + sub; n < N; n += 8) { a += qe[n] * rf[n]; c += qf[n] * re[n]; }   // N % 32 tail
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+            if (sub == 0) { Gef[j] = a; Gfe[j] = c; }
+            mxe = fmaxf(mxe, a); mxf = fmaxf(mxf, c);
+        }
     }
     mxe = wave_max(mxe); mxf = wave_max(mxf);
     if (lane == 0) { red[wave] = mxe; red[4 + wave] = mxf; }
