@@ -149,8 +149,10 @@ __device__ __forceinline__ void bn_dz_pair(const BnBwdArgs& a, float y0, float y
         }
     }
     const bool first = a0 >= a1;                       // ties -> first (torch max_pool)
-    dz0 = first ? g * m0 * act_grad(z0, a.act) : 0.f;
-    dz1 = first ? 0.f : g * m1 * act_grad(z1, a.act);
+    // ONE derivative, at the winner (two selects of act_grad(z0) / act_grad(z1) evaluate both)
+    const float d = g * (first ? m0 : m1) * act_grad(first ? z0 : z1, a.act);
+    dz0 = first ? d : 0.f;
+    dz1 = first ? 0.f : d;
 }
 
 template <bool APPLY>
