@@ -172,6 +172,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+            from tools import gloo_staging           # one-GPU rehearsal of the N > 1 path (tests only)
+            gloo_staging.install()
         group = dist.group.WORLD
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 

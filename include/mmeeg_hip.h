@@ -96,6 +96,14 @@ int mm_conv1d_wgrad_many_slots(int B, int T, int Cin, int Cout, int* slots_host,
  * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */
 int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, int nrep,
                      hipStream_t stream);
+/* PositionalEncoding.forward as a stand-alone op (enhanced_models_v4.py:44-55 =
+ * crossmodal_v4_enhancements.py:40-50): out[b][l][d] = dropout(x[b][l][d] + pe[l][d]) on the fp32
+ * stream, x (B,L,D), pe (L,D) = rows of the sinusoid buffer; fp32 and/or bf16 output.  pe == NULL is
+ * the op's backward: dx = dout * the same dropout mask (same p, seed).  D % 4 == 0.
+ * (Inside the encoders the add rides in the conv-3 / fusion-conv epilogue: mm_bn_act_fwd `pe`.) */
+int mm_add_pe(const float* x, const float* pe, float* out_f32, void* out_bf16, int B, int L, int D,
+              float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
+
 /* debugging: buf[idx] = 100 MHz wall clock, written in stream order (tools/ and bench --stamps) */
 int mm_debug_stamp(void* buf, int idx, hipStream_t stream);
 /* mm_prep_conv_weight for ndesc tensors in one launch per 64 descriptors; desc_host = HOST array
@@ -160,12 +168,17 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,
  * lse [B][H][L] fp32.  drop_p = attention-probability dropout (train mode).  The
- * head-averaged weights the reference computes and discards (:99) are not produced. */
+ * head-averaged weights the reference computes and discards (:99) are not produced.
+ * attn_mask (nullable): the `mask` of TemporalTransformerBlock.forward(x, mask)
+ * (enhanced_models_v4.py:88-98 -> self_attn(..., attn_mask=mask)) as an ADDITIVE fp32 (L, L)
+ * matrix shared by every batch element and head (a boolean mask = 0 / -inf; the (B*H, L, L)
+ * form is not supported).  A fully masked row yields NaN, as in PyTorch. */
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim,
-                float scale, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
+                float scale, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                const float* attn_mask, hipStream_t stream);
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                 float* delta_ws, int B, int L, int H, int head_dim, float scale, float drop_p,
-                uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
+                uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, hipStream_t stream);
 
 /* ---- small reductions / elementwise --------------------------------------- */
 int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, hipStream_t stream);
@@ -274,19 +287,19 @@ int mm_proj_heads_bwd(const float* dz, const float* z, const float* nrm, const f
 int mm_l2norm_fwd(const float* h, float* z, float* nrm, int B, int N, int ldz, hipStream_t stream);
 int mm_l2norm_bwd(const float* dz, const float* z, const float* nrm, float* dh, int B, int N, int ldz,
                   hipStream_t stream);
-/* batch-pairwise cosine-similarity matrix + symmetric InfoNCE.  Embeddings are
- * packed rows [ze (N) | zf (N)]: z_local [B][2N] = this rank's pairs, z_all
- * [Bg][2N] = the all-gathered global batch, local rows at [row0, row0+B).
- * scal4 += {loss, top1 e->f, top1 f->e, dloss/dlogit_scale}; dz_all [Bg][2N] +=
- * gradients w.r.t. the GLOBAL embeddings (reduce-scatter-sum across ranks).
+/* batch-pairwise cosine-similarity matrix + symmetric InfoNCE, bit-reproducible (no float atomics).
+ * Embeddings are packed rows [ze (N) | zf (N)]: z_all [Bg][2N] = the all-gathered global batch, this rank's
+ * pairs at rows [row0, row0+B).  C[r][j] = ze_r . zf_j; e->f = row softmax of exp(logit_scale) C, f->e =
+ * column softmax.  scal4 = {mean loss, top1 e->f, top1 f->e, d loss / d logit_scale} over the rank's own rows
+ * (plain stores: no zeroing needed); dz_local [B][2N] (nullable, plain stores) = d (SUM over ranks of their
+ * losses) / d z_local - exactly the block a reduce-scatter-sum of every rank's d loss / d z_all would
+ * deliver, so the step needs no reduce-scatter (every rank evaluates all Bg rows of the gathered batch:
+ * 2 Bg^2 N MACs).  ws = scratch of mm_clip_loss_ws_floats(B, Bg) floats (log-sum-exp of every row and
+ * column + per-row scalars), no initialisation needed.  N % 4 == 0.  Two launches on `stream`.
  * Extension a-X2: the reference trains a CE classifier (_test_bridge.py:858). */
-int mm_clip_loss(const float* z_local, const float* z_all, const float* logit_scale, float* scal4,
-                 float* dz_all, int B, int Bg, int N, int row0, hipStream_t stream);
-/* The same loss without the reduce-scatter: the rank evaluates ALL Bg rows of the gathered batch and keeps
- * what lands on its own rows, dz_local [B][2N] += d (sum over ranks of their losses) / d z_local - exactly the
- * block a reduce-scatter-sum of every rank's dz_all would deliver; scal4 counts the local rows only. */
-int mm_clip_loss_own_rows(const float* z_all, const float* logit_scale, float* scal4, float* dz_local, int B,
-                          int Bg, int N, int row0, hipStream_t stream);
+int mm_clip_loss_own_rows(const float* z_all, const float* logit_scale, float* scal4, float* dz_local, float* ws,
+                          int B, int Bg, int N, int row0, hipStream_t stream);
+int mm_clip_loss_ws_floats(int B, int Bg, int* floats_host, hipStream_t stream);
 
 /* ---- fused tails of the small models (forward) ------------------------------ */
 /* fMRIFusionNet weighted concat (fmri_utils.py:93-96) */
@@ -345,6 +358,11 @@ int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out,
  * (several scales write side by side into one activation tensor). */
 int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, int T, int nfft, int hop,
                   int ch_off, int ch_total, hipStream_t stream);
+/* normalize_modality (run_training_lite.py:48-51; applied per sample to the power features at :162):
+ * out[b] = bf16((x[b] - mean(x[b])) / (std_unbiased(x[b]) + eps)) over all rows x ch_valid elements of
+ * sample b; x / out [B][rows][ch_total] channels-last, channels >= ch_valid are written as zeros. */
+int mm_sample_zscore_bf16(const float* x, void* out_bf16, int B, int rows, int ch_valid, int ch_total, float eps,
+                          hipStream_t stream);
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 /* Encoder tail (enhanced_models_v4.py:161-167, 186-191: mean over time -> output_proj = Linear -> GELU ->
  * Dropout).  mm_linear_fwd_meanpool is the last transformer block's linear2 (+ dropout + residual, fp32 rows

@@ -310,7 +310,7 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     dh = D // blk.nhead
     pa, sa = s.get("attn_drop", (0.0, 0))
     _hip.call("mm_attn_bwd", s["qkv"], s["o"], do, s["lse"], dqkv, delta, B, L, blk.nhead, dh, float(dh) ** -0.5,
-              float(pa), int(sa), ops.EP())
+              float(pa), int(sa), ops.EP(), s.get("mask"))
     dx0 = _empty((M, D), _F32, dx2)
     emit = _empty((M, D), _BF, dx2) if emit_for is not None else None
     ep, es = emit_for if emit_for is not None else (0.0, 0)
@@ -479,15 +479,34 @@ class PowerEncoderFn(_ModuleFn):
         return (None, dx, None) + tuple(bag.result(p) for p in ctx.params)
 
 
-class TransformerBlockFn(_ModuleFn):
-    @staticmethod
-    def run(blk, x):
-        return TransformerBlockFn.apply(blk, x, *_module_params(blk))
+class AddPositionalFn(torch.autograd.Function):
+    """stand-alone PositionalEncoding.forward (enhanced_models_v4.py:44-55): dropout(x + pe[:L]);
+    backward = the same counter-hash mask on the incoming gradient."""
 
     @staticmethod
-    def forward(ctx, blk, x, *params):
+    def forward(ctx, x, pe, p):
+        seed = ops._next_seed() if p > 0 else 0
+        ctx.p, ctx.seed, ctx.dtype = p, seed, x.dtype
+        return ops.add_positional_impl(x, pe, p, seed)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.p > 0:
+            dx = ops.add_positional_impl(dout, None, ctx.p, ctx.seed, backward=True)
+        else:
+            dx = dout
+        return dx.to(ctx.dtype), None, None
+
+
+class TransformerBlockFn(_ModuleFn):
+    @staticmethod
+    def run(blk, x, mask=None):
+        return TransformerBlockFn.apply(blk, x, mask, *_module_params(blk))
+
+    @staticmethod
+    def forward(ctx, blk, x, mask, *params):
         xf = x.float().contiguous()
-        out, saved = ops.transformer_block_fwd(xf, blk, blk.training, True, save=True)
+        out, saved = ops.transformer_block_fwd(xf, blk, blk.training, True, save=True, mask=mask)
         ctx.blk, ctx.saved, ctx.params = blk, saved, params
         return out
 
@@ -497,7 +516,7 @@ class TransformerBlockFn(_ModuleFn):
         B, L, D = dout.shape
         with deferred(bag, dout.device):
             dx, _ = transformer_block_bwd(bag, ctx.saved, dout.contiguous().view(B * L, D).float())
-        return _ModuleFn._finish(ctx, bag, ctx.params, dx.view(B, L, D))
+        return (None, dx.view(B, L, D), None) + tuple(bag.result(p) for p in ctx.params)
 
 
 def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
@@ -656,27 +675,27 @@ class ContrastiveEmbedFn(torch.autograd.Function):
 
 
 class ClipLossFn(torch.autograd.Function):
-    """z (B, 2N) packed local embeddings -> (loss, acc_e2f, acc_f2e).  With a
-    process group the columns are the all-gathered global batch and the column
-    gradients travel back by reduce-scatter (sum)."""
+    """z (B, 2N) packed local embeddings -> (loss, acc_e2f, acc_f2e).  With a process group the columns are
+    the all-gathered global batch; every rank evaluates all rows of it (``mm_clip_loss_own_rows``), so the
+    backward hands out d (sum over ranks of their losses) / d z_local directly - what a reduce-scatter of the
+    gathered gradients would deliver - and the usual gradient all-reduce of data parallelism completes it."""
 
     @staticmethod
     def forward(ctx, z, logit_scale, group):
         from . import dp
-        z = z.contiguous()
+        z = z.contiguous().float()
         B, N2 = z.shape
         N = N2 // 2
         world, rank = dp.world_size(group), dp.rank(group)
         z_all = dp.gather_embeddings(z, group)
         need_grad = z.requires_grad or logit_scale.requires_grad
-        scal = _zeros((4,), z)
-        dz_all = _zeros((world * B, N2), z) if need_grad else None
+        scal = _empty((4,), _F32, z)
+        dz = _empty((B, N2), _F32, z) if need_grad else None
+        ws = _empty((6 * world * B,), _F32, z)
         ls = logit_scale.detach().reshape(1).float().contiguous()
-        _hip.call("mm_clip_loss", z, z_all, ls, scal, dz_all, B, world * B, N, rank * B)
+        _hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, ws, B, world * B, N, rank * B)
         if need_grad:
-            dz = dp.scatter_column_grads(dz_all, group)
             ctx.save_for_backward(dz, scal)
-        ctx.mark_non_differentiable(*(()))
         return scal[0].clone(), scal[1].clone(), scal[2].clone()
 
     @staticmethod

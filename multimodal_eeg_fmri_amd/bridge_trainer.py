@@ -62,6 +62,10 @@ class BridgeTrainer(nn.Module):
                         + [p for p in br.parameters() if p.requires_grad] + [self.head.logit_scale])
         self.bucket = FlatBucket(train_params)
         self.bucket.state[2] = lr
+        # {loss, top-1 e->f, top-1 f->e, d loss / d logit_scale} of the last step: owned by this trainer
+        # (plain stores of the loss kernel), so the tensors a step returns are overwritten only by THIS
+        # trainer's next step - keep a value with .item() / .clone()
+        self._scal = torch.zeros(4, device=device)
         ops.weights_changed()
 
     @property
@@ -152,11 +156,12 @@ class BridgeTrainer(nn.Module):
     def _seg_loss(self, z_all, scal, dz):
         """symmetric InfoNCE of this rank's rows against the gathered batch, gradient w.r.t. ITS rows only
         (``mm_clip_loss_own_rows``: every rank evaluates all rows of the gathered batch, so no reduce-scatter
-        of column gradients is needed).  ``scal`` / ``dz`` are cleared slices of the step's scratch arena."""
+        of column gradients is needed).  ``scal`` = the trainer's own 4-float result buffer, ``dz`` (B, 2N): both written with plain stores."""
         N2 = z_all.shape[1]
         B = dz.shape[0]
         ls = self.head.logit_scale.detach().reshape(1)
-        _hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
+        ws = ops._empty((6 * z_all.shape[0],), torch.float32, z_all)
+        _hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, ws, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
         self._stamp(6)
 
     def _seg_backward(self, saved, dz, scal):
@@ -230,7 +235,7 @@ class BridgeTrainer(nn.Module):
     def _step_manual_body(self, eeg, fmri):
         z, saved = self._seg_forward(eeg, fmri)
         z_all = dp.gather_embeddings(z, self.group)
-        scal, dz = ops._zeros((4,), z), ops._zeros(tuple(z.shape), z)            # cleared arena slices: no fills
+        scal, dz = self._scal, ops._empty(tuple(z.shape), torch.float32, z)
         self._seg_loss(z_all, scal, dz)
         self._seg_backward(saved, dz, scal)
         self._seg_optimizer()
@@ -272,11 +277,11 @@ class BridgeTrainer(nn.Module):
 
         B = eeg.shape[0]
         N2 = 2 * self.head.bridge.bridge_dim
-        c["scal"] = torch.zeros(4, device=dev)
+        c["scal"] = self._scal
         if world == 1 and not (self.force_segments and self.group is not None):
             def whole():
                 z, saved = self._seg_forward(c["eeg"], c["fmri"])
-                c["scal"], c["dz"] = ops._zeros((4,), z), ops._zeros(tuple(z.shape), z)   # arena: no fills
+                c["dz"] = ops._empty(tuple(z.shape), torch.float32, z)
                 self._seg_loss(z, c["scal"], c["dz"])
                 self._seg_backward(saved, c["dz"], c["scal"])
                 self._seg_adamw()
@@ -284,8 +289,7 @@ class BridgeTrainer(nn.Module):
         else:
             def seg1():
                 c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"])
-                # loss scalars and the embedding-gradient buffer: slices of the arena this segment has just cleared
-                c["scal"], c["dz"] = ops._zeros((4,), c["z"]), ops._zeros((B, N2), c["z"])
+                c["dz"] = ops._empty((B, N2), torch.float32, c["z"])
             record(seg1)
             c["z_all"] = torch.empty(world * B, N2, device=dev)
 
@@ -301,8 +305,9 @@ class BridgeTrainer(nn.Module):
         if self._cap is None or self._cap["eeg"].shape != eeg.shape or self._cap["fmri"].shape != fmri.shape:
             self._capture(eeg, fmri)
         c = self._cap
-        if eeg.data_ptr() != c["eeg"].data_ptr():
+        if eeg.data_ptr() != c["eeg"].data_ptr():          # each input on its own: a loader may fill only one in place
             c["eeg"].copy_(eeg)
+        if fmri.data_ptr() != c["fmri"].data_ptr():
             c["fmri"].copy_(fmri)
         g = c["graphs"]
         if len(g) == 1:

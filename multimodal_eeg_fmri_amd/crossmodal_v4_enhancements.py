@@ -263,13 +263,19 @@ class BalancedTriModalDataset(torch.utils.data.Dataset):
 class MultiScaleSTFTPowerEncoder(nn.Module):
     """BASELINE config #5 front-end (north-star extension a-X3; the reference loads
     MATLAB spectra instead, eeg_data_utils.py:86-119): raw EEG (B, C, T) -> Hann STFT
-    power at several window sizes -> (B, C * sum(F), frames) -> EnhancedPowerEncoder.
-    Semantics of the spectra = torch.stft(center=True, reflect) ** 2 per channel."""
+    power at several window sizes -> (B, C * sum(F), frames) -> [per-sample z-score] -> EnhancedPowerEncoder.
+    Semantics of the spectra = torch.stft(center=True, reflect) ** 2 per channel.  ``normalize`` (default):
+    the reference feeds its power features through normalize_modality - (x - mean) / (std + 1e-8) over the
+    whole feature array of a sample - before any model sees them (run_training_lite.py:48-51, 162); the
+    front-end does the same in fp32 before the bf16 cast, so the encoder's operands are O(1) like every
+    other modality (raw |.|^2 values span ~6 decades and cost the bf16 path a digit of parity)."""
 
     def __init__(self, in_channels: int, n_ffts=(64, 128), hop: int = 32, hidden_dim: int = 128,
-                 num_transformer_layers: int = 2, num_heads: int = 4, dropout: float = 0.3):
+                 num_transformer_layers: int = 2, num_heads: int = 4, dropout: float = 0.3,
+                 normalize: bool = True):
         super().__init__()
         self.n_ffts, self.hop = tuple(int(n) for n in n_ffts), int(hop)
+        self.normalize = bool(normalize)
         self.spec_channels = in_channels * sum(n // 2 + 1 for n in self.n_ffts)
         self.encoder = EnhancedPowerEncoder(self.spec_channels, hidden_dim, num_transformer_layers,
                                             num_heads, dropout)

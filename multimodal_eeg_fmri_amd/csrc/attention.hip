@@ -46,11 +46,12 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // DROP: attention-probability dropout compiled in (no per-score branch); FULL: L is a multiple of
 // the key and query chunk sizes, so no score needs a validity mask (3 VALU instructions each)
-template <bool DROP, bool FULL>
+// MASK: additive fp32 attention mask [L][L] (nn.MultiheadAttention attn_mask; -inf = not allowed), general path only
+template <bool DROP, bool FULL, bool MASK = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int L, int H, float scale_log2,
                                                        uint32_t dthresh, uint32_t dseed, float dinv,
-                                                       const uint32_t* epoch) {
+                                                       const uint32_t* epoch, const float* __restrict__ amask) {
     dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vt[DH * VS];
@@ -119,17 +120,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                sacc[r] = (FULL || key < kn) ? sacc[r] * scale_log2 : -INFINITY;
+                float sc = sacc[r] * scale_log2;
+                if (MASK && key < kn) sc += amask[(size_t)min(q, L - 1) * L + k0 + key] * 1.4426950408889634f;
+                sacc[r] = (FULL || key < kn) ? sc : -INFINITY;
                 mx = fmaxf(mx, sacc[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = fast_exp2(m_run - m_new);  // m_run = -inf first time -> 0
+            // a row whose keys so far are all masked out keeps m = -inf: subtract 0 instead (exp2(-inf) = 0)
+            const float m_sub = (MASK && m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - m_sub);  // m_run = -inf first time -> 0
             float ps = 0.f;
             bf16x8 pf[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = fast_exp2(sacc[r] - m_new);
+                float p = fast_exp2(sacc[r] - m_sub);
                 ps += p;
                 if (DROP) p *= attn_keep(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv);
                 pf[r >> 3][r & 7] = (bf16)p;
@@ -169,12 +174,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 // In both, the first product is oriented so that its accumulator tile is the
 // B operand of the following products (rows = reduction index).
 // ---------------------------------------------------------------------------
-template <bool DROP, bool FULL>
+template <bool DROP, bool FULL, bool MASK = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           bf16* __restrict__ dqkv, float* __restrict__ delta,
                                                           int L, int H, float scale, uint32_t dthresh,
-                                                          uint32_t dseed, float dinv, const uint32_t* epoch) {
+                                                          uint32_t dseed, float dinv, const uint32_t* epoch,
+                                                          const float* __restrict__ amask) {
     dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * KS];
@@ -256,7 +262,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float p = (FULL || key < kn) ? fast_exp2(sacc[r] * scale_log2 - lse2) : 0.f;
+                float sc = sacc[r] * scale_log2 - lse2;
+                if (MASK && key < kn) sc += amask[(size_t)min(q, L - 1) * L + k0 + key] * 1.4426950408889634f;
+                const float p = (FULL || key < kn) ? fast_exp2(sc) : 0.f;
                 float dpr = dp[r];
                 if (DROP) dpr *= attn_keep(dseed, b * H + h, q, k0 + key, L, dthresh, dinv);
                 dsf[r >> 3][r & 7] = (bf16)(p * (dpr - dl));
@@ -281,12 +289,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 constexpr int QCH = 128;                 // queries staged per chunk in the dK/dV pass
 constexpr int QS = QCH + 8;              // transposed row stride
 
-template <bool DROP, bool FULL>
+template <bool DROP, bool FULL, bool MASK = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16* __restrict__ dqkv, int L, int H, float scale,
                                                            uint32_t dthresh, uint32_t dseed, float dinv,
-                                                           const uint32_t* epoch) {
+                                                           const uint32_t* epoch, const float* __restrict__ amask) {
     dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Qs[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Ds[QCH * KS];
@@ -371,7 +379,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float p = (FULL || kok) ? fast_exp2(sacc[r] * scale_log2 - Ls[qi]) : 0.f;
+                float sc = sacc[r] * scale_log2 - Ls[qi];
+                if (MASK && kok && qi < qn) sc += amask[(size_t)(q0 + qi) * L + key] * 1.4426950408889634f;
+                const float p = (FULL || kok) ? fast_exp2(sc) : 0.f;
                 const float keep = DROP ? attn_keep(dseed, b * H + h, q0 + qi, key, L, dthresh, dinv) : 1.f;
                 pf[r >> 3][r & 7] = (bf16)(p * keep);
                 dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] * keep - Dl[qi]));
@@ -405,7 +415,7 @@ extern "C" {
 static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, float scale,
-                float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+                float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_fwd: drop_p");
     MM_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0, "attn_fwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_fwd: head_dim=%d (kernel is specialised for 32)", head_dim);
@@ -413,15 +423,16 @@ int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int
     const bool full = L % KCH == 0;
     auto kern = drop_p > 0.f ? (full ? attn_fwd_kernel<true, true> : attn_fwd_kernel<true, false>)
                              : (full ? attn_fwd_kernel<false, true> : attn_fwd_kernel<false, false>);
+    if (attn_mask) kern = drop_p > 0.f ? attn_fwd_kernel<true, false, true> : attn_fwd_kernel<false, false, true>;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
                        scale * 1.4426950408889634f, attn_thresh(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
-                       seed_epoch);
+                       seed_epoch, attn_mask);
     return mm_check_launch("attn_fwd");
 }
 
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
                 int B, int L, int H, int head_dim, float scale, float drop_p, uint32_t seed,
-                const uint32_t* seed_epoch, hipStream_t st) {
+                const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
     const uint32_t dth = attn_thresh(drop_p);
     const float dinv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
@@ -432,12 +443,16 @@ int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
                    : (full ? attn_bwd_dq_kernel<false, true> : attn_bwd_dq_kernel<false, false>);
     auto kdkv = dth ? (full ? attn_bwd_dkv_kernel<true, true> : attn_bwd_dkv_kernel<true, false>)
                     : (full ? attn_bwd_dkv_kernel<false, true> : attn_bwd_dkv_kernel<false, false>);
+    if (attn_mask) {
+        kdq = dth ? attn_bwd_dq_kernel<true, false, true> : attn_bwd_dq_kernel<false, false, true>;
+        kdkv = dth ? attn_bwd_dkv_kernel<true, false, true> : attn_bwd_dkv_kernel<false, false, true>;
+    }
     hipLaunchKernelGGL(kdq, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)out,
-                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv, seed_epoch);
+                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv, seed_epoch, attn_mask);
     int rc = mm_check_launch("attn_bwd_dq");
     if (rc) return rc;
     hipLaunchKernelGGL(kdkv, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
-                       delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv, seed_epoch);
+                       delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv, seed_epoch, attn_mask);
     return mm_check_launch("attn_bwd_dkv");
 }
 

@@ -532,6 +532,33 @@ __global__ void act_bwd_kernel(const float* __restrict__ g_f32, const bf16* __re
     }
 }
 
+// PositionalEncoding.forward as a stand-alone op: out[b][l][d] = (x[b][l][d] + pe[l][d]) * dropout_mask.
+// pe == nullptr is its backward (dx = dout * the same mask).  float4 per thread (D % 4 == 0).
+__global__ void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ out_f32,
+                              bf16* __restrict__ out_bf16, size_t n4, int LD4, uint32_t thresh, uint32_t seed,
+                              float inv_keep, const uint32_t* epoch) {
+    seed = mm_eff_seed(seed, epoch);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (pe) {
+            const float4 t = reinterpret_cast<const float4*>(pe)[i % (size_t)LD4];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (thresh) {
+            const uint32_t e = (uint32_t)(i * 4);
+            v.x *= dropout_scale(seed, e, thresh, inv_keep);
+            v.y *= dropout_scale(seed, e + 1, thresh, inv_keep);
+            v.z *= dropout_scale(seed, e + 2, thresh, inv_keep);
+            v.w *= dropout_scale(seed, e + 3, thresh, inv_keep);
+        }
+        if (out_f32) reinterpret_cast<float4*>(out_f32)[i] = v;
+        if (out_bf16) {
+            bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+            reinterpret_cast<bf16x4*>(out_bf16)[i] = o;
+        }
+    }
+}
+
 inline int grid_for(size_t n, int block = 256, int cap = 4096) {
     size_t g = (n + block - 1) / block;
     return (int)(g < (size_t)cap ? (g ? g : 1) : cap);
@@ -690,6 +717,17 @@ int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out,
                        (const bf16*)z, (bf16*)out, (size_t)n, act, thresh_of(drop_p), seed,
                        drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch);
     return mm_check_launch("act_bwd");
+}
+
+int mm_add_pe(const float* x, const float* pe, float* out_f32, void* out_bf16, int B, int L, int D, float drop_p,
+              uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(x && (out_f32 || out_bf16) && B > 0 && L > 0 && D > 0, "add_pe: null/invalid");
+    MM_REQUIRE(D % 4 == 0, "add_pe: D=%d must be a multiple of 4", D);
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "add_pe: drop_p");
+    const size_t n4 = (size_t)B * L * D / 4;
+    hipLaunchKernelGGL(add_pe_kernel, dim3(grid_for(n4)), dim3(256), 0, st, x, pe, out_f32, (bf16*)out_bf16, n4,
+                       L * D / 4, thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed_epoch);
+    return mm_check_launch("add_pe");
 }
 
 }  // extern "C"

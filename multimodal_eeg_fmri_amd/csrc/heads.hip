@@ -242,119 +242,152 @@ __global__ __launch_bounds__(256) void proj_heads_bwd_kernel(HeadsArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// symmetric InfoNCE over local rows [row0, row0+B) vs Bg global columns.
-//   S_ef[i][j] = s * ze_i . zf_all_j     S_fe[i][j] = s * zf_i . ze_all_j
-//   loss = 0.5 * (CE(S_ef, row0+i) + CE(S_fe, row0+i)) averaged over the B rows
-// One workgroup per local row i.  Outputs:
-//   scal[0] += loss_i/B, scal[1] += top1(e->f)/B, scal[2] += top1(f->e)/B,
-//   scal[3] += d loss / d logit_scale
-//   dze_all[Bg][N], dzf_all[Bg][N] += gradients w.r.t. the GLOBAL embeddings
-//   (row role at row0+i, column role at every j); the host reduce-scatters them.
+// symmetric InfoNCE over the gathered batch, bit-reproducible (no float atomics).
+//   C[r][j] = ze_r . zf_j  (cosines; Bg x Bg),  s = exp(logit_scale)
+//   e->f problem = row softmax of s C, f->e problem = column softmax of s C
+//   loss_r = 0.5 * (CE(row r, target r) + CE(column r, target r))
+// This rank owns rows/columns [row0, row0 + B).  Its step loss is mean_r loss_r over its own r; the
+// gradient it needs is that of the SUM over all ranks' losses w.r.t. its own embeddings (what a
+// reduce-scatter of every rank's d loss_rank / d z_all would deliver; AdamW applies the 1/world):
+//   dL/dC[r][j] = 0.5/B * s * (P_row[r][j] + P_col[r][j] - 2 delta_rj)
+//   dze_r = sum_j dL/dC[r][j] zf_j        dzf_r = sum_j dL/dC[j][r] ze_j
+// P_col[r][j] needs column j's normaliser, P_row[j][r] row j's: a global dependency, so two launches:
+//   clip_lse_kernel  (one workgroup per GLOBAL row r): row r and column r of C -> their log-sum-exp,
+//                     the row's loss / top-1 flags / d loss_r / d logit_scale            -> ws[6][Bg]
+//   clip_rows_kernel (one workgroup per OWN row): recomputes its row and column of C, forms dL/dC from
+//                     ws, writes dz[own row] with plain stores; workgroup 0 also sums the own rows'
+//                     scalars in a fixed order into scal[4] = {loss, top1 e->f, top1 f->e, d/d logit_scale}.
+// Every sum runs in a fixed order (lane-strided partials, xor-shuffle trees, fixed wave order).
 // ---------------------------------------------------------------------------
-// OWN = true: the "no reduce-scatter" form.  Every rank runs ALL Bg rows (it holds the gathered embeddings
-// anyway) and keeps only what lands on its own rows [row0, row0 + B): the row-role gradient of its rows and the
-// column-role contributions of every global row to its columns - the sum a reduce-scatter of the dz_all
-// buffers would have delivered.  dz_all is then this rank's [B][2N] block; loss / top-1 / d logit_scale count
-// the local rows only, as before.  z_loc is unused (row i is read from z_all).
-template <bool OWN>
-__global__ __launch_bounds__(256) void clip_loss_kernel(const float* __restrict__ z_loc, const float* __restrict__ z_all,
-                                                        const float* __restrict__ logit_scale, float* __restrict__ scal,
-                                                        float* __restrict__ dz_all, int B, int Bg, int N, int row0) {
-    // packed rows: [ze (N) | zf (N)], leading dimension 2N
-    const int LD = 2 * N;
-    const float* ze = OWN ? z_all : z_loc;
-    const float* zf = ze + N;
-    const float* ze_all = z_all;
-    const float* zf_all = z_all + N;
-    float* dze_all = dz_all;
-    float* dzf_all = dz_all ? dz_all + N : nullptr;
-    extern __shared__ float sm[];
-    float* qe = sm;                 // ze_i [N]
-    float* qf = qe + N;             // zf_i [N]
-    float* Gef = qf + N;            // [Bg]
-    float* Gfe = Gef + Bg;          // [Bg]
-    float* red = Gfe + Bg;          // [8 * 4]
-    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float s = __expf(logit_scale[0]);
-    for (int n = tid; n < N; n += 256) { qe[n] = ze[(size_t)i * LD + n]; qf[n] = zf[(size_t)i * LD + n]; }
+struct ClipShared {
+    float *qe, *qf, *cr, *cc, *red;
+};
+__device__ __forceinline__ ClipShared clip_shared(float* sm, int N, int Bg) {
+    ClipShared s;
+    s.qe = sm; s.qf = sm + N; s.cr = s.qf + N; s.cc = s.cr + Bg; s.red = s.cc + Bg;
+    return s;
+}
+// cr[j] = ze_r . zf_j, cc[j] = ze_j . zf_r for all j (8 lanes per column, float4 strides); returns the
+// two maxima in every thread
+__device__ __forceinline__ void clip_cosines(const float* __restrict__ z_all, int r, int Bg, int N, const ClipShared& sh,
+                                             float& mxr, float& mxc) {
+    const int LD = 2 * N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int n = tid; n < N; n += 256) { sh.qe[n] = z_all[(size_t)r * LD + n]; sh.qf[n] = z_all[(size_t)r * LD + N + n]; }
     __syncthreads();
-    // raw cosines: 8 lanes per column j (float4 strides over the embedding), so that a batch of 32 columns
-    // keeps all 256 threads busy instead of 32 threads walking 128 elements each
-    float mxe = -INFINITY, mxf = -INFINITY;
-    {
-        const int sub = tid & 7;
-        for (int j = tid >> 3; j < Bg; j += 32) {
-            float a = 0.f, c = 0.f;
-            const float* rf = zf_all + (size_t)j * LD;
-            const float* re = ze_all + (size_t)j * LD;
-            for (int n = sub * 4; n + 3 < N; n += 32) {
-                const float4 vf = *reinterpret_cast<const float4*>(rf + n);
-                const float4 ve = *reinterpret_cast<const float4*>(re + n);
-                a += qe[n] * vf.x + qe[n + 1] * vf.y + qe[n + 2] * vf.z + qe[n + 3] * vf.w;
-                c += qf[n] * ve.x + qf[n + 1] * ve.y + qf[n + 2] * ve.z + qf[n + 3] * ve.w;
-            }
-            for (int n = (N & ~31) + sub; n < N; n += 8) { a += qe[n] * rf[n]; c += qf[n] * re[n]; }   // N % 32 tail
+    float a_mx = -INFINITY, c_mx = -INFINITY;
+    const int sub = tid & 7, n32 = N & ~31;                // the float4 sweep covers whole 32-element chunks only
+    for (int j = tid >> 3; j < Bg; j += 32) {
+        float a = 0.f, c = 0.f;
+        const float* re = z_all + (size_t)j * LD;
+        const float* rf = re + N;
+        for (int n = sub * 4; n < n32; n += 32) {
+            const float4 vf = *reinterpret_cast<const float4*>(rf + n);
+            const float4 ve = *reinterpret_cast<const float4*>(re + n);
+            a += sh.qe[n] * vf.x + sh.qe[n + 1] * vf.y + sh.qe[n + 2] * vf.z + sh.qe[n + 3] * vf.w;
+            c += sh.qf[n] * ve.x + sh.qf[n + 1] * ve.y + sh.qf[n + 2] * ve.z + sh.qf[n + 3] * ve.w;
+        }
+        for (int n = n32 + sub; n < N; n += 8) { a += sh.qe[n] * rf[n]; c += sh.qf[n] * re[n]; }   // N % 32 tail
 #pragma unroll
-            for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
-            if (sub == 0) { Gef[j] = a; Gfe[j] = c; }
-            mxe = fmaxf(mxe, a); mxf = fmaxf(mxf, c);
-        }
+        for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+        if (sub == 0) { sh.cr[j] = a; sh.cc[j] = c; }
+        a_mx = fmaxf(a_mx, a); c_mx = fmaxf(c_mx, c);
     }
-    mxe = wave_max(mxe); mxf = wave_max(mxf);
-    if (lane == 0) { red[wave] = mxe; red[4 + wave] = mxf; }
+    a_mx = wave_max(a_mx); c_mx = wave_max(c_mx);
+    if (lane == 0) { sh.red[wave] = a_mx; sh.red[4 + wave] = c_mx; }
     __syncthreads();
-    mxe = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    mxf = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    mxr = fmaxf(fmaxf(sh.red[0], sh.red[1]), fmaxf(sh.red[2], sh.red[3]));
+    mxc = fmaxf(fmaxf(sh.red[4], sh.red[5]), fmaxf(sh.red[6], sh.red[7]));
     __syncthreads();
-    float se = 0.f, sf = 0.f;
-    for (int j = tid; j < Bg; j += 256) { se += __expf(s * (Gef[j] - mxe)); sf += __expf(s * (Gfe[j] - mxf)); }
-    se = wave_sum(se); sf = wave_sum(sf);
-    if (lane == 0) { red[wave] = se; red[4 + wave] = sf; }
+}
+// fixed-order workgroup sum of two values (4 waves)
+__device__ __forceinline__ void clip_sum2(float& a, float& c, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    a = wave_sum(a); c = wave_sum(c);
+    if (lane == 0) { red[wave] = a; red[4 + wave] = c; }
     __syncthreads();
-    se = red[0] + red[1] + red[2] + red[3];
-    sf = red[4] + red[5] + red[6] + red[7];
-    const int tgt = OWN ? i : row0 + i;
-    const bool mine = !OWN || (i >= row0 && i < row0 + B);      // wave-uniform
-    const float ce = Gef[tgt], cf = Gfe[tgt];
-    const float invB = 1.f / (float)B;
-    if (tid == 0 && mine) {
-        const float le = -(s * (ce - mxe) - __logf(se)), lf = -(s * (cf - mxf) - __logf(sf));
-        atomicAdd(&scal[0], 0.5f * (le + lf) * invB);
-        atomicAdd(&scal[1], (ce >= mxe ? 1.f : 0.f) * invB);
-        atomicAdd(&scal[2], (cf >= mxf ? 1.f : 0.f) * invB);
-    }
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    c = (red[4] + red[5]) + (red[6] + red[7]);
     __syncthreads();
-    // G = 0.5/B * (softmax - onehot); d/ds accumulates G * cos
-    float dsc = 0.f;
+}
+
+__global__ __launch_bounds__(256) void clip_lse_kernel(const float* __restrict__ z_all, const float* __restrict__ logit_scale,
+                                                       float* __restrict__ ws, int Bg, int N) {
+    extern __shared__ float sm[];
+    const ClipShared sh = clip_shared(sm, N, Bg);
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float s = __expf(logit_scale[0]);
+    float mxr, mxc;
+    clip_cosines(z_all, r, Bg, N, sh, mxr, mxc);
+    float se = 0.f, sf = 0.f, ee = 0.f, ef = 0.f;           // sum exp, sum exp * cos
     for (int j = tid; j < Bg; j += 256) {
-        const float ce_j = Gef[j], cf_j = Gfe[j];
-        float ge = __expf(s * (ce_j - mxe)) / se, gf = __expf(s * (cf_j - mxf)) / sf;
-        if (j == tgt) { ge -= 1.f; gf -= 1.f; }
-        ge *= 0.5f * invB; gf *= 0.5f * invB;
-        dsc += ge * ce_j + gf * cf_j;
-        Gef[j] = ge; Gfe[j] = gf;
+        const float a = sh.cr[j], c = sh.cc[j];
+        const float pa = __expf(s * (a - mxr)), pc = __expf(s * (c - mxc));
+        se += pa; sf += pc; ee += pa * a; ef += pc * c;
     }
-    dsc = wave_sum(dsc);
-    if (lane == 0 && mine) atomicAdd(&scal[3], dsc * s);      // d/d logit_scale = s * d/ds
-    __syncthreads();
-    if (!dze_all) return;
-    // row-role gradients:  dze_i += s * sum_j Gef[j] zf_all_j ; dzf_i += s * sum_j Gfe[j] ze_all_j
-    if (mine) {
-        const size_t orow = (size_t)(OWN ? i - row0 : tgt) * LD;
-        for (int n = tid; n < N; n += 256) {
-            float a = 0.f, c = 0.f;
-            for (int j = 0; j < Bg; ++j) { a += Gef[j] * zf_all[(size_t)j * LD + n]; c += Gfe[j] * ze_all[(size_t)j * LD + n]; }
-            atomicAdd(&dze_all[orow + n], s * a);
-            atomicAdd(&dzf_all[orow + n], s * c);
+    clip_sum2(se, sf, sh.red);
+    clip_sum2(ee, ef, sh.red);
+    if (tid == 0) {
+        const float diag = sh.cr[r];
+        const float lse_r = s * mxr + __logf(se), lse_c = s * mxc + __logf(sf);
+        ws[r] = lse_r;
+        ws[Bg + r] = lse_c;
+        ws[2 * Bg + r] = 0.5f * ((lse_r - s * diag) + (lse_c - s * sh.cc[r]));
+        ws[3 * Bg + r] = diag >= mxr ? 1.f : 0.f;
+        ws[4 * Bg + r] = sh.cc[r] >= mxc ? 1.f : 0.f;
+        // d loss_r / d logit_scale = s * 0.5 * (E_row[cos] - cos_rr + E_col[cos] - cos_rr)
+        ws[5 * Bg + r] = s * 0.5f * ((ee / se - diag) + (ef / sf - sh.cc[r]));
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_rows_kernel(const float* __restrict__ z_all, const float* __restrict__ logit_scale,
+                                                        const float* __restrict__ ws, float* __restrict__ scal,
+                                                        float* __restrict__ dz, int B, int Bg, int N, int row0) {
+    extern __shared__ float sm[];
+    const ClipShared sh = clip_shared(sm, N, Bg);
+    const int i = blockIdx.x, gi = row0 + i, tid = threadIdx.x, LD = 2 * N;
+    const float s = __expf(logit_scale[0]);
+    const float invB = 1.f / (float)B;
+    if (i == 0 && tid < 64) {                               // the own rows' scalars, summed in a fixed order
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r0 = 0; r0 < B; r0 += 64) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (r0 + tid < B) ? ws[(size_t)(2 + q) * Bg + row0 + r0 + tid] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += wave_sum(v[q]);
         }
+        if (tid < 4) scal[tid] = (tid == 0 ? acc[0] : tid == 1 ? acc[1] : tid == 2 ? acc[2] : acc[3]) * invB;
     }
-    // column-role gradients: dzf_all_j += s * Gef[j] ze_i ; dze_all_j += s * Gfe[j] zf_i
-    const int j0 = OWN ? row0 : 0, nj = OWN ? B : Bg;
-    for (int idx = tid; idx < nj * N; idx += 256) {
-        const int jl = idx / N, n = idx - jl * N;
-        const int j = j0 + jl;
-        atomicAdd(&dzf_all[(size_t)(OWN ? jl : j) * LD + n], s * Gef[j] * qe[n]);
-        atomicAdd(&dze_all[(size_t)(OWN ? jl : j) * LD + n], s * Gfe[j] * qf[n]);
+    if (!dz) return;
+    float mxr, mxc;
+    clip_cosines(z_all, gi, Bg, N, sh, mxr, mxc);
+    // dL/dC[gi][j] -> cr[j],  dL/dC[j][gi] -> cc[j]
+    const float lse_rg = ws[gi], lse_cg = ws[Bg + gi];
+    const float k = 0.5f * invB * s;
+    for (int j = tid; j < Bg; j += 256) {
+        const float a = s * sh.cr[j], c = s * sh.cc[j];
+        float ga = __expf(a - lse_rg) + __expf(a - ws[Bg + j]);          // P_row[gi][j] + P_col[gi][j]
+        float gc = __expf(c - ws[j]) + __expf(c - lse_cg);               // P_row[j][gi] + P_col[j][gi]
+        if (j == gi) { ga -= 2.f; gc -= 2.f; }
+        sh.cr[j] = k * ga; sh.cc[j] = k * gc;
+    }
+    __syncthreads();
+    float* orow = dz + (size_t)i * LD;
+    for (int n = tid; n < 2 * N; n += 256) {                // first half: dze (columns of zf), second half: dzf
+        const bool first = n < N;
+        const float* g = first ? sh.cr : sh.cc;
+        const float* col = z_all + (first ? N + n : n - N);
+        float acc = 0.f;
+        int j = 0;
+        for (; j + 8 <= Bg; j += 8) {                       // 8 loads in flight, summed in order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = col[(size_t)(j + q) * LD];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += g[j + q] * v[q];
+        }
+        for (; j < Bg; ++j) acc += g[j] * col[(size_t)j * LD];
+        orow[n] = acc;
     }
 }
 
@@ -909,6 +942,43 @@ __global__ void stft_power_kernel(const float* __restrict__ x, bf16* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// normalize_modality (run_training_lite.py:48-51, applied to every sample's power features at :162):
+// x[b] <- (x[b] - mean(x[b])) / (std_unbiased(x[b]) + eps) over ALL elements of sample b, fp32 in ->
+// bf16 channels-last out (the Power encoder's first-conv operand).  x [B][rows][ch_total]; only channels
+// < ch_valid count (the padding channels stay zero).  One workgroup per sample, two sweeps; fixed-order
+// sums (bit-reproducible); the mean is subtracted before squaring (two-pass variance).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sample_zscore_kernel(const float* __restrict__ x, bf16* __restrict__ out,
+                                                             int rows, int ch_valid, int ch_total, float eps) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xs = x + (size_t)b * rows * ch_total;
+    bf16* os = out + (size_t)b * rows * ch_total;
+    const size_t n = (size_t)rows * ch_total;
+    const float cnt = (float)rows * (float)ch_valid;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        return t;
+    };
+    float s = 0.f;
+    for (size_t i = tid; i < n; i += 1024) s += ((int)(i % ch_total) < ch_valid) ? xs[i] : 0.f;
+    const float mean = block_sum(s) / cnt;
+    float q = 0.f;
+    for (size_t i = tid; i < n; i += 1024) {
+        const float d = ((int)(i % ch_total) < ch_valid) ? xs[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float inv = 1.f / (sqrtf(block_sum(q) / fmaxf(cnt - 1.f, 1.f)) + eps);
+    for (size_t i = tid; i < n; i += 1024) os[i] = (bf16)(((int)(i % ch_total) < ch_valid) ? (xs[i] - mean) * inv : 0.f);
+}
+
 __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] * b[i];
 }
@@ -1122,26 +1192,24 @@ int mm_l2norm_bwd(const float* dz, const float* z, const float* nrm, float* dh, 
     return mm_check_launch("l2norm_bwd");
 }
 
-int mm_clip_loss(const float* z_local, const float* z_all, const float* logit_scale, float* scal4, float* dz_all,
-                 int B, int Bg, int N, int row0, hipStream_t st) {
-    MM_REQUIRE(z_local && z_all && logit_scale && scal4, "clip_loss: null");
-    MM_REQUIRE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg && N > 0, "clip_loss: B=%d Bg=%d row0=%d", B, Bg, row0);
-    const size_t lds = (size_t)(2 * N + 2 * Bg + 32) * sizeof(float);
-    MM_REQUIRE(lds <= 64 * 1024, "clip_loss: N/Bg too large for LDS");
-    hipLaunchKernelGGL(clip_loss_kernel<false>, dim3(B), dim3(256), lds, st, z_local, z_all, logit_scale, scal4, dz_all, B,
-                       Bg, N, row0);
-    return mm_check_launch("clip_loss");
+int mm_clip_loss_ws_floats(int B, int Bg, int* floats_host, hipStream_t) {
+    MM_REQUIRE(floats_host && B > 0 && Bg >= B, "clip_loss_ws_floats: bad args");
+    *floats_host = 6 * Bg;
+    return 0;
 }
 
-int mm_clip_loss_own_rows(const float* z_all, const float* logit_scale, float* scal4, float* dz_local, int B, int Bg, int N,
-                          int row0, hipStream_t st) {
-    MM_REQUIRE(z_all && logit_scale && scal4, "clip_loss_own_rows: null");
+int mm_clip_loss_own_rows(const float* z_all, const float* logit_scale, float* scal4, float* dz_local, float* ws, int B,
+                          int Bg, int N, int row0, hipStream_t st) {
+    MM_REQUIRE(z_all && logit_scale && scal4 && ws, "clip_loss_own_rows: null");
     MM_REQUIRE(B > 0 && Bg >= B && row0 >= 0 && row0 + B <= Bg && N > 0, "clip_loss_own_rows: B=%d Bg=%d row0=%d", B, Bg, row0);
+    MM_REQUIRE(N % 4 == 0, "clip_loss_own_rows: N=%d must be a multiple of 4 (16-byte row loads)", N);
     const size_t lds = (size_t)(2 * N + 2 * Bg + 32) * sizeof(float);
     MM_REQUIRE(lds <= 64 * 1024, "clip_loss_own_rows: N/Bg too large for LDS");
-    hipLaunchKernelGGL(clip_loss_kernel<true>, dim3(Bg), dim3(256), lds, st, nullptr, z_all, logit_scale, scal4, dz_local, B,
-                       Bg, N, row0);
-    return mm_check_launch("clip_loss_own_rows");
+    hipLaunchKernelGGL(clip_lse_kernel, dim3(Bg), dim3(256), lds, st, z_all, logit_scale, ws, Bg, N);
+    int rc = mm_check_launch("clip_loss_own_rows(lse)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(clip_rows_kernel, dim3(B), dim3(256), lds, st, z_all, logit_scale, ws, scal4, dz_local, B, Bg, N, row0);
+    return mm_check_launch("clip_loss_own_rows(rows)");
 }
 
 int mm_sumsq(const float* g, float* state, int64_t n, hipStream_t st) {
@@ -1261,6 +1329,13 @@ int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, 
     hipLaunchKernelGGL(stft_power_kernel, dim3(ceil_div(frames, 8), C, B), dim3(256), lds, st, x, (bf16*)out_bf16, out_f32,
                        C, T, nfft, hop, frames, ch_off, ch_total);
     return mm_check_launch("stft_power");
+}
+
+int mm_sample_zscore_bf16(const float* x, void* out_bf16, int B, int rows, int ch_valid, int ch_total, float eps,
+                          hipStream_t st) {
+    MM_REQUIRE(x && out_bf16 && B > 0 && rows > 0 && ch_valid > 0 && ch_valid <= ch_total, "sample_zscore: null/invalid");
+    hipLaunchKernelGGL(sample_zscore_kernel, dim3(B), dim3(1024), 0, st, x, (bf16*)out_bf16, rows, ch_valid, ch_total, eps);
+    return mm_check_launch("sample_zscore");
 }
 
 int mm_attn_1xk(const float* p0, const float* p1, const float* p2, const float* p3, int K, const float* dctx,

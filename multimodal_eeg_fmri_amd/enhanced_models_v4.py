@@ -71,10 +71,9 @@ class TemporalTransformerBlock(nn.Module):
         self.nhead = nhead
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if mask is not None:
-            raise NotImplementedError("attention masks are not on the reference hot path "
-                                      "(enhanced_models_v4.py:169-193 never passes one)")
-        return ops.transformer_block(x, self, self.training)
+        # ``mask`` = nn.MultiheadAttention's attn_mask (reference :98): 2-D (L, L), boolean (True = not
+        # allowed) or additive float; the encoders themselves never pass one (reference :169-193)
+        return ops.transformer_block(x, self, self.training, mask)
 
 
 def _transformer_stack(hidden_dim, layers, heads, dropout):

@@ -314,14 +314,28 @@ def layernorm(x2d: torch.Tensor, ln, want_stat: bool):
     return out, stat
 
 
-def attention(qkv: torch.Tensor, nhead: int, want_lse: bool, drop_p: float = 0.0, seed: int = 0):
+def attention(qkv: torch.Tensor, nhead: int, want_lse: bool, drop_p: float = 0.0, seed: int = 0, mask=None):
     B, L, E3 = qkv.shape
     E = E3 // 3
     dh = E // nhead
     out = _empty((B, L, E), _BF, qkv)
     lse = _empty((B, nhead, L), _F32, qkv) if want_lse else None
-    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), int(seed), EP())
+    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), int(seed), EP(), mask)
     return out, lse
+
+
+def additive_attn_mask(mask, L: int, like: torch.Tensor):
+    """nn.MultiheadAttention's ``attn_mask`` (enhanced_models_v4.py:98) as the additive fp32 (L, L)
+    matrix the kernels take: a boolean mask marks NOT-allowed positions with True (-> -inf)."""
+    if mask is None:
+        return None
+    if mask.dim() != 2 or tuple(mask.shape) != (L, L):
+        raise NotImplementedError(f"attn_mask: only the 2-D (L, L) = ({L}, {L}) form is supported, got {tuple(mask.shape)}")
+    if mask.dtype == torch.bool:
+        m = torch.zeros((L, L), dtype=_F32, device=like.device)
+        m.masked_fill_(mask.to(like.device), float("-inf"))
+        return m
+    return mask.to(device=like.device, dtype=_F32).contiguous()
 
 
 # ------------------------------------------------------------------- stages
@@ -365,7 +379,7 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
 
 def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False,
                           save: Optional[bool] = None, pool_out: Optional[torch.Tensor] = None,
-                          prenorm=None, next_norm=None):
+                          prenorm=None, next_norm=None, mask=None):
     """x fp32 (B, L, d) -> fp32 (B, L, d); returns (out, saved).  ``training``
     switches dropout on; ``save`` (default = training) keeps what backward needs.
     ``pool_out`` (zeroed fp32 (B, d)): the second FFN Linear also accumulates the mean over time of
@@ -384,7 +398,7 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
                       need_dgrad=need_dgrad)["bf16"]
     pa = float(blk.self_attn.dropout) if training else 0.0      # attention-probability dropout
     sa = _next_seed() if pa > 0 else 0
-    o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save, pa, sa)
+    o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save, pa, sa, mask)
     s1 = _next_seed() if p > 0 else 0
     if fuse_ln:
         wf, _, cinp, _ = weights.get(blk.self_attn.out_proj.weight, need_dgrad)
@@ -422,7 +436,8 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
     saved = None
     if save:
         saved = dict(x=x2, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2,
-                     z=f1["pre"], g=f1["bf16"], p=p, seeds=(s1, s2, s3), attn_drop=(pa, sa), B=B, L=L, blk=blk)
+                     z=f1["pre"], g=f1["bf16"], p=p, seeds=(s1, s2, s3), attn_drop=(pa, sa), B=B, L=L, blk=blk,
+                     mask=mask)
     if next_norm is not None:
         return x2o.view(B, L, D), saved, nxt
     return x2o.view(B, L, D), saved
@@ -523,29 +538,40 @@ def _wants_grad(m, x) -> bool:
 
 
 def add_positional(x, pe, drop_p, training):
-    """PositionalEncoding.forward on the fp32 stream (reference quirk kept:
-    a (B, 1, d) input is read as (seq, batch=1, d))."""
+    """PositionalEncoding.forward on the fp32 stream (reference quirk kept, enhanced_models_v4.py:49:
+    a 3-D input is batch-first unless ``x.size(1) == 1``, which is read as (seq, batch=1, d))."""
     _need_gpu(x)
-    if x.dim() == 3 and x.size(1) != 1:
-        B, L, D = x.shape
-        tab = pe[:L, 0, :].contiguous()
+    if x.dim() != 3:
+        raise ValueError("PositionalEncoding: expected a 3-D input (batch, seq, d_model) or (seq, 1, d_model)")
+    L = x.size(1) if x.size(1) != 1 else x.size(0)
+    if L > pe.shape[0]:
+        raise ValueError(f"sequence length {L} exceeds PositionalEncoding max_len {pe.shape[0]}")
+    from .autograd import AddPositionalFn
+    return AddPositionalFn.apply(x, pe, float(drop_p) if training else 0.0)
+
+
+def add_positional_impl(x, pe, p: float, seed: int, backward: bool = False):
+    """one mm_add_pe launch; x (B, L, D) batch-first or (L, 1, D); ``backward``: mask only."""
+    shape = x.shape
+    if x.size(1) != 1:
+        B, L, D = shape
     else:
-        L, B, D = x.shape[0], 1, x.shape[-1]
-        tab = pe[:L, 0, :].contiguous()
-        x = x.reshape(1, L, D)
-    out = torch.empty_like(x, dtype=_F32)
-    seed = _next_seed() if (training and drop_p > 0) else 0
-    _hip.call("mm_add_pe", x.float().contiguous(), tab, out, None, B, L, D, float(drop_p if training else 0.0), seed)
-    return out if x.shape == out.shape else out.view_as(x)
+        L, B, D = shape[0], 1, shape[2]
+    xf = x.float().contiguous()
+    tab = None if backward else pe[:L, 0, :].contiguous()
+    out = _empty(tuple(shape), _F32, xf)
+    _hip.call("mm_add_pe", xf, tab, out, None, B, L, D, float(p), int(seed), EP())
+    return out
 
 
-def transformer_block(x, blk, training):
+def transformer_block(x, blk, training, mask=None):
     _need_gpu(x)
+    mask = additive_attn_mask(mask, x.shape[1], x)
     if training or (torch.is_grad_enabled() and x.requires_grad):
         from .autograd import TransformerBlockFn
-        return TransformerBlockFn.run(blk, x)
+        return TransformerBlockFn.run(blk, x, mask)
     with torch.no_grad():
-        return transformer_block_fwd(x.float().contiguous(), blk, False)[0]
+        return transformer_block_fwd(x.float().contiguous(), blk, False, mask=mask)[0]
 
 
 # --------------------------------------------------------- 3-D voxel encoder
@@ -719,8 +745,20 @@ def clip_loss(ze, zf, logit_scale, group=None):
     """symmetric InfoNCE over the (all-gathered) batch -> (loss, top1 e->f, top1 f->e)."""
     _need_gpu(ze)
     from .autograd import ClipLossFn
-    z = ze._base if (ze._base is not None and ze._base is zf._base) else torch.cat([ze, zf], dim=1)
-    return ClipLossFn.apply(z, logit_scale, group)
+    return ClipLossFn.apply(_packed_pair(ze, zf), logit_scale, group)
+
+
+def _packed_pair(ze: torch.Tensor, zf: torch.Tensor) -> torch.Tensor:
+    """(B, 2N) [ze | zf]: the shared base when ze / zf are EXACTLY its two column halves (what
+    contrastive_embed returns), a concatenation for anything else (row subsets, other views)."""
+    base = ze._base
+    if (base is not None and base is zf._base and base.dim() == 2 and base.is_contiguous()
+            and ze.dim() == 2 and ze.shape == zf.shape and base.shape == (ze.shape[0], 2 * ze.shape[1])
+            and ze.stride() == base.stride() and zf.stride() == base.stride()
+            and ze.storage_offset() == base.storage_offset()
+            and zf.storage_offset() == base.storage_offset() + ze.shape[1]):
+        return base
+    return torch.cat([ze, zf], dim=1)
 
 
 
@@ -979,20 +1017,29 @@ def _power_merged(m, device):
     return torch.cat(ws, dim=0).contiguous(), torch.cat(o4, dim=1).contiguous()
 
 
-def stft_front_end(x: torch.Tensor, n_ffts, hop: int) -> torch.Tensor:
+def stft_front_end(x: torch.Tensor, n_ffts, hop: int, normalize: bool = False) -> torch.Tensor:
     """(B, C, T) fp32 -> channels-last bf16 (B, frames, Cp) multi-scale STFT power,
-    channel order [scale][c][f] as torch.cat([stft_power(x, n) ...], dim=1)."""
+    channel order [scale][c][f] as torch.cat([stft_power(x, n) ...], dim=1).
+    ``normalize``: z-score every sample's spectra (the reference's normalize_modality on its power
+    features, run_training_lite.py:48-51, 162) in fp32 before the bf16 cast."""
     B, C, T = x.shape
     widths = [C * (n // 2 + 1) for n in n_ffts]
     total = sum(widths)
     cp = cpad(total)
     frames = T // hop + 1
-    out = torch.zeros((B, frames, cp), dtype=_BF, device=x.device) if cp != total else _empty((B, frames, cp), _BF, x)
-    off = 0
     xc = x.float().contiguous()
+    if normalize:
+        spec = torch.zeros((B, frames, cp), dtype=_F32, device=x.device) if cp != total else _empty((B, frames, cp), _F32, x)
+        out = _empty((B, frames, cp), _BF, x)
+    else:
+        spec = None
+        out = torch.zeros((B, frames, cp), dtype=_BF, device=x.device) if cp != total else _empty((B, frames, cp), _BF, x)
+    off = 0
     for n, wdt in zip(n_ffts, widths):
-        _hip.call("mm_stft_power", xc, out, None, B, C, T, int(n), int(hop), off, cp)
+        _hip.call("mm_stft_power", xc, None if normalize else out, spec, B, C, T, int(n), int(hop), off, cp)
         off += wdt
+    if normalize:
+        _hip.call("mm_sample_zscore_bf16", spec, out, B, frames, total, cp, 1e-8)
     return out
 
 
@@ -1006,10 +1053,10 @@ def stft_power_encoder_forward(m, x):
             raise NotImplementedError("MultiScaleSTFTPowerEncoder: no gradient w.r.t. the raw EEG input is built")
         from .autograd import PowerEncoderFn
         with torch.no_grad():
-            spec = stft_front_end(x, m.n_ffts, m.hop)
+            spec = stft_front_end(x, m.n_ffts, m.hop, m.normalize)
         return PowerEncoderFn.run(enc, spec, packed=True)
     with torch.no_grad():
-        return _power_forward_ntc(enc, stft_front_end(x, m.n_ffts, m.hop))
+        return _power_forward_ntc(enc, stft_front_end(x, m.n_ffts, m.hop, m.normalize))
 
 
 def power_encoder_forward(m, x):

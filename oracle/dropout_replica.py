@@ -1,0 +1,76 @@
+"""TEST INFRASTRUCTURE ONLY.  Host replica of the HIP path's counter-hash dropout masks
+(csrc/common.h: mm_hash / dropout_scale, csrc/attention.hip: attn_keep) and a restatement of the
+reference's TRAIN-mode EnhancedERPEncoder forward (enhanced_models_v4.py:128-144, 44-55, 88-105,
+161-193) with an explicit keep-mask at every nn.Dropout site, so that a whole-encoder forward/backward
+with dropout > 0 can be checked against the CPU oracle.  The reference draws its masks from torch's RNG
+stream, which no kernel can reproduce; what is pinned here is that every dropout site exists, sits at
+the right place in the graph, and that backward differentiates the same masked function.
+
+Mask element index = flat index of the dropped tensor in the kernels' channels-last layout:
+conv stages (B, T, C), token stages (B*L, d), attention probabilities (B*H, L, L), head (B, H)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as TF
+
+from . import ref_functional as RF
+
+
+def keep_scale(seed: int, n: int, p: float) -> torch.Tensor:
+    """[n] float32: 1/(1-p) where hash(seed, i) >= p * 2^32, else 0 (common.h: dropout_scale)."""
+    if p <= 0.0:
+        return torch.ones(n)
+    idx = torch.arange(n, dtype=torch.int64)
+    x = (idx * 0x9E3779B1 + int(seed)) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 13
+    return (x >= int(p * 4294967296.0)).float() / (1.0 - p)
+
+
+def erp_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int], p: float, p_attn: float,
+                                 p_pe: float, nhead: int = 4):
+    """``seeds``: the dropout seeds in the order the product path draws them (ops._next_seed):
+    conv1, conv2, conv3, positional, then per block (attention probs, dropout1, FFN activation,
+    dropout2), then the output head."""
+    F = RF.F                                             # honours oracle.bf16_emulation.bf16_operands()
+    it = iter(seeds)
+    c = "conv_layers."
+
+    def drop_bct(h, prob):                               # (B, C, T) tensor, mask indexed as (B, T, C)
+        B, C, T = h.shape
+        m = keep_scale(next(it), B * T * C, prob).view(B, T, C).transpose(1, 2)
+        return h * m
+
+    h = RF.gelu(RF._bn(sd, c + "1.", F.conv1d(x, sd[c + "0.weight"], sd[c + "0.bias"], padding=3), True))
+    h = drop_bct(h, p)
+    h = RF.gelu(RF._bn(sd, c + "5.", F.conv1d(h, sd[c + "4.weight"], sd[c + "4.bias"], padding=2), True))
+    h = drop_bct(TF.max_pool1d(h, 2), p)
+    h = RF.gelu(RF._bn(sd, c + "10.", F.conv1d(h, sd[c + "9.weight"], sd[c + "9.bias"], padding=1), True))
+    h = drop_bct(h, p)
+    t = RF.positional_encoding(sd, "pos_encoder.", h.transpose(1, 2))
+    B, L, D = t.shape
+    t = t * keep_scale(next(it), B * L * D, p_pe).view(B, L, D)
+    for i in range(RF._num_layers(sd, "")):
+        q = f"transformer_layers.{i}."
+        sa, s1, s2, s3 = next(it), next(it), next(it), next(it)
+        hn = RF._ln(sd, q + "norm1.", t)
+        W, b = sd[q + "self_attn.in_proj_weight"], sd[q + "self_attn.in_proj_bias"]
+        qkv = F.linear(hn, W, b)
+        dh = D // nhead
+        qh, kh, vh = (u.view(B, L, nhead, dh).transpose(1, 2) for u in qkv.split(D, dim=2))
+        a = torch.softmax((qh @ kh.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+        a = a * keep_scale(sa, B * nhead * L * L, p_attn).view(B, nhead, L, L)
+        o = (a @ vh).transpose(1, 2).reshape(B, L, D)
+        o = F.linear(o, sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"])
+        t = t + o * keep_scale(s1, B * L * D, p).view(B, L, D)
+        hn = RF._ln(sd, q + "norm2.", t)
+        f = RF.gelu(F.linear(hn, sd[q + "linear1.weight"], sd[q + "linear1.bias"]))
+        f = f * keep_scale(s2, f.numel(), p).view(f.shape)
+        f = F.linear(f, sd[q + "linear2.weight"], sd[q + "linear2.bias"])
+        t = t + f * keep_scale(s3, B * L * D, p).view(B, L, D)
+    out = RF.gelu(F.linear(t.mean(dim=1), sd["output_proj.2.weight"], sd["output_proj.2.bias"]))
+    return out * keep_scale(next(it), out.numel(), p).view(out.shape)

@@ -75,8 +75,9 @@ def positional_encoding(sd: SD, p: str, x):
 # --------------------------------------------------------------------------
 # nn.MultiheadAttention arithmetic (packed in_proj, batch_first)
 # --------------------------------------------------------------------------
-def multihead_attention(sd: SD, p: str, q_in, kv_in, nhead: int):
-    """returns (out (B,Lq,E), head-averaged weights (B,Lq,Lk))."""
+def multihead_attention(sd: SD, p: str, q_in, kv_in, nhead: int, attn_mask=None):
+    """returns (out (B,Lq,E), head-averaged weights (B,Lq,Lk)).  ``attn_mask`` (Lq, Lk): boolean
+    (True = not allowed) or additive float, as nn.MultiheadAttention takes it (enhanced_models_v4.py:98)."""
     E = q_in.shape[-1]
     W, b = sd[p + "in_proj_weight"], sd[p + "in_proj_bias"]
     q = F.linear(q_in, W[:E], b[:E])
@@ -89,6 +90,11 @@ def multihead_attention(sd: SD, p: str, q_in, kv_in, nhead: int):
     k = k.view(B, Lk, nhead, dh).transpose(1, 2)
     v = v.view(B, Lk, nhead, dh).transpose(1, 2)
     s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            s = s.masked_fill(attn_mask, float("-inf"))
+        else:
+            s = s + attn_mask.to(s.dtype)
     a = torch.softmax(s, dim=-1)
     o = (a @ v).transpose(1, 2).reshape(B, Lq, E)
     o = F.linear(o, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
@@ -98,9 +104,9 @@ def multihead_attention(sd: SD, p: str, q_in, kv_in, nhead: int):
 # --------------------------------------------------------------------------
 # a2 TemporalTransformerBlock (enhanced_models_v4.py:89-107), pre-norm
 # --------------------------------------------------------------------------
-def transformer_block(sd: SD, p: str, x, nhead: int):
+def transformer_block(sd: SD, p: str, x, nhead: int, mask=None):
     h = _ln(sd, p + "norm1.", x)
-    h, _ = multihead_attention(sd, p + "self_attn.", h, h, nhead)
+    h, _ = multihead_attention(sd, p + "self_attn.", h, h, nhead, attn_mask=mask)
     x = x + h
     h = _ln(sd, p + "norm2.", x)
     h = _lin(sd, p + "linear2.", gelu(_lin(sd, p + "linear1.", h)))
@@ -385,10 +391,23 @@ def clip_loss(ze, zf_all, ze_all, zf, logit_scale, row0: int = 0):
     return loss, acc_e, acc_f, s_ef
 
 
-def stft_power_encoder(sd: SD, x, n_ffts=(64, 128), hop: int = 32, p: str = "encoder.", nhead: int = 4):
-    """a-X3 + a4: multi-scale STFT power (channel-concatenated) -> EnhancedPowerEncoder."""
+def normalize_modality(feat, eps: float = 1e-8):
+    """run_training_lite.py:48-51: z-score over ALL elements of one sample's feature array
+    (torch .std() = unbiased), here batched: feat (B, ...)."""
+    flat = feat.flatten(1)
+    mean = flat.mean(dim=1).view(-1, *([1] * (feat.dim() - 1)))
+    std = flat.std(dim=1).view(-1, *([1] * (feat.dim() - 1))) + eps
+    return (feat - mean) / std
+
+
+def stft_power_encoder(sd: SD, x, n_ffts=(64, 128), hop: int = 32, p: str = "encoder.", nhead: int = 4,
+                       normalize: bool = True, train: bool = False):
+    """a-X3 + a4: multi-scale STFT power (channel-concatenated) [-> per-sample z-score, the reference's
+    normalize_modality on its power features, run_training_lite.py:162] -> EnhancedPowerEncoder."""
     spec = torch.cat([stft_power(x, n, hop) for n in n_ffts], dim=1)
-    return power_encoder(sd, spec, p, nhead)
+    if normalize:
+        spec = normalize_modality(spec)
+    return power_encoder(sd, spec, p, nhead, train=train)
 
 
 def stft_power(x, n_fft: int, hop: int):

@@ -37,7 +37,7 @@ def test_argument_errors_are_reported_not_crashed():
     rc = lib.mm_pack_nct_bf16(None, None, 0, 0, 0, 0, None)
     assert rc == -1 and b"pack_nct" in lib.mm_last_error()
     rc = lib.mm_attn_fwd(ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 16, 4, 64, ctypes.c_float(0.1),
-                         ctypes.c_float(0.0), 0, None, None)
+                         ctypes.c_float(0.0), 0, None, None, None)
     assert rc == -1 and b"head_dim" in lib.mm_last_error()
 
 
@@ -249,3 +249,24 @@ def test_fused_adamw_state_dict_is_torch_adamw_layout():
     fused2.load_state_dict(ref.state_dict())
     assert torch.equal(fused2.bucket.m, fused.bucket.m) and torch.equal(fused2.bucket.v, fused.bucket.v)
     assert fused2.bucket.state[0] == 7.0 and fused2.param_groups[0]["lr"] == 3e-4 and fused2.betas == (0.8, 0.95)
+
+
+def test_every_mm_name_used_by_the_package_is_declared_in_the_header():
+    """the ctypes signatures are parsed from include/mmeeg_hip.h, so a declared-but-missing symbol is caught at
+    load time; this closes the other direction: a call to a name that was never declared (round 1:
+    ops.add_positional -> "mm_add_pe") must fail here, on the CPU, not on first use on the GPU."""
+    import glob
+    import re
+    declared = set(_hip.parse_header()) | {"mm_last_error", "mm_abi_version"}
+    pkg = os.path.dirname(_hip.__file__)
+    root = os.path.dirname(pkg)
+    used = {}
+    for path in glob.glob(os.path.join(pkg, "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")) + \
+            [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        for name in re.findall(r"[\"'](mm_[a-z0-9_]+)[\"']", open(path).read()):
+            used.setdefault(name, path)
+    used.pop("mm_name", None)                      # _hip.py's own docstring example
+    missing = {n: p for n, p in used.items() if n not in declared}
+    assert not missing, f"called but not declared in include/mmeeg_hip.h: {missing}"
+    lib = _hip.load()
+    assert all(hasattr(lib, n) for n in declared)

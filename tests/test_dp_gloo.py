@@ -2,8 +2,10 @@
 contrastive step (multimodal_eeg_fmri_amd/dp.py) reproduce the single-process
 global-batch computation.  The per-rank loss math is done here with the CPU
 oracle standing in for the HIP kernel (which needs a GPU); what is under test is
-the distributed algebra the GPU path uses verbatim: row offsets, the
-reduce-scatter of column gradients and the 1/world gradient scaling."""
+the distributed algebra the GPU path uses verbatim: row offsets, "every rank
+evaluates all rows of the gathered batch, so no reduce-scatter of column gradients
+is needed" (mm_clip_loss_own_rows), the 1/world gradient scaling, and the split of
+the flat gradient bucket into separately all-reduced parts."""
 import os
 import socket
 
@@ -33,18 +35,30 @@ def _worker(rank, world, port, B, N, out_q):
         scale = torch.tensor(3.0)
         h = (h_all[rank * B:(rank + 1) * B] * w).requires_grad_(True)
         z = torch.cat([RF.l2_normalize(h[:, :N]), RF.l2_normalize(h[:, N:])], dim=1)
-        # --- the DP step exactly as ClipLossFn does it
+        # --- the DP step exactly as ClipLossFn / BridgeTrainer do it: all-gather, then every rank evaluates
+        # ALL rows of the gathered batch and keeps the gradient rows of its own pairs
         z_all = dp.gather_embeddings(z.detach(), None if world == 1 else dist.group.WORLD)
         assert z_all.shape == (world * B, 2 * N)
         za = z_all.clone().requires_grad_(True)
-        zl = za[rank * B:(rank + 1) * B]
-        loss_r = RF.clip_loss(zl[:, :N], za[:, N:], za[:, :N], zl[:, N:], scale, row0=rank * B)[0]
-        loss_r.backward()                                            # d loss_r / d z_all (row + column roles)
-        dz_local = dp.scatter_column_grads(za.grad, dist.group.WORLD)
+        total = 0.0
+        for r in range(world):                                       # sum over ranks of their (local-mean) losses
+            zr = za[r * B:(r + 1) * B]
+            lr_ = RF.clip_loss(zr[:, :N], za[:, N:], za[:, :N], zr[:, N:], scale, row0=r * B)[0]
+            total = total + lr_
+            if r == rank:
+                loss_r = lr_
+        total.backward()
+        dz_local = za.grad[rank * B:(rank + 1) * B]                  # what mm_clip_loss_own_rows writes
         z.backward(dz_local)                                         # into this rank's "encoder"
         gw = (h.grad * h_all[rank * B:(rank + 1) * B]).sum(0)        # d/dw on this rank
         flat = gw.clone()
-        dp.allreduce_sum_(flat, dist.group.WORLD)
+        # the flat bucket goes out in parts (bridge_trainer: the branch that finishes first is reduced
+        # while the other still runs); the parts are disjoint views, so the result is the one all-reduce
+        cut = flat.numel() // 3
+        works = [dp.allreduce_sum_(flat[:cut], dist.group.WORLD, async_op=True),
+                 dp.allreduce_sum_(flat[cut:], dist.group.WORLD, async_op=True)]
+        for wk in works:
+            wk.wait()
         flat /= world                                                # grad_scale = 1/world in the AdamW kernel
         losses = [torch.zeros(()) for _ in range(world)]
         dist.all_gather(losses, loss_r.detach())

@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import ref_functional as RF
+
 pytestmark = pytest.mark.gpu
 
 
@@ -102,7 +104,7 @@ def test_attention_fwd_bwd(B, L, H):
     qg = qkv.cuda().to(torch.bfloat16)
     out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None)
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
     qr = qkv.clone().requires_grad_(True)
     o_ref, lse_ref = _attn_ref(qr, H)
     torch.testing.assert_close(out.float().cpu(), o_ref.detach(), rtol=2e-2, atol=2e-2)
@@ -110,7 +112,7 @@ def test_attention_fwd_bwd(B, L, H):
     o_ref.backward(do)
     dqkv = torch.empty_like(qg)
     delta = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None)
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
     got, want = dqkv.float().cpu(), qr.grad
     assert ((got - want).norm() / want.norm()).item() < 2e-2
     torch.testing.assert_close(got, want, rtol=5e-2, atol=3e-2)
@@ -192,41 +194,45 @@ def test_layernorm_fwd_bwd(M, D):
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-3)
 
 
-def test_clip_loss_own_rows_equals_reduce_scatter_of_all_ranks():
-    """a-X2 / a-X5: mm_clip_loss_own_rows on rank r == the block a reduce-scatter-sum over ranks of
-    mm_clip_loss's dz_all would deliver to rank r (four emulated ranks on one GPU), with identical loss /
-    top-1 / d logit_scale for the local rows; fp32 atomics in a different order: 1e-5."""
+@pytest.mark.parametrize("N", [128, 16, 48, 100])
+def test_clip_loss_own_rows_vs_oracle_and_bit_reproducible(N):
+    """a-X2 / a-X5: mm_clip_loss_own_rows on rank r (four emulated ranks on one GPU) == autograd of the CPU
+    oracle: scal = this rank's mean loss / top-1 / d loss_r / d logit_scale, dz = d (SUM over ranks of their
+    losses) / d (its own embeddings) - the block a reduce-scatter-sum of every rank's gradient w.r.t. the
+    gathered batch would deliver.  N not a multiple of 32 exercises the dot-product tail (round-1 bug: double
+    counting).  No float atomics: two runs are bit-identical.  fp32 kernels: 1e-5."""
     hip = _hip()
     g = torch.Generator().manual_seed(21)
-    W, B, N = 4, 16, 128
+    W, B = 4, 16
     Bg = W * B
-    z_all = torch.cat([F.normalize(torch.randn(Bg, N, generator=g), dim=1),
-                       F.normalize(torch.randn(Bg, N, generator=g), dim=1)], dim=1).cuda().contiguous()
-    ls = torch.tensor([math.log(1 / 0.07)], device="cuda")
-    total = torch.zeros(Bg, 2 * N, device="cuda")
-    scal_old = []
+    z_cpu = torch.cat([F.normalize(torch.randn(Bg, N, generator=g), dim=1),
+                       F.normalize(torch.randn(Bg, N, generator=g), dim=1)], dim=1)
+    z_all = z_cpu.cuda().contiguous()
+    ls0 = math.log(1 / 0.07)
+    ls = torch.tensor([ls0], device="cuda")
+    za = z_cpu.clone().requires_grad_(True)
+    lso = torch.tensor(ls0, requires_grad=True)
+    per_rank = []
     for r in range(W):
-        dz_all = torch.zeros(Bg, 2 * N, device="cuda")
-        scal = torch.zeros(4, device="cuda")
-        hip.call("mm_clip_loss", z_all[r * B:(r + 1) * B].contiguous(), z_all, ls, scal, dz_all, B, Bg, N, r * B)
-        total += dz_all
-        scal_old.append(scal)
+        zr = za[r * B:(r + 1) * B]
+        per_rank.append(RF.clip_loss(zr[:, :N], za[:, N:], za[:, :N], zr[:, N:], lso.exp(), row0=r * B))
+    dls = [torch.autograd.grad(pr[0], lso, retain_graph=True)[0] for pr in per_rank]
+    sum(pr[0] for pr in per_rank).backward()
+    ws = torch.empty(6 * Bg, device="cuda")
     for r in range(W):
-        dz = torch.zeros(B, 2 * N, device="cuda")
-        scal = torch.zeros(4, device="cuda")
-        hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, B, Bg, N, r * B)
-        torch.testing.assert_close(dz, total[r * B:(r + 1) * B], rtol=1e-5, atol=1e-7)
-        torch.testing.assert_close(scal, scal_old[r], rtol=1e-5, atol=1e-7)
-    # world of one rank: the two entry points are the same computation
-    dz1, dz2 = torch.zeros(B, 2 * N, device="cuda"), torch.zeros(B, 2 * N, device="cuda")
-    s1, s2 = torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda")
-    zl = z_all[:B].contiguous()
-    hip.call("mm_clip_loss", zl, zl, ls, s1, dz1, B, B, N, 0)
-    hip.call("mm_clip_loss_own_rows", zl, ls, s2, dz2, B, B, N, 0)
-    torch.testing.assert_close(dz1, dz2, rtol=1e-5, atol=1e-7)
-    torch.testing.assert_close(s1, s2, rtol=1e-6, atol=1e-7)
+        dz = torch.full((B, 2 * N), float("nan"), device="cuda")
+        scal = torch.full((4,), float("nan"), device="cuda")
+        hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, ws, B, Bg, N, r * B)
+        torch.testing.assert_close(dz.cpu(), za.grad[r * B:(r + 1) * B], rtol=1e-4, atol=1e-6)
+        want = torch.stack([per_rank[r][0].detach(), per_rank[r][1], per_rank[r][2], dls[r]])
+        torch.testing.assert_close(scal.cpu(), want, rtol=1e-5, atol=1e-6)
+        dz2, scal2 = torch.empty_like(dz), torch.empty_like(scal)
+        hip.call("mm_clip_loss_own_rows", z_all, ls, scal2, dz2, ws, B, Bg, N, r * B)
+        assert torch.equal(dz, dz2) and torch.equal(scal, scal2)
     with pytest.raises(Exception):
-        hip.call("mm_clip_loss_own_rows", z_all, ls, s2, dz2, B, Bg, N, Bg)
+        hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, ws, B, Bg, N, Bg)
+    with pytest.raises(Exception, match="multiple of 4"):
+        hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, ws, B, Bg, 6, 0)
 
 
 def test_grouped_linear_wgrads_equal_separate_launches():
@@ -551,9 +557,9 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     qg = qkv.cuda().to(torch.bfloat16)
     out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), p, seed, None)
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None)
     out0 = torch.empty_like(out)
-    hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None)
+    hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
     # recover the mask from V = identity-like probe: compare row sums of kept probabilities
     # host replica of the attention kernels' index hash (attention.hip: attn_keep)
     def keep_mask():
@@ -573,6 +579,6 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     o_ref.backward(do.double())
     dqkv = torch.empty_like(qg)
     delta = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed, None)
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None)
     dq_got = dqkv.float().cpu()[:, :, :E].view(B, L, H, 32).transpose(1, 2)
     assert ((dq_got - q.grad.float()).norm() / q.grad.float().norm()).item() < 3e-2

@@ -202,3 +202,44 @@ def test_f1_full_v4_classifiers(golden, tag, name, n_in):
             continue
         got = sd[n].grad.double().norm().item()
         assert abs(got - gn) <= 1e-4 * gn, (n, got, gn)
+
+
+def test_a1_a2_standalone_pe_and_masked_block_vs_reference_golden(golden):
+    """round-2 fixture (oracle/make_goldens_r2.py): PositionalEncoding.forward in both layout branches
+    and TemporalTransformerBlock.forward(x, mask) for mask = None / boolean causal / additive float."""
+    import multimodal_eeg_fmri_amd.enhanced_models_v4 as E
+    from oracle.make_goldens_r2 import masks
+    fx = golden("a1a2_standalone.npz")
+    pe = E.PositionalEncoding(128, dropout=0.1).pe
+    s1, s2 = (int(v) for v in fx["pe_x_seeds"])
+    xb, xs = seeded_randn(s1, 2, 96, 128), seeded_randn(s2, 40, 1, 128)
+    torch.testing.assert_close(RF.positional_encoding({"pe": pe}, "", xb), torch.as_tensor(fx["pe_out_bf"]), rtol=0, atol=1e-6)
+    torch.testing.assert_close(RF.positional_encoding({"pe": pe}, "", xs), torch.as_tensor(fx["pe_out_sf"]), rtol=0, atol=1e-6)
+    m = build(E.TemporalTransformerBlock, int(fx["blk_seed"]), 128, 4, 512, 0.1).eval()
+    np.testing.assert_allclose(checksum(m), fx["blk_cks"], rtol=1e-6, atol=1e-6)
+    x = seeded_randn(int(fx["blk_x_seed"]), 2, 96, 128)
+    mk = masks(96)
+    torch.testing.assert_close(mk["float"], torch.as_tensor(fx["mask_float"]))
+    for tag, msk in mk.items():
+        with torch.no_grad():
+            y = RF.transformer_block(m.state_dict(), "", x, 4, mask=msk)
+        torch.testing.assert_close(y, torch.as_tensor(fx[f"blk_out_{tag}"]), rtol=1e-5, atol=1e-5)
+
+
+def test_a3_train_grads_at_c2_shape_vs_reference_golden(golden):
+    """the oracle's train-mode forward and every gradient at the shape bench.py times (64 ch x 1024, B = 2)"""
+    import multimodal_eeg_fmri_amd.enhanced_models_v4 as E
+    fx = golden("a3_erp_train_grads_c2.npz")
+    B, C, T = (int(v) for v in fx["shape"])
+    m = build(E.EnhancedERPEncoder, int(fx["seed"]), C, 128, 2, 4, 0.0).train()
+    np.testing.assert_allclose(checksum(m), fx["cks"], rtol=1e-6, atol=1e-6)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    x = seeded_randn(int(fx["x_seed"]), B, C, T).requires_grad_(True)
+    y = RF.erp_encoder(sd, x, train=True)
+    y.backward(seeded_randn(int(fx["gy_seed"]), B, 128))
+    torch.testing.assert_close(y.detach(), torch.as_tensor(fx["out"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(x.grad[:, :, ::8], torch.as_tensor(fx["dx_t8"]), rtol=1e-3, atol=1e-5)
+    for n, gn in zip((str(n) for n in fx["gnames"]), fx["gnorms"]):
+        if gn < 1e-4:
+            continue
+        assert abs(sd[n].grad.double().norm().item() - gn) <= 1e-3 * gn, n

@@ -38,6 +38,96 @@ def test_contrastive_head_and_loss_match_oracle():
     assert mg.logit_scale.grad is not None
 
 
+def _oracle_step(tr, eeg, fmri, emulate):
+    """the CPU oracle's forward + backward of one contrastive step on the trainer's current weights:
+    (loss, ze, zf, {parameter name: gradient}) with names prefixed e. / f. / h. as in bench.cpu_baseline"""
+    import contextlib
+    from oracle.bf16_emulation import bf16_operands
+    sd = {}
+    for pre, m in (("e.", tr.eeg_encoder), ("f.", tr.fmri_encoder), ("h.", tr.head)):
+        for k, v in m.state_dict().items():
+            sd[pre + k] = v.detach().cpu().clone().requires_grad_(v.is_floating_point())
+    with (bf16_operands() if emulate else contextlib.nullcontext()):
+        fe = RF.erp_encoder(sd, eeg.cpu(), "e.", train=True)
+        ff = RF.volume_encoder3d(sd, fmri.cpu(), "f.", train=True)
+        ze, zf = RF.contrastive_head(sd, fe, ff, "h.bridge.")
+        loss = RF.clip_loss(ze, zf, ze, zf, sd["h.logit_scale"].exp())[0]
+        loss.backward()
+    return loss.item(), ze.detach(), zf.detach(), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+def test_c2_shaped_train_step_vs_oracle():
+    """BASELINE config #2 shapes (64 ch x 1024 EEG + 32^3 fMRI; B = 4 so that the CPU oracle finishes in
+    seconds), dropout 0, the autograd-free tape run eagerly segment by segment - the step bench.py times:
+    loss (1e-3), both L2-normalised embeddings (cos >= 1 - 1e-4 vs the fp32 oracle), every parameter gradient
+    of the flat bucket: <= 6e-2 rel-L2 vs the oracle with bf16-rounded GEMM operands; the voxel encoder
+    additionally <= 2e-1 vs pure fp32 (bf16 rounding flips 2x2x2 max-pool argmaxes)."""
+    import torch.nn.functional as F
+    from multimodal_eeg_fmri_amd import ops
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    ops.set_seed_epoch(None)
+    torch.manual_seed(0)
+    tr = BridgeTrainer(eeg_channels=64, dropout=0.0, mode="manual").train()
+    eeg, fmri = synthetic_pairs(4, 64, 1024, (32, 32, 32), seed=4321)
+    l32, ze32, zf32, g32 = _oracle_step(tr, eeg, fmri, emulate=False)
+    l16, _, _, g16 = _oracle_step(tr, eeg, fmri, emulate=True)
+    with torch.no_grad():
+        z, saved = tr._seg_forward(eeg, fmri)
+        dz = torch.empty_like(z)
+        tr._seg_loss(z, tr._scal, dz)
+        tr._seg_backward(saved, dz, tr._scal)
+        ops.arena.end()
+    torch.cuda.synchronize()
+    N = tr.head.bridge.bridge_dim
+    ze, zf = z[:, :N].cpu(), z[:, N:].cpu()
+    cos_e = F.cosine_similarity(ze.double(), ze32.double(), dim=1).min().item()
+    cos_f = F.cosine_similarity(zf.double(), zf32.double(), dim=1).min().item()
+    assert cos_e >= 1 - 1e-4 and cos_f >= 1 - 1e-4, (cos_e, cos_f)
+    assert abs(tr._scal[0].item() - l32) <= 1e-3 * max(1.0, abs(l32)), (tr._scal[0].item(), l32, l16)
+    named = {}
+    for pre, m in (("e.", tr.eeg_encoder), ("f.", tr.fmri_encoder), ("h.", tr.head)):
+        named.update({pre + k: v for k, v in m.named_parameters()})
+    worst16, worst32f = ("", 0.0), ("", 0.0)
+    checked = 0
+    for n, p in named.items():
+        sink = getattr(p, "_mm_grad", None)
+        if sink is None or n not in g16 or g16[n].norm() < 1e-5:
+            continue
+        got = sink.detach().cpu().view(g16[n].shape).double()
+        e16 = ((got - g16[n].double()).norm() / g16[n].double().norm()).item()
+        worst16 = max(worst16, (n, e16), key=lambda t: t[1])
+        if n.startswith("f."):
+            e32 = ((got - g32[n].double()).norm() / g32[n].double().norm()).item()
+            worst32f = max(worst32f, (n, e32), key=lambda t: t[1])
+        checked += 1
+    assert checked >= 60, checked
+    assert worst16[1] <= 6e-2, ("vs bf16-operand oracle", worst16)
+    assert worst32f[1] <= 2e-1, ("voxel encoder vs fp32 oracle", worst32f)
+
+
+def test_step_results_are_owned_by_the_trainer():
+    """the returned loss / top-1 tensors must not alias scratch another trainer rewrites"""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    torch.manual_seed(0)
+    a = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-3, mode="graph").train()
+    b = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-2, mode="graph").train()
+    eeg, fmri = synthetic_pairs(8, 16, 256, (16, 16, 16))
+    for _ in range(3):
+        out_a = a.train_step(eeg, fmri)
+    la = out_a["loss"].item()
+    for _ in range(5):
+        b.train_step(eeg, fmri)
+    torch.cuda.synchronize()
+    assert out_a["loss"].item() == la
+    # a loader that fills only ONE of the static input buffers in place: the other must still be refreshed
+    bufs = a.input_buffers()
+    eeg2, fmri2 = synthetic_pairs(8, 16, 256, (16, 16, 16), seed=99)
+    bufs[0].copy_(eeg2)
+    l_new = a.train_step(bufs[0], fmri2)["loss"].item()
+    assert torch.equal(a.input_buffers()[1], fmri2)
+    assert l_new != la
+
+
 def test_trainer_steps_reduce_loss_and_retrieve():
     from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
     torch.manual_seed(0)

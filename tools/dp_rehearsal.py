@@ -23,6 +23,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+        from tools import gloo_staging
+        gloo_staging.install()                        # gloo carrying device tensors: rehearsal only
         torch.cuda.set_device(0)
         eeg, fmri = synthetic_pairs(8, 16, 256, (16, 16, 16), seed=1234 + rank)
         losses = {}
