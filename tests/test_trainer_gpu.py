@@ -100,7 +100,7 @@ def test_c2_shaped_train_step_vs_oracle():
             e32 = ((got - g32[n].double()).norm() / g32[n].double().norm()).item()
             worst32f = max(worst32f, (n, e32), key=lambda t: t[1])
         checked += 1
-    assert checked >= 60, checked
+    assert checked >= 50, checked                      # conv biases in front of BatchNorm have ~0 gradient: skipped
     assert worst16[1] <= 6e-2, ("vs bf16-operand oracle", worst16)
     assert worst32f[1] <= 2e-1, ("voxel encoder vs fp32 oracle", worst32f)
 
