@@ -194,14 +194,13 @@ int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out,
 /* ---- 3-D voxel convolution, k=3 pad=1 (north-star extension: the reference has
  * no volume code, SURVEY.md section 0; semantics = torch.nn.Conv3d / BatchNorm3d /
  * MaxPool3d(2)).  Volumes are channels-last [B][D][H][W][C] bf16. */
-/* ablation switches for tools/kbench.py (bit0 skip stores, bit1 skip MFMA loop, bit2 skip
- * halo prefetch in the W-resident conv3d kernel); 0 in production */
-int mm_debug_flags(int flags, hipStream_t stream);
 /* (B,1,D,H,W) fp32 -> [B][D][H][W][Cp] bf16, channel 0 = voxel value, rest 0 */
 int mm_pack_volume_bf16(const float* x, void* y, int64_t nvox, int Cp, hipStream_t stream);
 /* Y = X (*) W + shift; W image [Cout][27][Cin] (mm_prep_conv_weight with k=27);
- * optional stats[2][Cout] (sum, sumsq) for training BatchNorm.  LDS-staged
- * (TD+2)x10x10 halo block -> 27 tap-shifted A fragments -> bf16 MFMA. */
+ * optional stats[32][2][Cout] replicated (sum, sumsq of the fp32 results) for training BatchNorm; fp32 and/or
+ * bf16 output.  Generic path: LDS-staged (TD+2)x10x10 halo block -> 27 tap-shifted A fragments -> bf16 MFMA.
+ * Cin = 32, Cout = 64 with bf16 output only and >= 64 tiles of 4x8x8 voxels (layer 2 of the voxel encoder)
+ * runs the weight-resident persistent kernel of csrc/conv3d_wres.hip. */
 int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int Cin, int Cout,
                   const float* shift, float* stats, float* out_f32, void* out_bf16, hipStream_t stream);
 int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W,
@@ -209,18 +208,18 @@ int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
                     int64_t rep_stride, int slot_mode, hipStream_t stream);
 /* slot_mode as in mm_conv1d_wgrad; *slots_host (HOST int) = slots a slot-mode launch writes */
 int mm_conv3d_wgrad_slots(int B, int D, int H, int W, int Cin, int Cout, int* slots_host, hipStream_t stream);
-/* y fp32 [B][D][H][W][N] -> act(BN(y)) -> MaxPool3d(2) -> dropout -> bf16 [B][D/2][H/2][W/2][N].
- * Training also keeps, per pooled element, the winner's pre-BN value (ysel fp32) and its index in
- * the 2x2x2 window (arg, one byte: 4 d + 2 h + w); both null in eval.  The reduction of the
- * BatchNorm gradient sums then reads only pooled data (gradients vanish off the winners) and the
- * apply pass (dy bf16, full volume) takes the argmax from `arg`. */
-int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, float* ysel, void* arg, int B, int D,
+/* y bf16 [B][D][H][W][N] (the convolution's pre-BatchNorm output) -> act(BN(y)) -> MaxPool3d(2) -> dropout ->
+ * bf16 [B][D/2][H/2][W/2][N].  N % 8 == 0.  Training also keeps, per pooled element, the winner's pre-BN
+ * value (ysel bf16) and its index in the 2x2x2 window (arg, one byte: 4 d + 2 h + w); both null in eval.
+ * The reduction of the BatchNorm gradient sums then reads only pooled data (gradients vanish off the
+ * winners) and the apply pass (dy bf16, full volume) takes the argmax from `arg`. */
+int mm_pool3d_bn_act_fwd(const void* y, const float* out4, void* out_bf16, void* ysel, void* arg, int B, int D,
                          int H, int W, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                          hipStream_t stream);
-int mm_pool3d_bn_act_bwd_reduce(const float* ysel, const float* out4, const void* dout_bf16, float* sums_out,
+int mm_pool3d_bn_act_bwd_reduce(const void* ysel, const float* out4, const void* dout_bf16, float* sums_out,
                                 int B, int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
                                 const uint32_t* seed_epoch, hipStream_t stream);
-int mm_pool3d_bn_act_bwd_apply(const float* y, const void* arg, const float* out4, const void* dout_bf16,
+int mm_pool3d_bn_act_bwd_apply(const void* y, const void* arg, const float* out4, const void* dout_bf16,
                                const float* sums, void* dy, int B, int D, int H, int W, int N, int act,
                                float drop_p, uint32_t seed, const uint32_t* seed_epoch, int train,
                                hipStream_t stream);

@@ -15,7 +15,7 @@
 // parity(lr >> 2)) so that every ds_read_b128 lane group ({0-3,12-15,20-27}, ...)
 // reads a 4 x 4 voxel patch: 16 rows that are distinct mod 16 on the pitch of 12,
 // i.e. conflict-free with the 80-byte row stride (see the W-resident kernel below).
-#include "common.h"
+#include "conv3d_args.h"
 
 namespace {
 
@@ -29,16 +29,6 @@ constexpr int GDP = HB * GWP;     // halo d-pitch
 __device__ __forceinline__ int row_h(int m) { return (m >> 3) & 7; }
 __device__ __forceinline__ int row_w(int m) { return (m & 3) + 4 * (__builtin_popcount((m >> 2) & 7) & 1); }
 
-struct Conv3dArgs {
-    const bf16* x; const bf16* w;
-    int B, D, H, W, Cin, Cout;
-    const float* shift;           // [Cout] bias (nullptr = 0)
-    int dbg;                      // ablation switches for tools/kbench.py (0 in production)
-    int kc;                       // generic kernel: channels per LDS chunk (32 or 64), set by launch3d
-    float* stats;                 // [2][Cout] sum / sumsq of (acc + shift)   (nullptr)
-    float* out_f32;               // [B][D][H][W][Cout]
-    bf16* out_bf16;
-};
 
 template <int TD, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
@@ -241,327 +231,6 @@ int launch3d(Conv3dArgs a, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------
-// W-resident persistent variant for Cin = 32, Cout = 64 (layer 2 of the voxel
-// encoder): 64 x 27 x 32 bf16 = 108 KiB of weights stay in LDS for the lifetime
-// of one workgroup per CU, which walks 4x8x8 output tiles (256 GEMM rows, wave w
-// owns depth slice w: 64 rows x 64 columns = 2x2 MFMA tiles).
-//
-// What the in-kernel timeline (tools/kbench.py tl) asked for:
-//  * LDS fragment reads are software-pipelined one K-step ahead in distinct
-//    registers; issued back to back with the MFMAs that consume them they cost
-//    their full latency per step (one wave per SIMD: nothing else hides it).
-//  * ds_read_b128 is served in four NON-contiguous 16-lane groups
-//    ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32).  GEMM row -> voxel is therefore
-//    (h, w) = (lr >> 3, (lr & 3) + 4 * parity(lr >> 2)): each group reads a 4(h) x
-//    4(w) patch, and with a halo w-pitch of 12 rows those 16 rows are distinct mod
-//    16 for every tap shift, i.e. conflict-free under the XOR swizzle below (the
-//    natural lr -> (lr >> 3, lr & 7) map on a pitch of 10 is 3-way conflicted).
-//  * no LDS epilogue: a finished tile's accumulators stay where they are (two
-//    accumulator sets alternate) and leave as 128-byte row segments (32 lanes x
-//    fp32) DURING the next tile's MFMA loop, two registers per K-step, so the
-//    16.7 MB/round HBM write burst overlaps the MFMAs instead of stalling every CU
-//    at once; BatchNorm partial sums are taken from the same registers there.
-//  * weights arrive in three kd planes; tile 0 starts on plane 0 while planes
-//    1-2 are still in flight (they are written to LDS after its first 18 K-steps).
-//  * next tile's (6x10x10)-row halo is fetched into registers during the MFMAs.
-// All LDS rows are unpadded 64-B rows; the 16-B chunk index is XOR-swizzled with
-// (row >> 2) & 3 (halo) / (n >> 2) & 3 (weights).
-// ---------------------------------------------------------------------------
-#ifndef WR_ABL
-#define WR_ABL 0      // ablation builds (tools/abl_build.sh): 1 no LDS reads in the K loop, 2 no stores, 4 fixed A address
-#endif
-constexpr int WR_CIN = 32;
-constexpr int WR_BN = 64;
-constexpr int WR_TD = 4;                              // tile depth: 4 x 8 x 8 = 256 GEMM rows
-constexpr int WR_WP = 12;                             // halo w-pitch in LDS rows (10 used)
-constexpr int WR_DP = HB * WR_WP;                     // halo d-pitch (120 rows)
-constexpr int WR_HROWS = (WR_TD + 2) * HB * HB;       // 600 rows fetched per tile
-constexpr int WR_LROWS = (WR_TD + 2) * WR_DP;         // 720 LDS rows
-constexpr int WR_HREGS = (WR_HROWS * 4 + 255) / 256;  // uint4 per thread per halo tile (10)
-constexpr int WR_STEPS = 54;                          // 27 taps x 2 k-steps of 16 channels
-
-__device__ __forceinline__ int swz(int row_key, int seg) { return seg ^ ((row_key >> 2) & 3); }
-
-struct WrTile { int b, d0, h0, w0; };
-
-template <int V> struct WrMode { static constexpr int value = V; };
-
-__global__ __launch_bounds__(256) void conv3d_fwd_wres_kernel(Conv3dArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* Wl = reinterpret_cast<bf16*>(smem);                       // [64*27][32]
-    bf16* Hl = Wl + WR_BN * 27 * WR_CIN;                             // [720][32]
-    float* sstat = reinterpret_cast<float*>(Hl + WR_LROWS * WR_CIN); // [4 waves][2][64] partial BatchNorm sums
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: keeps tile addressing in SGPRs
-    const int lr = lane & 31, lh = lane >> 5;
-    const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8, td = (a.D + WR_TD - 1) / WR_TD;
-    const int ntiles = a.B * td * th * tw;
-    // dbg & 512: 100 MHz wall-clock stamps of this workgroup's phases into out_bf16 (tools/kbench.py tl)
-    long long* stamps = reinterpret_cast<long long*>(a.out_bf16) + blockIdx.x * 16;
-#define WR_STAMP(idx) do { if ((a.dbg & 512) && tid == 0 && (idx) < 16) stamps[idx] = wall_clock64(); } while (0)
-    WR_STAMP(0);
-    if ((a.dbg & 512) && tid == 0) stamps[12] = clock64();          // shader-clock counter, for the MHz estimate
-
-    auto coords = [&](int tile) {
-        WrTile t;
-        t.w0 = (tile % tw) * 8; tile /= tw;
-        t.h0 = (tile % th) * 8; tile /= th;
-        t.d0 = (tile % td) * WR_TD; tile /= td;
-        t.b = tile;
-        return t;
-    };
-    auto load_halo = [&](int tile, uint4 (&regs)[WR_HREGS]) {
-        const WrTile t = coords(tile);
-        const bf16* xb = a.x + (size_t)t.b * a.D * a.H * a.W * WR_CIN;    // uniform; one sample < 2^31 elements
-        int tq = tid;
-        asm volatile("" : "+v"(tq));         // re-derive the row decomposition per tile: hoisted, it pins ~40 VGPRs
-#pragma unroll
-        for (int i = 0; i < WR_HREGS; ++i) {
-            const int s = tq + i * 256;
-            const int r = s >> 2, sg = s & 3;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r < WR_HROWS) {
-                const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
-                const int d = t.d0 + hd - 1, h = t.h0 + hh - 1, w = t.w0 + hw - 1;
-                if (d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                    v = *reinterpret_cast<const uint4*>(xb + (unsigned)(((d * a.H + h) * a.W + w) * WR_CIN + sg * 8));
-            }
-            regs[i] = v;
-        }
-    };
-    auto store_halo = [&](const uint4 (&regs)[WR_HREGS]) {
-        int tq = tid;
-        asm volatile("" : "+v"(tq));
-#pragma unroll
-        for (int i = 0; i < WR_HREGS; ++i) {
-            const int s = tq + i * 256;
-            const int r = s >> 2, sg = s & 3;
-            if (r < WR_HROWS) {
-                const int R = (r / HB) * WR_WP + r % HB;             // (hd*10 + hh) * 12 + hw
-                *reinterpret_cast<uint4*>(Hl + R * WR_CIN + swz(R, sg) * 8) = regs[i];
-            }
-        }
-    };
-
-    // GEMM row m = wave*64 + i*32 + lr  <->  voxel (d, h, w) = (wave, i*4 + (lr >> 3), wl)
-    const int wl = (lr & 3) + 4 * (__builtin_popcount((lr >> 2) & 7) & 1);
-    const int abase0 = (wave * HB + (lr >> 3)) * WR_WP + wl;
-    const float sh0 = a.shift ? a.shift[lr] : 0.f, sh1 = a.shift ? a.shift[32 + lr] : 0.f;
-    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
-
-    uint4 nxt[WR_HREGS];
-    int tile = blockIdx.x;
-    load_halo(tile, nxt);                                            // grid <= ntiles: every workgroup has a tile
-    // ---- weights: three kd planes of 64 x 9 rows; all loads are issued before the
-    // first LDS write (a load->store loop would serialise on load latency).
-    // thread's chunk i of a plane: n = c / 36, (tap-in-plane, segment) = c % 36 with c = tid + 256 i;
-    // planes 1, 2 sit 9 taps (576 B) and 18 taps further in global memory and in LDS
-    constexpr int PREGS = WR_BN * 9 * 4 / 256;                       // 9 x 16 B per thread per plane
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // native vector: plain loads, no struct memcpy
-    u32x4 wv0[PREGS], wv1[PREGS], wv2[PREGS];
-    unsigned wsrc[PREGS], wdst[PREGS];
-#pragma unroll
-    for (int i = 0; i < PREGS; ++i) {
-        const unsigned c = tid + i * 256, n = c / 36, rem = c % 36;
-        wsrc[i] = (n * 27 + (rem >> 2)) * WR_CIN + (rem & 3) * 8;
-        wdst[i] = (n * 27 + (rem >> 2)) * WR_CIN + swz(n, rem & 3) * 8;
-    }
-#define WR_LOAD_PLANE(p, regs)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < PREGS; ++i)                                            \
-        regs[i] = *reinterpret_cast<const u32x4*>(a.w + wsrc[i] + (p) * 9 * WR_CIN);
-#define WR_STORE_PLANE(p, regs)                                                                  \
-    _Pragma("unroll") for (int i = 0; i < PREGS; ++i)                                            \
-        *reinterpret_cast<u32x4*>(Wl + wdst[i] + (p) * 9 * WR_CIN) = regs[i];
-    WR_LOAD_PLANE(0, wv0)
-    WR_LOAD_PLANE(1, wv1)
-    WR_LOAD_PLANE(2, wv2)
-    WR_STORE_PLANE(0, wv0)
-    WR_STAMP(1);
-
-    f32x16 accA[2][2], accB[2][2];                                   // alternate between "current" and "previous"
-    WrTile pt = {0, 0, 0, 0};
-    bool prev_full = false;
-    float* pbase = nullptr;                                          // wave-uniform: (b, d0 + wave, h0, w0, 0)
-    const size_t rowpitch = (size_t)a.W * WR_BN;                     // one h step of the output, in floats
-    // accumulator register r of a lane holds GEMM row (r & 3) + 8 (r >> 2) + 4 lh, i.e. voxel
-    // (h, w) = (r >> 2, (r & 3) + 4 (parity(r >> 2) ^ lh)): odd-parity registers swap the halves
-    const unsigned lane_off_e = 4 * lh * WR_BN + lr, lane_off_o = 4 * (1 - lh) * WR_BN + lr;
-
-    // previous-tile register pair (j = 0, 1) -> two 128-B row segments per half-wave, + BatchNorm sums
-    auto store_pair = [&](auto mode, int q, const f32x16 (&prev)[2][2]) {
-        constexpr int MODE = decltype(mode)::value;
-        const int i = q >> 4, r = q & 15;
-        const int hh = i * 4 + (r >> 2), par = __builtin_popcount(r >> 2) & 1;
-        const unsigned lo = par ? lane_off_o : lane_off_e;
-        bool ok = true;
-        if (MODE == 2) ok = (pt.d0 + wave < a.D) && (pt.h0 + hh < a.H) && (pt.w0 + (r & 3) + 4 * (par ^ lh) < a.W);
-        if (ok) {
-            const float v0 = prev[i][0][r] + sh0, v1 = prev[i][1][r] + sh1;
-            float* o = pbase + hh * rowpitch;                       // SGPR base + VGPR lane offset + immediate
-            o[lo + (r & 3) * WR_BN] = v0;
-            o[lo + (r & 3) * WR_BN + 32] = v1;
-            st1[0] += v0; st2[0] += v0 * v0;
-            st1[1] += v1; st2[1] += v1 * v1;
-        }
-    };
-
-    // K-steps [S0, S1) of one tile into `cur`; MODE 0 = nothing to store yet, 1 = previous tile is
-    // interior (unconditional stores), 2 = previous tile is ragged
-    auto run_steps = [&](auto mode, auto first, auto last, f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2]) {
-        constexpr int MODE = decltype(mode)::value;
-        constexpr int S0 = decltype(first)::value, S1 = decltype(last)::value;
-        int abase = abase0;
-        asm volatile("" : "+v"(abase));      // recompute the swizzled A addresses per tile (54 hoisted VGPRs otherwise)
-        auto frags_a = [&](int s, bf16x8 (&fa)[2]) {
-            const int tap = s >> 1, sg = (s & 1) * 2 + lh;
-            const int arow = (WR_ABL & 4) ? abase : abase + (tap / 9) * WR_DP + ((tap / 3) % 3) * WR_WP + (tap % 3);
-            const bf16* ap = Hl + arow * WR_CIN + swz(arow, sg) * 8;
-            fa[0] = *reinterpret_cast<const bf16x8*>(ap);
-            fa[1] = *reinterpret_cast<const bf16x8*>(ap + 4 * WR_WP * WR_CIN);     // +48 rows: same swizzle key
-        };
-        auto frags_b = [&](int s, bf16x8 (&fb)[2]) {
-            const int tap = s >> 1, sg = (s & 1) * 2 + lh;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = j * 32 + lr;
-                fb[j] = *reinterpret_cast<const bf16x8*>(Wl + (n * 27 + tap) * WR_CIN + swz(n, sg) * 8);
-            }
-        };
-        auto frags = [&](int s, bf16x8 (&fa)[2], bf16x8 (&fb)[2]) { frags_a(s, fa); frags_b(s, fb); };
-        // fragments are fetched TWO steps ahead into a rotating set of three.  One wave per SIMD
-        // issues everything itself, so the reads, their address arithmetic and the previous tile's
-        // stores must sit in the shadow of the MFMAs (32 cycles each).  Left alone the compiler
-        // sinks the reads next to their use (each MFMA then waits out an LDS round trip); fenced
-        // into blocks by sched_barrier(0) the matrix pipe idles while ~15 other instructions issue
-        // (SQ_VALU_MFMA_BUSY 64 %).  So: a per-step barrier that only LDS operations may not
-        // cross - the reads keep their two-step lead, everything else interleaves freely.
-        bf16x8 fa[3][2], fb[3][2];
-        frags(S0, fa[0], fb[0]);
-        if (S0 + 1 < S1) frags(S0 + 1, fa[1], fb[1]);
-#pragma unroll
-        for (int s = S0; s < S1; ++s) {
-            const int c = (WR_ABL & 1) ? ((s - S0) & 1) : (s - S0) % 3, n2 = (s - S0 + 2) % 3;
-            const bool pf = s + 2 < S1 && !(WR_ABL & 1);
-            // half steps: two LDS reads behind two MFMAs (four in a burst from four lock-stepped
-            // waves queue up in front of the next MFMA)
-            if (pf) frags_a(s + 2, fa[n2]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                cur[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][0], fb[c][j], cur[0][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0x047F);                 // everything but LDS ops may cross
-            if (pf) frags_b(s + 2, fb[n2]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                cur[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][1], fb[c][j], cur[1][j], 0, 0, 0);
-            if (MODE != 0 && s < 32 && !(WR_ABL & 2)) store_pair(mode, s, prev);
-            __builtin_amdgcn_sched_barrier(0x047F);                 // everything but LDS ops may cross
-        }
-    };
-    auto prefetch_next = [&](int t) {                                // next halo -> registers, in flight during the MFMAs
-        const int tnext = t + gridDim.x;
-        if (tnext < ntiles) load_halo(tnext, nxt);
-    };
-    auto begin_tile = [&](int t, f32x16 (&cur)[2][2]) {              // halo -> LDS, zero the accumulators
-        __syncthreads();                                            // previous tile's LDS reads are done
-        store_halo(nxt);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cur[i][j][r] = 0.f;
-    };
-    auto commit = [&](int t) {                                      // the tile just computed becomes "previous"
-        pt = coords(t);
-        prev_full = pt.d0 + WR_TD <= a.D && pt.h0 + 8 <= a.H && pt.w0 + 8 <= a.W;
-        pbase = a.out_f32 + ((((size_t)pt.b * a.D + pt.d0 + wave) * a.H + pt.h0) * a.W + pt.w0) * WR_BN;
-    };
-    auto next_tile = [&](int t, int iter, f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2]) {
-        begin_tile(t, cur);
-        prefetch_next(t);
-        WR_STAMP(2 + 2 * iter);
-        if (prev_full) run_steps(WrMode<1>{}, WrMode<0>{}, WrMode<WR_STEPS>{}, cur, prev);
-        else run_steps(WrMode<2>{}, WrMode<0>{}, WrMode<WR_STEPS>{}, cur, prev);
-        WR_STAMP(3 + 2 * iter);                                     // MFMAs and the previous tile's stores issued
-        commit(t);
-    };
-    auto flush = [&](const f32x16 (&prev)[2][2]) {                   // the last tile's stores have nothing to hide behind
-        if (prev_full) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) store_pair(WrMode<1>{}, q, prev);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) store_pair(WrMode<2>{}, q, prev);
-        }
-    };
-
-    // ---- first tile (peeled: the weight-plane registers die before the second accumulator set is live)
-    begin_tile(tile, accA);
-    WR_STAMP(2);                                                    // halo 0 and weight plane 0 in LDS
-    run_steps(WrMode<0>{}, WrMode<0>{}, WrMode<18>{}, accA, accA);
-    WR_STORE_PLANE(1, wv1)                                          // taps of kd = 1, 2 are needed from step 18 on
-    WR_STORE_PLANE(2, wv2)
-    __syncthreads();
-    prefetch_next(tile);                                            // only now: its 40 registers were the weight planes'
-    run_steps(WrMode<0>{}, WrMode<18>{}, WrMode<WR_STEPS>{}, accA, accA);
-    WR_STAMP(3);
-    commit(tile);
-    int iter = 1;
-    bool last_in_a = true;
-    for (tile += gridDim.x; tile < ntiles; tile += 2 * gridDim.x, iter += 2) {
-        next_tile(tile, iter, accB, accA);
-        last_in_a = false;
-        const int t2 = tile + gridDim.x;
-        if (t2 >= ntiles) break;
-        next_tile(t2, iter + 1, accA, accB);
-        last_in_a = true;
-    }
-    if (last_in_a) flush(accA);
-    else flush(accB);
-    WR_STAMP(14);
-    if (a.stats) {
-        // lanes l and l+32 hold the same two columns (rows differ)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            st1[j] += __shfl_xor(st1[j], 32);
-            st2[j] += __shfl_xor(st2[j], 32);
-        }
-        if (lh == 0) {                                   // every wave parks its column sums: no LDS atomics
-            float* mine = sstat + wave * 2 * WR_BN;
-            mine[lr] = st1[0];
-            mine[32 + lr] = st1[1];
-            mine[WR_BN + lr] = st2[0];
-            mine[WR_BN + 32 + lr] = st2[1];
-        }
-        __syncthreads();
-        float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * WR_BN;
-        if (tid < 2 * WR_BN)
-            atomicAdd(&rep[tid], (sstat[tid] + sstat[2 * WR_BN + tid]) + (sstat[4 * WR_BN + tid] + sstat[6 * WR_BN + tid]));
-    }
-    WR_STAMP(15);
-    if ((a.dbg & 512) && tid == 0) stamps[13] = clock64();
-#undef WR_STAMP
-#undef WR_LOAD_PLANE
-#undef WR_STORE_PLANE
-}
-
-int launch3d_wres(const Conv3dArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)(WR_BN * 27 + WR_LROWS) * WR_CIN * sizeof(bf16) + 4 * 2 * WR_BN * sizeof(float);
-    static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = conv3d_fwd_wres_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const int ntiles = a.B * ceil_div(a.D, WR_TD) * ceil_div(a.H, 8) * ceil_div(a.W, 8);
-    const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-    return mm_check_launch("conv3d_fwd_wres");
-}
-
-// ---------------------------------------------------------------------------
 // weight gradient (transposed LDS reads, see igemm1d.hip).  grid.z = kd plane:
 // each workgroup accumulates the 9 taps of one kd for a 64(n) x BC(c) block over
 // a run of output tiles, then adds them atomically into dW (element strides).
@@ -729,56 +398,57 @@ __global__ void pack_vol_kernel(const float* __restrict__ x, bf16* __restrict__ 
 // One thread = 4 channels of one pooled voxel (8 x 16-byte loads).
 // ---------------------------------------------------------------------------
 struct Pool3Args {
-    const float* y; const float* out4; const bf16* dout; const float* sums;
+    const bf16* y; const float* out4; const bf16* dout; const float* sums;
     bf16* out; float* sums_out; bf16* dy;
-    float* ysel; uint8_t* arg;                 // pooled [B][D/2][H/2][W/2][N]
+    bf16* ysel; uint8_t* arg;                  // pooled [B][D/2][H/2][W/2][N]
     int B, D, H, W, N, act, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
     const uint32_t* epoch;
 };
 
+// One thread = 8 channels of one pooled voxel: eight 16-byte loads of the bf16 pre-BatchNorm volume.
 template <int MODE>   // 0 fwd, 2 bwd-apply
 __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
     a.seed = mm_eff_seed(a.seed, a.epoch);
-    const int nv = a.N / 4;
+    const int nv = a.N / 8;
     const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
     const size_t nrows = (size_t)a.B * Do * Ho * Wo;
     const int rows_per_blk = 256 / nv > 0 ? 256 / nv : 1;
     const int vi = threadIdx.x % nv, ri = threadIdx.x / nv;
     if (ri >= rows_per_blk) return;
-    const int n4 = vi * 4;
-    float sc[4], sh[4], mu[4], rs[4], c0[4], c1[4];
+    const int n8 = vi * 8;
+    float sc[8], sh[8], mu[8], rs[8], c0[8], c1[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        sc[q] = a.out4[n4 + q]; sh[q] = a.out4[a.N + n4 + q];
-        mu[q] = a.out4[2 * a.N + n4 + q]; rs[q] = a.out4[3 * a.N + n4 + q];
-        c0[q] = (MODE == 2 && a.train) ? a.sums[n4 + q] * a.inv_count : 0.f;    // compact [2][N] sums
-        c1[q] = (MODE == 2 && a.train) ? a.sums[a.N + n4 + q] * a.inv_count : 0.f;
+    for (int q = 0; q < 8; ++q) {
+        sc[q] = a.out4[n8 + q]; sh[q] = a.out4[a.N + n8 + q];
+        mu[q] = a.out4[2 * a.N + n8 + q]; rs[q] = a.out4[3 * a.N + n8 + q];
+        c0[q] = (MODE == 2 && a.train) ? a.sums[n8 + q] * a.inv_count : 0.f;    // compact [2][N] sums
+        c1[q] = (MODE == 2 && a.train) ? a.sums[a.N + n8 + q] * a.inv_count : 0.f;
     }
     for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
         size_t q = row;
         const int ow = (int)(q % Wo); q /= Wo;
         const int oh = (int)(q % Ho); q /= Ho;
         const int od = (int)(q % Do); q /= Do;
-        const size_t base = ((((size_t)q * a.D + 2 * od) * a.H + 2 * oh) * a.W + 2 * ow) * a.N + n4;
+        const size_t base = ((((size_t)q * a.D + 2 * od) * a.H + 2 * oh) * a.W + 2 * ow) * a.N + n8;
         const size_t sw = a.N, shh = (size_t)a.W * a.N, sd = (size_t)a.H * a.W * a.N;
-        float4 t[8];
+        bf16x8 t[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            t[j] = *reinterpret_cast<const float4*>(a.y + base + (j >> 2) * sd + ((j >> 1) & 1) * shh + (j & 1) * sw);
-        const size_t oidx = row * a.N + n4;
+            t[j] = *reinterpret_cast<const bf16x8*>(a.y + base + (j >> 2) * sd + ((j >> 1) & 1) * shh + (j & 1) * sw);
+        const size_t oidx = row * a.N + n8;
         if (MODE == 0) {
-            bf16x4 o;
-            float ys[4];
-            uint32_t args = 0;
+            bf16x8 o, ys;
+            uint32_t args[2] = {0u, 0u};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float zmax = -INFINITY, zmin = INFINITY, ymax = 0.f, ymin = 0.f;
+            for (int c = 0; c < 8; ++c) {
+                float zmax = -INFINITY, zmin = INFINITY;
+                bf16 ymax = (bf16)0.f, ymin = (bf16)0.f;
                 int jmax = 0, jmin = 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float yv = (&t[j].x)[c];
-                    const float z = yv * sc[c] + sh[c];
+                    const bf16 yv = t[j][c];
+                    const float z = (float)yv * sc[c] + sh[c];
                     if (z > zmax) { zmax = z; jmax = j; ymax = yv; }       // strict: first occurrence wins, as PyTorch
                     if (z < zmin) { zmin = z; jmin = j; ymin = yv; }
                 }
@@ -786,40 +456,40 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
                 const bool lo = amin > amax;
                 float v = lo ? amin : amax;
                 ys[c] = lo ? ymin : ymax;
-                args |= (uint32_t)(lo ? jmin : jmax) << (8 * c);
+                args[c >> 2] |= (uint32_t)(lo ? jmin : jmax) << (8 * (c & 3));
                 if (a.thresh) v *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
                 o[c] = (bf16)v;
             }
-            *reinterpret_cast<bf16x4*>(a.out + oidx) = o;
+            *reinterpret_cast<bf16x8*>(a.out + oidx) = o;
             if (a.ysel) {
-                *reinterpret_cast<float4*>(a.ysel + oidx) = make_float4(ys[0], ys[1], ys[2], ys[3]);
-                *reinterpret_cast<uint32_t*>(a.arg + oidx) = args;
+                *reinterpret_cast<bf16x8*>(a.ysel + oidx) = ys;
+                *reinterpret_cast<uint2*>(a.arg + oidx) = make_uint2(args[0], args[1]);
             }
         } else {
-            const bf16x4 gv = *reinterpret_cast<const bf16x4*>(a.dout + oidx);
-            const uint32_t args = *reinterpret_cast<const uint32_t*>(a.arg + oidx);
-            float dzs[4];
-            int arg[4];
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(a.dout + oidx);
+            const uint2 args = *reinterpret_cast<const uint2*>(a.arg + oidx);
+            float dzs[8];
+            int arg[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                arg[c] = (args >> (8 * c)) & 7;
+            for (int c = 0; c < 8; ++c) {
+                arg[c] = ((c < 4 ? args.x : args.y) >> (8 * (c & 3))) & 7;
                 float ysel = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ysel = (j == arg[c]) ? (&t[j].x)[c] : ysel;
+                for (int j = 0; j < 8; ++j) ysel = (j == arg[c]) ? (float)t[j][c] : ysel;
                 float g = (float)gv[c];
                 if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
                 dzs[c] = g * act_grad(ysel * sc[c] + sh[c], a.act);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                bf16x4 o;
+                bf16x8 o;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 8; ++c) {
                     const float dz = (j == arg[c]) ? dzs[c] : 0.f;
-                    const float xh = ((&t[j].x)[c] - mu[c]) * rs[c];
+                    const float xh = ((float)t[j][c] - mu[c]) * rs[c];
                     o[c] = (bf16)(a.train ? sc[c] * (dz - c0[c] - xh * c1[c]) : sc[c] * dz);
                 }
-                *reinterpret_cast<bf16x4*>(a.dy + base + (j >> 2) * sd + ((j >> 1) & 1) * shh + (j & 1) * sw) = o;
+                *reinterpret_cast<bf16x8*>(a.dy + base + (j >> 2) * sd + ((j >> 1) & 1) * shh + (j & 1) * sw) = o;
             }
         }
     }
@@ -828,27 +498,27 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
 // BN-gradient partial sums from the pooled winners only:  sums[0][n] += dz, sums[1][n] += dz * xhat
 __global__ __launch_bounds__(256) void pool3_bwd_reduce_kernel(Pool3Args a) {
     a.seed = mm_eff_seed(a.seed, a.epoch);
-    const int nv = a.N / 4;
+    const int nv = a.N / 8;
     const size_t nrows = (size_t)a.B * (a.D / 2) * (a.H / 2) * (a.W / 2);
     const int rows_per_blk = 256 / nv > 0 ? 256 / nv : 1;
     const int vi = threadIdx.x % nv, ri = threadIdx.x / nv;
     const bool active = ri < rows_per_blk;
-    const int n4 = vi * 4;
-    float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    const int n8 = vi * 8;
+    float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
-        float sc[4], sh[4], mu[4], rs[4];
+        float sc[8], sh[8], mu[8], rs[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            sc[q] = a.out4[n4 + q]; sh[q] = a.out4[a.N + n4 + q];
-            mu[q] = a.out4[2 * a.N + n4 + q]; rs[q] = a.out4[3 * a.N + n4 + q];
+        for (int q = 0; q < 8; ++q) {
+            sc[q] = a.out4[n8 + q]; sh[q] = a.out4[a.N + n8 + q];
+            mu[q] = a.out4[2 * a.N + n8 + q]; rs[q] = a.out4[3 * a.N + n8 + q];
         }
         for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
-            const size_t oidx = row * a.N + n4;
-            const float4 ys = *reinterpret_cast<const float4*>(a.ysel + oidx);
-            const bf16x4 gv = *reinterpret_cast<const bf16x4*>(a.dout + oidx);
+            const size_t oidx = row * a.N + n8;
+            const bf16x8 ys = *reinterpret_cast<const bf16x8*>(a.ysel + oidx);
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(a.dout + oidx);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float yv = (&ys.x)[c];
+            for (int c = 0; c < 8; ++c) {
+                const float yv = (float)ys[c];
                 float g = (float)gv[c];
                 if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);
                 const float dz = g * act_grad(yv * sc[c] + sh[c], a.act);
@@ -858,11 +528,11 @@ __global__ __launch_bounds__(256) void pool3_bwd_reduce_kernel(Pool3Args a) {
         }
     }
     // plain stores + column walk (LDS float atomics with rows_per_blk-way same-address conflicts are slow)
-    __shared__ __attribute__((aligned(16))) float part[2048];        // [rows_per_blk][2][N]
+    __shared__ __attribute__((aligned(16))) float part[4096];        // [rows_per_blk][2][N]
     if (active) {
-        float* dst = part + (size_t)ri * 2 * a.N + n4;
-        *reinterpret_cast<float4*>(dst) = make_float4(s0[0], s0[1], s0[2], s0[3]);
-        *reinterpret_cast<float4*>(dst + a.N) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        float* dst = part + (size_t)ri * 2 * a.N + n8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { dst[c] = s0[c]; dst[a.N + c] = s1[c]; }
     }
     __syncthreads();
     float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
@@ -877,10 +547,10 @@ inline uint32_t thresh3(float p) { return p > 0.f ? (uint32_t)((double)p * 42949
 
 int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
     MM_REQUIRE(a.out4 && a.B > 0 && a.D % 2 == 0 && a.H % 2 == 0 && a.W % 2 == 0, "pool3d_bn_act: dims must be even");
-    MM_REQUIRE(a.N % 4 == 0 && a.N <= 1024, "pool3d_bn_act: N");
+    MM_REQUIRE(a.N % 8 == 0 && a.N <= 1024, "pool3d_bn_act: N must be a multiple of 8");
     a.thresh = thresh3(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)a.B * a.D * a.H * a.W);
-    const int rpb = 256 / (a.N / 4) > 0 ? 256 / (a.N / 4) : 1;
+    const int rpb = 256 / (a.N / 8) > 0 ? 256 / (a.N / 8) : 1;
     const size_t rows = (size_t)a.B * (a.D / 2) * (a.H / 2) * (a.W / 2);
     int grid = (int)((rows + rpb - 1) / rpb);
     if (mode == 1) {
@@ -896,8 +566,6 @@ int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
 
 }  // namespace
 
-static int g_dbg = 0;
-
 namespace {
 __global__ void stamp_kernel(long long* buf, int idx) { buf[idx] = wall_clock64(); }
 }
@@ -912,8 +580,6 @@ int mm_debug_stamp(void* buf, int idx, hipStream_t st) {
     return mm_check_launch("debug_stamp");
 }
 
-int mm_debug_flags(int flags, hipStream_t) { g_dbg = flags; return 0; }
-
 int mm_pack_volume_bf16(const float* x, void* y, int64_t nvox, int Cp, hipStream_t st) {
     MM_REQUIRE(x && y && nvox > 0 && Cp % 8 == 0, "pack_volume: bad args");
     size_t n = (size_t)nvox * (Cp / 8);
@@ -927,10 +593,9 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
                   float* stats, float* out_f32, void* out_bf16, hipStream_t st) {
     MM_REQUIRE(x && w && (out_f32 || out_bf16) && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: null/invalid");
     MM_REQUIRE(Cin == 16 || Cin % 32 == 0, "conv3d_fwd: Cin=%d must be 16 or a multiple of 32", Cin);
-    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, g_dbg, 0, stats, out_f32, (bf16*)out_bf16};
+    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, 0, stats, out_f32, (bf16*)out_bf16};
     const long tiles2 = (long)B * ceil_div(D, 2) * ceil_div(H, 8) * ceil_div(W, 8);
-    const bool stamp_run = (g_dbg & 512) != 0;                       // out_bf16 is then the stamp buffer
-    if (Cin == WR_CIN && Cout == WR_BN && out_f32 && (!out_bf16 || stamp_run) && tiles2 >= 512) return launch3d_wres(a, st);
+    if (conv3d_wres_applies(a)) return launch3d_wres(a, st);          // Cin 32 -> Cout 64, bf16 out: conv3d_wres.hip
     if (Cout <= 32) return launch3d<2, 32, 4, 1>(a, st);
     if (Cout <= 64) {
         if (tiles2 >= 256 && D % 2 == 0) return launch3d<2, 64, 4, 1>(a, st);
@@ -978,32 +643,32 @@ int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
     return mm_check_launch("conv3d_wgrad");
 }
 
-int mm_pool3d_bn_act_fwd(const float* y, const float* out4, void* out_bf16, float* ysel, void* arg, int B, int D,
+int mm_pool3d_bn_act_fwd(const void* y, const float* out4, void* out_bf16, void* ysel, void* arg, int B, int D,
                          int H, int W, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                          hipStream_t st) {
     MM_REQUIRE(y && out_bf16 && (!ysel == !arg), "pool3d_bn_act_fwd: null out / ysel and arg go together");
     Pool3Args a{};
-    a.y = y; a.out4 = out4; a.out = (bf16*)out_bf16; a.ysel = ysel; a.arg = (uint8_t*)arg;
+    a.y = (const bf16*)y; a.out4 = out4; a.out = (bf16*)out_bf16; a.ysel = (bf16*)ysel; a.arg = (uint8_t*)arg;
     a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch;
     return pool3_launch(0, a, drop_p, st);
 }
 
-int mm_pool3d_bn_act_bwd_reduce(const float* ysel, const float* out4, const void* dout_bf16, float* sums_out, int B,
+int mm_pool3d_bn_act_bwd_reduce(const void* ysel, const float* out4, const void* dout_bf16, float* sums_out, int B,
                                 int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
                                 const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(ysel && dout_bf16 && sums_out, "pool3d_bn_act_bwd_reduce: null");
     Pool3Args a{};
-    a.ysel = const_cast<float*>(ysel); a.out4 = out4; a.dout = (const bf16*)dout_bf16; a.sums_out = sums_out;
+    a.ysel = (bf16*)const_cast<void*>(ysel); a.out4 = out4; a.dout = (const bf16*)dout_bf16; a.sums_out = sums_out;
     a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch; a.train = 1;
     return pool3_launch(1, a, drop_p, st);
 }
 
-int mm_pool3d_bn_act_bwd_apply(const float* y, const void* arg, const float* out4, const void* dout_bf16,
+int mm_pool3d_bn_act_bwd_apply(const void* y, const void* arg, const float* out4, const void* dout_bf16,
                                const float* sums, void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
                                uint32_t seed, const uint32_t* seed_epoch, int train, hipStream_t st) {
     MM_REQUIRE(y && arg && dout_bf16 && dy && (!train || sums), "pool3d_bn_act_bwd_apply: null");
     Pool3Args a{};
-    a.y = y; a.arg = (uint8_t*)const_cast<void*>(arg); a.out4 = out4; a.dout = (const bf16*)dout_bf16; a.sums = sums;
+    a.y = (const bf16*)y; a.arg = (uint8_t*)const_cast<void*>(arg); a.out4 = out4; a.dout = (const bf16*)dout_bf16; a.sums = sums;
     a.dy = (bf16*)dy; a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch;
     a.train = train;
     return pool3_launch(2, a, drop_p, st);

@@ -1,0 +1,18 @@
+// Argument block shared by the 3-D convolution forward kernels (conv3d.hip: generic LDS-tiled
+// implicit GEMM; conv3d_wres.hip: the weight-resident persistent kernel for Cin = 32, Cout = 64).
+#pragma once
+#include "common.h"
+
+struct Conv3dArgs {
+    const bf16* x; const bf16* w;
+    int B, D, H, W, Cin, Cout;
+    const float* shift;           // [Cout] bias (nullptr = 0)
+    int kc;                       // generic kernel: channels per LDS chunk (32 or 64), set by launch3d
+    float* stats;                 // [MM_REPL][2][Cout] sum / sumsq of (acc + shift)   (nullptr)
+    float* out_f32;               // [B][D][H][W][Cout]
+    bf16* out_bf16;
+};
+
+// conv3d_wres.hip
+bool conv3d_wres_applies(const Conv3dArgs& a);
+int launch3d_wres(const Conv3dArgs& a, hipStream_t st);

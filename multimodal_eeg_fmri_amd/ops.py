@@ -588,21 +588,24 @@ def pack_volume(x: torch.Tensor) -> torch.Tensor:
 def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, drop_p: float,
                   need_dgrad: bool):
     """Conv3d(k3,p1) -> BatchNorm3d -> GELU [-> MaxPool3d(2)] [-> Dropout] on
-    channels-last bf16 volumes.  Returns (out, saved)."""
+    channels-last bf16 volumes.  Returns (out, saved).  A pooled layer keeps its pre-BatchNorm
+    tensor in bf16 (half the traffic of the conv's output, the pooling pass and the backward; the
+    statistics come from the fp32 accumulators); the un-pooled last layer keeps fp32."""
     B, D, H, W, cinp = xv.shape
     cout = conv.out_channels
     wf, _, cp, _ = weights.get(conv.weight, need_dgrad)
     assert cp == cinp, (cp, cinp)
-    y = _empty((B, D, H, W, cout), _F32, xv)
+    y = _empty((B, D, H, W, cout), _BF if pool else _F32, xv)
+    yf, yb = (None, y) if pool else (y, None)
     if training:
         stats = _zeros((REPL, 2, cout), xv)
         end = kernel_timer.bracket(f"conv3d_fwd_c{cinp}")
-        _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, stats, y, None)
+        _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, stats, yf, yb)
         if end is not None:
             end.record()
         out4 = bn_finalize_train(bn, stats, B * D * H * W)
     else:
-        _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, None, None, y, None)
+        _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, None, None, yf, yb)
         out4 = bn_fold_eval(bn, conv.bias)
     seed = _next_seed() if (training and drop_p > 0) else 0
     p = drop_p if training else 0.0
@@ -610,7 +613,7 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     if pool:
         out = _empty((B, D // 2, H // 2, W // 2, cout), _BF, xv)
         if training:                                   # the window winners: all that BN-backward's reduction needs
-            ysel = _empty(out.shape, _F32, xv)
+            ysel = _empty(out.shape, _BF, xv)
             arg = _empty(out.shape, torch.uint8, xv)
         _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, ysel, arg, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
     else:

@@ -495,11 +495,41 @@ def test_conv3d_fwd_wgrad_dgrad(B, Cin, Cout, D, H, W):
     torch.testing.assert_close(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1), rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,D,H,W", [(4, 16, 16, 16), (32, 16, 16, 16), (8, 32, 32, 24), (24, 14, 16, 20), (2, 16, 24, 20)])
+def test_conv3d_weight_resident_kernel_vs_torch(B, D, H, W):
+    """csrc/conv3d_wres.hip (Cin 32 -> Cout 64, bf16 out + BatchNorm sums; layer 2 of the voxel encoder,
+    bench.py's roofline kernel) against F.conv3d on bf16-rounded operands: one tile per workgroup (64 tiles),
+    the C2 shape (512 tiles: two per workgroup, the second one's K loop carries the first one's stores), the
+    config-#4 shape (768 tiles), ragged tiles (14 = 3.5 tiles deep, 20 = 2.5 wide; stored by the predicated
+    path) mixed with interior ones, and the XCD-aware tile lists.  bf16 output: 1e-2; statistics come from the
+    fp32 accumulators: 1e-3."""
+    hip = _hip()
+    Cin, Cout = 32, 64
+    assert B * ((D + 3) // 4) * ((H + 7) // 8) * ((W + 7) // 8) >= 64       # else the generic kernel runs
+    g = torch.Generator().manual_seed(D + H + W)
+    x = _bf(torch.randn(B, Cin, D, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin))
+    bias = torch.randn(Cout, generator=g)
+    want = F.conv3d(x, w, bias, padding=1).permute(0, 2, 3, 4, 1)
+    wf, _ = _prep_w(hip, w.reshape(Cout, Cin, 27), Cin)
+    xg = _vol_cl(x)
+    out = torch.full((B, D, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
+    hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, bias.cuda(), stats, None, out)
+    torch.testing.assert_close(out.float().cpu(), want, rtol=1e-2, atol=1e-2)
+    st = stats.sum(0).cpu()
+    torch.testing.assert_close(st[0], want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
+    torch.testing.assert_close(st[1], (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
+    out2 = torch.empty_like(out)                                        # no bias, no statistics (eval form)
+    hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, None, None, None, out2)
+    torch.testing.assert_close(out2.float().cpu(), want - bias, rtol=1e-2, atol=1e-2)
+
+
 def test_pool3d_bn_act_train_fwd_bwd():
     hip = _hip()
     g = torch.Generator().manual_seed(9)
     B, D, H, W, N = 2, 4, 8, 4, 32
-    y = torch.randn(B, D, H, W, N, generator=g) * 1.5 + 0.3
+    y = _bf(torch.randn(B, D, H, W, N, generator=g) * 1.5 + 0.3)      # the conv's pre-BN output is kept in bf16
     gam = 0.5 + torch.rand(N, generator=g)
     bet = torch.randn(N, generator=g) * 0.2
     yr, gr, br = y.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
@@ -507,7 +537,7 @@ def test_pool3d_bn_act_train_fwd_bwd():
     a = F.max_pool3d(F.gelu(z), 2).permute(0, 2, 3, 4, 1)
     dout = _bf(torch.randn(a.shape, generator=g))
     a.backward(dout)
-    yg = y.cuda()
+    yg = y.cuda().to(torch.bfloat16)
     flat = y.reshape(-1, N)
     stats = torch.zeros(32, 2, N)
     stats[0] = torch.stack([flat.sum(0), (flat * flat).sum(0)])
@@ -516,7 +546,7 @@ def test_pool3d_bn_act_train_fwd_bwd():
     hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"),
              None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0, None)
     ob = torch.empty(B, D // 2, H // 2, W // 2, N, dtype=torch.bfloat16, device="cuda")
-    ysel = torch.empty(ob.shape, device="cuda")
+    ysel = torch.empty(ob.shape, dtype=torch.bfloat16, device="cuda")
     arg = torch.empty(ob.shape, dtype=torch.uint8, device="cuda")
     hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob, ysel, arg, B, D, H, W, N, 1, 0.0, 0, None)
     torch.testing.assert_close(ob.float().cpu(), a.detach(), rtol=1e-2, atol=1e-2)
@@ -526,7 +556,7 @@ def test_pool3d_bn_act_train_fwd_bwd():
     d_, h_, w_ = idx // (H * W), (idx // W) % H, idx % W
     torch.testing.assert_close(arg.cpu().long(), (d_ % 2) * 4 + (h_ % 2) * 2 + (w_ % 2))
     want = torch.gather(y.reshape(B, D * H * W, N), 1, idx.reshape(B, -1, N)).reshape(ob.shape)
-    torch.testing.assert_close(ysel.cpu(), want)
+    torch.testing.assert_close(ysel.float().cpu(), want)
     ob2 = torch.empty_like(ob)                                                  # eval form: no winners kept
     hip.call("mm_pool3d_bn_act_fwd", yg, out4, ob2, None, None, B, D, H, W, N, 1, 0.0, 0, None)
     assert torch.equal(ob2, ob)

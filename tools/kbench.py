@@ -82,12 +82,13 @@ def conv3d_dims_case(B, D, H, W, Cin, Cout):
     w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
     wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
     _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
-    of = torch.empty(B, D, H, W, Cout, device="cuda")
+    wres = Cin == 32 and Cout == 64                      # the weight-resident kernel writes bf16 only
+    of = torch.empty(B, D, H, W, Cout, device="cuda", dtype=BF if wres else torch.float32)
     stats = torch.zeros(32, 2, Cout, device="cuda")
     b = torch.randn(Cout, device="cuda")
 
     def fn():
-        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, b, stats, of, None)
+        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, b, stats, None if wres else of, of if wres else None)
     us = graph_time(fn, n=10)
     fl = 2.0 * B * D * H * W * Cin * Cout * 27
     print(f"conv3d B={B} {D}x{H}x{W} Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s "
@@ -99,12 +100,13 @@ def conv3d_case(B, S, Cin, Cout, wgrad=True):
     w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
     wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
     _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
-    of = torch.empty(B, S, S, S, Cout, device="cuda")
+    wres = Cin == 32 and Cout == 64                      # the weight-resident kernel writes bf16 only
+    of = torch.empty(B, S, S, S, Cout, device="cuda", dtype=BF if wres else torch.float32)
     stats = torch.zeros(32, 2, Cout, device="cuda")
     b = torch.randn(Cout, device="cuda")
 
     def fn():
-        _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, of, None)
+        _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, None if wres else of, of if wres else None)
     us = graph_time(fn)
     fl = 2.0 * B * S ** 3 * Cin * Cout * 27
     print(f"conv3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s (graph-replayed)")
@@ -117,35 +119,6 @@ def conv3d_case(B, S, Cin, Cout, wgrad=True):
         _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin, 8, Cout * 27 * Cin, 0)
     us = timeit(fn2)
     print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
-
-
-def timeline_case(B=32, S=16, Cin=32, Cout=64):
-    """per-workgroup phase stamps of conv3d_fwd_wres_kernel (debug flag 512; 100 MHz clock)"""
-    x = torch.randn(B, S, S, S, Cin, device="cuda").to(BF)
-    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
-    wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
-    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
-    of = torch.empty(B, S, S, S, Cout, device="cuda")
-    stats = torch.zeros(32, 2, Cout, device="cuda")
-    b = torch.randn(Cout, device="cuda")
-    for _ in range(3):
-        _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, of, None)
-    dbgbuf = torch.zeros(256 * 16, dtype=torch.int64, device="cuda")
-    _hip.call("mm_debug_flags", 512)
-    _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, of, dbgbuf)
-    torch.cuda.synchronize()
-    _hip.call("mm_debug_flags", 0)
-    ts = dbgbuf.view(256, 16).cpu().double()
-    t0 = ts[:, 0].min()
-    us = (ts - t0) / 100.0
-    names = {0: "start", 1: "W plane 0 stored", 2: "halo0 in LDS", 3: "mfma0 issued", 4: "halo1 in LDS",
-             5: "mfma1+stores0 issued", 14: "tail stores issued", 15: "done"}
-    print("phase stamps, us since the first workgroup started (min / mean / max over 256 workgroups)")
-    for i, n in names.items():
-        c = us[:, i]
-        print(f"  {n:22s} {c.min():7.2f} {c.mean():7.2f} {c.max():7.2f}")
-    mhz = ((ts[:, 13] - ts[:, 12]) / ((ts[:, 15] - ts[:, 0]) / 100.0)).mean()
-    print(f"  s_memtime ticks per us over the kernel: {mhz:.0f}")
 
 
 def attn_case(B=32, L=512, H=4, p=0.1):
@@ -294,20 +267,11 @@ def main():
         for p_ in (0.0, 0.1, 0.3):
             attn_case(p=p_)
         return
-    if "tl" in flt:
-        timeline_case()
-        return
     if "c4" in flt:                 # full-resolution fMRI (64x64x48): layer 2 runs at 32x32x24
         for B in (4, 8, 32):
             conv3d_dims_case(B, 32, 32, 24, 32, 64)
         conv3d_dims_case(32, 16, 16, 16, 32, 64)
         return
-    if "abl" in flt:
-        for f in (0, 1, 2, 3):
-            _hip.call("mm_debug_flags", f)
-            print("dbg flags", f, end=": ")
-            conv3d_case(32, 16, 32, 64, wgrad=False)
-        _hip.call("mm_debug_flags", 0)
     if "conv3" in flt or not flt:
         conv3d_case(32, 16, 32, 64)
         conv3d_case(32, 8, 64, 128)
