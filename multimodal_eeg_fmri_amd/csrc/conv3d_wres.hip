@@ -32,7 +32,11 @@
 //    assumption only; any placement computes the same result.
 //  * the previous tile's stores are spread evenly over the 54 K-steps of the current one.
 #include "conv3d_args.h"
+#ifdef WRES_ASM_INC                              // ablation builds (tools/abl_build.sh) substitute a variant stream
+#include WRES_ASM_INC
+#else
 #include "conv3d_wres_asm.inc"
+#endif
 
 #include <mutex>
 
@@ -54,8 +58,6 @@ constexpr int H_BYTES = LROWS * ROWB;            // 46 080
 constexpr int S_OFF = H_OFF + H_BYTES;           // per-wave BatchNorm partial sums [4][2][64] fp32
 constexpr int LDS_BYTES = S_OFF + 4 * 2 * BN * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
-constexpr int PLANE_CHUNKS = BN * 9 * 4;         // 16-byte chunks of one kd weight plane (2304)
-constexpr int PREGS = PLANE_CHUNKS / 256;        // per thread per plane (9)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -66,9 +68,43 @@ __device__ __forceinline__ int parity3(int v) { return __builtin_popcount(v & 7)
 
 __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef WRES_STAMPS      // diagnostic builds only (tools/abl_build.sh s*): shader-clock timeline of the workgroup
+    const long long t_begin = __builtin_readcyclecounter(), r_begin = wall_clock64();
+    long long kcyc = 0;
+    float tl[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define WR_TL(i) tl[i] = (float)(__builtin_readcyclecounter() - t_begin);
+#define WR_T0 const long long t0_ = __builtin_readcyclecounter();
+#define WR_T1 kcyc += __builtin_readcyclecounter() - t0_;
+#else
+#define WR_TL(i)
+#define WR_T0
+#define WR_T1
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile addressing stays in SGPRs
     const int lr = lane & 31, lh = lane >> 5;
+    // ---- weights: global -> LDS by LDS-DMA (no registers, no ds_write, lands while the wave does something else),
+    // issued before anything else.  LDS image [tap][rho][slot] x 16 B; a DMA writes wave-uniform base + 16 * lane,
+    // so wave w, instruction k of a kd plane p covers tap 9 p + k, rows rho = 16 w + (lane >> 2), slot = lane & 3:
+    // the permutation (channel n = 2 (rho & 31) + (rho >> 5), channel segment = slot ^ key(rho)) sits in the SOURCE
+    // address, which is affine in the tap (+64 bytes).
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    const bf16* wlane;
+    {
+        const int rho = wave * 16 + (lane >> 2), slot = lane & 3;
+        const int n = 2 * (rho & 31) + (rho >> 5);
+        wlane = a.w + (size_t)n * 27 * CIN + ((slot ^ ((rho >> 2) & 3)) << 3);
+    }
+    auto dma_plane = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(wlane + (9 * p + k) * CIN), (lptr_t*)(smem + (9 * p + k) * BN * ROWB + wave * 1024),
+                                             16, 0, 0);
+    };
+    dma_plane(0);
+    dma_plane(1);
+    dma_plane(2);
     const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8, td = (a.D + TD - 1) / TD;
     const int ntiles = a.B * td * th * tw;
 
@@ -79,6 +115,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     int tile = lo + slot;
     if (tile >= hi) return;                                        // uniform: nothing to do
 
+    // tile coordinates advance incrementally (one runtime division chain per workgroup, not per tile)
     auto coords = [&](int t) __attribute__((always_inline)) {
         Tile c;
         c.w0 = (t % tw) * 8; t /= tw;
@@ -87,38 +124,58 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
         c.b = t;
         return c;
     };
-    auto load_halo = [&](int t, u32x4 (&regs)[HREGS]) {
-        const Tile c = coords(t);
-        const bf16* xb = a.x + (size_t)c.b * a.D * a.H * a.W * CIN;  // uniform; one sample < 2^31 elements
-        int tq = tid;
-        asm volatile("" : "+v"(tq));           // re-derive the row decomposition per tile (hoisted, it pins ~40 VGPRs)
+    const Tile stepT = coords(nper);                                // nper decomposed in the same mixed radix
+    auto advance = [&](Tile c) __attribute__((always_inline)) {
+        c.w0 += stepT.w0; if (c.w0 >= tw * 8) { c.w0 -= tw * 8; c.h0 += 8; }
+        c.h0 += stepT.h0; if (c.h0 >= th * 8) { c.h0 -= th * 8; c.d0 += TD; }
+        c.d0 += stepT.d0; if (c.d0 >= td * TD) { c.d0 -= td * TD; c.b += 1; }
+        c.b += stepT.b;
+        return c;
+    };
+    // ---- the halo as 16-byte chunks: chunk s = tid + 256 i is halo row r = s >> 2 = (hd, hh, hw), channel
+    // segment s & 3.  Everything that does not depend on the tile is computed once: the global offset relative to
+    // the tile's first voxel, the swizzled LDS address, and a one-hot selector (1 << hd | 1 << (6 + hh) |
+    // 1 << (16 + hw)) that is tested against the tile's in-volume mask - two VALU instructions per chunk and tile
+    // instead of ~40 (div / mod by 10 and six compares; PMC showed ~800 VALU per tile boundary).
+    int goff[HREGS], ldso[HREGS];
+    unsigned sel[HREGS];
+    {   // row r = (tid >> 2) + 64 i: one small division for i = 0, then +64 rows = +6 h-rows +4 w with carries
+        const int q = tid >> 2, sg = tid & 3;
+        int hh = (q * 205) >> 11, hw = q - hh * HB, hd = 0;          // q < 64: exact
 #pragma unroll
         for (int i = 0; i < HREGS; ++i) {
-            const int s = tq + i * 256;
-            const int r = s >> 2, sg = s & 3;
-            u32x4 v = u32x4{0u, 0u, 0u, 0u};
-            if (r < HROWS) {
-                const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
-                const int d = c.d0 + hd - 1, h = c.h0 + hh - 1, w = c.w0 + hw - 1;
-                if (d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                    v = *reinterpret_cast<const u32x4*>(xb + (unsigned)(((d * a.H + h) * a.W + w) * CIN + sg * 8));
-            }
-            regs[i] = v;
+            goff[i] = ((((hd - 1) * a.H + (hh - 1)) * a.W + (hw - 1)) * CIN + sg * 8) * 2;       // bytes
+            ldso[i] = H_OFF + ((hd * HB + hh) * WP + hw) * ROWB + ((sg ^ (hh & 3)) << 4);
+            sel[i] = (i < HREGS - 1 || q + 64 * i < HROWS) ? (1u << hd) | (1u << (6 + hh)) | (1u << (16 + hw)) : 0x80000000u;
+            hw += 4; hh += 6;
+            if (hw >= HB) { hw -= HB; hh += 1; }
+            if (hh >= HB) { hh -= HB; hd += 1; }
+        }
+    }
+    auto range_mask = [](int lo_, int hi_, int n) __attribute__((always_inline)) {      // bits [max(lo,0), min(hi,n))
+        lo_ = lo_ < 0 ? 0 : lo_;
+        hi_ = hi_ > n ? n : hi_;
+        return hi_ > lo_ ? ((1u << hi_) - 1u) & ~((1u << lo_) - 1u) : 0u;
+    };
+    // buffer loads: a chunk outside the volume gets an out-of-range offset and the hardware returns zeros - no
+    // exec masking, no zero-initialised registers (the whole input is < 4 GiB: checked on the host)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(a.x), 0, (unsigned)((size_t)a.B * a.D * a.H * a.W * CIN * 2), 0x00020000);
+    auto load_halo = [&](const Tile& c, u32x4 (&regs)[HREGS]) __attribute__((always_inline)) {
+        const unsigned toff = (unsigned)((((c.b * a.D + c.d0) * a.H + c.h0) * a.W + c.w0) * CIN * 2);   // uniform, bytes
+        // halo index k is inside the volume iff 0 <= c0 + k - 1 < extent
+        const unsigned M = range_mask(1 - c.d0, a.D - c.d0 + 1, TD + 2) | (range_mask(1 - c.h0, a.H - c.h0 + 1, HB) << 6) |
+                           (range_mask(1 - c.w0, a.W - c.w0 + 1, HB) << 16);
+#pragma unroll
+        for (int i = 0; i < HREGS; ++i) {
+            const unsigned off = ((M & sel[i]) == sel[i]) ? toff + (unsigned)goff[i] : 0xFFFFFFF0u;
+            regs[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
         }
     };
-    auto store_halo = [&](const u32x4 (&regs)[HREGS]) {
-        int tq = tid;
-        asm volatile("" : "+v"(tq));
+    auto store_halo = [&](const u32x4 (&regs)[HREGS]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < HREGS; ++i) {
-            const int s = tq + i * 256;
-            const int r = s >> 2, sg = s & 3;
-            if (r < HROWS) {
-                const int hw = r % HB, hh = (r / HB) % HB, hd = r / (HB * HB);
-                const int R = (hd * HB + hh) * WP + hw;
-                *reinterpret_cast<u32x4*>(smem + H_OFF + R * ROWB + ((sg ^ (hh & 3)) << 4)) = regs[i];
-            }
-        }
+        for (int i = 0; i < HREGS; ++i)
+            if (i < HREGS - 1 || (int)sel[i] >= 0) *reinterpret_cast<u32x4*>(smem + ldso[i]) = regs[i];
     };
 
     // ---- per-lane fragment bases (bytes into smem).  GEMM row m = wave*64 + i*32 + lr  <->  voxel
@@ -145,29 +202,10 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     const float sh0 = a.shift ? a.shift[2 * lr] : 0.f, sh1 = a.shift ? a.shift[2 * lr + 1] : 0.f;
 
     u32x4 nxt[HREGS];
-    load_halo(tile, nxt);
-    // ---- weights: three kd planes of 64 x 9 rows, all loads issued before the first LDS write.
-    // chunk c = tid + 256 i of a plane: n = c / 36, (tap-in-plane, slot) = c % 36; LDS row of channel n is
-    // rho = (n & 1) * 32 + (n >> 1) inside tap block (9 p + t) * 64
-    u32x4 wv0[PREGS], wv1[PREGS], wv2[PREGS];
-    unsigned wsrc[PREGS], wdst[PREGS];
-#pragma unroll
-    for (int i = 0; i < PREGS; ++i) {
-        const unsigned c = tid + i * 256, n = c / 36, rem = c % 36, t9 = rem >> 2, sg = rem & 3;
-        const unsigned rho = (n & 1) * 32 + (n >> 1);
-        wsrc[i] = (n * 27 + t9) * CIN + sg * 8;                                   // elements
-        wdst[i] = (t9 * BN + rho) * ROWB + ((sg ^ ((rho >> 2) & 3)) << 4);         // bytes
-    }
-#define WR_LOAD_PLANE(p, regs)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < PREGS; ++i)                                            \
-        regs[i] = *reinterpret_cast<const u32x4*>(a.w + wsrc[i] + (p) * 9 * CIN);
-#define WR_STORE_PLANE(p, regs)                                                                  \
-    _Pragma("unroll") for (int i = 0; i < PREGS; ++i)                                            \
-        *reinterpret_cast<u32x4*>(smem + wdst[i] + (p) * 9 * BN * ROWB) = regs[i];
-    WR_LOAD_PLANE(0, wv0)
-    WR_LOAD_PLANE(1, wv1)
-    WR_LOAD_PLANE(2, wv2)
-    WR_STORE_PLANE(0, wv0)
+    Tile curT = coords(tile);                                        // the tile whose halo sits in `nxt`
+    WR_TL(0)
+    load_halo(curT, nxt);
+    WR_TL(1)
 
     // ---- the K loop and the previous tile's epilogue are hand-scheduled instruction streams
     // (tools/gen_wres_asm.py -> conv3d_wres_asm.inc): accumulator sets X = a[48:111], Y = a[112:175] and the
@@ -266,9 +304,9 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
             }
     };
     auto is_full = [&](const Tile& c) __attribute__((always_inline)) { return c.d0 + TD <= a.D && c.h0 + 8 <= a.H && c.w0 + 8 <= a.W; };
-    auto prefetch_next = [&](int t) __attribute__((always_inline)) {                                // next halo -> registers, in flight during the MFMAs
-        const int tnext = t + nper;
-        if (tnext < hi) load_halo(tnext, nxt);
+    auto prefetch_next = [&](int t) __attribute__((always_inline)) {  // next halo -> registers, in flight during the MFMAs
+        curT = advance(curT);
+        if (t + nper < hi) load_halo(curT, nxt);
     };
     auto begin_tile = [&]() __attribute__((always_inline)) {                                        // halo -> LDS
         __syncthreads();                                            // previous tile's LDS reads are done
@@ -277,25 +315,32 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     };
     bool pending = false;                                           // an interior tile waits in the set not being computed
     // one tile into set CUR (0 = X, 1 = Y); the pending tile, if any, is in the other set
+    bool first_boundary = true;
     auto next_tile = [&](int cur, int t) __attribute__((always_inline)) {
+        if (first_boundary) { WR_TL(7) }
         begin_tile();
+        if (first_boundary) { WR_TL(8) }
+        const Tile me = curT;
         prefetch_next(t);
+        if (first_boundary) { WR_TL(9) }
+        first_boundary = false;
+        WR_T0
         if (pending) k_epi(cur, tile_base(pt));
         else k_plain(cur);
-        pt = coords(t);
+        WR_T1
+        pt = me;
         pending = is_full(pt);
         if (!pending) store_ragged(cur, pt);
     };
 
-    // ---- first tile (peeled: tile 0 starts on weight plane 0 while planes 1, 2 are still in flight)
-    begin_tile();
-    asm volatile(WRES_K_X_0_18 : : WR_K_OPERANDS : "memory", WRES_AGPR_CLOBBERS);   // taps of kd = 0
-    WR_STORE_PLANE(1, wv1)
-    WR_STORE_PLANE(2, wv2)
-    __syncthreads();
-    prefetch_next(tile);                                            // only now: its registers were the weight planes'
-    asm volatile(WRES_K_X_18_54 : : WR_K_OPERANDS : "memory", WRES_AGPR_CLOBBERS);
-    pt = coords(tile);
+    // ---- first tile: its halo and the weights were the first things this workgroup asked for
+    begin_tile();                                                   // (the barriers also cover the weight DMA: vmcnt(0) first)
+    WR_TL(3)
+    pt = curT;
+    prefetch_next(tile);
+    WR_TL(5)
+    k_plain(0);
+    WR_TL(6)
     pending = is_full(pt);
     if (!pending) store_ragged(0, pt);
     bool last_in_x = true;
@@ -311,6 +356,15 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
         if (last_in_x) flush(0, tile_base(pt));
         else flush(1, tile_base(pt));
     }
+#ifdef WRES_STAMPS
+    if (a.stats && tid == 0) {          // [32][2][64] statistics, then per workgroup {K-loop cycles, kernel cycles, kernel 100 MHz ticks, tiles, 12 timeline stamps}
+        float* o = a.stats + MM_REPL * 2 * BN + blockIdx.x * 16;
+        o[0] = (float)kcyc; o[1] = (float)(__builtin_readcyclecounter() - t_begin);
+        o[2] = (float)(wall_clock64() - r_begin); o[3] = (float)((hi - lo - slot + nper - 1) / nper);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o[4 + i] = tl[i];
+    }
+#endif
     float st1[2] = {s10, s11}, st2[2] = {s20, s21};
     if (a.stats) {
         float* sstat = reinterpret_cast<float*>(smem + S_OFF);
@@ -332,8 +386,6 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
         if (tid < 2 * BN)
             atomicAdd(&rep[tid], (sstat[tid] + sstat[2 * BN + tid]) + (sstat[4 * BN + tid] + sstat[6 * BN + tid]));
     }
-#undef WR_LOAD_PLANE
-#undef WR_STORE_PLANE
 #undef WR_K_OPERANDS
 #undef WR_EPI_OUT
 #undef WR_EPI_IN
@@ -344,7 +396,8 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
 
 bool conv3d_wres_applies(const Conv3dArgs& a) {
     const long tiles = (long)a.B * ceil_div(a.D, TD) * ceil_div(a.H, 8) * ceil_div(a.W, 8);
-    return a.Cin == CIN && a.Cout == BN && a.out_bf16 && !a.out_f32 && tiles >= 64;
+    const size_t in_bytes = (size_t)a.B * a.D * a.H * a.W * CIN * 2;   // halo chunks are fetched with 32-bit buffer offsets
+    return a.Cin == CIN && a.Cout == BN && a.out_bf16 && !a.out_f32 && tiles >= 64 && in_bytes < 0xFFFF0000ull;
 }
 
 int launch3d_wres(const Conv3dArgs& a, hipStream_t st) {

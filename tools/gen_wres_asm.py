@@ -29,7 +29,15 @@ that they have left the vmcnt queue before the compiler's wait for the next halo
 usage: python tools/gen_wres_asm.py   (writes the .inc; commit it)
 """
 import os
+import sys
 
+# ablation builds (tools/abl_build.sh): 1 no epilogue instructions, 2 no ds_reads inside the K loop, 4 no MFMAs,
+# 8 no global stores, 16 epilogue reads v_mov instead of v_accvgpr_read.  0 in the product.
+ABL = int(os.environ.get("WRES_ABL", "0"))
+# cache policy of the output stores: write-through ("sc0 sc1") - the 16.8 MB leave the XCD's L2 while the kernel
+# still computes instead of as one write-back burst at the kernel boundary (measured at C2, graph-replayed:
+# plain 17.9 us, sc1 / nt 16.6, sc0 sc1 15.8); the consumer is on another XCD's L2 anyway.
+STORE_BITS = os.environ.get("WRES_STORE_BITS", "sc0 sc1")
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                    "multimodal_eeg_fmri_amd", "csrc", "conv3d_wres_asm.inc")
 ACC = {"X": 48, "Y": 112}
@@ -72,7 +80,9 @@ class Stream:
     def emit(self, s):
         self.lines.append(s)
 
-    def read(self, step, which):
+    def read(self, step, which, force=False):
+        if (ABL & 2) and not force:
+            return
         k = step % 3
         if which[0] == "A":
             self.emit(a_read(step, int(which[1]), frag(k, which)))
@@ -82,6 +92,8 @@ class Stream:
 
     def need(self, step):
         """all four fragments of `step` must have landed"""
+        if not any(st == step for st, _ in self.ds):
+            return
         idx = max(i for i, (st, _) in enumerate(self.ds) if st == step)
         if idx < self.done:
             return
@@ -101,10 +113,14 @@ def epilogue_pieces(prev, q):
     if (r & 3) == 0 and q != 0:                       # new h row of the output tile: advance both lane offsets
         g[0] += ["v_add_u32 %[voffe], %[pitch], %[voffe]", "v_add_u32 %[voffo], %[pitch], %[voffo]"]
     t2 = "%[t2]"
-    g[0] += [f"v_accvgpr_read_b32 %[t0], a{a0}", f"v_accvgpr_read_b32 %[t1], a{a1}"]
+    if ABL & 16:
+        g[0] += ["v_mov_b32 %[t0], 1.0", "v_mov_b32 %[t1], 1.0"]
+    else:
+        g[0] += [f"v_accvgpr_read_b32 %[t0], a{a0}", f"v_accvgpr_read_b32 %[t1], a{a1}"]
     g[1] += ["v_add_f32 %[t0], %[t0], %[sh0]", "v_add_f32 %[t1], %[t1], %[sh1]", f"v_cvt_pk_bf16_f32 {t2}, %[t0], %[t1]"]
-    g[2] += [f"global_store_dword {'%[voffo]' if par else '%[voffe]'}, {t2}, %[pbase] offset:{(r & 3) * BN * 2}",
-             "v_add_f32 %[s10], %[s10], %[t0]", "v_fmac_f32 %[s20], %[t0], %[t0]"]
+    if not (ABL & 8):
+        g[2] += [f"global_store_dword {'%[voffo]' if par else '%[voffe]'}, {t2}, %[pbase] offset:{(r & 3) * BN * 2} {STORE_BITS}".rstrip()]
+    g[2] += ["v_add_f32 %[s10], %[s10], %[t0]", "v_fmac_f32 %[s20], %[t0], %[t0]"]
     g[3] += ["v_add_f32 %[s11], %[s11], %[t1]", "v_fmac_f32 %[s21], %[t1], %[t1]"]
     return g
 
@@ -122,20 +138,23 @@ def kloop(cur, s0, s1, prev=None):
     for s in (s0, s0 + 1):
         if s < s1:
             for w in ("A0", "A1", "B0", "B1"):
-                st.read(s, w)
+                st.read(s, w, force=True)
     for s in range(s0, s1):
         k = s % 3
         n = s + 2 if s + 2 < s1 else None
-        ep = epilogue_pieces(prev, s) if (prev is not None and s < EPI_STEPS) else [[], [], [], []]
+        ep = epilogue_pieces(prev, s) if (prev is not None and s < EPI_STEPS and not (ABL & 1)) else [[], [], [], []]
         st.need(s)
         for g, (i, j, w) in enumerate(((0, 0, "A0"), (0, 1, "A1"), (1, 0, "B0"), (1, 1, "B1"))):
             c = "0" if s == 0 else acc(cur, i, j)
-            st.emit(f"v_mfma_f32_32x32x16_bf16 {acc(cur, i, j)}, {frag(k, 'A%d' % i)}, {frag(k, 'B%d' % j)}, {c}")
+            if not (ABL & 4):
+                st.emit(f"v_mfma_f32_32x32x16_bf16 {acc(cur, i, j)}, {frag(k, 'A%d' % i)}, {frag(k, 'B%d' % j)}, {c}")
             if n is not None:
                 st.read(n, w)
             for ins in ep[g]:
                 st.emit(ins)
-    assert st.done == len(st.ds), "a fragment was read but never waited for"
+    if st.done != len(st.ds):
+        assert ABL, "a fragment was read but never waited for"
+        st.emit("s_waitcnt lgkmcnt(0)")
     return st.lines
 
 
@@ -163,17 +182,16 @@ def main():
              "#define WRES_AGPR_CLOBBERS " + ", ".join(f'"a{i}"' for i in range(NAGPR))]
     for cur in ("X", "Y"):
         other = "Y" if cur == "X" else "X"
-        parts.append(f"#define WRES_K_{cur}_0_18 \\\n" + cstr(kloop(cur, 0, 18)).replace("\n", " \\\n"))
-        parts.append(f"#define WRES_K_{cur}_18_54 \\\n" + cstr(kloop(cur, 18, STEPS)).replace("\n", " \\\n"))
         parts.append(f"#define WRES_K_{cur}_ALL \\\n" + cstr(kloop(cur, 0, STEPS)).replace("\n", " \\\n"))
         parts.append(f"#define WRES_K_{cur}_ALL_EPI \\\n" + cstr(kloop(cur, 0, STEPS, prev=other)).replace("\n", " \\\n"))
         parts.append(f"#define WRES_FLUSH_{cur} \\\n" + cstr(flush(cur)).replace("\n", " \\\n"))
         for t in range(4):
             parts.append(f"#define WRES_EXTRACT_{cur}_{t} \\\n" + cstr(extract(cur, t)).replace("\n", " \\\n"))
-    with open(OUT, "w") as f:
+    out = sys.argv[1] if len(sys.argv) > 1 else OUT
+    with open(out, "w") as f:
         f.write("\n".join(parts) + "\n")
     n = sum(len(kloop("X", 0, STEPS, prev="Y")) for _ in range(1))
-    print(f"wrote {OUT}: K loop with epilogue = {n} instructions")
+    print(f"wrote {out}: K loop with epilogue = {n} instructions")
 
 
 if __name__ == "__main__":

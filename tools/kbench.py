@@ -121,6 +121,32 @@ def conv3d_case(B, S, Cin, Cout, wgrad=True):
     print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
 
 
+def stamp_case(B, D, H, W):
+    """in-kernel cycle stamps of a WRES_STAMPS build (tools/abl_build.sh s0; MMEEG_HIP_LIB=.../abl_s0.so)"""
+    Cin, Cout = 32, 64
+    x = torch.randn(B, D, H, W, Cin, device="cuda").to(BF)
+    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
+    wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
+    of = torch.empty(B, D, H, W, Cout, device="cuda", dtype=BF)
+    stats = torch.zeros(32 * 2 * Cout + 256 * 16, device="cuda")
+    b = torch.randn(Cout, device="cuda")
+    for _ in range(20):
+        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, b, stats, None, of)
+    torch.cuda.synchronize()
+    st = stats[32 * 2 * Cout:].view(256, 16).cpu().double()
+    k, tot, ticks, tiles = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+    ghz = (tot / (ticks / 100.0)).mean() / 1e3
+    print(f"stamps B={B} {D}x{H}x{W}: tiles/WG {tiles.mean():.1f}; kernel {tot.mean():.0f} cyc = {(ticks / 100).mean():.2f} us "
+          f"({ghz:.2f} GHz); K loops {k.mean():.0f} cyc = {(k / tiles).mean():.0f} per tile (6912 = MFMA-bound); "
+          f"outside K loops {(tot - k).mean():.0f} cyc = {((tot - k) / tiles).mean():.0f} per tile; per-WG kernel cyc min {tot.min():.0f} max {tot.max():.0f}")
+    names = ["setup done", "all loads issued", "W plane 0 in LDS", "halo 0 in LDS (barrier)", "K 0-18 issued", "planes 1,2 in LDS + next halo issued",
+             "K 18-54 issued", "tile 2: boundary start", "tile 2: halo in LDS", "tile 2: next halo issued"]
+    for i, nm in enumerate(names):
+        c = st[:, 4 + i]
+        print(f"    {nm:40s} {c.mean():8.0f} cyc (min {c.min():.0f} max {c.max():.0f})")
+
+
 def attn_case(B=32, L=512, H=4, p=0.1):
     E = H * 32
     qkv = (torch.randn(B, L, 3 * E, device="cuda") * 0.5).to(BF)
@@ -262,6 +288,17 @@ def main():
         return
     if "pmc3d" in flt:
         conv3d_case(32, 16, 32, 64, wgrad=False)
+        return
+    if "stamp" in flt:
+        stamp_case(32, 32, 32, 24)
+        stamp_case(32, 16, 16, 16)
+        return
+    if "c4b" in flt:                # the two roofline shapes only (ablation sweeps)
+        conv3d_dims_case(32, 32, 32, 24, 32, 64)
+        conv3d_dims_case(32, 16, 16, 16, 32, 64)
+        return
+    if "pmc4" in flt:               # BASELINE config #4: layer 2 at 32 x 32 x 24
+        conv3d_dims_case(32, 32, 32, 24, 32, 64)
         return
     if "attn" in flt:
         for p_ in (0.0, 0.1, 0.3):
