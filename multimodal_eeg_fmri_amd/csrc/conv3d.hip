@@ -593,7 +593,7 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
                   float* stats, float* out_f32, void* out_bf16, hipStream_t st) {
     MM_REQUIRE(x && w && (out_f32 || out_bf16) && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: null/invalid");
     MM_REQUIRE(Cin == 16 || Cin % 32 == 0, "conv3d_fwd: Cin=%d must be 16 or a multiple of 32", Cin);
-    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, 0, stats, out_f32, (bf16*)out_bf16};
+    Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, 0, stats, out_f32, (bf16*)out_bf16, 0u, 0u, 0u};
     const long tiles2 = (long)B * ceil_div(D, 2) * ceil_div(H, 8) * ceil_div(W, 8);
     if (conv3d_wres_applies(a)) return launch3d_wres(a, st);          // Cin 32 -> Cout 64, bf16 out: conv3d_wres.hip
     if (Cout <= 32) return launch3d<2, 32, 4, 1>(a, st);

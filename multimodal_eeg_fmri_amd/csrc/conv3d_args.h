@@ -11,6 +11,7 @@ struct Conv3dArgs {
     float* stats;                 // [MM_REPL][2][Cout] sum / sumsq of (acc + shift)   (nullptr)
     float* out_f32;               // [B][D][H][W][Cout]
     bf16* out_bf16;
+    unsigned mtw, mth, mtd;       // conv3d_wres: floor(2^32 / d) + 1 for d = tiles along W, H, D (q = mulhi(x, m) = x / d for x < 2^24)
 };
 
 // conv3d_wres.hip

@@ -5,6 +5,7 @@ reference's."""
 import ctypes
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -270,3 +271,37 @@ def test_every_mm_name_used_by_the_package_is_declared_in_the_header():
     assert not missing, f"called but not declared in include/mmeeg_hip.h: {missing}"
     lib = _hip.load()
     assert all(hasattr(lib, n) for n in declared)
+
+
+def test_hand_scheduled_conv3d_kernel_keeps_the_accumulator_file_to_itself():
+    """csrc/conv3d_wres.hip keeps accumulators, fragments, the prefetched halo and per-lane constants in literal
+    AGPRs a0-a251 across inline-asm statements.  That is only sound while the COMPILER never touches those
+    registers between the statements (it does not know they are live): audit the compiled ISA - no accumulator-file
+    instruction or operand outside the ;;#ASMSTART / ;;#ASMEND blocks, no scratch, no spills - and that the
+    committed instruction streams are what tools/gen_wres_asm.py generates."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(_hip.__file__))
+    csrc = os.path.join(root, "multimodal_eeg_fmri_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        inc = os.path.join(tmp, "gen.inc")
+        subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wres_asm.py"), inc], check=True, capture_output=True,
+                       env={k: v for k, v in os.environ.items() if not k.startswith("WRES_")})
+        assert open(inc).read() == open(os.path.join(csrc, "conv3d_wres_asm.inc")).read(), "regenerate conv3d_wres_asm.inc"
+        out = os.path.join(tmp, "wres.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{csrc}",
+                        f"-I{os.path.join(root, 'include')}", "-S", "--cuda-device-only", "-o", out,
+                        os.path.join(csrc, "conv3d_wres.hip")], check=True, capture_output=True)
+        text = open(out).read()
+    import re
+    assert re.search(r"; ScratchSize: 0\b", text) and ".vgpr_spill_count: 0" in text.replace("    ", " ")
+    inside, bad = False, []
+    for line in text.splitlines():
+        if "#ASMSTART" in line:
+            inside = True
+        elif "#ASMEND" in line:
+            inside = False
+        elif not inside and not line.lstrip().startswith((";", ".")) and re.search(r"\bv_accvgpr|\ba\[?\d", line):
+            bad.append(line.strip())
+    assert not bad, bad[:5]
+    assert text.count("#ASMSTART") >= 10

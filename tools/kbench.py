@@ -140,8 +140,8 @@ def stamp_case(B, D, H, W):
     print(f"stamps B={B} {D}x{H}x{W}: tiles/WG {tiles.mean():.1f}; kernel {tot.mean():.0f} cyc = {(ticks / 100).mean():.2f} us "
           f"({ghz:.2f} GHz); K loops {k.mean():.0f} cyc = {(k / tiles).mean():.0f} per tile (6912 = MFMA-bound); "
           f"outside K loops {(tot - k).mean():.0f} cyc = {((tot - k) / tiles).mean():.0f} per tile; per-WG kernel cyc min {tot.min():.0f} max {tot.max():.0f}")
-    names = ["setup done", "all loads issued", "W plane 0 in LDS", "halo 0 in LDS (barrier)", "K 0-18 issued", "planes 1,2 in LDS + next halo issued",
-             "K 18-54 issued", "tile 2: boundary start", "tile 2: halo in LDS", "tile 2: next halo issued"]
+    names = ["halo 0 prefetch issued", "weight DMA issued", "halo constants parked", "first boundary done (halo 0 + W in LDS)",
+             "K loop 1 issued", "K loop 2 issued", "last K loop issued", "flush issued"]
     for i, nm in enumerate(names):
         c = st[:, 4 + i]
         print(f"    {nm:40s} {c.mean():8.0f} cyc (min {c.min():.0f} max {c.max():.0f})")
