@@ -599,6 +599,9 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     yf, yb = (None, y) if pool else (y, None)
     if training:
         stats = _zeros((REPL, 2, cout), xv)
+        cal = kernel_timer.bracket(f"event_pair_c{cinp}")    # an EMPTY bracket on the same stream: what a pair of
+        if cal is not None:                                  # HIP event records costs by itself (calibration)
+            cal.record()
         end = kernel_timer.bracket(f"conv3d_fwd_c{cinp}")
         _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, stats, yf, yb)
         if end is not None:
