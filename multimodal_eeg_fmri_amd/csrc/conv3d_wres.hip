@@ -16,10 +16,13 @@
 //    per pipe cycle as 32x32x16, but the chip holds a ~14 % higher clock on it under this kernel's load.
 //    MFMA row m of M-tile i <-> voxel (h, w) = (4 (i >> 1) + (m >> 2), 4 (i & 1) + (m & 3)): 4 x 4 patches.
 //  * the per-tile instruction streams are hand-scheduled (tools/gen_wres_asm.py -> conv3d_wres_asm.inc): the
-//    K loop with the next tap's fragment reads, the previous tile's pack / store / BatchNorm-sum and the next
-//    tile's halo prefetch in the MFMA gaps, and the tile boundary (halo registers -> LDS between two barriers).
-//    Accumulators, fragments, the prefetched halo and the per-lane halo constants live in the accumulator
-//    file (a0-a251), which only those statements touch (tests/test_abi_and_host.py audits the compiled ISA).
+//    K loop with the next tap's fragment reads, the previous tile's pack / store / BatchNorm-sum, the next
+//    tile's halo prefetch and its way into LDS in the MFMA gaps.  Accumulators, fragments, the prefetched halo,
+//    per-lane constants, the BatchNorm sums and the bias live in the accumulator file (a0-a255), which only
+//    those statements touch (tests/test_abi_and_host.py audits the compiled ISA).
+//  * the halo is a ring of six depth planes and a workgroup walks its tiles down the (b, h, w) columns: the
+//    next tile shares two planes and its four new ones replace planes that die during this tile's kd phases,
+//    one barrier per phase inside the K loop - no boundary between the tiles of a column, 1/3 less halo traffic.
 //  * LDS rows are unpadded 64-byte rows whose 16-byte slots are XOR-swizzled with 2 * (row-of-patch parity):
 //    slot = segment ^ (2 * ((h + kh) & 1)) for the halo (h = the lane's patch row), segment ^ (2 * ((rho >> 2)
 //    & 1)) for the weights.  Each ds_read_b128 lane group then touches 16 distinct 16-byte slots for every tap
@@ -50,18 +53,18 @@ constexpr int TD = 4;                            // tile depth: 4 x 8 x 8 = 256 
 constexpr int HB = 10;                           // halo edge of an 8-wide tile face
 constexpr int WP = 12;                           // halo w-pitch in LDS rows (10 used)
 constexpr int DP = HB * WP;                      // halo d-pitch (120 rows)
-constexpr int HROWS = (TD + 2) * HB * HB;        // 600 rows fetched per tile
-constexpr int LROWS = (TD + 2) * DP;             // 720 LDS rows
-constexpr int HREGS = (HROWS * 4 + 255) / 256;   // 16-byte chunks per thread per halo (10)
+constexpr int LROWS = (TD + 2) * DP;             // 720 LDS rows: six plane slots of 120
+constexpr int PCHUNKS = HB * HB * 4;             // 16-byte chunks of one halo plane (400): two per thread
 constexpr int ROWB = CIN * 2;                    // bytes per LDS row (64)
 constexpr int W_BYTES = 27 * BN * ROWB;          // 110 592
 constexpr int H_OFF = W_BYTES;
 constexpr int H_BYTES = LROWS * ROWB;            // 46 080
+constexpr int SLOTB = DP * ROWB;                 // 7 680 bytes per plane slot
 constexpr int S_OFF = H_OFF + H_BYTES;           // per-wave BatchNorm partial sums [4][2][64] fp32
 constexpr int LDS_BYTES = S_OFF + 4 * 2 * BN * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 
-struct Tile { int b, d0, h0, w0; };
+struct Tile { int b, d, h0, w0; };               // d = tile index along the depth (first output depth = 4 d)
 
 __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,19 +77,19 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
 #define WR_T1 kcyc += __builtin_readcyclecounter() - t0_;
 #define WR_TLK if (tl[4] == 0.f) { WR_TL(4) } else if (tl[5] == 0.f) { WR_TL(5) }
 #else
-#define WR_TLK
 #define WR_TL(i)
 #define WR_T0
 #define WR_T1
+#define WR_TLK
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile addressing stays in SGPRs
     const int lc = lane & 15, lg = lane >> 4;                       // MFMA lane = (row / column 0-15, group 0-3)
-    // ---- weights: global -> LDS by LDS-DMA, issued before anything else.  LDS image [tap][rho][slot] x 16 B; a
-    // DMA writes wave-uniform base + 16 * lane, so wave w, instruction k covers tap k, rows rho = 16 w + (lane >> 2),
-    // slot = lane & 3.  LDS row rho holds output channel n = 4 (rho & 15) + (rho >> 4) (column tile j = rho >> 4,
-    // lane column c = rho & 15 <-> channel 4 c + j); the channel segment in slot s is s ^ 2 ((rho >> 2) & 1).  Both
-    // permutations sit in the SOURCE address, which is affine in the tap (+64 bytes).
+    // ---- weights: global -> LDS by LDS-DMA.  LDS image [tap][rho][slot] x 16 B; a DMA writes wave-uniform base +
+    // 16 * lane, so wave w, instruction k covers tap k, rows rho = 16 w + (lane >> 2), slot = lane & 3.  LDS row rho
+    // holds output channel n = 4 (rho & 15) + (rho >> 4) (column tile j = rho >> 4, lane column c = rho & 15 <->
+    // channel 4 c + j); the channel segment in slot s is s ^ 2 ((rho >> 2) & 1).  Both permutations sit in the
+    // SOURCE address, which is affine in the tap (+64 bytes).
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
     const bf16* wlane;
@@ -108,55 +111,52 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8, td = (a.D + TD - 1) / TD;
     const int ntiles = a.B * td * th * tw;
 
-    // ---- XCD-aware tile list: XCD x (= blockIdx % 8 under round-robin dispatch) owns tiles [lo, hi)
+    // ---- tile list: depth index fastest, so that consecutive tiles walk down a (b, h, w) column.  XCD x (=
+    // blockIdx % 8 under round-robin dispatch) owns the x-th eighth of the list, each of its workgroups a contiguous run.
     const int xcd = blockIdx.x & 7, slot_ = blockIdx.x >> 3;
     const int nper = (gridDim.x - xcd + 7) >> 3;                    // workgroups of this XCD
-    const int lo = (int)((long)ntiles * xcd / 8), hi = (int)((long)ntiles * (xcd + 1) / 8);
-    int tile = lo + slot_;
-    const bool has_work = tile < hi;                                // (uniform) a workgroup without tiles still drains its DMA
-
-    // tile coordinates advance incrementally (one runtime division chain per workgroup, not per tile)
+    const int xlo = (int)((long)ntiles * xcd / 8), xn = (int)((long)ntiles * (xcd + 1) / 8) - xlo;
+    const int per = xn / nper, rem = xn - per * nper;
+    const int lo = xlo + slot_ * per + (slot_ < rem ? slot_ : rem), hi = lo + per + (slot_ < rem ? 1 : 0);
+    const bool has_work = lo < hi;                                  // (uniform) a workgroup without tiles still drains its DMA
     auto coords = [&](int t) __attribute__((always_inline)) {       // divisions by host-made reciprocals (t < 2^24)
         Tile c;
-        int q = (int)__umulhi((unsigned)t, a.mtw); c.w0 = (t - q * tw) * 8; t = q;
-        q = (int)__umulhi((unsigned)t, a.mth); c.h0 = (t - q * th) * 8; t = q;
-        q = (int)__umulhi((unsigned)t, a.mtd); c.d0 = (t - q * td) * TD;
+        int q = (int)__umulhi((unsigned)t, a.mtd); c.d = t - q * td; t = q;
+        q = (int)__umulhi((unsigned)t, a.mtw); c.w0 = (t - q * tw) * 8; t = q;
+        q = (int)__umulhi((unsigned)t, a.mth); c.h0 = (t - q * th) * 8;
         c.b = q;
         return c;
     };
-    const Tile stepT = coords(nper);                                // nper decomposed in the same mixed radix
-    auto advance = [&](Tile c) __attribute__((always_inline)) {
-        c.w0 += stepT.w0; if (c.w0 >= tw * 8) { c.w0 -= tw * 8; c.h0 += 8; }
-        c.h0 += stepT.h0; if (c.h0 >= th * 8) { c.h0 -= th * 8; c.d0 += TD; }
-        c.d0 += stepT.d0; if (c.d0 >= td * TD) { c.d0 -= td * TD; c.b += 1; }
-        c.b += stepT.b;
+    auto next_of = [&](Tile c) __attribute__((always_inline)) {     // successor in list order
+        if (++c.d == td) {
+            c.d = 0; c.w0 += 8;
+            if (c.w0 >= tw * 8) { c.w0 = 0; c.h0 += 8; if (c.h0 >= th * 8) { c.h0 = 0; c.b += 1; } }
+        }
         return c;
     };
-    // ---- the halo as 16-byte chunks: chunk q of a thread is halo row r = (tid >> 2) + 64 q = (hd, hh, hw), channel
-    // segment tid & 3.  What does not depend on the tile is computed once and parked in the accumulator file: the
-    // global byte offset relative to the tile's first voxel and a one-hot selector (1 << hd | 1 << (6 + hh) |
-    // 1 << (16 + hw)) that is tested against the tile's in-volume mask.  The swizzled LDS addresses stay in VGPRs.
-    int ldso[HREGS];
-    {
-        int goff[HREGS];
-        unsigned sel[HREGS];
-        const int q0 = tid >> 2, sg = tid & 3;
-        int hh = (q0 * 205) >> 11, hw = q0 - hh * HB, hd = 0;        // q0 < 64: exact division by 10
+    // ---- a halo plane (10 x 10 voxels x 32 channels) as 16-byte chunks: chunk j of a thread is c = tid + 256 j <
+    // 400, row c >> 2 = (hh, hw), channel segment c & 3.  Per-lane constants, computed once: the byte offset relative
+    // to the plane's voxel (h0, w0), a one-hot (hh, hw) selector tested against the column's in-volume mask, and the
+    // swizzled byte offset inside a ring slot (chunks past 400 park in an unused pitch column).
+    int ldsp[2];
+    float sh[4];                                                     // a lane's four channels: 4 lc + j
 #pragma unroll
-        for (int i = 0; i < HREGS; ++i) {
-            const bool real = i < HREGS - 1 || q0 + 64 * i < HROWS;
-            goff[i] = ((((hd - 1) * a.H + (hh - 1)) * a.W + (hw - 1)) * CIN + sg * 8) * 2;       // bytes
-            // rows past the halo (the last chunk of threads 96-255) park in an unused pitch column of row 0
-            ldso[i] = H_OFF + (real ? ((hd * HB + hh) * WP + hw) * ROWB + ((sg ^ (2 * (hh & 1))) << 4) : (HB + (q0 & 1)) * ROWB + (sg << 4));
-            sel[i] = real ? (1u << hd) | (1u << (6 + hh)) | (1u << (16 + hw)) : 0x80000000u;
-            hw += 4; hh += 6;
-            if (hw >= HB) { hw -= HB; hh += 1; }
-            if (hh >= HB) { hh -= HB; hd += 1; }
+    for (int j = 0; j < 4; ++j) sh[j] = a.shift ? a.shift[4 * lc + j] : 0.f;
+    {
+        int goffp[2];
+        unsigned selp[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = tid + 256 * j;
+            const bool real = c < PCHUNKS;
+            const int r = real ? c >> 2 : 0, sg = c & 3;
+            const int hh = (r * 205) >> 11, hw = r - hh * HB;       // r < 100: exact division by 10
+            goffp[j] = (((hh - 1) * a.W + (hw - 1)) * CIN + sg * 8) * 2;
+            selp[j] = real ? (1u << hh) | (1u << (10 + hw)) : 0x80000000u;
+            ldsp[j] = real ? (hh * WP + hw) * ROWB + ((sg ^ (2 * (hh & 1))) << 4) : (HB + (tid & 1)) * ROWB + (sg << 4);
         }
-        asm volatile(WRES_INIT : : [g0] "v"(goff[0]), [g1] "v"(goff[1]), [g2] "v"(goff[2]), [g3] "v"(goff[3]), [g4] "v"(goff[4]),
-                     [g5] "v"(goff[5]), [g6] "v"(goff[6]), [g7] "v"(goff[7]), [g8] "v"(goff[8]), [g9] "v"(goff[9]),
-                     [s0] "v"(sel[0]), [s1] "v"(sel[1]), [s2] "v"(sel[2]), [s3] "v"(sel[3]), [s4] "v"(sel[4]), [s5] "v"(sel[5]),
-                     [s6] "v"(sel[6]), [s7] "v"(sel[7]), [s8] "v"(sel[8]), [s9] "v"(sel[9]) : WRES_CLOBBERS);
+        asm volatile(WRES_INIT : : [g0] "v"(goffp[0]), [g1] "v"(goffp[1]), [s0] "v"(selp[0]), [s1] "v"(selp[1]),
+                     [sh0] "v"(sh[0]), [sh1] "v"(sh[1]), [sh2] "v"(sh[2]), [sh3] "v"(sh[3]) : WRES_CLOBBERS);
     }
     WR_TL(2)
     dma_batch(1);
@@ -169,78 +169,59 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     // (the whole input is < 4 GiB: checked on the host)
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(a.x), 0, (unsigned)((size_t)a.B * a.D * a.H * a.W * CIN * 2), 0x00020000);
-    struct Pf { unsigned toff, mask; };
-    auto pf_args = [&](const Tile& c, bool valid) __attribute__((always_inline)) {      // uniform
+    const unsigned planeb = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN * 2));   // one depth step of the input, bytes
+    // planes p0 .. p0 + n - 1 of column c (plane p holds input depth p - 1): byte offset of plane p0's voxel (h0, w0),
+    // which planes lie inside the volume, and which (hh, hw) of the column do
+    struct Pf { unsigned off0, pvalid, mhw; };
+    auto pf_args = [&](const Tile& c, int p0, int n, bool any) __attribute__((always_inline)) {      // uniform
         Pf p;
-        p.toff = (unsigned)((((c.b * a.D + c.d0) * a.H + c.h0) * a.W + c.w0) * CIN * 2);
-        // halo index k is inside the volume iff 0 <= c0 + k - 1 < extent; no next tile: nothing is in-volume
-        p.mask = valid ? range_mask(1 - c.d0, a.D - c.d0 + 1, TD + 2) | (range_mask(1 - c.h0, a.H - c.h0 + 1, HB) << 6) |
-                             (range_mask(1 - c.w0, a.W - c.w0 + 1, HB) << 16) : 0u;
-        p.toff = __builtin_amdgcn_readfirstlane(p.toff);
-        p.mask = __builtin_amdgcn_readfirstlane(p.mask);
+        p.off0 = (unsigned)((((c.b * a.D + (p0 - 1)) * a.H + c.h0) * a.W + c.w0) * CIN * 2);
+        p.pvalid = any ? range_mask(1 - p0, a.D + 1 - p0, n) : 0u;
+        p.mhw = range_mask(1 - c.h0, a.H - c.h0 + 1, HB) | (range_mask(1 - c.w0, a.W - c.w0 + 1, HB) << 10);
+        p.off0 = __builtin_amdgcn_readfirstlane(p.off0);
+        p.pvalid = __builtin_amdgcn_readfirstlane(p.pvalid);
+        p.mhw = __builtin_amdgcn_readfirstlane(p.mhw);
         return p;
     };
-
-    Tile curT = coords(has_work ? tile : 0);                         // the tile whose halo is in flight / in the halo registers
-    {   // first halo: everything else of the set-up overlaps its latency and the weight DMA
-        const Pf pf = pf_args(curT, has_work);
-        asm volatile(WRES_PREFETCH : : [vmask] "s"(pf.mask), [toff] "s"(pf.toff), [rsrc] "s"(xrsrc) : "memory", WRES_CLOBBERS);
+    Tile curT = coords(has_work ? lo : 0);
+    {   // the first tile's six planes: everything else of the set-up overlaps their latency and the weight DMA
+        const Pf pf = pf_args(curT, 4 * curT.d, 6, has_work);
+        asm volatile(WRES_PREFETCH : : [off0] "s"(pf.off0), [planeb] "s"(planeb), [pvalid] "s"(pf.pvalid), [mhw] "s"(pf.mhw),
+                     [rsrc] "s"(xrsrc) : "memory", WRES_CLOBBERS);
     }
     WR_TL(0)
     dma_batch(2);
 
     // ---- per-lane fragment bases (absolute LDS byte addresses).  Lane (lc, lg) of MFMA tile i reads the halo row
-    // of voxel (d, h, w) = (wave, 4 (i >> 1) + (lc >> 2), 4 (i & 1) + (lc & 3)) shifted by the tap, channel segment lg;
-    // of column tile j the weight row rho = 16 j + lc.
+    // of voxel (h, w) = (4 (i >> 1) + (lc >> 2), 4 (i & 1) + (lc & 3)) shifted by (kh, kw), channel segment lg, in the
+    // ring slot of plane d0 + kd + wave; of column tile j the weight row rho = 16 j + lc.
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const int arow = ((wave * HB + (lc >> 2)) * WP + (lc & 3)) * ROWB + H_OFF + lds0;
-    const int ab0 = arow + ((lg ^ (2 * (((lc >> 2) + 0) & 1))) << 4);        // taps with kh even
-    const int ab1 = arow + ((lg ^ (2 * (((lc >> 2) + 1) & 1))) << 4);        // kh odd
+    const int hbase = lds0 + H_OFF;
+    const int arow = hbase + ((lc >> 2) * WP + (lc & 3)) * ROWB;
+    const int lane_a0 = arow + ((lg ^ (2 * (((lc >> 2) + 0) & 1))) << 4);    // taps with kh even
+    const int lane_a1 = arow + ((lg ^ (2 * (((lc >> 2) + 1) & 1))) << 4);    // kh odd
     const int bb0 = lds0 + lc * ROWB + ((lg ^ (2 * ((lc >> 2) & 1))) << 4);
     const int bb1 = bb0 + 13 * BN * ROWB;                                     // taps 13..26: ds offsets are 16-bit
-    // a lane's four channels: 4 lc + j
-    float sh[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sh[j] = a.shift ? a.shift[4 * lc + j] : 0.f;
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};       // BatchNorm sums of those channels
     const unsigned pitch_b = (unsigned)a.W * BN * 2;                 // one h step of the output, in bytes
     const unsigned pitch4 = __builtin_amdgcn_readfirstlane(4 * pitch_b);
     // accumulator register r of lane (lc, lg) in MFMA tile (i, j) is voxel (h, w) = (4 (i >> 1) + lg, 4 (i & 1) + r)
     const unsigned voff0 = lg * pitch_b + lc * 8;
+    float rs1[4] = {0.f, 0.f, 0.f, 0.f}, rs2[4] = {0.f, 0.f, 0.f, 0.f};     // BatchNorm sums of ragged tiles (ordinary code)
+    auto slot_of = [&](int p) __attribute__((always_inline)) { return (p % 6) * SLOTB; };       // p >= 0, uniform
 
-    auto tile_base = [&](const Tile& c) __attribute__((always_inline)) {                           // wave-uniform: (b, d0 + wave, h0, w0, 0)
-        bf16* p = a.out_bf16 + ((((size_t)c.b * a.D + c.d0 + wave) * a.H + c.h0) * a.W + c.w0) * BN;
+    auto tile_base = [&](const Tile& c) __attribute__((always_inline)) {                           // wave-uniform: (b, 4 d + wave, h0, w0, 0)
+        bf16* p = a.out_bf16 + ((((size_t)c.b * a.D + 4 * c.d + wave) * a.H + c.h0) * a.W + c.w0) * BN;
         // provably uniform for the "s" operand of the hand-written stores (cdna_hip_programming.md T20)
         const unsigned long long u = reinterpret_cast<unsigned long long>(p);
         const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)u), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
         return reinterpret_cast<bf16*>(((unsigned long long)hi_ << 32) | lo_);
     };
-#define WR_BASES [ab0] "v"(ab0), [ab1] "v"(ab1), [bb0] "v"(bb0), [bb1] "v"(bb1)
-#define WR_K_IN WR_BASES, [vmask] "s"(pf.mask), [toff] "s"(pf.toff), [rsrc] "s"(xrsrc)
-#define WR_EPI_OUT [s10] "=&v"(p1[0]), [s11] "=&v"(p1[1]), [s12] "=&v"(p1[2]), [s13] "=&v"(p1[3]), [s20] "=&v"(p2[0]),      \
-                   [s21] "=&v"(p2[1]), [s22] "=&v"(p2[2]), [s23] "=&v"(p2[3])
-#define WR_EPI_IN [sh0] "v"(sh[0]), [sh1] "v"(sh[1]), [sh2] "v"(sh[2]), [sh3] "v"(sh[3]), [pbase] "s"(pbase), [pitch4] "s"(pitch4), \
-                  [voff0] "v"(voff0)
-    // K loop of one tile into set CUR (0 = X, 1 = Y) with the halo prefetch described by pf in its last taps
-    auto k_plain = [&](int cur, const Pf& pf) __attribute__((always_inline)) {
-        if (cur == 0) asm volatile(WRES_K_X : : WR_K_IN : "memory", WRES_CLOBBERS);
-        else asm volatile(WRES_K_Y : : WR_K_IN : "memory", WRES_CLOBBERS);
-    };
-    // ... and the pending interior tile in the other set packed, stored and summed in the first 16 taps
-    auto k_epi = [&](int cur, const Pf& pf, const bf16* pbase) __attribute__((always_inline)) {
-        float p1[4], p2[4];                                          // this tile's BatchNorm partial sums
-        if (cur == 0) asm volatile(WRES_K_X_EPI : WR_EPI_OUT : WR_K_IN, WR_EPI_IN : "memory", WRES_CLOBBERS);
-        else asm volatile(WRES_K_Y_EPI : WR_EPI_OUT : WR_K_IN, WR_EPI_IN : "memory", WRES_CLOBBERS);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[j] += p1[j]; s2[j] += p2[j]; }
-    };
-    auto flush = [&](int set, const bf16* pbase) __attribute__((always_inline)) {                  // the last tile's stores have nothing to hide behind
-        float p1[4], p2[4];
-        if (set == 0) asm volatile(WRES_FLUSH_X : WR_EPI_OUT : WR_EPI_IN : "memory", WRES_CLOBBERS, WRES_FLUSH_CLOBBERS);
-        else asm volatile(WRES_FLUSH_Y : WR_EPI_OUT : WR_EPI_IN : "memory", WRES_CLOBBERS, WRES_FLUSH_CLOBBERS);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[j] += p1[j]; s2[j] += p2[j]; }
-    };
+#define WR_AB [ab00] "v"(ab[0][0]), [ab01] "v"(ab[0][1]), [ab10] "v"(ab[1][0]), [ab11] "v"(ab[1][1]), [ab20] "v"(ab[2][0]), \
+              [ab21] "v"(ab[2][1]), [bb0] "v"(bb0), [bb1] "v"(bb1)
+#define WR_PF [off0] "s"(pf.off0), [planeb] "s"(planeb), [pvalid] "s"(pf.pvalid), [mhw] "s"(pf.mhw), [rsrc] "s"(xrsrc)
+#define WR_MARCH [abn] "v"(abn), [sb0] "s"(sb[0]), [sb1] "s"(sb[1]), [sb2] "s"(sb[2]), [sb3] "s"(sb[3]), [ldsp0] "v"(ldsp[0]),   \
+                 [ldsp1] "v"(ldsp[1])
+#define WR_EPI [pbase] "s"(pbase), [pitch4] "s"(pitch4), [voff0] "v"(voff0)
     // a ragged tile (volume edge) leaves the accumulator file through sixteen "=v" operands per MFMA-tile row and is
     // stored by ordinary code with per-voxel predicates, right after its K loop (exposed; edge tiles only)
 #define WR_X16(v) "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]), "=v"(v[8]), \
@@ -264,60 +245,130 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int hh = 4 * (i >> 1) + lg, ww = 4 * (i & 1) + r;
-                if ((c.d0 + wave < a.D) && (c.h0 + hh < a.H) && (c.w0 + ww < a.W)) {
+                if ((4 * c.d + wave < a.D) && (c.h0 + hh < a.H) && (c.w0 + ww < a.W)) {
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         o[j] = v[i][4 * j + r] + sh[j];
-                        s1[j] += o[j]; s2[j] += o[j] * o[j];
+                        rs1[j] += o[j]; rs2[j] += o[j] * o[j];
                     }
                     bf16x4 pk = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
                     *reinterpret_cast<bf16x4*>(pbase + ((size_t)hh * a.W + ww) * BN + 4 * lc) = pk;
                 }
             }
     };
-    auto is_full = [&](const Tile& c) __attribute__((always_inline)) { return c.d0 + TD <= a.D && c.h0 + 8 <= a.H && c.w0 + 8 <= a.W; };
-#define WR_LDSO [l0] "v"(ldso[0]), [l1] "v"(ldso[1]), [l2] "v"(ldso[2]), [l3] "v"(ldso[3]), [l4] "v"(ldso[4]), [l5] "v"(ldso[5]),   \
-                [l6] "v"(ldso[6]), [l7] "v"(ldso[7]), [l8] "v"(ldso[8]), [l9] "v"(ldso[9])
-    // prefetched halo -> LDS, between two barriers.  after_epi: the statement before was a K loop with an epilogue,
-    // whose 16 stores were issued after the halo loads and may stay in flight (counted vmcnt); otherwise wait for all
-    auto boundary = [&](bool after_epi) __attribute__((always_inline)) {
-        // (the statement ends with the fragment reads of the new tile's first tap: they fly during the scalar set-up)
-        if (after_epi) asm volatile(WRES_BOUNDARY_EPI : : WR_LDSO, WR_BASES : "memory", WRES_CLOBBERS);
-        else asm volatile(WRES_BOUNDARY_ALL : : WR_LDSO, WR_BASES : "memory", WRES_CLOBBERS);
-    };
+    auto is_full = [&](const Tile& c) __attribute__((always_inline)) { return 4 * c.d + TD <= a.D && c.h0 + 8 <= a.H && c.w0 + 8 <= a.W; };
 
-    Tile pt = curT;
     bool pending = false;                                           // an interior tile waits in the set not being computed
-    bool last_in_x = true, epi_before = false;
+    bool last_in_x = true;
+    const bf16* base_prev = a.out_bf16;                              // output base of the pending tile (wave-uniform)
     if (has_work) {
-        int cur = 0;
-        for (; tile < hi; tile += nper, cur ^= 1) {
-            boundary(epi_before);                                    // (the first one also waits for the weight DMA)
-            if (cur == 0 && !epi_before) { WR_TL(3) }
-            epi_before = pending;                                    // this tile's K loop carries an epilogue iff one is pending
-            const Tile me = curT;
-            curT = advance(curT);
-            const Pf pf = pf_args(curT, tile + nper < hi);
-            WR_T0
-            if (cur == 0) {
-                if (pending) k_epi(0, pf, tile_base(pt));
-                else k_plain(0, pf);
-            } else {
-                if (pending) k_epi(1, pf, tile_base(pt));
-                else k_plain(1, pf);
+        // the first tile's six planes -> ring slots, between two barriers (the vmcnt(0) in front also covers the weight DMA)
+        auto full_boundary = [&](const Tile& c, bool counted) __attribute__((always_inline)) {
+            int sb[6];
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) sb[pp] = __builtin_amdgcn_readfirstlane(hbase + slot_of(4 * c.d + pp));
+            const int abn = lane_a0 + slot_of(4 * c.d + wave);
+            // counted: the statement before was a K loop with an epilogue, whose 16 stores were issued after the plane
+            // loads and may stay in flight; otherwise wait for everything
+            if (counted)
+                asm volatile(WRES_BOUNDARY_EPI : : [sb0] "s"(sb[0]), [sb1] "s"(sb[1]), [sb2] "s"(sb[2]), [sb3] "s"(sb[3]), [sb4] "s"(sb[4]),
+                             [sb5] "s"(sb[5]), [ldsp0] "v"(ldsp[0]), [ldsp1] "v"(ldsp[1]), [abn] "v"(abn), [bb0] "v"(bb0) : "memory", WRES_CLOBBERS);
+            else
+                asm volatile(WRES_BOUNDARY_ALL : : [sb0] "s"(sb[0]), [sb1] "s"(sb[1]), [sb2] "s"(sb[2]), [sb3] "s"(sb[3]), [sb4] "s"(sb[4]),
+                             [sb5] "s"(sb[5]), [ldsp0] "v"(ldsp[0]), [ldsp1] "v"(ldsp[1]), [abn] "v"(abn), [bb0] "v"(bb0) : "memory", WRES_CLOBBERS);
+        };
+        full_boundary(curT, false);
+        WR_TL(3)
+        int cur = 0, tile = lo;
+        while (tile < hi) {
+            // ---- a column segment: tiles `tile` .. `tile + nseg - 1` walk down one (b, h, w) column.  What changes
+            // from tile to tile is kept as running scalars (no per-tile divisions, masks or multiplications):
+            //   so[k]  ring-slot byte address (LDS) of plane d0 + k, k = 0..5;  sw[k] = the same for plane d0 + k + wave
+            //   offn   byte offset (input) of plane d0 + 6's voxel (h0, w0);  base_me  output base of the tile
+            const Tile col = curT;
+            const int nseg = (td - col.d) < (hi - tile) ? (td - col.d) : (hi - tile);
+            int d0 = 4 * col.d;
+            int so[6], sw[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                so[k] = __builtin_amdgcn_readfirstlane(hbase + slot_of(d0 + k));
+                sw[k] = __builtin_amdgcn_readfirstlane(slot_of(d0 + k + wave));
             }
-            WR_T1
-            WR_TLK
-            pt = me;
-            pending = is_full(pt);
-            if (!pending) { store_ragged(cur, pt); epi_before = false; }   // compiler stores in between: wait for all
-            last_in_x = cur == 0;
+            unsigned offn = __builtin_amdgcn_readfirstlane((unsigned)((((col.b * a.D + d0 + 5) * a.H + col.h0) * a.W + col.w0) * CIN * 2));
+            const unsigned mhw = __builtin_amdgcn_readfirstlane(range_mask(1 - col.h0, a.H - col.h0 + 1, HB) |
+                                                                (range_mask(1 - col.w0, a.W - col.w0 + 1, HB) << 10));
+            const bool hw_full = col.h0 + 8 <= a.H && col.w0 + 8 <= a.W;
+            const bf16* base_me = tile_base(col);
+            const size_t out_step = (size_t)4 * a.H * a.W * BN;      // four output depths, in elements
+            for (int k = 0; k < nseg; ++k, ++tile, cur ^= 1) {
+                const bool last = k == nseg - 1;                     // last tile of the segment: column change or end of the run
+                int ab[3][2];
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) { ab[kd][0] = lane_a0 + sw[kd]; ab[kd][1] = lane_a1 + sw[kd]; }
+                const bf16* pbase = base_prev;
+                const bool me_full = hw_full && d0 + TD <= a.D;
+                WR_T0
+                if (!last) {
+                    // new planes d0 + 6 .. d0 + 9 take the slots of planes d0 .. d0 + 3 as those die
+                    int nv = a.D - (d0 + 5);                         // how many of the four new planes lie inside the volume
+                    nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+                    Pf pf;
+                    pf.off0 = offn; pf.pvalid = __builtin_amdgcn_readfirstlane((1u << nv) - 1u); pf.mhw = mhw;
+                    const int abn = lane_a0 + sw[4];                 // the next tile's kd = 0 plane of this wave: d0 + 4 + wave
+                    const int sb[4] = {__builtin_amdgcn_readfirstlane(so[0]), __builtin_amdgcn_readfirstlane(so[1]),
+                                       __builtin_amdgcn_readfirstlane(so[2]), __builtin_amdgcn_readfirstlane(so[3])};
+                    if (cur == 0) {
+                        if (pending) asm volatile(WRES_K_X_EPI_MARCH : : WR_AB, WR_PF, WR_MARCH, WR_EPI : "memory", WRES_CLOBBERS);
+                        else asm volatile(WRES_K_X_MARCH : : WR_AB, WR_PF, WR_MARCH : "memory", WRES_CLOBBERS);
+                    } else {
+                        if (pending) asm volatile(WRES_K_Y_EPI_MARCH : : WR_AB, WR_PF, WR_MARCH, WR_EPI : "memory", WRES_CLOBBERS);
+                        else asm volatile(WRES_K_Y_MARCH : : WR_AB, WR_PF, WR_MARCH : "memory", WRES_CLOBBERS);
+                    }
+                } else {
+                    // six planes of the next tile's column (end of the run: nothing valid to fetch)
+                    Tile nx = col; nx.d = col.d + k;
+                    nx = next_of(nx);
+                    const bool has_next = tile + 1 < hi;
+                    const Pf pf = pf_args(nx, 4 * nx.d, 6, has_next);
+                    const bool epi = pending;
+                    if (cur == 0) {
+                        if (pending) asm volatile(WRES_K_X_EPI_COL : : WR_AB, WR_PF, WR_EPI : "memory", WRES_CLOBBERS);
+                        else asm volatile(WRES_K_X_COL : : WR_AB, WR_PF : "memory", WRES_CLOBBERS);
+                    } else {
+                        if (pending) asm volatile(WRES_K_Y_EPI_COL : : WR_AB, WR_PF, WR_EPI : "memory", WRES_CLOBBERS);
+                        else asm volatile(WRES_K_Y_COL : : WR_AB, WR_PF : "memory", WRES_CLOBBERS);
+                    }
+                    curT = nx;
+                    if (!me_full) {                                  // ordinary stores before the boundary: it waits for all
+                        Tile me = col; me.d = col.d + k;
+                        store_ragged(cur, me);
+                    }
+                    if (has_next) full_boundary(nx, epi && me_full);
+                }
+                WR_T1
+                WR_TLK
+                if (!last && !me_full) {
+                    Tile me = col; me.d = col.d + k;
+                    store_ragged(cur, me);
+                }
+                pending = me_full;
+                last_in_x = cur == 0;
+                base_prev = base_me;
+                // ---- down the column: d0 += 4, the ring turns by four slots
+                d0 += 4;
+                offn += 4 * planeb;
+                base_me += out_step;
+                const int t0 = so[0], t1 = so[1], u0 = sw[0], u1 = sw[1];
+                so[0] = so[4]; so[1] = so[5]; so[4] = so[2]; so[5] = so[3]; so[2] = t0; so[3] = t1;
+                sw[0] = sw[4]; sw[1] = sw[5]; sw[4] = sw[2]; sw[5] = sw[3]; sw[2] = u0; sw[3] = u1;
+            }
         }
         WR_TL(6)
         if (pending) {
-            if (last_in_x) flush(0, tile_base(pt));
-            else flush(1, tile_base(pt));
+            const bf16* pbase = base_prev;
+            if (last_in_x) asm volatile(WRES_FLUSH_X : : WR_EPI : "memory", WRES_CLOBBERS);
+            else asm volatile(WRES_FLUSH_Y : : WR_EPI : "memory", WRES_CLOBBERS);
         }
         WR_TL(7)
     } else {
@@ -327,20 +378,26 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     if (a.stats && tid == 0) {          // [32][2][64] statistics, then per workgroup {K-loop cycles, kernel cycles, kernel 100 MHz ticks, tiles, 12 timeline stamps}
         float* o = a.stats + MM_REPL * 2 * BN + blockIdx.x * 16;
         o[0] = (float)kcyc; o[1] = (float)(__builtin_readcyclecounter() - t_begin);
-        o[2] = (float)(wall_clock64() - r_begin); o[3] = (float)((hi - lo - slot_ + nper - 1) / nper);
+        o[2] = (float)(wall_clock64() - r_begin); o[3] = (float)(hi - lo);
 #pragma unroll
         for (int i = 0; i < 12; ++i) o[4 + i] = tl[i];
+        o[12] = (float)(r_begin & 0xFFFFFF); o[13] = (float)(wall_clock64() & 0xFFFFFF);     // absolute 100 MHz ticks: start stagger and span over workgroups
     }
 #endif
     if (a.stats) {
         float* sstat = reinterpret_cast<float*>(smem + S_OFF);
+        float st[8];
+        asm volatile(WRES_STATS_OUT : "=v"(st[0]), "=v"(st[1]), "=v"(st[2]), "=v"(st[3]), "=v"(st[4]), "=v"(st[5]), "=v"(st[6]), "=v"(st[7])
+                     : : WRES_CLOBBERS);
+        float s1[4], s2[4];
         // the four lane groups hold the same four channels (rows differ)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            s1[j] = st[j] + rs1[j]; s2[j] = st[4 + j] + rs2[j];
             s1[j] += __shfl_xor(s1[j], 16); s1[j] += __shfl_xor(s1[j], 32);
             s2[j] += __shfl_xor(s2[j], 16); s2[j] += __shfl_xor(s2[j], 32);
         }
-        __syncthreads();                                 // the last tile's LDS reads are done (sstat is its own region anyway)
+        __syncthreads();                                 // (sstat is its own LDS region; the barrier orders it after the last tile anyway)
         if (lg == 0) {                                   // every wave parks its channel sums: no LDS atomics
             float* mine = sstat + wave * 2 * BN;
 #pragma unroll
@@ -354,11 +411,10 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
         if (tid < 2 * BN)
             atomicAdd(&rep[tid], (sstat[tid] + sstat[2 * BN + tid]) + (sstat[4 * BN + tid] + sstat[6 * BN + tid]));
     }
-#undef WR_LDSO
-#undef WR_BASES
-#undef WR_K_IN
-#undef WR_EPI_OUT
-#undef WR_EPI_IN
+#undef WR_AB
+#undef WR_PF
+#undef WR_MARCH
+#undef WR_EPI
 #undef WR_X16
 }
 

@@ -140,6 +140,10 @@ def stamp_case(B, D, H, W):
     print(f"stamps B={B} {D}x{H}x{W}: tiles/WG {tiles.mean():.1f}; kernel {tot.mean():.0f} cyc = {(ticks / 100).mean():.2f} us "
           f"({ghz:.2f} GHz); K loops {k.mean():.0f} cyc = {(k / tiles).mean():.0f} per tile (6912 = MFMA-bound); "
           f"outside K loops {(tot - k).mean():.0f} cyc = {((tot - k) / tiles).mean():.0f} per tile; per-WG kernel cyc min {tot.min():.0f} max {tot.max():.0f}")
+    b0, e0 = st[:, 12], st[:, 13]
+    if (e0.max() > b0.min()):
+        print(f"    absolute 100 MHz clock: first start -> last end {(e0.max() - b0.min()) / 100:.2f} us; start stagger {(b0.max() - b0.min()) / 100:.2f} us; "
+              f"end stagger {(e0.max() - e0.min()) / 100:.2f} us")
     names = ["halo 0 prefetch issued", "weight DMA issued", "halo constants parked", "first boundary done (halo 0 + W in LDS)",
              "K loop 1 issued", "K loop 2 issued", "last K loop issued", "flush issued"]
     for i, nm in enumerate(names):
