@@ -596,6 +596,7 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
     Conv3dArgs a{(const bf16*)x, (const bf16*)w, B, D, H, W, Cin, Cout, shift, 0, stats, out_f32, (bf16*)out_bf16, 0u, 0u, 0u};
     const long tiles2 = (long)B * ceil_div(D, 2) * ceil_div(H, 8) * ceil_div(W, 8);
     if (conv3d_wres_applies(a)) return launch3d_wres(a, st);          // Cin 32 -> Cout 64, bf16 out: conv3d_wres.hip
+    if (conv3d_stream_applies(a)) return launch3d_stream(a, st);      // 64 -> 128, 128 -> 64, 64 -> 32: conv3d_stream.hip
     if (Cout <= 32) return launch3d<2, 32, 4, 1>(a, st);
     if (Cout <= 64) {
         if (tiles2 >= 256 && D % 2 == 0) return launch3d<2, 64, 4, 1>(a, st);

@@ -17,3 +17,7 @@ struct Conv3dArgs {
 // conv3d_wres.hip
 bool conv3d_wres_applies(const Conv3dArgs& a);
 int launch3d_wres(const Conv3dArgs& a, hipStream_t st);
+
+// conv3d_stream.hip: weight-streaming kernel for (Cin, Cout) = (64, 128), (128, 64), (64, 32)
+bool conv3d_stream_applies(const Conv3dArgs& a);
+int launch3d_stream(const Conv3dArgs& a, hipStream_t st);

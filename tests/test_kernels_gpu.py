@@ -525,6 +525,35 @@ def test_conv3d_weight_resident_kernel_vs_torch(B, D, H, W):
     torch.testing.assert_close(out2.float().cpu(), want - bias, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(32, 64, 128, 8, 8, 8), (2, 128, 64, 8, 8, 8), (3, 64, 32, 5, 16, 16),
+                                              (2, 64, 128, 3, 12, 20), (1, 128, 64, 2, 20, 12), (2, 64, 32, 4, 10, 9)])
+def test_conv3d_weight_streaming_kernel_vs_torch(B, Cin, Cout, D, H, W):
+    """csrc/conv3d_stream.hip (layer 3 forward 64 -> 128, its data gradient 128 -> 64, layer 2's data gradient
+    64 -> 32: one 1 x 8 x 8 face per workgroup, weights streamed through an LDS ring by LDS-DMA, K-groups summed
+    through LDS) against F.conv3d on bf16-rounded operands: the C2 shapes, ragged faces (12, 20, 10, 9 wide),
+    grids that are / are not a multiple of 8 (XCD-aware tile order on / off), fp32 and bf16 outputs, BatchNorm sums."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(Cin + Cout + D + H)
+    x = _bf(torch.randn(B, Cin, D, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin))
+    bias = torch.randn(Cout, generator=g)
+    want = F.conv3d(x, w, bias, padding=1).permute(0, 2, 3, 4, 1)
+    wf, _ = _prep_w(hip, w.reshape(Cout, Cin, 27), Cin)
+    xg = _vol_cl(x)
+    out = torch.full((B, D, H, W, Cout), float("nan"), device="cuda")
+    outb = torch.full((B, D, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
+    hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, bias.cuda(), stats, out, outb)
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(outb.float().cpu(), want, rtol=1e-2, atol=1e-2)
+    st = stats.sum(0).cpu()
+    torch.testing.assert_close(st[0], want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
+    torch.testing.assert_close(st[1], (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
+    out2 = torch.full_like(outb, float("nan"))                         # the data-gradient form: no bias, no statistics, bf16 out
+    hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, None, None, None, out2)
+    torch.testing.assert_close(out2.float().cpu(), want - bias, rtol=1e-2, atol=1e-2)
+
+
 def test_pool3d_bn_act_train_fwd_bwd():
     hip = _hip()
     g = torch.Generator().manual_seed(9)

@@ -76,16 +76,16 @@ def conv1d_wgrad_case(B, T, Cin, Cout, k):
     print(f"wgrad1d B={B} T={T} Cin={Cin} Cout={Cout} k={k}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
 
 
-def conv3d_dims_case(B, D, H, W, Cin, Cout):
+def conv3d_dims_case(B, D, H, W, Cin, Cout, dgrad=False):
     """layer-2-shaped forward at arbitrary volume dims (BASELINE config #4: 64x64x48 input -> 32x32x24 here)"""
     x = torch.randn(B, D, H, W, Cin, device="cuda").to(BF)
     w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
     wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
     _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
-    wres = Cin == 32 and Cout == 64                      # the weight-resident kernel writes bf16 only
+    wres = (Cin == 32 and Cout == 64) or dgrad           # the weight-resident kernel writes bf16 only; so do data gradients
     of = torch.empty(B, D, H, W, Cout, device="cuda", dtype=BF if wres else torch.float32)
-    stats = torch.zeros(32, 2, Cout, device="cuda")
-    b = torch.randn(Cout, device="cuda")
+    stats = None if dgrad else torch.zeros(32, 2, Cout, device="cuda")
+    b = None if dgrad else torch.randn(Cout, device="cuda")
 
     def fn():
         _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, b, stats, None if wres else of, of if wres else None)
@@ -148,6 +148,27 @@ def stamp_case(B, D, H, W):
              "K loop 1 issued", "K loop 2 issued", "last K loop issued", "flush issued"]
     for i, nm in enumerate(names):
         c = st[:, 4 + i]
+        print(f"    {nm:40s} {c.mean():8.0f} cyc (min {c.min():.0f} max {c.max():.0f})")
+
+
+def stream_stamp_case(B, D, H, W, Cin, Cout):
+    """in-kernel cycle stamps of a STREAM_STAMPS build (tools/abl_stream.sh s0; MMEEG_HIP_LIB=.../sabl_0-DSTREAM_STAMPS.so)"""
+    x = torch.randn(B, D, H, W, Cin, device="cuda").to(BF)
+    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
+    wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
+    of = torch.empty(B, D, H, W, Cout, device="cuda", dtype=BF)
+    ntiles = B * D * ((H + 7) // 8) * ((W + 7) // 8)
+    stats = torch.zeros(32 * 2 * Cout + ntiles * 8, device="cuda")
+    for _ in range(20):
+        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, None, stats, None, of)
+    torch.cuda.synchronize()
+    st = stats[32 * 2 * Cout:].view(ntiles, 8).cpu().double()
+    names = ["halo loads + writes issued", "halo + first stages in LDS (barrier)", "K loop done", "K-groups summed", "outputs stored", "stores drained"]
+    print(f"stream stamps B={B} {D}x{H}x{W} {Cin}->{Cout}: {ntiles} workgroups; first start -> last end {(st[:, 7].max() - st[:, 6].min()) / 100:.2f} us; "
+          f"start stagger {(st[:, 6].max() - st[:, 6].min()) / 100:.2f} us; mean workgroup {((st[:, 7] - st[:, 6]) / 100).mean():.2f} us")
+    for i, nm in enumerate(names):
+        c = st[:, i]
         print(f"    {nm:40s} {c.mean():8.0f} cyc (min {c.min():.0f} max {c.max():.0f})")
 
 
@@ -293,7 +314,7 @@ def main():
     if "pmc3d" in flt:
         conv3d_case(32, 16, 32, 64, wgrad=False)
         return
-    if "stamp" in flt:
+    if flt == "stamp":
         stamp_case(32, 32, 32, 24)
         stamp_case(32, 16, 16, 16)
         return
@@ -313,6 +334,18 @@ def main():
             conv3d_dims_case(B, 32, 32, 24, 32, 64)
         conv3d_dims_case(32, 16, 16, 16, 32, 64)
         return
+    if flt == "sstamp":
+        stream_stamp_case(32, 8, 8, 8, 64, 128)
+        stream_stamp_case(32, 8, 8, 8, 128, 64)
+        stream_stamp_case(32, 16, 16, 16, 64, 32)
+    if "stream" in flt:
+        # conv3d_stream.hip: layer 3 forward, its data gradient, layer 2's data gradient (C2, then config #4 volumes)
+        conv3d_dims_case(32, 8, 8, 8, 64, 128)
+        conv3d_dims_case(32, 8, 8, 8, 128, 64, dgrad=True)
+        conv3d_dims_case(32, 16, 16, 16, 64, 32, dgrad=True)
+        conv3d_dims_case(32, 16, 16, 12, 64, 128)
+        conv3d_dims_case(32, 16, 16, 12, 128, 64, dgrad=True)
+        conv3d_dims_case(32, 32, 32, 24, 64, 32, dgrad=True)
     if "conv3" in flt or not flt:
         conv3d_case(32, 16, 32, 64)
         conv3d_case(32, 8, 64, 128)
