@@ -5,40 +5,36 @@
 //   Y[b, v, n] = bias[n] + sum_{tap, c} X[b, v + off(tap), c] * W[n, tap, c]
 //
 // Here the weights (27 * Cin * Cout * 2 B = 110-442 KB) do not fit beside the halo, or there are too few
-// output tiles to amortise loading them (8^3 volumes: one tile per CU).  So one workgroup owns ONE 1 x 8 x 8
-// face of output voxels (64 GEMM rows) x all Cout columns, stages the 3 x 10 x 10 x Cin halo once, and the
-// weights stream through a ring of NST stage buffers by LDS-DMA (global_load_lds_dwordx4: no registers, no
-// ds_write), NST - 2 stages ahead of the MFMAs.  A "unit" is one tap x 32 input channels (one MFMA K-step);
-// a stage is U units.
+// output tiles to amortise loading them (8^3 volumes: one tile per CU).  One workgroup owns ONE 1 x 8 x 8
+// face of output voxels (64 GEMM rows) x all Cout columns and stages the 3 x 10 x 10 x Cin halo in LDS once;
+// the weights never touch LDS: every wave loads its B operands (its column group, its K-group's 32-channel
+// slice of a tap = one "unit" = one MFMA K-step) straight from L2 into registers, DEPTH units ahead of the
+// MFMAs, in exactly the lane layout the MFMA wants (lane (c, g) <- 16 bytes of weight row n(c), channels
+// 8 g .. 8 g + 7); mm_prep_conv_weight writes the image of these shapes in that order (common.h:
+// conv_image_index), so a wave load is 1 KB contiguous - from the plain [n][tap][c] image the same load touched
+// 16 cache lines and ran at a quarter of the rate.  Per CU the kernel needs 64 B of weights per clock at full MFMA rate - the vector-memory
+// path's peak - so an LDS hop on top (LDS-DMA ring, first version: 384 LDS cycles per 256 MFMA cycles, measured
+// 504) is what it cannot afford; A fragments alone keep the LDS pipe half busy.
 //
-//  * wave tile = 64 rows x 64 columns (4 x 4 MFMA tiles: 8 fragment reads per 16 MFMAs - the LDS pipe is then
-//    exactly as busy as the MFMA pipes; a 64 x 32 wave tile measured LDS-bound) or 64 x 32 for Cout = 32.
-//    The four waves split the column groups first and the units of a stage (K) second (WK = 4 / WN K-groups:
-//    2 for 64 -> 128, 4 for the two data gradients); K-groups are summed through LDS (the dead ring) after the
-//    loop, each wave keeping 4 / WK row tiles for the epilogue.
-//  * LDS images are those of conv3d_wres.hip per 32-channel slice: unpadded 64-byte rows, 16-byte slots
+//  * wave tile = 64 rows x 64 columns (4 x 4 MFMA tiles: 4 A reads from LDS + 4 B loads from L2 per 16 MFMAs),
+//    64 x 32 for Cout = 32.  The four waves split the column groups first and K second (WK = 4 / WN K-groups:
+//    unit g of the 27 * Cin / 32 belongs to K-group g % WK); K-groups are summed through LDS (the dead halo)
+//    after the loop, each wave keeping 4 / WK row tiles for the epilogue.  No barrier inside the K loop.
+//  * the halo image is that of conv3d_wres.hip per 32-channel slice: unpadded 64-byte rows, 16-byte slots
 //    XOR-swizzled with 2 * (patch-row parity) - conflict-free ds_read_b128 for every tap shift - and
 //    MFMA row m of row tile i <-> voxel (h, w) = (4 (i >> 1) + (m >> 2), 4 (i & 1) + (m & 3)).
-//    Column c of column tile j of group wn is channel WTN wn + TJ c + j: a lane holds TJ adjacent channels.
-//  * no barrier in the K loop: a wave's DMA share of a stage is exactly the slice it reads itself (its K-group's
-//    unit, its column group's rows), so the ring is private to the wave - counted vmcnt before the fragment
-//    reads of the next stage, and a buffer is refilled right after its fragments have arrived in registers.
-//    The waves drift apart and fill each other's LDS / MFMA gaps (with a barrier per stage all four issued their
-//    reads at the same moment: 450 cycles per stage against 256 of MFMA work).  The fragment reads are inline
-//    asm with explicit lgkmcnt waits: the compiler would otherwise order every LDS read behind ALL outstanding
-//    LDS-DMA (it cannot tell the ring buffers apart) and serialise the pipeline.
+//    Column c of column tile j of group wn is channel WTN wn + TJ c + j: a lane holds TJ adjacent channels
+//    (one 16-byte fp32 / 8-byte bf16 store per voxel).
+//  * the A-fragment reads are inline asm with explicit lgkmcnt waits so that they stay where the software
+//    pipeline puts them (one unit ahead); the B loads are ordinary loads, the compiler counts vmcnt.
 #include "conv3d_args.h"
 
-#include <mutex>
-
-#ifndef STREAM_ABL      // diagnostic builds (tools/abl_stream.sh): 1 no DMA in the loop, 2 no MFMAs, 4 no fragment reads
+#ifndef STREAM_ABL      // diagnostic builds (tools/abl_stream.sh): 1 no B loads in the loop, 2 no MFMAs, 4 no fragment reads
 #define STREAM_ABL 0
 #endif
 
 namespace {
 
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SHB = 10;                 // halo edge of an 8-wide face
@@ -47,27 +43,21 @@ constexpr int SDP = SHB * SWP;          // rows per halo plane
 constexpr int SROWB = 64;               // bytes per LDS row (32 channels)
 constexpr int HKS = 3 * SDP * SROWB;    // bytes of one 32-channel halo image (23 040)
 
-template <int CIN, int COUT, int NST_>
+template <int CIN, int COUT, int DEPTH_>
 struct StreamCfg {
     static constexpr int KS = CIN / 32;                 // K-steps (units) per tap
     static constexpr int WTN = COUT >= 64 ? 64 : 32;    // wave tile columns
     static constexpr int TJ = WTN / 16;                 // MFMA column tiles per wave
     static constexpr int WN = COUT / WTN;               // column groups = waves along N
     static constexpr int WK = 4 / WN;                   // K-groups
-    static constexpr int U = KS > WK ? KS : WK;         // units per stage
-    static constexpr int UPG = U / WK;                  // units per K-group per stage
     static constexpr int NU = 27 * KS;                  // units in all
-    static constexpr int NS = (NU + U - 1) / U;         // stages
-    static constexpr int NST = NST_;                    // ring depth
-    static constexpr int UNITB = COUT * SROWB;          // bytes of a unit's weight image
-    static constexpr int STAGEB = U * UNITB;
-    static constexpr int DPW = STAGEB / 4096;           // DMA instructions (1 KB each) per wave per stage
+    static constexpr int NUW = (NU + WK - 1) / WK;      // units per wave
+    static constexpr int DEPTH = DEPTH_;                // B operands in flight, in units
     static constexpr int H_BYTES = KS * HKS;
-    static constexpr int R_OFF = H_BYTES;
-    static constexpr int S_OFF = R_OFF + NST * STAGEB;  // [4 waves][2][WTN] fp32 BatchNorm partials
+    static constexpr int PARK = WK > 1 ? 4 * 4 * TJ * 1024 : 0;     // [wave][i][j][lane] x 16 B, overlays the halo
+    static constexpr int S_OFF = H_BYTES > PARK ? H_BYTES : PARK;   // [4 waves][2][WTN] fp32 BatchNorm partials
     static constexpr int LDS = S_OFF + 4 * 2 * WTN * 4;
-    static_assert(WN >= 1 && WN <= 4 && WN * WK == 4 && U % WK == 0 && STAGEB % 4096 == 0, "shape");
-    static_assert(NST * STAGEB >= 4 * TJ * 4096 || WK == 1, "the ring doubles as the K-group reduction buffer");
+    static_assert(WN >= 1 && WN <= 4 && WN * WK == 4 && DEPTH <= NUW, "shape");
     static_assert(LDS <= 160 * 1024, "LDS");
 };
 
@@ -82,11 +72,10 @@ __device__ __forceinline__ u32x4 lds_read128(int addr) {
     return v;
 }
 
-template <int CIN, int COUT, int NST_>
+template <int CIN, int COUT, int DEPTH_>
 __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
-    using C = StreamCfg<CIN, COUT, NST_>;
-    constexpr int KS = C::KS, WN = C::WN, WK = C::WK, U = C::U, UPG = C::UPG, NU = C::NU, NS = C::NS, NST = C::NST;
-    constexpr int UNITB = C::UNITB, STAGEB = C::STAGEB, DPW = C::DPW, WTN = C::WTN, TJ = C::TJ;
+    using C = StreamCfg<CIN, COUT, DEPTH_>;
+    constexpr int KS = C::KS, WN = C::WN, WK = C::WK, NU = C::NU, NUW = C::NUW, DEPTH = C::DEPTH, WTN = C::WTN, TJ = C::TJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef STREAM_STAMPS
     const long long t_begin = __builtin_readcyclecounter(), r_begin = wall_clock64();
@@ -101,33 +90,24 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
     const int lc = lane & 15, lg = lane >> 4;
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- weight DMA: every wave fetches exactly the slice it reads itself - unit(s) kg UPG + e / TJ of a stage, rows
-    // rho = WTN wn + 16 (e % TJ) + (lane >> 2), slot lane & 3 - so the ring needs no barrier: a wave orders its own
-    // DMA (counted vmcnt) against its own fragment reads.  Row rho = WTN wn + 16 j + c holds channel WTN wn + TJ c + j;
-    // slot s holds channel segment s ^ 2 ((rho >> 2) & 1).  Both permutations sit in the source address.
-    static_assert(DPW == UPG * TJ, "a wave's DMA share is its own slice");
-    int wsrc[TJ];
+    // ---- B operands: unit u of this wave is global unit g = u WK + kg = (tap, ks); the image (common.h:
+    // conv_image_index) holds, per unit and column group, TJ x 1 KB in lane order: column tile j of lane (lc, lg) is
+    // weight row n0 + j, channels 32 ks + 8 lg .. + 7 of the tap
+    const int n0 = WTN * wn + TJ * lc;
+    const bf16* wlane = a.w + (wn * TJ * 64 + lane) * 8;
+    auto load_b = [&](int u, u32x4 (&dst)[TJ]) __attribute__((always_inline)) {
+        int g = u * WK + kg;
+        g = g < NU ? g : NU - 1;                               // a K-group without a last unit re-reads a valid one (unused)
+        const bf16* p = wlane + g * (COUT * 32);
 #pragma unroll
-    for (int e = 0; e < TJ; ++e) {
-        const int rho = wn * WTN + e * 16 + (lane >> 2), slot = lane & 3;
-        const int n = (rho / WTN) * WTN + TJ * (rho & 15) + ((rho % WTN) >> 4);
-        wsrc[e] = n * 27 * CIN + ((slot ^ (2 * ((rho >> 2) & 1))) << 3);
-    }
-    auto dma_stage = [&](int s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < UPG; ++u) {
-            int g = s * U + kg * UPG + u;
-            g = g < NU ? g : NU - 1;                          // a short last stage still issues DPW loads (counted vmcnt)
-            const int tap = g / KS, ks = g % KS;
-            char* dst = smem + C::R_OFF + (s % NST) * STAGEB + (kg * UPG + u) * UNITB + wn * WTN * SROWB;
-#pragma unroll
-            for (int e = 0; e < TJ; ++e)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(a.w + wsrc[e] + tap * CIN + ks * 32), (lptr_t*)(dst + e * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < TJ; ++j) dst[j] = *reinterpret_cast<const u32x4*>(p + j * 512);
     };
+    u32x4 bq[DEPTH][TJ];
 #pragma unroll
-    for (int s = 0; s < NST; ++s)
-        if (s < NS) dma_stage(s);
+    for (int u = 0; u < DEPTH; ++u) load_b(u, bq[u]);
+    float sh[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) sh[j] = a.shift ? a.shift[n0 + j] : 0.f;
 
     // ---- tile: XCD x (= blockIdx % 8 under round-robin dispatch) takes the x-th eighth of the (b, d, h, w)-ordered list
     const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8;
@@ -155,7 +135,7 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
                 const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
                 v[q] = u32x4{0u, 0u, 0u, 0u};
                 if (c0 + q < PER && c < NCH && d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                    v[q] = *reinterpret_cast<const u32x4*>(xb + (((size_t)d * a.H + h) * a.W + w) * CIN + seg * 8);
+                    v[q] = *reinterpret_cast<const u32x4*>(xb + ((d * a.H + h) * a.W + w) * CIN + seg * 8);
             }
 #pragma unroll
             for (int q = 0; q < BATCH; ++q) {
@@ -169,11 +149,10 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
         }
     }
 
-    // ---- per-lane fragment bases (absolute LDS byte addresses)
+    // ---- per-lane A-fragment bases (absolute LDS byte addresses)
     const int arow = ((lc >> 2) * SWP + (lc & 3)) * SROWB;
     const int lane_a0 = lds0 + arow + ((lg ^ (2 * (((lc >> 2) + 0) & 1))) << 4);     // taps with kh even
     const int lane_a1 = lds0 + arow + ((lg ^ (2 * (((lc >> 2) + 1) & 1))) << 4);     // kh odd
-    const int lane_b = lds0 + C::R_OFF + (wn * WTN + lc) * SROWB + ((lg ^ (2 * ((lc >> 2) & 1))) << 4);
 
     f32x4 acc[4][TJ];
 #pragma unroll
@@ -181,75 +160,47 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // unit (s, e) of this wave's K-group: g = s U + kg UPG + e -> (tap, ks).  Compile-time when WK == 1.
-    auto a_addr = [&](int s, int e, int i) __attribute__((always_inline)) {
-        const int g = s * U + kg * UPG + e;
+    // unit u of this wave -> (tap, ks); the tap is a compile-time constant whenever WK divides KS
+    auto a_addr = [&](int u, int i) __attribute__((always_inline)) {
+        const int g = u * WK + kg;
         const int tap = g / KS, ks = g % KS;
         const int kh = (tap / 3) % 3;
         return ((kh & 1) ? lane_a1 : lane_a0) + ks * HKS + tap_off(tap) + ((4 * (i >> 1)) * SWP + 4 * (i & 1)) * SROWB;
     };
-    auto b_addr = [&](int s, int e, int j) __attribute__((always_inline)) {
-        return lane_b + (s % NST) * STAGEB + (kg * UPG + e) * UNITB + j * 16 * SROWB;
-    };
-    auto unit_valid = [&](int s, int e) __attribute__((always_inline)) { return s * U + kg * UPG + e < NU; };
 
     ST_TL(0)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                              // the halo (all waves' writes) and this wave's stages 0 .. NST - 1 are in LDS
-
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // the halo (all waves' writes) is in LDS
     ST_TL(1)
-    u32x4 fa[4], fb[TJ];                                        // fragments of the unit about to run
+
+    u32x4 fa[4];                                               // A fragments of the unit about to run
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = lds_read128(a_addr(0, 0, i));
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) fb[j] = lds_read128(b_addr(0, 0, j));
+    for (int i = 0; i < 4; ++i) fa[i] = lds_read128(a_addr(0, i));
 
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int u = 0; u < NUW; ++u) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]));   // requested one unit ago
+        const bool valid = (u * WK + WK <= NU) ? true : (u * WK + kg < NU);
+        u32x4 ca[4], cb[TJ];
 #pragma unroll
-        for (int e = 0; e < UPG; ++e) {
-            // the fragments of (s, e) were requested one unit ago
-            if constexpr (TJ == 4)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]));
-            const bool valid = (s * U + U <= NU) ? true : unit_valid(s, e);
-            u32x4 ca[4], cb[TJ];
+        for (int i = 0; i < 4; ++i) ca[i] = fa[i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ca[i] = fa[i];
+        for (int j = 0; j < TJ; ++j) cb[j] = bq[u % DEPTH][j];
+        if (u + 1 < NUW && !(STREAM_ABL & 4)) {
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) cb[j] = fb[j];
-            if (e == 0 && s > 0 && s + NST - 1 < NS && !(STREAM_ABL & 1)) dma_stage(s + NST - 1);   // into stage s - 1's buffer: its reads are done
-            const int s2 = e + 1 < UPG ? s : s + 1, e2 = e + 1 < UPG ? e + 1 : 0;
-            if (s2 < NS && !(STREAM_ABL & 4)) {
-                if (e2 == 0) {
-                    // this wave's stage s + 1 has landed; stages s + 2 .. s + NST - 1 may still be in flight
-                    const int later = (NS - 2 - s) < (NST - 2) ? (NS - 2 - s) : (NST - 2);
-                    if (later * DPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else if (later * DPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else if (later * DPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else if (later * DPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else if (later * DPW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (later * DPW == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                // request the next unit's fragments: they overlap this unit's MFMAs
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = lds_read128(a_addr(s2, e2, i));
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) fb[j] = lds_read128(b_addr(s2, e2, j));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (valid && !(STREAM_ABL & 2)) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ca[i]), __builtin_bit_cast(bf16x8, cb[j]),
-                                                                             acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 4; ++i) fa[i] = lds_read128(a_addr(u + 1, i));
         }
+        if (u + DEPTH < NUW && !(STREAM_ABL & 1)) load_b(u + DEPTH, bq[u % DEPTH]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (valid && !(STREAM_ABL & 2)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ca[i]), __builtin_bit_cast(bf16x8, cb[j]),
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     ST_TL(2)
@@ -262,9 +213,8 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j) res[i][j] = acc[i][j];
     } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // every wave is done with the ring
-        f32x4* park = reinterpret_cast<f32x4*>(smem + C::R_OFF);    // [wave][i][j][lane]
+        __syncthreads();                                       // every wave is done with the halo
+        f32x4* park = reinterpret_cast<f32x4*>(smem);          // [wave][i][j][lane]
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -283,33 +233,34 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
 
     ST_TL(3)
     // ---- epilogue: register r of lane (lc, lg) in row tile i is voxel (h, w) = (4 (i >> 1) + lg, 4 (i & 1) + r), channels
-    // n0 = WTN wn + TJ lc .. n0 + TJ - 1
-    const int n0 = WTN * wn + TJ * lc;
-    float sh[TJ], s1[TJ], s2[TJ];
+    // n0 .. n0 + TJ - 1
+    float s1[TJ], s2[TJ];
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) { sh[j] = a.shift ? a.shift[n0 + j] : 0.f; s1[j] = 0.f; s2[j] = 0.f; }
-    const size_t plane = ((size_t)b * a.D + d0) * a.H;
+    for (int j = 0; j < TJ; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const size_t obase = ((((size_t)b * a.D + d0) * a.H + h0) * a.W + w0) * COUT + n0;
+    float* of = a.out_f32 ? a.out_f32 + obase : nullptr;
+    bf16* ob = a.out_bf16 ? a.out_bf16 + obase : nullptr;
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
         const int i = kg * OWN + o;
-        const int h = h0 + 4 * (i >> 1) + lg;
+        const int hh = 4 * (i >> 1) + lg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int w = w0 + 4 * (i & 1) + r;
-            if (h < a.H && w < a.W) {
+            const int ww = 4 * (i & 1) + r;
+            if (h0 + hh < a.H && w0 + ww < a.W) {
                 float v[TJ];
 #pragma unroll
                 for (int j = 0; j < TJ; ++j) {
                     v[j] = res[o][j][r] + sh[j];
                     s1[j] += v[j]; s2[j] += v[j] * v[j];
                 }
-                const size_t off = ((plane + h) * a.W + w) * COUT + n0;
+                const int off = (hh * a.W + ww) * COUT;
                 if constexpr (TJ == 4) {
-                    if (a.out_f32) *reinterpret_cast<f32x4*>(a.out_f32 + off) = f32x4{v[0], v[1], v[2], v[3]};
-                    if (a.out_bf16) *reinterpret_cast<bf16x4*>(a.out_bf16 + off) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    if (of) *reinterpret_cast<f32x4*>(of + off) = f32x4{v[0], v[1], v[2], v[3]};
+                    if (ob) *reinterpret_cast<bf16x4*>(ob + off) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 } else {
-                    if (a.out_f32) *reinterpret_cast<float2*>(a.out_f32 + off) = float2{v[0], v[1]};
-                    if (a.out_bf16) *reinterpret_cast<bf16x2*>(a.out_bf16 + off) = bf16x2{(bf16)v[0], (bf16)v[1]};
+                    if (of) *reinterpret_cast<float2*>(of + off) = float2{v[0], v[1]};
+                    if (ob) *reinterpret_cast<bf16x2*>(ob + off) = bf16x2{(bf16)v[0], (bf16)v[1]};
                 }
             }
         }
@@ -350,14 +301,15 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
     }
 }
 
-template <int CIN, int COUT, int NST_>
+template <int CIN, int COUT, int DEPTH_>
 int launch_stream(const Conv3dArgs& a, hipStream_t st) {
-    using C = StreamCfg<CIN, COUT, NST_>;
-    auto kern = conv3d_stream_kernel<CIN, COUT, NST_>;
-    static std::once_flag once;
-    std::call_once(once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    });
+    using C = StreamCfg<CIN, COUT, DEPTH_>;
+    auto kern = conv3d_stream_kernel<CIN, COUT, DEPTH_>;
+    if (C::LDS > 64 * 1024) {
+        static const hipError_t attr =                              // the only process-wide state: an immutable kernel attribute
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+        (void)attr;
+    }
     const int ntiles = a.B * a.D * ceil_div(a.H, 8) * ceil_div(a.W, 8);
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), C::LDS, st, a);
     return mm_check_launch("conv3d_stream");
@@ -366,12 +318,14 @@ int launch_stream(const Conv3dArgs& a, hipStream_t st) {
 }  // namespace
 
 bool conv3d_stream_applies(const Conv3dArgs& a) {
-    return (a.Cin == 64 && a.Cout == 128) || (a.Cin == 128 && a.Cout == 64) || (a.Cin == 64 && a.Cout == 32);
+    // offsets inside a sample are 32-bit
+    return ((a.Cin == 64 && a.Cout == 128) || (a.Cin == 128 && a.Cout == 64) || (a.Cin == 64 && a.Cout == 32)) &&
+           (size_t)a.D * a.H * a.W * a.Cin < (1u << 31) && (size_t)a.D * a.H * a.W * a.Cout < (1u << 31);
 }
 
 int launch3d_stream(const Conv3dArgs& a, hipStream_t st) {
-    if (a.Cin == 64 && a.Cout == 128) return launch_stream<64, 128, 5>(a, st);
+    if (a.Cin == 64 && a.Cout == 128) return launch_stream<64, 128, 4>(a, st);
     if (a.Cin == 128 && a.Cout == 64) return launch_stream<128, 64, 4>(a, st);
-    if (a.Cin == 64 && a.Cout == 32) return launch_stream<64, 32, 4>(a, st);
+    if (a.Cin == 64 && a.Cout == 32) return launch_stream<64, 32, 7>(a, st);
     return mm_fail(MM_ERR_UNSUPPORTED, "conv3d_stream: Cin %d Cout %d", a.Cin, a.Cout);
 }

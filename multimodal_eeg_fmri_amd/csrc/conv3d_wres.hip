@@ -257,7 +257,6 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
                 }
             }
     };
-    auto is_full = [&](const Tile& c) __attribute__((always_inline)) { return 4 * c.d + TD <= a.D && c.h0 + 8 <= a.H && c.w0 + 8 <= a.W; };
 
     bool pending = false;                                           // an interior tile waits in the set not being computed
     bool last_in_x = true;

@@ -756,7 +756,7 @@ __global__ void softmax2_concat_bwd_kernel(const float* __restrict__ dout, const
 __global__ void weighted_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
                                    const float* __restrict__ cw, float* __restrict__ out, float* __restrict__ dlogits,
                                    int B, int C) {
-    __shared__ float wsum_s, loss_s;
+    __shared__ float wsum_s;
     if (threadIdx.x == 0) {
         float ws = 0.f, ls = 0.f;
         for (int b = 0; b < B; ++b) {
@@ -769,7 +769,7 @@ __global__ void weighted_ce_kernel(const float* __restrict__ logits, const long 
             const float w = cw ? cw[t] : 1.f;
             ws += w; ls += w * (m + __logf(se) - z[t]);
         }
-        wsum_s = ws; loss_s = ls;
+        wsum_s = ws;
         out[0] += ls / ws;
     }
     __syncthreads();

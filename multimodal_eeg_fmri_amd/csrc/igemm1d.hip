@@ -460,12 +460,12 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, bf16* __restrict
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_f + total_d; i += gridDim.x * blockDim.x) {
         if (i < total_f) {
             const int c = i % Cinp, tap = (i / Cinp) % k, n = i / (Cinp * k);
-            wf[i] = (bf16)(c < Cin ? w[((size_t)n * Cin + c) * k + tap] : 0.f);
+            wf[conv_image_index(Cout, k, Cinp, n, tap, c)] = (bf16)(c < Cin ? w[((size_t)n * Cin + c) * k + tap] : 0.f);
         } else {
             const int d = i - total_f;
             const int n = d % Coutp, tap = (d / Coutp) % k, c = d / (Coutp * k);
             const float v = (c < Cin && n < Cout) ? w[((size_t)n * Cin + c) * k + (k - 1 - tap)] : 0.f;
-            wd[d] = (bf16)v;
+            wd[conv_image_index(CinRows, k, Coutp, c, tap, n)] = (bf16)v;
         }
     }
 }
@@ -484,11 +484,12 @@ __global__ void prep_many_kernel(PrepTable tab) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_f + total_d; i += gridDim.x * blockDim.x) {
         if (i < total_f) {
             const int c = i % d.Cinp, tap = (i / d.Cinp) % d.k, n = i / (d.Cinp * d.k);
-            d.wf[i] = (bf16)(c < d.Cin ? d.w[((size_t)n * d.Cin + c) * d.k + tap] : 0.f);
+            d.wf[conv_image_index(d.Cout, d.k, d.Cinp, n, tap, c)] = (bf16)(c < d.Cin ? d.w[((size_t)n * d.Cin + c) * d.k + tap] : 0.f);
         } else {
             const int e = i - total_f;
             const int n = e % d.Coutp, tap = (e / d.Coutp) % d.k, c = e / (d.Coutp * d.k);
-            d.wd[e] = (bf16)((c < d.Cin && n < d.Cout) ? d.w[((size_t)n * d.Cin + c) * d.k + (d.k - 1 - tap)] : 0.f);
+            d.wd[conv_image_index(d.Cinp, d.k, d.Coutp, c, tap, n)] =
+                (bf16)((c < d.Cin && n < d.Cout) ? d.w[((size_t)n * d.Cin + c) * d.k + (d.k - 1 - tap)] : 0.f);
         }
     }
 }
