@@ -122,15 +122,14 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // ---- layout of a 3-D convolution weight image (k = 27).  Images are made by mm_prep_conv_weight / mm_prep_many and
 // consumed by mm_conv3d_fwd only, so the two agree on this function.  Plain: [row n][tap][channel c].  For the shapes
 // csrc/conv3d_stream.hip serves - (rows, channels) = (128, 64), (64, 128), (32, 64) - the image is stored in the lane
-// order of that kernel's B-operand loads: unit g = tap * (ch / 32) + c / 32, column group wn = n / WTN (WTN = 64, or 32
-// for 32 rows), MFMA column tile j = n % TJ, lane column lc = (n % WTN) / TJ (TJ = WTN / 16), lane group lg = (c % 32) / 8:
-//   position = ((((g * WN + wn) * TJ + j) * 64 + 16 lg + lc) * 8 + c % 8      (one wave load = 1 KB contiguous)
+// order of that kernel's B-operand loads: unit g = tap * (ch / 32) + c / 32, column group grp = n / 32, MFMA column
+// tile j = n % 2, lane column lc = (n % 32) / 2, lane group lg = (c % 32) / 8:
+//   position = ((((g * (rows / 32) + grp) * 2 + j) * 64 + 16 lg + lc) * 8 + c % 8      (one wave load = 1 KB contiguous)
 __host__ __device__ __forceinline__ bool conv3d_stream_shape(int rows, int ch) {
     return (rows == 128 && ch == 64) || (rows == 64 && ch == 128) || (rows == 32 && ch == 64);
 }
 __host__ __device__ __forceinline__ int conv_image_index(int rows, int k, int ch, int n, int tap, int c) {
     if (k != 27 || !conv3d_stream_shape(rows, ch)) return (n * k + tap) * ch + c;
-    const int WTN = rows >= 64 ? 64 : 32, TJ = WTN / 16, WN = rows / WTN;
-    const int g = tap * (ch / 32) + c / 32, wn = n / WTN, local = n % WTN;
-    return ((((g * WN + wn) * TJ + local % TJ) * 64 + 16 * ((c % 32) / 8) + local / TJ) * 8) + c % 8;
+    const int g = tap * (ch / 32) + c / 32, grp = n / 32, local = n % 32;
+    return ((((g * (rows / 32) + grp) * 2 + (local & 1)) * 64 + 16 * ((c % 32) / 8) + (local >> 1)) * 8) + c % 8;
 }
