@@ -231,139 +231,6 @@ int launch3d(Conv3dArgs a, hipStream_t st) {
 
 
 // ---------------------------------------------------------------------------
-// weight gradient (transposed LDS reads, see igemm1d.hip).  grid.z = kd plane:
-// each workgroup accumulates the 9 taps of one kd for a 64(n) x BC(c) block over
-// a run of output tiles, then adds them atomically into dW (element strides).
-// ---------------------------------------------------------------------------
-constexpr int W3_LD = 96;          // LDS row stride (elements) == 192 B (mod 256)
-
-__device__ __forceinline__ bf16x8 tr_frag_rows(const bf16* tile, int rowA, int rowB, int col0, int lane) {
-    // rowA/rowB: LDS rows of k = 8*(lane>>5) + (li>>2) and that + 4 (per lane)
-    const int li = lane & 15, g = lane >> 4;
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const bf16* pa = tile + rowA * W3_LD + col0 + (g & 1) * 16 + 4 * (li & 3);
-    const bf16* pb = tile + rowB * W3_LD + col0 + (g & 1) * 16 + 4 * (li & 3);
-    union { s16x4 s[2]; bf16x8 v; } u;
-    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pa);
-    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)pb);
-    return u.v;
-}
-
-struct Wgrad3dArgs {
-    const bf16* dy; const bf16* x; float* dw; float* dbias;
-    int B, D, H, W, Cin, Cout, Cin_real, tiles_per_wg, nrep;
-    long sn, sc, stap, rep_stride;
-    int slot_mode;            // 1: tile-chunk x stores its partial dW into slot blockIdx.x (no atomics)
-};
-
-__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
-    // tile = 1 x 8 x 8 output voxels (64 GEMM-k rows); halo = 3 x 10 x 10
-    __shared__ __attribute__((aligned(16))) bf16 Ys[64 * W3_LD];
-    __shared__ __attribute__((aligned(16))) bf16 Xs[HB * HB * W3_LD];           // the kd-th halo plane only
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wc = wave & 1;
-    const int kd = blockIdx.z % 3, cblk = blockIdx.z / 3;
-    const int n0 = blockIdx.y * 64, c0 = cblk * 64;
-    const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8;
-    const int tiles_total = a.B * a.D * th * tw;
-    const int tbeg = blockIdx.x * a.tiles_per_wg;
-    const int tend = min(tiles_total, tbeg + a.tiles_per_wg);
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bsum = 0.f;
-    const int li = lane & 15, g = lane >> 4;
-
-    // The next tile's dY rows and halo plane are fetched into registers while the current tile's
-    // MFMAs run (a tile is 0.5 us of MFMA work behind ~6 global-load round trips: staged with a
-    // load -> LDS-store loop the kernel spent 90 % of its time waiting on them).
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NY = 64 * 8 / 256, NX = (HB * HB * 8 + 255) / 256;            // 2, 4 chunks per thread
-    u32x4 ry[NY], rx[NX];
-    auto fetch = [&](int tile) {
-        int q = tile;
-        const int w0 = (q % tw) * 8; q /= tw;
-        const int h0 = (q % th) * 8; q /= th;
-        const int d = q % a.D; q /= a.D;
-        const int b = q;
-#pragma unroll
-        for (int i = 0; i < NY; ++i) {
-            const int s = tid + i * 256;
-            const int r = s >> 3, sg = s & 7;
-            const int h = h0 + (r >> 3), w = w0 + (r & 7), n = n0 + sg * 8;
-            ry[i] = u32x4{0u, 0u, 0u, 0u};
-            if (h < a.H && w < a.W && n < a.Cout)
-                ry[i] = *reinterpret_cast<const u32x4*>(a.dy + ((((size_t)b * a.D + d) * a.H + h) * a.W + w) * a.Cout + n);
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int s = tid + i * 256;
-            const int r = s >> 3, sg = s & 7;
-            const int hh = r / HB, hw = r % HB;
-            const int dd = d + kd - 1, h = h0 + hh - 1, w = w0 + hw - 1, c = c0 + sg * 8;
-            rx[i] = u32x4{0u, 0u, 0u, 0u};
-            if (s < HB * HB * 8 && dd >= 0 && dd < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W && c < a.Cin)
-                rx[i] = *reinterpret_cast<const u32x4*>(a.x + ((((size_t)b * a.D + dd) * a.H + h) * a.W + w) * a.Cin + c);
-        }
-    };
-    if (tbeg < tend) fetch(tbeg);
-    for (int tile = tbeg; tile < tend; ++tile) {
-        __syncthreads();                                   // previous tile's LDS reads are done
-#pragma unroll
-        for (int i = 0; i < NY; ++i) {
-            const int s = tid + i * 256;
-            *reinterpret_cast<u32x4*>(Ys + (s >> 3) * W3_LD + (s & 7) * 8) = ry[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int s = tid + i * 256;
-            if (s < HB * HB * 8) *reinterpret_cast<u32x4*>(Xs + (s >> 3) * W3_LD + (s & 7) * 8) = rx[i];
-        }
-        __syncthreads();
-        if (tile + 1 < tend) fetch(tile + 1);              // in flight during the MFMAs below
-#pragma unroll
-        for (int kk = 0; kk < 64; kk += 16) {
-            // k rows supplied by this lane: kA = kk + 8*(g>>1) + (li>>2), kB = kA + 4
-            const int kA = kk + 8 * (g >> 1) + (li >> 2), kB = kA + 4;
-            const bf16x8 af = tr_frag_rows(Ys, kA, kB, wn * 32, lane);
-            if (a.dbias && kd == 0 && cblk == 0 && wc == 0)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += (float)af[j];
-            const int hA = (kA >> 3) * HB + (kA & 7), hB = (kB >> 3) * HB + (kB & 7);
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) {
-                const int toff = (t9 / 3) * HB + (t9 % 3);
-                const bf16x8 bfr = tr_frag_rows(Xs, hA + toff, hB + toff, wc * 32, lane);
-                acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t9], 0, 0, 0);
-            }
-        }
-    }
-    const int c = c0 + wc * 32 + (lane & 31);
-    float* dwr = a.dw + (size_t)(a.slot_mode ? blockIdx.x : blockIdx.x % a.nrep) * a.rep_stride;
-    if (c < a.Cin_real) {
-#pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < a.Cout) {
-                    float* o = dwr + n * a.sn + c * a.sc + (kd * 9 + t9) * a.stap;
-                    if (a.slot_mode) *o = acc[t9][r];
-                    else atomicAdd(o, acc[t9][r]);
-                }
-            }
-    }
-    if (a.dbias && kd == 0 && cblk == 0 && wc == 0) {
-        bsum += __shfl_xor(bsum, 32, 64);
-        const int n = n0 + wn * 32 + (lane & 31);
-        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(blockIdx.x % MM_REPL) * a.Cout + n, bsum);
-    }
-}
-
-// ---------------------------------------------------------------------------
 // (B,1,D,H,W) fp32 -> (B,D,H,W,Cp) bf16 with channel 0 = value, rest zero
 // ---------------------------------------------------------------------------
 __global__ void pack_vol_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t nvox, int Cp) {
@@ -604,44 +471,6 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
     }
     if (tiles2 * ceil_div(Cout, 128) >= 256 && D % 2 == 0) return launch3d<2, 128, 2, 2>(a, st);
     return launch3d<1, 64, 2, 2>(a, st);
-}
-
-// tiles per workgroup.  Atomic mode: every workgroup ends with 64 x 64 x 9 fp32 atomics, so few, long
-// workgroups win once the tile loop is software-pipelined: >= 12 tiles each, at most ~384 workgroups
-// (sweep: L2 54.7 us at 384, L3 35.5 us at 128-160; 64 / 56 us before).  Slot mode keeps the same plan.
-static int wgrad3d_tiles_per_wg(int B, int D, int H, int W, int Cin, int Cout) {
-    const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
-    const int par = ceil_div(Cout, 64) * 3 * ceil_div(Cin, 64);
-    int chunks = ceil_div(384, par);
-    if (chunks > tiles_total / 12) chunks = tiles_total / 12;
-    if (chunks > tiles_total) chunks = tiles_total;
-    if (chunks < 1) chunks = 1;
-    return ceil_div(tiles_total, chunks);
-}
-
-int mm_conv3d_wgrad_slots(int B, int D, int H, int W, int Cin, int Cout, int* slots_host, hipStream_t) {
-    MM_REQUIRE(slots_host && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_wgrad_slots: bad args");
-    const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
-    *slots_host = ceil_div(tiles_total, wgrad3d_tiles_per_wg(B, D, H, W, Cin, Cout));
-    return 0;
-}
-
-int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int D, int H, int W, int Cin,
-                    int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep, int64_t rep_stride,
-                    int slot_mode, hipStream_t st) {
-    MM_REQUIRE(dy && x && dw && B > 0, "conv3d_wgrad: null/invalid");
-    MM_REQUIRE(nrep >= 1 && (slot_mode || nrep <= 64), "conv3d_wgrad: nrep");
-    MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cin_real <= Cin, "conv3d_wgrad: channels");
-    Wgrad3dArgs a;
-    a.dy = (const bf16*)dy; a.x = (const bf16*)x; a.dw = dw; a.dbias = dbias;
-    a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cin_real = Cin_real;
-    a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride; a.slot_mode = slot_mode;
-    const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
-    a.tiles_per_wg = wgrad3d_tiles_per_wg(B, D, H, W, Cin, Cout);
-    dim3 grid(ceil_div(tiles_total, a.tiles_per_wg), ceil_div(Cout, 64), 3 * ceil_div(Cin, 64));
-    MM_REQUIRE(!slot_mode || nrep >= (int)grid.x, "conv3d_wgrad: slot mode needs %d slots, got %d", (int)grid.x, nrep);
-    hipLaunchKernelGGL(conv3d_wgrad_kernel, grid, dim3(256), 0, st, a);
-    return mm_check_launch("conv3d_wgrad");
 }
 
 int mm_pool3d_bn_act_fwd(const void* y, const float* out4, void* out_bf16, void* ysel, void* arg, int B, int D,

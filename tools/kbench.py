@@ -95,7 +95,7 @@ def conv3d_dims_case(B, D, H, W, Cin, Cout, dgrad=False):
           f"({fl / us / 1e6 / 2500:.3f} of 2.5 PF; graph-replayed)")
 
 
-def conv3d_case(B, S, Cin, Cout, wgrad=True):
+def conv3d_case(B, S, Cin, Cout, wgrad=True, fwd=True):
     x = torch.randn(B, S, S, S, Cin, device="cuda").to(BF)
     w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
     wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
@@ -107,18 +107,28 @@ def conv3d_case(B, S, Cin, Cout, wgrad=True):
 
     def fn():
         _hip.call("mm_conv3d_fwd", x, wf, B, S, S, S, Cin, Cout, b, stats, None if wres else of, of if wres else None)
-    us = graph_time(fn)
     fl = 2.0 * B * S ** 3 * Cin * Cout * 27
-    print(f"conv3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s (graph-replayed)")
+    if fwd:
+        us = graph_time(fn)
+        print(f"conv3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s (graph-replayed)")
     if not wgrad:
         return
     dy = torch.randn(B, S, S, S, Cout, device="cuda").to(BF)
-    ws = torch.zeros(8, Cout, 27, Cin, device="cuda")
+    import ctypes
+    n = ctypes.c_int(0)
+    _hip.call("mm_conv3d_wgrad_slots", B, S, S, S, Cin, Cout, ctypes.addressof(n))
+    ws = torch.zeros(n.value, Cout, 27, Cin, device="cuda")           # slot mode, as in the training step
 
     def fn2():
-        _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin, 8, Cout * 27 * Cin, 0)
-    us = timeit(fn2)
-    print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s")
+        _hip.call("mm_conv3d_wgrad", dy, x, ws, None, B, S, S, S, Cin, Cout, Cin, 27 * Cin, 1, Cin, n.value, Cout * 27 * Cin, 1)
+    us = graph_time(fn2)
+    if os.environ.get("W3_DBG"):
+        torch.cuda.synchronize()
+        v = ws.view(n.value, -1)[:, :4].cpu()
+        print(f"    cycles (kd = 2 workgroups): set-up + ring prologue {v[:, 0].mean():.0f} | tile loop done {v[:, 1].mean():.0f} | "
+              f"K-split sum done {v[:, 2].mean():.0f} | stores drained {v[:, 3].mean():.0f}")
+    print(f"wgrad3d B={B} {S}^3 Cin={Cin} Cout={Cout}: {us:8.1f} us  {fl / us / 1e6:8.1f} TF/s ({fl / us / 1e6 / 2500:.3f} of 2.5 PF; "
+          f"{n.value} slots, graph-replayed)")
 
 
 def stamp_case(B, D, H, W):
@@ -349,6 +359,10 @@ def main():
         conv3d_dims_case(32, 16, 16, 12, 64, 128)
         conv3d_dims_case(32, 16, 16, 12, 128, 64, dgrad=True)
         conv3d_dims_case(32, 32, 32, 24, 64, 32, dgrad=True)
+    if flt == "wgrad3":
+        conv3d_case(32, 16, 32, 64, fwd=False)
+        conv3d_case(32, 8, 64, 128, fwd=False)
+        return
     if "conv3" in flt or not flt:
         conv3d_case(32, 16, 32, 64)
         conv3d_case(32, 8, 64, 128)
