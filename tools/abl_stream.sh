@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # ablation builds of one kernel file: csrc/build/sabl_<N>.so for each value N of the file's ablation macro
-# (default: conv3d_stream.hip / STREAM_ABL; ABL_FILE=conv3d ABL_MACRO=W3_ABL for the 3-D weight-gradient kernel).
+# (default: conv3d_stream.hip / STREAM_ABL; ABL_FILE=conv3d_wgrad tools/abl_stream.sh s0 = the 3-D weight-gradient kernel with cycle stamps).
 # Diagnostic only: these libraries compute wrong results by construction.
 # a leading 's' (s0, s1, ...) also defines STREAM_STAMPS (in-kernel cycle stamps, kbench.py sstamp).
 # usage: tools/abl_stream.sh 1 2 4 ...   then   MMEEG_HIP_LIB=.../csrc/build/sabl_N.so python tools/kbench.py stream
