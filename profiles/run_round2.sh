@@ -36,11 +36,16 @@ cd "$root"
 MMEEG_HIP_LIB="$root/multimodal_eeg_fmri_amd/csrc/build/abl_s0.so" python3 tools/kbench.py stamp 2>&1 | grep -v amdgpu > "$out/r02_wres_cycle_stamps.txt"
 {
   echo "ablation builds of conv3d_wres_kernel (tools/abl_build.sh; bits: tools/gen_wres_asm.py), tools/kbench.py stamp:"
-  for n in s0 s1 s2 s64 s3 s67; do
+  for n in s0 s128 s256; do
     echo "== WRES_ABL=${n#s}"
     MMEEG_HIP_LIB="$root/multimodal_eeg_fmri_amd/csrc/build/abl_$n.so" python3 tools/kbench.py stamp 2>&1 | grep "stamps B"
   done
 } > "$out/r02_wres_ablation.txt"
 python3 tools/kbench.py c4b 2>&1 | grep conv3d > "$out/r02_wres_graph_replayed.txt"
-python3 tools/kbench.py conv3 2>&1 | grep -v amdgpu > "$out/r02_conv3d_family_standalone.txt"
+{ python3 tools/kbench.py stream 2>&1 | grep conv3d; python3 tools/kbench.py wgrad3 2>&1 | grep wgrad3d; } > "$out/r02_conv3d_family_standalone.txt"
+# in-kernel cycle stamps of the streaming kernel and of the weight-gradient kernel (tools/abl_stream.sh s0 builds)
+MMEEG_HIP_LIB="$root/multimodal_eeg_fmri_amd/csrc/build/sabl_stream_s0.so" python3 tools/kbench.py sstamp 2>&1 | grep -v amdgpu > "$out/r02_stream_cycle_stamps.txt"
+W3_DBG=1 MMEEG_HIP_LIB="$root/multimodal_eeg_fmri_amd/csrc/build/sabl_wgrad_s0.so" python3 tools/kbench.py wgrad3 2>&1 | grep -v amdgpu > "$out/r02_wgrad3d_cycle_stamps.txt"
+# streaming kernel: SQ / TCC counters at the layer-3 forward shape
+"$root/profiles/run_pmc_wres.sh" r02_stream pmcs conv3d_stream > /dev/null 2>&1
 echo done
