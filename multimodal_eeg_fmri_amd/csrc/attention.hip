@@ -7,9 +7,10 @@
 //
 // One workgroup = 4 waves = 128 queries of one (b, h); each wave owns 32
 // queries.  Keys/values of the (b, h) pair are staged in LDS in chunks of KCH
-// keys: K row-major [key][32] (+16 B pad), V transposed [d][key] with the key
-// order inside each 16-key group permuted so that the P^T accumulator tile of
-// the first MFMA is directly the B operand of the second (no lane movement):
+// keys: K row-major [key][32] (+16 B pad), V row-major too but read TRANSPOSED by
+// ds_read_b64_tr_b16 (tr_frag32), its rows inside each 16-key group permuted so that
+// the P^T accumulator tile of the first MFMA is directly the B operand of the second
+// (no lane movement):
 //     S^T[key][q] = K_tile . Q^T          (A = K rows, B = Q^T from registers)
 //     O^T[d][q]  += V^T[d][key] . P^T     (A = V^T rows, B = exp(S^T) as bf16)
 // Each lane therefore owns one query column: the row max / row sum are 16
@@ -21,7 +22,22 @@ namespace {
 constexpr int DH = 32;
 constexpr int KCH = 256;                 // keys staged per chunk
 constexpr int KS = DH + 8;               // K row stride (elements): 80 B
-constexpr int VS = KCH + 8;              // V^T row stride (elements)
+
+constexpr int VR = DH + 16;              // row stride (elements) of a row-major tile read through ds_read_b64_tr_b16: 96 B,
+                                         // the four rows a lane group touches fall on distinct banks
+
+// MFMA A operand of a TRANSPOSED product from a row-major LDS tile [k][32] (row stride VR): row index = lane & 31 =
+// tile column, k-slots 8 (lane >> 5) + {0..7} = tile rows row0 + 8 (lane >> 5) + {0..7} (hardware transpose, as in
+// the weight-gradient kernels) - no scattered 2-byte writes into a transposed copy (they were 0.4 of the LDS cycles)
+__device__ __forceinline__ bf16x8 tr_frag32(const bf16* tile, int row0, int lane) {
+    const int li = lane & 15, g = lane >> 4;
+    const bf16* p = tile + (row0 + 8 * (g >> 1) + (li >> 2)) * VR + (g & 1) * 16 + 4 * (li & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * VR));
+    return u.v;
+}
 
 __device__ __forceinline__ int vperm(int key) {       // swap bits 2 and 3 of the key index
     return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
@@ -54,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
                                                        const uint32_t* epoch, const float* __restrict__ amask) {
     dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
-    __shared__ __attribute__((aligned(16))) bf16 Vt[DH * VS];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * VR];      // V row-major, row = vperm(key): read transposed by tr_frag32
     const int E = H * DH, E3 = 3 * E;
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,10 +115,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
                 const int s = tid + i * 256, key = s >> 2, sg = s & 3;
                 if (key >= kn32) continue;
                 *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
-                const bf16* ve = reinterpret_cast<const bf16*>(&vreg[i]);
-                const int pos = vperm(key);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Vt[(sg * 8 + j) * VS + pos] = ve[j];
+                *reinterpret_cast<uint4*>(Vs + vperm(key) * VR + sg * 8) = vreg[i];
             }
         }
         __syncthreads();
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             for (int r = 0; r < 16; ++r) o[r] *= alpha;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + lr * VS + kt + 16 * s + 8 * lh);
+                const bf16x8 vf = tr_frag32(Vs, kt + 16 * s, lane);
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o, 0, 0, 0);
             }
         }
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
     dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * KS];
-    __shared__ __attribute__((aligned(16))) bf16 Kt[DH * VS];
+    __shared__ __attribute__((aligned(16))) bf16 Kr[KCH * VR];      // K again, row = vperm(key), for the transposed product (tr_frag32)
     const int E = H * DH, E3 = 3 * E;
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,10 +253,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                 if (key >= kn32) continue;
                 *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
                 *reinterpret_cast<uint4*>(Vs + key * KS + sg * 8) = vreg[i];
-                const bf16* ke = reinterpret_cast<const bf16*>(&kreg[i]);
-                const int pos = vperm(key);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) Kt[(sg * 8 + j) * VS + pos] = ke[j];
+                *reinterpret_cast<uint4*>(Kr + vperm(key) * VR + sg * 8) = kreg[i];
             }
         }
         __syncthreads();
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(Kt + lr * VS + kt + 16 * s + 8 * lh);
+                const bf16x8 ktf = tr_frag32(Kr, kt + 16 * s, lane);
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[s], dq, 0, 0, 0);
             }
         }
@@ -287,7 +297,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 constexpr int QCH = 128;                 // queries staged per chunk in the dK/dV pass
-constexpr int QS = QCH + 8;              // transposed row stride
 
 template <bool DROP, bool FULL, bool MASK = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
@@ -298,8 +307,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     dseed = mm_eff_seed(dseed, epoch);
     __shared__ __attribute__((aligned(16))) bf16 Qs[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Ds[QCH * KS];
-    __shared__ __attribute__((aligned(16))) bf16 Qt[DH * QS];
-    __shared__ __attribute__((aligned(16))) bf16 Dt[DH * QS];
+    __shared__ __attribute__((aligned(16))) bf16 Qr[QCH * VR];      // Q and dO again, row = vperm(query), for the transposed
+    __shared__ __attribute__((aligned(16))) bf16 Dr[QCH * VR];      // products (tr_frag32)
     __shared__ float Ls[QCH], Dl[QCH];
     const int E = H * DH, E3 = 3 * E;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -347,14 +356,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                 if (qi >= qn32) continue;
                 *reinterpret_cast<uint4*>(Qs + qi * KS + sg * 8) = qreg[i];
                 *reinterpret_cast<uint4*>(Ds + qi * KS + sg * 8) = dreg[i];
-                const bf16* qe = reinterpret_cast<const bf16*>(&qreg[i]);
-                const bf16* de = reinterpret_cast<const bf16*>(&dreg[i]);
-                const int pos = vperm(qi);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    Qt[(sg * 8 + j) * QS + pos] = qe[j];
-                    Dt[(sg * 8 + j) * QS + pos] = de[j];
-                }
+                *reinterpret_cast<uint4*>(Qr + vperm(qi) * VR + sg * 8) = qreg[i];
+                *reinterpret_cast<uint4*>(Dr + vperm(qi) * VR + sg * 8) = dreg[i];
             }
         }
         for (int i = tid; i < qn32; i += 256) {
@@ -388,9 +391,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 dta = *reinterpret_cast<const bf16x8*>(Dt + lr * QS + qt + 16 * s + 8 * lh);
+                const bf16x8 dta = tr_frag32(Dr, qt + 16 * s, lane);
                 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dta, pf[s], dv, 0, 0, 0);
-                const bf16x8 qta = *reinterpret_cast<const bf16x8*>(Qt + lr * QS + qt + 16 * s + 8 * lh);
+                const bf16x8 qta = tr_frag32(Qr, qt + 16 * s, lane);
                 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsf[s], dk, 0, 0, 0);
             }
         }
