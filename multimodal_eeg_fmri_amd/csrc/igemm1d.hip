@@ -14,6 +14,9 @@
 // hit 16 distinct 16-B slots (row stride = odd multiple of 16 B).
 #include "common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
 
 
@@ -63,12 +66,34 @@ struct ConvArgs {
     EpiArgs e;
 };
 
+// Epilogue feature mask of a launch: which of epilogue_rows' optional steps it needs, the activation in bits 16-19 and
+// the fused activation derivative in bits 20-23.  The kernel is compiled once per tile shape with every step behind a
+// run-time test (FEAT = EF_ANY) and once more for each combination the training step uses, with the unused steps and
+// the activation switch compiled out: the generic epilogue cost ~2.4 us per million outputs in branches and dead work
+// (FFN-1 forward, 8.4 M outputs: 25.7 us generic, 17.5 us specialised).
+enum : unsigned { EF_RES = 1, EF_PE = 2, EF_PRE = 4, EF_GRADZ = 8, EF_STATS = 16, EF_POOLOUT = 32, EF_LNF = 64, EF_POOL2 = 128,
+                  EF_DROP = 256, EF_SCALE = 512, EF_F32 = 1024, EF_BF16 = 2048, EF_SHIFT = 4096, EF_LNBWD = 8192, EF_ANY = 0xFFFFFFFFu };
+static unsigned epi_mask(const EpiArgs& e) {
+    return (e.residual ? EF_RES : 0) | (e.pe ? EF_PE : 0) | (e.out_pre ? EF_PRE : 0) | (e.gradz ? EF_GRADZ : 0) | (e.stats ? EF_STATS : 0) |
+           (e.pool_out ? EF_POOLOUT : 0) | (e.lnf_out ? EF_LNF : 0) | (e.pool == 2 ? EF_POOL2 : 0) | (e.drop_thresh ? EF_DROP : 0) |
+           (e.scale ? EF_SCALE : 0) | (e.out_f32 ? EF_F32 : 0) | (e.out_bf16 ? EF_BF16 : 0) | (e.shift ? EF_SHIFT : 0) | (e.ln_x ? EF_LNBWD : 0) |
+           ((unsigned)e.act << 16) | ((unsigned)(e.gradz ? e.gradz_act : 0) << 20);
+}
+
+
 // Epilogue through LDS: the accumulator tile is parked as fp32 [BM][BN+4], then
 // every thread owns one 4-column group (fixed per thread) and walks rows, so
 // residual / positional loads and all stores are 16-byte, row-contiguous.
-template <int BM, int BN>
+template <int BM, int BN, unsigned FEAT>
 __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
                                               int n0, int N, float* sstat) {
+    // no implicit FMA contraction in here: which multiply-adds get fused would depend on what a specialisation folds
+    // away, and the variants of one op must agree bit for bit (tests compare them); the two intended FMAs are explicit
+#pragma clang fp contract(off)
+    constexpr bool ANY = FEAT == EF_ANY;
+#define EF_ON(bit, runtime) (ANY ? (bool)(runtime) : ((FEAT & (bit)) != 0))
+    const int act = ANY ? e.act : (int)((FEAT >> 16) & 15u);
+    const int gradz_act = ANY ? e.gradz_act : (int)((FEAT >> 20) & 15u);
     constexpr int LDC = BN + 4;
     constexpr int CG = BN / 4;                 // column groups
     constexpr int RPP = 256 / CG;              // rows per pass
@@ -77,14 +102,15 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
     const bool nok = n < N;                    // N % 4 == 0 is required
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (nok) {
-        if (e.scale) sc = *reinterpret_cast<const float4*>(e.scale + n);
-        if (e.shift) sh = *reinterpret_cast<const float4*>(e.shift + n);
+        if (EF_ON(EF_SCALE, e.scale)) sc = *reinterpret_cast<const float4*>(e.scale + n);
+        if (EF_ON(EF_SHIFT, e.shift)) sh = *reinterpret_cast<const float4*>(e.shift + n);
     }
     const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, pp[4] = {0, 0, 0, 0};
-    const uint32_t dseed = e.drop_thresh ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
-    const int To = T / e.pool;
-    const int step = e.pool;                   // rows consumed per item
+    const bool drop = EF_ON(EF_DROP, e.drop_thresh);
+    const uint32_t dseed = drop ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
+    const int step = ANY ? e.pool : ((FEAT & EF_POOL2) ? 2 : 1);      // rows consumed per item
+    const int To = T / step;
     for (int r0 = rr * step; r0 < BM; r0 += RPP * step) {
         float o[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         bool any = false;
@@ -96,39 +122,41 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
             float v[4] = {a4.x, a4.y, a4.z, a4.w};
             const size_t idx = ((size_t)b * T + t) * N + n;
             float4 res = make_float4(0.f, 0.f, 0.f, 0.f), pe = res;
-            if (e.residual) res = *reinterpret_cast<const float4*>(e.residual + idx);
-            if (e.pe) pe = *reinterpret_cast<const float4*>(e.pe + (size_t)t * N + n);
+            if (EF_ON(EF_RES, e.residual)) res = *reinterpret_cast<const float4*>(e.residual + idx);
+            if (EF_ON(EF_PE, e.pe)) pe = *reinterpret_cast<const float4*>(e.pe + (size_t)t * N + n);
             const float rs[4] = {res.x, res.y, res.z, res.w}, ps[4] = {pe.x, pe.y, pe.z, pe.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float val = v[c] * scs[c] + shs[c];
-                s1[c] += val; s2[c] += val * val;
+                float val = __builtin_fmaf(v[c], scs[c], shs[c]);
+                if (EF_ON(EF_STATS, e.stats)) { s1[c] += val; s2[c] = __builtin_fmaf(val, val, s2[c]); }
                 v[c] = val;
             }
-            if (e.out_pre) {
+            if (EF_ON(EF_PRE, e.out_pre)) {
                 bf16x4 pv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                 *reinterpret_cast<bf16x4*>(e.out_pre + idx) = pv;
             }
-            if (e.gradz) {
+            if (EF_ON(EF_GRADZ, e.gradz)) {
                 const bf16x4 zz = *reinterpret_cast<const bf16x4*>(e.gradz + idx);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] *= act_grad((float)zz[c], e.gradz_act);
+                for (int c = 0; c < 4; ++c) v[c] *= act_grad((float)zz[c], gradz_act);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float val = apply_act(v[c], e.act);
-                if (e.drop_thresh) val *= dropout_scale(dseed, (uint32_t)(idx + c), e.drop_thresh, e.drop_inv_keep);
-                val += rs[c] + ps[c];
+                float val = apply_act(v[c], act);
+                const float rp = rs[c] + ps[c];
+                if (drop) val = __builtin_fmaf(val, dropout_scale(dseed, (uint32_t)(idx + c), e.drop_thresh, e.drop_inv_keep), rp);
+                else val += rp;
                 o[c] = fmaxf(o[c], val);
             }
         }
         if (!any) continue;
+        if (EF_ON(EF_POOLOUT, e.pool_out))
 #pragma unroll
-        for (int c = 0; c < 4; ++c) pp[c] += o[c];
+            for (int c = 0; c < 4; ++c) pp[c] += o[c];
         const int t = t0 + r0;
         const size_t oi = ((size_t)b * To + t / step) * N + n;
         if constexpr (BN == 128) {
-            if (e.lnf_out) {                       // host guarantees N == 128, pool == 1: 32 lanes hold this row
+            if (EF_ON(EF_LNF, e.lnf_out)) {                       // host guarantees N == 128, pool == 1: 32 lanes hold this row
                 float sm = (o[0] + o[1]) + (o[2] + o[3]);
 #pragma unroll
                 for (int k = 16; k > 0; k >>= 1) sm += __shfl_xor(sm, k, 64);
@@ -149,13 +177,13 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
                 }
             }
         }
-        if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
-        if (e.out_bf16) {
+        if (EF_ON(EF_F32, e.out_f32)) *reinterpret_cast<float4*>(e.out_f32 + oi) = make_float4(o[0], o[1], o[2], o[3]);
+        if (EF_ON(EF_BF16, e.out_bf16)) {
             bf16x4 ov = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
             *reinterpret_cast<bf16x4*>(e.out_bf16 + oi) = ov;
         }
     }
-    if (e.pool_out) {
+    if (EF_ON(EF_POOLOUT, e.pool_out)) {
         // fused mean over rows (all rows of this tile belong to one group: pool_rows % BM == 0, host-checked)
         __syncthreads();
         float* part = const_cast<float*>(Cs);              // [RPP][BN]
@@ -169,9 +197,9 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
                 for (int r = 0; r < RPP; ++r) s += part[r * BN + i];
                 atomicAdd(&e.pool_out[grp * N + n0 + i], s * e.pool_scale);
             }
-        if (e.stats) __syncthreads();
+        if (EF_ON(EF_STATS, e.stats)) __syncthreads();
     }
-    if (e.stats) {
+    if (EF_ON(EF_STATS, e.stats)) {
         // block reduction of the per-thread column sums: plain stores into the (now dead) C tile, then a
         // column walk.  LDS float atomics with RPP-way same-address conflicts cost ~2 us per workgroup.
         __syncthreads();                                   // every thread is done reading Cs
@@ -191,6 +219,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
             }
         }
     }
+#undef EF_ON
 }
 
 // dgrad GEMM -> LayerNorm backward in one pass (N == BN == 128, T % BM == 0: checked on the host).
@@ -260,7 +289,7 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KCT>
+template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT>
 __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
@@ -398,21 +427,53 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
             return;
         }
     }
-    epilogue_rows<BM, BN>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
+    epilogue_rows<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
 }
 
-template <int BM, int BN, int WM, int WN, int KCT>
-int launch_fwd(const ConvArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT>
+int launch_fwd_feat(const ConvArgs& a, hipStream_t st) {
     const size_t stage = (size_t)(BM + a.taps - 1 + BN * a.taps) * (KCT + KPAD) * sizeof(bf16);
     const size_t ctile = (size_t)(BM * (BN + 4) + 2 * BN) * sizeof(float);
     const size_t need = stage > ctile ? stage : ctile;
     if (need > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_fwd: LDS %zu B > 160 KiB", need);
-    auto kern = conv1d_fwd_kernel<BM, BN, WM, WN, KCT>;
+    auto kern = conv1d_fwd_kernel<BM, BN, WM, WN, KCT, FEAT>;
     if (need > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
     dim3 grid(a.B * ceil_div(a.T, BM), ceil_div(a.Cout, BN));
     hipLaunchKernelGGL(kern, grid, dim3(256), need, st, a);
     return mm_check_launch("conv1d_fwd");
+}
+
+// the combinations of the contrastive training step (logged with MM_EPI_LOG=1), each on the tile shape it runs on;
+// everything else takes the generic epilogue
+template <int BM, int BN, int WM, int WN, int KCT>
+int launch_fwd(const ConvArgs& a, hipStream_t st) {
+    const unsigned m = epi_mask(a.e);
+    if (getenv("MM_EPI_LOG")) fprintf(stderr, "EPI %d %d %d mask %06x K=%d N=%d taps=%d\n", BM, BN, KCT, m, a.Cin, a.Cout, a.taps);
+#define EPI_CASE(mask) case mask: return launch_fwd_feat<BM, BN, WM, WN, KCT, mask>(a, st);
+    if constexpr (BM == 64 && BN == 128 && KCT == 128) {
+        switch (m) {
+            EPI_CASE(0x001800u)          // QKV projection: bias, bf16 out
+            EPI_CASE(0x011904u)          // FFN-1 forward: bias, GELU, dropout, pre-activation copy, bf16 out
+            EPI_CASE(0x100908u)          // FFN-2 data gradient: GELU', dropout mask, bf16 out
+            default: break;
+        }
+    } else if constexpr (BM == 32 && BN == 128 && KCT == 128) {
+        switch (m) {
+            EPI_CASE(0x001541u)          // out-proj / FFN-2 forward: bias, dropout, residual, fp32 out, LayerNorm of the result
+            EPI_CASE(0x001521u)          // last FFN-2 forward: ... and the mean over tokens instead of the LayerNorm
+            EPI_CASE(0x000800u)          // plain data gradient, bf16 out
+            default: break;
+        }
+    } else if constexpr (BM == 64 && BN == 64 && KCT == 64) {
+        switch (m) {
+            EPI_CASE(0x001410u)          // conv block forward: bias, BatchNorm sums, fp32 out
+            EPI_CASE(0x000800u)          // conv data gradient, bf16 out
+            default: break;
+        }
+    }
+#undef EPI_CASE
+    return launch_fwd_feat<BM, BN, WM, WN, KCT, EF_ANY>(a, st);
 }
 
 // ------------------------------------------------------------------ packers
