@@ -274,8 +274,9 @@ struct Pool3Args {
 };
 
 // One thread = 8 channels of one pooled voxel: eight 16-byte loads of the bf16 pre-BatchNorm volume.
-template <int MODE>   // 0 fwd, 2 bwd-apply
+template <int MODE, int ACT = -1>   // MODE 0 fwd, 2 bwd-apply; ACT >= 0: compiled for that activation (no per-element switch)
 __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
+    if (ACT >= 0) a.act = ACT;
     a.seed = mm_eff_seed(a.seed, a.epoch);
     const int nv = a.N / 8;
     const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
@@ -363,7 +364,9 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
 }
 
 // BN-gradient partial sums from the pooled winners only:  sums[0][n] += dz, sums[1][n] += dz * xhat
+template <int ACT = -1>
 __global__ __launch_bounds__(256) void pool3_bwd_reduce_kernel(Pool3Args a) {
+    if (ACT >= 0) a.act = ACT;
     a.seed = mm_eff_seed(a.seed, a.epoch);
     const int nv = a.N / 8;
     const size_t nrows = (size_t)a.B * (a.D / 2) * (a.H / 2) * (a.W / 2);
@@ -422,11 +425,15 @@ int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
     int grid = (int)((rows + rpb - 1) / rpb);
     if (mode == 1) {
         if (grid > 512) grid = 512;
-        hipLaunchKernelGGL(pool3_bwd_reduce_kernel, dim3(grid), dim3(256), 0, st, a);
+        if (a.act == MM_ACT_GELU) hipLaunchKernelGGL((pool3_bwd_reduce_kernel<MM_ACT_GELU>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pool3_bwd_reduce_kernel<>), dim3(grid), dim3(256), 0, st, a);
     } else {
         if (grid > 4096) grid = 4096;
-        if (mode == 0) hipLaunchKernelGGL(pool3_bn_act_kernel<0>, dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(pool3_bn_act_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+        const bool gelu = a.act == MM_ACT_GELU;
+        if (mode == 0 && gelu) hipLaunchKernelGGL((pool3_bn_act_kernel<0, MM_ACT_GELU>), dim3(grid), dim3(256), 0, st, a);
+        else if (mode == 0) hipLaunchKernelGGL((pool3_bn_act_kernel<0>), dim3(grid), dim3(256), 0, st, a);
+        else if (gelu) hipLaunchKernelGGL((pool3_bn_act_kernel<2, MM_ACT_GELU>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pool3_bn_act_kernel<2>), dim3(grid), dim3(256), 0, st, a);
     }
     return mm_check_launch("pool3d_bn_act");
 }

@@ -54,15 +54,19 @@ struct BnActArgs {
     const uint32_t* epoch;
 };
 
+template <int ACT>
 __device__ __forceinline__ float bnact_one(const BnActArgs& a, float y, float sc, float sh, uint32_t idx, bool drop_here) {
-    float v = apply_act(y * sc + sh, a.act);
+    float v = apply_act(y * sc + sh, ACT >= 0 ? ACT : a.act);
     if (drop_here && a.thresh) v *= dropout_scale(a.seed, idx, a.thresh, a.inv_keep);
     return v;
 }
 
+// ACT >= 0 / POOL > 0: compiled for that activation / pool size (GELU with pool 1 and 2: every BatchNorm of the encoders)
+template <int ACT = -1, int POOL = 0>
 __global__ void bn_act_fwd_kernel(BnActArgs a) {
     a.seed = mm_eff_seed(a.seed, a.epoch);
     a.seed2 = mm_eff_seed(a.seed2, a.epoch);
+    if (POOL > 0) a.pool = POOL;
     const int So = a.S / a.pool;
     const int nv = a.N / 4;
     const size_t total = (size_t)a.R * So * nv;
@@ -84,15 +88,15 @@ __global__ void bn_act_fwd_kernel(BnActArgs a) {
             const float y1s[4] = {y1.x, y1.y, y1.z, y1.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v0 = bnact_one(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), a.drop_first);
-                const float v1 = bnact_one(a, y1s[q], scs[q], shs[q], (uint32_t)(in0 + a.N + q), a.drop_first);
+                const float v0 = bnact_one<ACT>(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), a.drop_first);
+                const float v1 = bnact_one<ACT>(a, y1s[q], scs[q], shs[q], (uint32_t)(in0 + a.N + q), a.drop_first);
                 float m = fmaxf(v0, v1);
                 if (!a.drop_first && a.thresh) m *= dropout_scale(a.seed, (uint32_t)(oidx + q), a.thresh, a.inv_keep);
                 o[q] = m;
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = bnact_one(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), true);
+            for (int q = 0; q < 4; ++q) o[q] = bnact_one<ACT>(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), true);
         }
         if (a.pe) {
             const float4 p = *reinterpret_cast<const float4*>(a.pe + (size_t)so * a.N + n4);
@@ -126,18 +130,22 @@ struct BnBwdArgs {
     int sums_nrep;               // apply: sums is [sums_nrep][2][N]; the block reduces the replicas itself
 };
 
-// computes dz for the (up to) two inputs of one pooled output element
+// computes dz for the (up to) two inputs of one pooled output element.  ACT >= 0 / POOL > 0: compiled for that activation /
+// pool size (the per-element switch and the two-way pool logic of the generic form made these passes VALU-bound)
+template <int ACT, int POOL>
 __device__ __forceinline__ void bn_dz_pair(const BnBwdArgs& a, float y0, float y1, float sc, float sh, float g,
                                            uint32_t i0, uint32_t i1, uint32_t io, float& dz0, float& dz1) {
+    const int act = ACT >= 0 ? ACT : a.act;
+    const int pool = POOL > 0 ? POOL : a.pool;
     const float z0 = y0 * sc + sh;
-    if (a.pool == 1) {
+    if (pool == 1) {
         float m = a.thresh ? dropout_scale(a.seed, i0, a.thresh, a.inv_keep) : 1.f;
-        dz0 = g * m * act_grad(z0, a.act);
+        dz0 = g * m * act_grad(z0, act);
         dz1 = 0.f;
         return;
     }
     const float z1 = y1 * sc + sh;
-    float a0 = apply_act(z0, a.act), a1 = apply_act(z1, a.act);
+    float a0 = apply_act(z0, act), a1 = apply_act(z1, act);
     float m0 = 1.f, m1 = 1.f;
     if (a.thresh) {
         if (a.drop_first) {
@@ -150,15 +158,16 @@ __device__ __forceinline__ void bn_dz_pair(const BnBwdArgs& a, float y0, float y
     }
     const bool first = a0 >= a1;                       // ties -> first (torch max_pool)
     // ONE derivative, at the winner (two selects of act_grad(z0) / act_grad(z1) evaluate both)
-    const float d = g * (first ? m0 : m1) * act_grad(first ? z0 : z1, a.act);
+    const float d = g * (first ? m0 : m1) * act_grad(first ? z0 : z1, act);
     dz0 = first ? d : 0.f;
     dz1 = first ? 0.f : d;
 }
 
-template <bool APPLY>
+template <bool APPLY, int ACT = -1, int POOL = 0>
 __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     a.seed = mm_eff_seed(a.seed, a.epoch);
     a.seed2 = mm_eff_seed(a.seed2, a.epoch);
+    if (POOL > 0) a.pool = POOL;
     // block = 256 threads = (N/4 channel-vectors) x rows; grid-stride over pooled rows
     const int nv = a.N / 4;
     const int So = a.S / a.pool;
@@ -218,7 +227,7 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
             float d0[4], d1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                bn_dz_pair(a, y0s[q], y1s[q], scs[q], shs[q], g[q], (uint32_t)(in0 + q),
+                bn_dz_pair<ACT, POOL>(a, y0s[q], y1s[q], scs[q], shs[q], g[q], (uint32_t)(in0 + q),
                            (uint32_t)(in0 + a.N + q), (uint32_t)(oidx + q), d0[q], d1[q]);
                 const float xh0 = (y0s[q] - mus[q]) * rss[q], xh1 = (y1s[q] - mus[q]) * rss[q];
                 if (APPLY) {
@@ -588,7 +597,9 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
                 thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
                 thresh_of(drop2_p), seed2, drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f, seed_epoch};
     const size_t total = (size_t)R * (S / pool) * (N / 4);
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, a);
+    if (act == MM_ACT_GELU && pool == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 1>), dim3(grid_for(total)), dim3(256), 0, st, a);
+    else if (act == MM_ACT_GELU && pool == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 2>), dim3(grid_for(total)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<>), dim3(grid_for(total)), dim3(256), 0, st, a);
     return mm_check_launch("bn_act_fwd");
 }
 
@@ -613,8 +624,15 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
     const size_t rows = (size_t)R * (S / pool);
     int grid = (int)((rows + rpb - 1) / rpb);
     if (grid > 1024) grid = 1024;
-    if (apply) hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    // GELU with pool 1 / 2 (every BatchNorm of the encoders on the training path) is compiled in; anything else is generic
+    if (act == MM_ACT_GELU && pool == 1) {
+        if (apply) hipLaunchKernelGGL((bn_act_bwd_kernel<true, MM_ACT_GELU, 1>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((bn_act_bwd_kernel<false, MM_ACT_GELU, 1>), dim3(grid), dim3(256), 0, st, a);
+    } else if (act == MM_ACT_GELU && pool == 2) {
+        if (apply) hipLaunchKernelGGL((bn_act_bwd_kernel<true, MM_ACT_GELU, 2>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((bn_act_bwd_kernel<false, MM_ACT_GELU, 2>), dim3(grid), dim3(256), 0, st, a);
+    } else if (apply) hipLaunchKernelGGL((bn_act_bwd_kernel<true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<false>), dim3(grid), dim3(256), 0, st, a);
     return mm_check_launch("bn_act_bwd");
 }
 
