@@ -289,8 +289,10 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT>
+// FEAT: epilogue combination (EF_ANY = all run-time); TAPS > 0: compiled for that tap count (1 = the Linear layers)
+template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT, int TAPS>
 __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
+    if (TAPS > 0) a.taps = TAPS;
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     static_assert(WM * WN == 4, "4 waves");
@@ -430,13 +432,13 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     epilogue_rows<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
 }
 
-template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT>
+template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT, int TAPS = 0>
 int launch_fwd_feat(const ConvArgs& a, hipStream_t st) {
     const size_t stage = (size_t)(BM + a.taps - 1 + BN * a.taps) * (KCT + KPAD) * sizeof(bf16);
     const size_t ctile = (size_t)(BM * (BN + 4) + 2 * BN) * sizeof(float);
     const size_t need = stage > ctile ? stage : ctile;
     if (need > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_fwd: LDS %zu B > 160 KiB", need);
-    auto kern = conv1d_fwd_kernel<BM, BN, WM, WN, KCT, FEAT>;
+    auto kern = conv1d_fwd_kernel<BM, BN, WM, WN, KCT, FEAT, TAPS>;
     if (need > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
     dim3 grid(a.B * ceil_div(a.T, BM), ceil_div(a.Cout, BN));
@@ -450,22 +452,25 @@ template <int BM, int BN, int WM, int WN, int KCT>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     const unsigned m = epi_mask(a.e);
     if (getenv("MM_EPI_LOG")) fprintf(stderr, "EPI %d %d %d mask %06x K=%d N=%d taps=%d\n", BM, BN, KCT, m, a.Cin, a.Cout, a.taps);
-#define EPI_CASE(mask) case mask: return launch_fwd_feat<BM, BN, WM, WN, KCT, mask>(a, st);
+#define EPI_CASE(mask) case mask: return launch_fwd_feat<BM, BN, WM, WN, KCT, mask, LT>(a, st);
     if constexpr (BM == 64 && BN == 128 && KCT == 128) {
-        switch (m) {
+        constexpr int LT = 1;                 // the Linear layers: one tap
+        if (a.taps == 1) switch (m) {
             EPI_CASE(0x001800u)          // QKV projection: bias, bf16 out
             EPI_CASE(0x011904u)          // FFN-1 forward: bias, GELU, dropout, pre-activation copy, bf16 out
             EPI_CASE(0x100908u)          // FFN-2 data gradient: GELU', dropout mask, bf16 out
             default: break;
         }
     } else if constexpr (BM == 32 && BN == 128 && KCT == 128) {
-        switch (m) {
+        constexpr int LT = 1;
+        if (a.taps == 1) switch (m) {
             EPI_CASE(0x001541u)          // out-proj / FFN-2 forward: bias, dropout, residual, fp32 out, LayerNorm of the result
             EPI_CASE(0x001521u)          // last FFN-2 forward: ... and the mean over tokens instead of the LayerNorm
             EPI_CASE(0x000800u)          // plain data gradient, bf16 out
             default: break;
         }
     } else if constexpr (BM == 64 && BN == 64 && KCT == 64) {
+        constexpr int LT = 0;                 // k = 3, 5, 7 convolutions: tap count at run time
         switch (m) {
             EPI_CASE(0x001410u)          // conv block forward: bias, BatchNorm sums, fp32 out
             EPI_CASE(0x000800u)          // conv data gradient, bf16 out
