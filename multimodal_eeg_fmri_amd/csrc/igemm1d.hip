@@ -225,20 +225,23 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
 // dgrad GEMM -> LayerNorm backward in one pass (N == BN == 128, T % BM == 0: checked on the host).
 // 32 lanes own one row (4 columns each): the two row means are 5-step half-wave shuffles; every
 // thread keeps its 4 columns' dgamma / dbeta partial sums over the rows it walks.
-template <int BM, int BN>
+template <int BM, int BN, unsigned FEAT>
 __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
                                                 float* sstat) {
     static_assert(BN == 128, "LayerNorm-128 epilogue");
+    constexpr bool ANY = FEAT == EF_ANY;
+#define EF_ON(bit, runtime) (ANY ? (bool)(runtime) : ((FEAT & (bit)) != 0))
     constexpr int LDC = BN + 4;
     const int cg = tid & 31, rr = tid >> 5;
     const float4 gg = *reinterpret_cast<const float4*>(e.ln_gamma + cg * 4);
     const float gam[4] = {gg.x, gg.y, gg.z, gg.w};
     float sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (e.shift) {
+    if (EF_ON(EF_SHIFT, e.shift)) {
         const float4 s4 = *reinterpret_cast<const float4*>(e.shift + cg * 4);
         sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
     }
-    const uint32_t dseed = e.drop_thresh ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
+    const bool drop = EF_ON(EF_DROP, e.drop_thresh);
+    const uint32_t dseed = drop ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
     float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int row = rr; row < BM; row += 8) {
@@ -247,7 +250,7 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
         const float4 a4 = *reinterpret_cast<const float4*>(Cs + row * LDC + cg * 4);
         const float4 xv = *reinterpret_cast<const float4*>(e.ln_x + base);
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e.residual) rv = *reinterpret_cast<const float4*>(e.residual + base);
+        if (EF_ON(EF_RES, e.residual)) rv = *reinterpret_cast<const float4*>(e.residual + base);
         const float2 st = *reinterpret_cast<const float2*>(e.ln_stat + 2 * m);
         const float dyv[4] = {a4.x + sh[0], a4.y + sh[1], a4.z + sh[2], a4.w + sh[3]};
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -265,12 +268,12 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
         float o4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) o4[c] = st.y * (dyv[c] * gam[c] - s1 - xh[c] * s2) + rs[c];
-        if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + base) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-        if (e.out_bf16) {
+        if (EF_ON(EF_F32, e.out_f32)) *reinterpret_cast<float4*>(e.out_f32 + base) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        if (EF_ON(EF_BF16, e.out_bf16)) {
             bf16x4 ob;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                ob[c] = (bf16)(e.drop_thresh ? o4[c] * dropout_scale(dseed, (uint32_t)(base + c), e.drop_thresh, e.drop_inv_keep)
+                ob[c] = (bf16)(drop ? o4[c] * dropout_scale(dseed, (uint32_t)(base + c), e.drop_thresh, e.drop_inv_keep)
                                              : o4[c]);
             *reinterpret_cast<bf16x4*>(e.out_bf16 + base) = ob;
         }
@@ -287,6 +290,7 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
         for (int r = 0; r < 8; ++r) s += part[r * 256 + tid];
         atomicAdd(&e.ln_dgb[(size_t)(blockIdx.x % MM_REPL) * 256 + tid], s);
     }
+#undef EF_ON
 }
 
 // FEAT: epilogue combination (EF_ANY = all run-time); TAPS > 0: compiled for that tap count (1 = the Linear layers)
@@ -424,8 +428,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
         for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
     __syncthreads();
     if constexpr (BM == 32 && BN == 128) {
-        if (a.e.ln_x) {
-            epilogue_ln_bwd<BM, BN>(Cs, a.e, tid, b, t0, a.T, sstat);
+        if ((FEAT == EF_ANY && a.e.ln_x) || (FEAT != EF_ANY && (FEAT & EF_LNBWD))) {
+            epilogue_ln_bwd<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, sstat);
             return;
         }
     }
@@ -467,6 +471,8 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
             EPI_CASE(0x001541u)          // out-proj / FFN-2 forward: bias, dropout, residual, fp32 out, LayerNorm of the result
             EPI_CASE(0x001521u)          // last FFN-2 forward: ... and the mean over tokens instead of the LayerNorm
             EPI_CASE(0x000800u)          // plain data gradient, bf16 out
+            EPI_CASE(0x002d01u)          // data gradient + LayerNorm backward: skip gradient in, fp32 and masked bf16 out
+            EPI_CASE(0x002401u)          // the same without the bf16 copy (first block)
             default: break;
         }
     } else if constexpr (BM == 64 && BN == 64 && KCT == 64) {
