@@ -294,10 +294,10 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
         c1[q] = (MODE == 2 && a.train) ? a.sums[a.N + n8 + q] * a.inv_count : 0.f;
     }
     for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
-        size_t q = row;
-        const int ow = (int)(q % Wo); q /= Wo;
-        const int oh = (int)(q % Ho); q /= Ho;
-        const int od = (int)(q % Do); q /= Do;
+        unsigned q = (unsigned)row;                                 // 32-bit divisions (rows < 2^31: checked on the host)
+        const int ow = (int)(q % (unsigned)Wo); q /= (unsigned)Wo;
+        const int oh = (int)(q % (unsigned)Ho); q /= (unsigned)Ho;
+        const int od = (int)(q % (unsigned)Do); q /= (unsigned)Do;
         const size_t base = ((((size_t)q * a.D + 2 * od) * a.H + 2 * oh) * a.W + 2 * ow) * a.N + n8;
         const size_t sw = a.N, shh = (size_t)a.W * a.N, sd = (size_t)a.H * a.W * a.N;
         bf16x8 t[8];
@@ -422,6 +422,7 @@ int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
     a.inv_count = 1.f / ((float)a.B * a.D * a.H * a.W);
     const int rpb = 256 / (a.N / 8) > 0 ? 256 / (a.N / 8) : 1;
     const size_t rows = (size_t)a.B * (a.D / 2) * (a.H / 2) * (a.W / 2);
+    MM_REQUIRE(rows < (1ull << 31), "pool3d_bn_act: %zu pooled voxels (32-bit indices)", rows);
     int grid = (int)((rows + rpb - 1) / rpb);
     if (mode == 1) {
         if (grid > 512) grid = 512;

@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < 27; ++t) s[t] = 0.f;
     for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
-        const int h = (int)(row % H), d = (int)((row / H) % D);
+        const unsigned rq = (unsigned)row / (unsigned)H;            // 32-bit divisions: rows = B D H < 2^31 (host-checked)
+        const int h = (int)((unsigned)row - rq * (unsigned)H), d = (int)(rq % (unsigned)D);
         const float* xr = x + row * W;
         float all = 0.f;
         for (int w = 0; w < W; ++w) all += (float)(bf16)xr[w];

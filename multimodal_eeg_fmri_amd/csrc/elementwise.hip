@@ -68,21 +68,22 @@ __global__ void bn_act_fwd_kernel(BnActArgs a) {
     a.seed2 = mm_eff_seed(a.seed2, a.epoch);
     if (POOL > 0) a.pool = POOL;
     const int So = a.S / a.pool;
-    const int nv = a.N / 4;
-    const size_t total = (size_t)a.R * So * nv;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int n4 = (int)(i % nv) * 4;
-        const size_t rs = i / nv;                    // r * So + so
-        const int so = (int)(rs % So);
-        const size_t r = rs / So;
+    const unsigned nv = a.N / 4;
+    const unsigned total = (unsigned)((size_t)a.R * So * nv);       // < 2^31 elements / 4: checked on the host
+    // index arithmetic in 32 bits and without divisions where the layout allows it: output element 4 i, input row
+    // (i / nv) * pool.  (Four 64-bit divisions per four elements made these passes 4x slower than their HBM traffic.)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned rs = i / nv;                                 // r * So + so
+        const int n4 = (int)(i - rs * nv) * 4;
+        const int so = a.pe ? (int)(rs % (unsigned)So) : 0;         // only the positional table needs the position itself
         const float4 sc = *reinterpret_cast<const float4*>(a.scale + n4);
         const float4 sh = *reinterpret_cast<const float4*>(a.shift + n4);
         float o[4];
-        const size_t in0 = (r * a.S + (size_t)so * a.pool) * a.N + n4;
+        const size_t in0 = (size_t)rs * a.pool * a.N + n4;           // r * S + so * pool = (r * So + so) * pool
         const float4 y0 = *reinterpret_cast<const float4*>(a.y + in0);
         const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
         const float y0s[4] = {y0.x, y0.y, y0.z, y0.w};
-        const size_t oidx = (r * So + so) * a.N + n4;
+        const size_t oidx = (size_t)i * 4;                           // (r * So + so) * N + n4
         if (a.pool == 2) {
             const float4 y1 = *reinterpret_cast<const float4*>(a.y + in0 + a.N);
             const float y1s[4] = {y1.x, y1.y, y1.z, y1.w};
@@ -205,9 +206,7 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     }
     if (active)
         for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
-            const size_t r = row / So;
-            const int so = (int)(row % So);
-            const size_t in0 = (r * a.S + (size_t)so * a.pool) * a.N + n4;
+            const size_t in0 = row * a.pool * a.N + n4;             // (r * S + so * pool) = row * pool: no division
             const size_t oidx = row * a.N + n4;
             float g[4];
             if (a.dout_f32) {
@@ -597,6 +596,7 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
                 thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
                 thresh_of(drop2_p), seed2, drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f, seed_epoch};
     const size_t total = (size_t)R * (S / pool) * (N / 4);
+    MM_REQUIRE(total < (1ull << 31), "bn_act_fwd: %zu vectors (32-bit indices)", total);
     if (act == MM_ACT_GELU && pool == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 1>), dim3(grid_for(total)), dim3(256), 0, st, a);
     else if (act == MM_ACT_GELU && pool == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 2>), dim3(grid_for(total)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<>), dim3(grid_for(total)), dim3(256), 0, st, a);
