@@ -456,6 +456,7 @@ template <int BM, int BN, int WM, int WN, int KCT>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     const unsigned m = epi_mask(a.e);
     if (getenv("MM_EPI_LOG")) fprintf(stderr, "EPI %d %d %d mask %06x K=%d N=%d taps=%d\n", BM, BN, KCT, m, a.Cin, a.Cout, a.taps);
+    if (getenv("MM_EPI_GENERIC")) return launch_fwd_feat<BM, BN, WM, WN, KCT, EF_ANY>(a, st);      // tests: generic vs compiled-in epilogues
 #define EPI_CASE(mask) case mask: return launch_fwd_feat<BM, BN, WM, WN, KCT, mask, LT>(a, st);
     if constexpr (BM == 64 && BN == 128 && KCT == 128) {
         constexpr int LT = 1;                 // the Linear layers: one tap

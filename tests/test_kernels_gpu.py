@@ -331,6 +331,52 @@ def test_linear_with_fused_mean_over_time_and_pooled_head():
     assert torch.equal(ref_mask.view(B, L, D) != 0, kept | (dx == 0))
 
 
+def test_compiled_in_epilogues_equal_the_generic_one_bit_for_bit(monkeypatch):
+    """csrc/igemm1d.hip compiles the conv1d / Linear epilogue once per feature combination of the training step
+    (launch_fwd's EPI_CASE table) besides the generic run-time form.  Every combination reachable through
+    mm_conv1d_fwd at a shape that selects its tile is run both ways (MM_EPI_GENERIC=1 forces the generic kernel)
+    and must agree bit for bit - outputs, pre-activation copy, BatchNorm sums."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(5)
+    M = 16384
+
+    def run(K, N, taps, **kw):
+        B, T = (32, 512) if taps > 1 else (1, M)
+        x = _bf(torch.randn(B, T, K, generator=g)).cuda().to(torch.bfloat16)
+        w = _bf(torch.randn(N, K, taps, generator=g) / math.sqrt(K * taps))
+        wf, _ = _prep_w(hip, w, K)
+        bias = torch.randn(N, generator=g).cuda()
+        res = torch.randn(B, T, N, generator=g).cuda() if kw.get("res") else None
+        gz = _bf(torch.randn(B, T, N, generator=g)).cuda().to(torch.bfloat16) if kw.get("gradz") else None
+        outs = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("MM_EPI_GENERIC", "1")
+            else:
+                monkeypatch.delenv("MM_EPI_GENERIC", raising=False)
+            of = torch.full((B, T, N), float("nan"), device="cuda") if kw.get("f32") else None
+            ob = None if kw.get("f32") else torch.full((B, T, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            op = torch.full((B, T, N), float("nan"), dtype=torch.bfloat16, device="cuda") if kw.get("pre") else None
+            st = torch.zeros(32, 2, N, device="cuda") if kw.get("stats") else None
+            hip.call("mm_conv1d_fwd", x, wf, B, T, K, N, taps, taps // 2, None, None if kw.get("nobias") else bias,
+                     1 if kw.get("gelu") else 0, res, None, 1, st, of, ob, op, kw.get("p", 0.0), 17, None, gz, 1 if gz is not None else 0)
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (of, ob, op, st) if t is not None])
+        monkeypatch.delenv("MM_EPI_GENERIC", raising=False)
+        for a_, b_ in zip(*outs):
+            if a_.dtype == torch.float32 and a_.shape[0] == 32 and a_.dim() == 3 and a_.shape[1] == 2:
+                torch.testing.assert_close(a_.sum(0), b_.sum(0), rtol=1e-5, atol=1e-3)      # sums: atomic order differs run to run
+            else:
+                assert torch.equal(a_, b_)
+
+    run(128, 384, 1)                                        # QKV projection
+    run(128, 512, 1, gelu=True, p=0.1, pre=True)            # FFN-1 forward
+    run(128, 512, 1, nobias=True, p=0.1, gradz=True)        # FFN-2 data gradient
+    run(128, 128, 1, nobias=True)                           # plain data gradient (32-row tile)
+    run(64, 64, 7, f32=True, stats=True)                    # conv block forward
+    run(128, 64, 5, nobias=True)                            # conv data gradient
+
+
 @pytest.mark.parametrize("M,K,p", [(512, 128, 0.0), (96, 512, 0.2)])
 def test_linear_with_fused_next_layernorm(M, K, p):
     """mm_linear_fwd_ln == mm_conv1d_fwd (same rows, bit for bit, same dropout mask) followed by
