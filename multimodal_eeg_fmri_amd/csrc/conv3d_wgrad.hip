@@ -36,7 +36,7 @@ namespace {
 
 constexpr int HB = 10;             // halo edge of an 8-wide face
 constexpr int W3_ROWB = 96;        // LDS row stride: 64 B of data (32 channels) + 32 B of padding
-constexpr int W3_ST = 4;           // stages of the LDS ring
+constexpr int W3_ST = 3;           // stages of the LDS ring (96 KB: a 45-52 KB workgroup of the EEG chain still fits on the CU)
 constexpr int W3_LA = 5;           // B fragments of look-ahead (2 LDS reads each + an A pair: 12 of lgkmcnt's 15); the ring of W3_LA + 1
                                    // fragments divides the 18 units of a stage, so the pipeline runs on across stages
 constexpr int W3_YB = 64 * W3_ROWB;                 // 6 144 B: dY face image = 6 DMA instructions
