@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int DH = 32;
-constexpr int KCH = 256;                 // keys staged per chunk
+constexpr int KCH = 128;                 // keys staged per chunk
 constexpr int KS = DH + 8;               // K row stride (elements): 80 B
 
 constexpr int VR = DH + 16;              // row stride (elements) of a row-major tile read through ds_read_b64_tr_b16: 96 B,
