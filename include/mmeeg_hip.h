@@ -17,13 +17,15 @@
  *     -3 unsupported shape); mm_last_error() gives the thread-local message;
  *   - `void*` tensors are bf16, `float*` fp32; channels-last layouts:
  *     1-D activations [B][T][C], tokens [M][D], volumes [B][D][H][W][C];
- *   - per-channel accumulators written by many workgroups (`stats`, `sums_out`, `dbias`,
- *     dgamma/dbeta scratch, wgrad workspaces) are REPLICATED: [32][...] zeroed buffers;
- *     a workgroup adds into replica blockIdx % 32 (same-address fp32 atomics from
- *     hundreds of workgroups serialise in L2).  mm_bn_finalize / mm_wgrad_scatter /
- *     mm_transpose_add sum the replicas themselves; everything else goes through
- *     mm_reduce_replicas.  The `sums` INPUT of the *_bwd_apply entry points is the
- *     compact [2][N] result;
+ *   - results are BIT-REPRODUCIBLE: no floating-point atomics anywhere.  Per-channel accumulators
+ *     written by many workgroups (`stats`, `sums_out`, `dbias`, dgamma/dbeta scratch, `tapsum`, ...) are
+ *     ACCUMULATOR WORKSPACES: the caller allocates and ZEROES 32 x n fp32-sized elements (written
+ *     "[32][...]" below) and hands them to the consumer untouched; their content is opaque - 16 replicas
+ *     of n 64-bit fixed-point sums (integer atomics are order-free; a workgroup adds rint(v * 2^k) into
+ *     replica blockIdx % 16; k = 28 for activation statistics, 40 for gradient sums: csrc/common.h).
+ *     mm_bn_finalize, the *_bwd_apply passes, mm_conv3d_l1_bwd and mm_transpose_add read them directly;
+ *     everything else goes through mm_acc_reduce / mm_reduce_many (-> fp32).  Weight gradients use
+ *     per-workgroup SLOTS (one writer per element) summed in slot order by mm_wgrad_scatter;
  *   - activation codes: 0 none, 1 GELU(erf), 2 ReLU, 3 tanh, 4 sigmoid;
  *   - dropout: keep iff hash(seed, element index) >= p * 2^32, scaled 1/(1-p);
  *     the backward entry points recompute the same mask from (p, seed).
@@ -74,11 +76,10 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
 /* dW[n][c][tap] (fp32, strides sn/sc/stap in elements) += sum_{b,t} dY[b,t,n]*X[b,t+tap-pad,c];
  * optional dbias[n] += sum dY.  Replaces the weight/bias gradients autograd
  * derives for the layers above (loss.backward(), run_training_lite.py:486).
- * slot_mode = 0: fp32 atomics into replica (workgroup % nrep) of dw.
- * slot_mode = 1: dw is a workspace of nrep >= mm_conv1d_wgrad_slots(...) slots of rep_stride floats;
+ * slot_mode must be 1 (0, fp32 atomics into replicas, is gone: -1): dw is a workspace of nrep >= mm_conv1d_wgrad_slots(...) slots of rep_stride floats;
  * workgroup row-chunk x stores (no atomics, no zeroing needed) its partial dW into slot x; the caller
- * sums the slots (mm_wgrad_scatter / mm_scatter_many with nrep = slots).  A launch's 10^6 same-tile
- * atomics were the whole cost of the Linear weight gradients. */
+ * sums the slots (mm_wgrad_scatter / mm_scatter_many with nrep = slots).  dbias (nullable) is an accumulator
+ * workspace [32][Cout]. */
 int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int B, int T, int Cin,
                     int Cout, int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap,
                     int nrep, int64_t rep_stride, int slot_mode, hipStream_t stream);
@@ -91,9 +92,8 @@ int mm_conv1d_wgrad_many(const void* desc_host, int n, hipStream_t stream);
 /* slot count of one problem of such a grouped launch (fewer, longer workgroups per problem than a stand-alone
  * mm_conv1d_wgrad: the group supplies the parallelism) */
 int mm_conv1d_wgrad_many_slots(int B, int T, int Cin, int Cout, int* slots_host, hipStream_t stream);
-/* dw[n][c][tap] += ws[n][tap][c]: conv weight gradients are accumulated by the
- * wgrad kernels in a channel-contiguous workspace (contiguous fp32 atomics run
- * ~17x faster than strided ones on MI355X) and moved to the parameter layout once. */
+/* dw[n][c][tap] += sum_slot ws[slot][n][tap][c] (nrep = slots, summed in slot order): the wgrad kernels write
+ * channel-contiguous slots; this moves the sum to the parameter layout once. */
 int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, int nrep,
                      hipStream_t stream);
 /* PositionalEncoding.forward as a stand-alone op (enhanced_models_v4.py:44-55 =
@@ -113,11 +113,16 @@ int mm_prep_many(const void* desc_host, int ndesc, hipStream_t stream);
 /* mm_wgrad_scatter for ndesc workspaces in one launch per 64 descriptors; desc_host = HOST array of
  * {const float* ws; float* dw; int32 Cout, Cin, taps, Cinp, nrep, 0} (40 bytes each) */
 int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t stream);
-/* ndesc independent replica reductions in one launch per 64 descriptors; desc_host =
- * HOST array of {const float* src; float* dst; int64 K, nrep, rep_stride} (40 bytes
- * each), copied into the kernel arguments (capturable in a hipGraph) */
+/* ndesc independent reductions into parameter gradients in one launch per 64 descriptors; desc_host =
+ * HOST array of {const void* src; float* dst; int64 K, nrep, rep_stride} (40 bytes each), copied into the
+ * kernel arguments (capturable in a hipGraph).  nrep = 16: src = a gradient accumulator workspace (8-byte
+ * aligned; element e of it is at byte offset 8 e; rep_stride in 64-bit elements), dst[k] += its sum in fp32;
+ * nrep = 1: src = compact fp32 vector, dst[k] += src[k]. */
 int mm_reduce_many(const void* desc_host, int ndesc, hipStream_t stream);
-/* dst[k] += sum_rep src[rep * rep_stride + k],  k < K */
+/* dst[k] += fp32(sum over the 16 replicas of acc[rep * rep_stride + k]),  k < K: gradient accumulator workspace
+ * (64-bit elements: offset e is byte offset 8 e) -> fp32 */
+int mm_acc_reduce(const float* acc, float* dst, int K, int64_t rep_stride, hipStream_t stream);
+/* fp32: dst[k] += sum_rep src[rep * rep_stride + k],  k < K  (replicas summed in order) */
 int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t rep_stride, hipStream_t stream);
 
 /* ---- BatchNorm / activation / pool ----------------------------------------
@@ -136,8 +141,8 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
                   void* out_bf16, float* out_f32, int R, int S, int N, int act, int pool,
                   int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
                   const uint32_t* seed_epoch, hipStream_t stream);
-/* drop2 = the PositionalEncoding dropout applied AFTER the table add (:55)  * mm_bn_act_bwd_apply: sums = [sums_nrep][2][N] as written by mm_bn_act_bwd_reduce (sums_nrep = 32:
- * the kernel adds the replicas up itself) or an already compacted [2][N] (sums_nrep = 1). */
+/* drop2 = the PositionalEncoding dropout applied AFTER the table add (:55)  * mm_bn_act_bwd_apply: sums = the accumulator workspace [32][2][N] as written by mm_bn_act_bwd_reduce
+ * (sums_nrep = 32: the kernel adds the replicas up itself) or a compact fp32 [2][N] (sums_nrep = 1). */
 int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16,
                          const float* dout_f32, float* sums_out, int R, int S, int N, int act,
                          int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p,
@@ -150,7 +155,7 @@ int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16
 /* ---- LayerNorm (nn.LayerNorm, enhanced_models_v4.py:80-81; bridge_utils.py:36,42,62) */
 int mm_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* out_bf16,
                      float* out_f32, float* stat, int M, int D, float eps, hipStream_t stream);
-/* dgb_repl = zeroed scratch [32][2][D]: replicated {dgamma, dbeta} partial sums;
+/* dgb_repl = zeroed accumulator workspace [32][2][D]: {dgamma, dbeta} partial sums;
  * dx_bf16 (optional) = bf16(dx * dropout_mask(drop_p, seed)): the masked GEMM operand of the
  * residual branch feeding this LayerNorm's input */
 int mm_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* stat,
@@ -197,7 +202,7 @@ int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out,
 /* (B,1,D,H,W) fp32 -> [B][D][H][W][Cp] bf16, channel 0 = voxel value, rest 0 */
 int mm_pack_volume_bf16(const float* x, void* y, int64_t nvox, int Cp, hipStream_t stream);
 /* Y = X (*) W + shift; W image [Cout][27][Cin] (mm_prep_conv_weight with k=27);
- * optional stats[32][2][Cout] replicated (sum, sumsq of the fp32 results) for training BatchNorm; fp32 and/or
+ * optional accumulator workspace stats[32][2][Cout] (sum, sumsq of the fp32 results) for training BatchNorm; fp32 and/or
  * bf16 output.  Generic path: LDS-staged (TD+2)x10x10 halo block -> 27 tap-shifted A fragments -> bf16 MFMA.
  * Cin = 32, Cout = 64 with bf16 output only and >= 64 tiles of 4x8x8 voxels (layer 2 of the voxel encoder)
  * runs the weight-resident persistent kernel of csrc/conv3d_wres.hip. */
@@ -237,7 +242,7 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
 /* Training backward of the same layer in ONE recompute pass (replaces modes 2 + 3): BatchNorm's
  * backward is linear in the two sums S1 = sum dz, S2 = sum dz * xhat, so
  *   dW = scale * (A1 - (S1/M) * T - (S2/M) * A3),  A1 = x^T dz, A3 = x^T xhat, T[tap] = sum_v x[v + tap].
- * Zeroed fp32 workspaces (32 replicas each): sums_out [32][2][32] (also the BatchNorm parameter
+ * Zeroed accumulator workspaces: sums_out [32][2][32] (also the BatchNorm parameter
  * gradients: dbeta = S1, dgamma = S2), a1 / a3 [32][27][32], tapsum [32][32].  dw (PyTorch layout
  * [32][1][3][3][3]) and dbias are ADDED to (dbias only when train == 0; it is identically 0 otherwise).
  * T depends on the input volume alone: mm_conv3d_l1_tapsum may fill it earlier (e.g. during the forward pass,
@@ -247,7 +252,7 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
                      float* sums_out, float* a1, float* a3, float* tapsum, int tapsum_ready, float* dw,
                      float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
                      const uint32_t* seed_epoch, hipStream_t stream);
-/* dst[c][r] += sum_rep src[rep][r][c] */
+/* dst[c][r] += fp32(sum over replicas of src[rep][r][c]); src = gradient accumulator workspace [32][R][C], nrep = 16 */
 int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t stream);
 
 /* ---- small fp32 row kernels (projection bridge, tabular fMRI/conn MLPs) ------
@@ -264,13 +269,15 @@ int mm_small_linear_bwd(const float* dy, const float* x, const float* W, float* 
 int mm_act_f32(const float* z, float* y, int64_t n, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 int mm_act_bwd_f32(const float* g, const float* z, float* out, int64_t n, int act, float drop_p,
                    uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
-/* stats[0][n] = sum_b x, stats[1][n] = sum_b x^2 (BatchNorm1d over (B, N)) */
+/* sum_b x and sum_b x^2 (BatchNorm1d over (B, N)) into replica 0 of the ZEROED statistics accumulator workspace
+ * stats [32][2][N] (the input of mm_bn_finalize) */
 int mm_colstats(const float* x, float* stats, int B, int N, hipStream_t stream);
 /* Both projection heads of the contrastive bridge (bridge_utils.py:34-45 eeg_proj / fmri_proj:
  * Linear(K -> N) -> LayerNorm -> GELU -> Dropout) followed by F.normalize, one launch each way.
  * x_* fp32 [B][K_*]; W_* [N][K_*]; z packed [B][2N] = [ze | zf]; nrm [2][B].  z1 / hn / stat
  * ([2][B][N], [2][B][N], [2][B][2]; all three or none) are what the backward needs.  The
- * backward ADDS parameter gradients with fp32 atomics (any of them may be null) and writes dx. */
+ * backward ADDS parameter gradients (any of them may be null; one writer per element, rows summed in order) and
+ * writes dx. */
 int mm_proj_heads_fwd(const float* x_e, const float* W_e, const float* b_e, const float* g_e, const float* be_e,
                       int K_e, const float* x_f, const float* W_f, const float* b_f, const float* g_f,
                       const float* be_f, int K_f, float* z1, float* hn, float* stat, float* z, float* nrm, int B,
@@ -326,7 +333,7 @@ int mm_attn_1x2(const float* proj_e, const float* proj_f, float* ctx, float* att
 int mm_attn_1x2_train(const float* proj_e, const float* proj_f, const float* dctx, float* ctx, float* attw,
                       float* dproj_e, float* dproj_f, int B, int E, int nhead, float drop_p, uint32_t seed,
                       const uint32_t* seed_epoch, int backward, hipStream_t stream);
-/* backward of mm_learned_fusion: df_m, ddyn, and (atomically, over rows) dlogits[M], dtemp[1] */
+/* backward of mm_learned_fusion: df_m, ddyn, and (ADDED; rows summed in a fixed order) dlogits[M], dtemp[1] */
 int mm_learned_fusion_bwd(const float* f0, const float* f1, const float* f2, const float* dyn,
                           const float* logits, const float* temperature, const float* dfused, float* df0,
                           float* df1, float* df2, float* ddyn, float* dlogits, float* dtemp, int B, int H,
@@ -366,8 +373,9 @@ int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_
 /* Encoder tail (enhanced_models_v4.py:161-167, 186-191: mean over time -> output_proj = Linear -> GELU ->
  * Dropout).  mm_linear_fwd_meanpool is the last transformer block's linear2 (+ dropout + residual, fp32 rows
  * out_f32 (M, 128)) that also accumulates the mean over each group of rows_per_group rows (one EEG epoch's
- * tokens) into the ZEROED pool_out (M / rows_per_group, 128).  mm_pooled_head_fwd applies the head to the
- * pooled rows in fp32 (W is the nn.Linear weight (N, D)); z_pre_bf16 / pooled_bf16 (nullable) are what the
+ * tokens) into the ZEROED pool_out, an accumulator of (M / rows_per_group) x 128 64-bit elements (ONE replica:
+ * 2 x that many floats).  mm_pooled_head_fwd applies the head to the pooled rows - fp32 `pooled`, or that
+ * accumulator as `pooled_acc` (exactly one non-null) - in fp32 (W is the nn.Linear weight (N, D)); z_pre_bf16 / pooled_bf16 (nullable) are what the
  * backward and the weight-gradient GEMM need.  mm_pooled_head_bwd: dz = dout * dropout mask * act'(z) (bf16 copy
  * dz_bf16 for the weight gradient), d pooled = dz W, and dx[b][l][:] = d pooled / L for every token; dx_bf16
  * (nullable) = the same rows times the consumer's dropout mask (emit_drop_p, emit_seed; element index as in
@@ -382,7 +390,7 @@ int mm_linear_fwd_meanpool(const void* x, const void* w, int M, int K, const flo
 int mm_linear_fwd_ln(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
                      float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* ln_gamma,
                      const float* ln_beta, float ln_eps, void* ln_out_bf16, float* ln_stat, hipStream_t stream);
-int mm_pooled_head_fwd(const float* pooled, const float* W, const float* bias, float* out, void* z_pre_bf16,
+int mm_pooled_head_fwd(const float* pooled, const float* pooled_acc, const float* W, const float* bias, float* out, void* z_pre_bf16,
                        void* pooled_bf16, int B, int D, int N, int act, float drop_p, uint32_t seed,
                        const uint32_t* seed_epoch, hipStream_t stream);
 int mm_pooled_head_bwd(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* dx,

@@ -1,7 +1,8 @@
 """Backward passes of the HIP path, exposed to torch.autograd as a handful of
 coarse ``Function``s (one per encoder / block / head) so the tape stays short.
 
-Parameter gradients are produced by the kernels as fp32 atomics.  When a
+Parameter gradients are produced without floating-point atomics (per-workgroup slots summed in
+order, or fixed-point accumulator workspaces: csrc/common.h), so a step is bit-reproducible.  When a
 parameter carries a gradient *sink* (``param._mm_grad``, a view into the
 trainer's flat gradient bucket) the kernels accumulate straight into it and
 autograd receives ``None``; otherwise a fresh tensor is returned to autograd.
@@ -14,21 +15,28 @@ import torch
 
 from . import _hip
 from . import ops
-from .ops import ACT, REPL, WREP, _BF, _F32, _empty, _zeros
+from .ops import ACT, AREPL, REPL, WREP, _BF, _F32, _empty, _zeros
 
 
 _BAG = {"cur": None}
 
 
 def _reduce_into(dst, src, K, stride, offset=0, nrep=REPL):
-    """dst[k] += sum_rep src[rep*stride + offset + k]   (deferred to GradBag.flush when a bag is active)"""
+    """dst[k] += sum_rep src[rep*stride + offset + k]   (deferred to GradBag.flush when a bag is active).
+    nrep = REPL: ``src`` is a gradient accumulator workspace (zeroed (REPL, ...) fp32-sized buffer holding AREPL
+    replicas of 64-bit fixed-point sums; ``stride`` / ``offset`` count its 64-bit elements); nrep = 1: compact fp32."""
     if dst is None:
         return
+    if nrep not in (1, REPL):
+        raise ValueError("_reduce_into: nrep is 1 (fp32 vector) or REPL (accumulator workspace)")
     bag = _BAG["cur"]
+    ptr = src.data_ptr() + (8 if nrep == REPL else 4) * offset
     if bag is not None:
-        bag.defer(src.data_ptr() + 4 * offset, dst, K, nrep, stride, keep=src)
+        bag.defer(ptr, dst, K, AREPL if nrep == REPL else 1, stride, keep=src)
+    elif nrep == REPL:
+        _hip.call("mm_acc_reduce", ptr, dst, K, stride)
     else:
-        _hip.call("mm_reduce_replicas", src.data_ptr() + 4 * offset, dst, K, nrep, stride)
+        _hip.call("mm_reduce_replicas", ptr, dst, K, 1, stride)
 
 
 def _scatter_into(dw, ws, cout, cin, taps, cinp, nrep):
@@ -104,9 +112,9 @@ def _ln_param_grads(bag, ln, dgb, D):
 
 
 def _compact(rep_buf, K):
-    """[REPL][K] replicated accumulator -> compact [K] (one parallel reduction)"""
+    """gradient accumulator workspace of K values per replica -> compact fp32 [K] (one parallel reduction)"""
     out = _zeros((K,), rep_buf)
-    _hip.call("mm_reduce_replicas", rep_buf, out, K, REPL, K)
+    _hip.call("mm_acc_reduce", rep_buf, out, K, K)
     return out
 
 

@@ -110,12 +110,42 @@ __device__ __forceinline__ uint32_t mm_eff_seed(uint32_t base, const uint32_t* e
     return epoch ? base ^ (epoch[0] * 0x85EBCA6Bu + 0xC2B2AE35u) : base;
 }
 
-// Per-channel reductions (BN statistics, dgamma/dbeta, dbias, weight-gradient
-// partials) are accumulated with fp32 atomics.  Hundreds of workgroups adding to
-// the SAME address serialise in L2 (~25 ns each), so every such accumulator is
-// replicated MM_REPL times; a workgroup adds into replica (blockIdx.x % MM_REPL)
-// and the consumer sums the replicas.
+// Per-channel reductions (BN statistics, dgamma/dbeta, dbias) are accumulated across workgroups with
+// 64-bit INTEGER atomics on fixed-point values: integer addition is associative, so the sum does not
+// depend on the order the workgroups arrive in and a training step is bit-reproducible (fp32 atomics
+// are not).  A contribution v (already a block-level partial sum, formed in a fixed order) is added as
+// rint(v * 2^K); the consumer converts sum * 2^-K back to fp32 once.
+//   K = MM_ACC_STAT (28) for sums of activations / their squares: resolution 3.7e-9, range +-3.4e10
+//   K = MM_ACC_GRAD (40) for sums of gradients:                     resolution 9.1e-13, range +-8.4e6
+// Hundreds of workgroups adding to the SAME address serialise in L2 (~25 ns each), so every such
+// accumulator is replicated: callers allocate (and zero) MM_REPL fp32-sized copies = MM_ACC_REPL
+// 64-bit ones; a workgroup adds into replica (blockIdx.x % MM_ACC_REPL) and the consumer sums the
+// replicas (as integers: also order-free).  The C ABI passes these workspaces as `float*` of
+// MM_REPL * n elements; their content is opaque to the caller (zero it, hand it to the consumer).
 #define MM_REPL 32
+#define MM_ACC_REPL 16
+#define MM_ACC_STAT 28
+#define MM_ACC_GRAD 40
+typedef long long mm_acc_t;
+#ifdef __HIPCC__
+template <int K> __device__ __forceinline__ void acc_add(mm_acc_t* p, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * (float)(1ull << K)));
+}
+template <int K> __device__ __forceinline__ float acc_val(mm_acc_t s) { return (float)s * (1.0f / (float)(1ull << K)); }
+// replica r of an accumulator workspace of n values per replica
+__device__ __forceinline__ mm_acc_t* acc_rep(float* ws, int r, size_t n) { return reinterpret_cast<mm_acc_t*>(ws) + (size_t)r * n; }
+// sum over the MM_ACC_REPL replicas of element i (all loads in flight at once)
+__device__ __forceinline__ mm_acc_t acc_sum(const float* ws, size_t n, size_t i) {
+    const mm_acc_t* p = reinterpret_cast<const mm_acc_t*>(ws) + i;
+    mm_acc_t v[MM_ACC_REPL];
+#pragma unroll
+    for (int r = 0; r < MM_ACC_REPL; ++r) v[r] = p[(size_t)r * n];
+    mm_acc_t s = 0;
+#pragma unroll
+    for (int r = 0; r < MM_ACC_REPL; ++r) s += v[r];
+    return s;
+}
+#endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

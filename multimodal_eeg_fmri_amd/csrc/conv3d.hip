@@ -199,14 +199,14 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(Conv3dArgs a) {
     }
     if (a.stats) {
         __syncthreads();
-        float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * a.Cout;
+        mm_acc_t* rep = acc_rep(a.stats, blockIdx.x % MM_ACC_REPL, 2 * (size_t)a.Cout);
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, col = i % BN;
             if (n0 + col < a.Cout) {
                 float t = 0.f;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) t += sstat[(w * 2 + which) * BN + col];
-                atomicAdd(&rep[which * a.Cout + n0 + col], t);
+                acc_add<MM_ACC_STAT>(&rep[which * a.Cout + n0 + col], t);
             }
         }
     }
@@ -405,11 +405,11 @@ __global__ __launch_bounds__(256) void pool3_bwd_reduce_kernel(Pool3Args a) {
         for (int c = 0; c < 8; ++c) { dst[c] = s0[c]; dst[a.N + c] = s1[c]; }
     }
     __syncthreads();
-    float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
+    mm_acc_t* rep = acc_rep(a.sums_out, blockIdx.x % MM_ACC_REPL, 2 * (size_t)a.N);
     for (int i = threadIdx.x; i < 2 * a.N; i += 256) {
         float s = 0.f;
         for (int r = 0; r < rows_per_blk; ++r) s += part[r * 2 * a.N + i];
-        atomicAdd(&rep[i], s);
+        acc_add<MM_ACC_GRAD>(&rep[i], s);
     }
 }
 

@@ -253,17 +253,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
         __syncthreads();
         if (lh == 0) red[wave][lr] = acc1;
         __syncthreads();
-        const int rep = blockIdx.x % MM_REPL;
+        // MODE 0: forward statistics (activation scale); MODE >= 2: sums of gradients
+        constexpr int KS = MODE == 0 ? MM_ACC_STAT : MM_ACC_GRAD;
+        const int rep = blockIdx.x % MM_ACC_REPL;
         if (tid < 32) {
             const float s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-            if (MODE == 3) { if (a.dbias) atomicAdd(&a.dbias[rep * 32 + tid], s); }
-            else atomicAdd(&a.stats[rep * 64 + tid], s);
+            if (MODE == 3) { if (a.dbias) acc_add<MM_ACC_GRAD>(acc_rep(a.dbias, rep, 32) + tid, s); }
+            else acc_add<KS>(acc_rep(a.stats, rep, 64) + tid, s);
         }
         if (MODE != 3) {
             __syncthreads();
             if (lh == 0) red[wave][lr] = acc2;
             __syncthreads();
-            if (tid < 32) atomicAdd(&a.stats[rep * 64 + 32 + tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+            if (tid < 32) acc_add<KS>(acc_rep(a.stats, rep, 64) + 32 + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
         }
     }
     if (MODE == 3 || MODE == 4) {
@@ -276,9 +278,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                 if (tap < 27) wred[wave][tap][lr] = pass ? dwacc3[r] : dwacc[r];
             }
             __syncthreads();
-            float* dwr = (pass ? a.dw3 : a.dw) + (size_t)(blockIdx.x % MM_REPL) * 27 * 32;
+            mm_acc_t* dwr = acc_rep(pass ? a.dw3 : a.dw, blockIdx.x % MM_ACC_REPL, 27 * 32);
             for (int i = tid; i < 27 * 32; i += 256)
-                atomicAdd(&dwr[i], ((&wred[0][0][0])[i] + (&wred[1][0][0])[i]) + ((&wred[2][0][0])[i] + (&wred[3][0][0])[i]));
+                acc_add<MM_ACC_GRAD>(&dwr[i], ((&wred[0][0][0])[i] + (&wred[1][0][0])[i]) + ((&wred[2][0][0])[i] + (&wred[3][0][0])[i]));
         }
     }
 }
@@ -312,49 +314,51 @@ __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict_
             }
         }
     }
-    __shared__ float red[32];
-    if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float red[4][32];                       // one row per wave, summed in wave order: no LDS atomics
 #pragma unroll
     for (int t = 0; t < 27; ++t) {
         const float v = wave_sum(s[t]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&red[t], v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 27) atomicAdd(&out[(blockIdx.x % MM_REPL) * 32 + threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x < 27)
+        acc_add<MM_ACC_STAT>(acc_rep(out, blockIdx.x % MM_ACC_REPL, 32) + threadIdx.x,
+                             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
-// dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1   (all inputs replicated x MM_REPL)
+// dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1   (all inputs: fixed-point accumulators x MM_ACC_REPL)
 __global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __restrict__ a3, const float* __restrict__ tapsum,
                                   const float* __restrict__ sums, const float* __restrict__ out4, float* __restrict__ dw,
                                   float* __restrict__ dbias, float inv_count, int train) {
-    // one output per 32 lanes, one replica per lane: a single load round trip + shuffle sums
-    // (the serial 32-replica loop was five dependent-latency chains: 11 us on 4 workgroups)
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, r = threadIdx.x & 31;
+    // one output per 16 lanes, one replica per lane: a single load round trip + (integer) shuffle sums
+    // (the serial replica loop was five dependent-latency chains: 11 us on 4 workgroups)
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, r = threadIdx.x & 15;
     if (i >= 32 * 27) return;
     const int n = i / 27, tap = i % 27;
-    float A1 = a1[(size_t)r * 864 + tap * 32 + n], A3 = a3[(size_t)r * 864 + tap * 32 + n];
-    float St = tapsum[r * 32 + tap], s0 = sums[r * 64 + n], s1 = sums[r * 64 + 32 + n];
+    const mm_acc_t *q1 = reinterpret_cast<const mm_acc_t*>(a1), *q3 = reinterpret_cast<const mm_acc_t*>(a3),
+                   *qt = reinterpret_cast<const mm_acc_t*>(tapsum), *qs = reinterpret_cast<const mm_acc_t*>(sums);
+    mm_acc_t iA1 = q1[(size_t)r * 864 + tap * 32 + n], iA3 = q3[(size_t)r * 864 + tap * 32 + n];
+    mm_acc_t iSt = qt[r * 32 + tap], is0 = qs[r * 64 + n], is1 = qs[r * 64 + 32 + n];
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-        A1 += __shfl_xor(A1, o, 64); A3 += __shfl_xor(A3, o, 64); St += __shfl_xor(St, o, 64);
-        s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64);
+    for (int o = 8; o > 0; o >>= 1) {
+        iA1 += __shfl_xor(iA1, o, 64); iA3 += __shfl_xor(iA3, o, 64); iSt += __shfl_xor(iSt, o, 64);
+        is0 += __shfl_xor(is0, o, 64); is1 += __shfl_xor(is1, o, 64);
     }
     if (r) return;
+    const float A1 = acc_val<MM_ACC_GRAD>(iA1), A3 = acc_val<MM_ACC_GRAD>(iA3), St = acc_val<MM_ACC_STAT>(iSt);
+    const float s0 = acc_val<MM_ACC_GRAD>(is0), s1 = acc_val<MM_ACC_GRAD>(is1);
     const float sc = out4[n];
     const float c0 = train ? s0 * inv_count : 0.f, c1 = train ? s1 * inv_count : 0.f;
     dw[i] += sc * (A1 - c0 * St - c1 * A3);
     if (tap == 0 && dbias && !train) dbias[n] += sc * s0;      // train: sum dy == 0 identically
 }
 
-// dst[c][r] += sum_rep src[rep][r][c]
-__global__ void transpose_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, int nrep) {
+// dst[c][r] += sum_rep acc[rep][r][c]   (acc: MM_ACC_REPL fixed-point gradient accumulators)
+__global__ void transpose_add_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < R * C) {
         const int r = i / C, c = i % C;
-        float s = 0.f;
-        for (int k = 0; k < nrep; ++k) s += src[(size_t)k * R * C + i];
-        dst[(size_t)c * R + r] += s;
+        dst[(size_t)c * R + r] += acc_val<MM_ACC_GRAD>(acc_sum(src, (size_t)R * C, i));
     }
 }
 
@@ -419,14 +423,15 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
         hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0,
                            st, x, tapsum, B, D, H, W);
     hipLaunchKernelGGL(conv3d_l1_kernel<4>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 32, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
+    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 16, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
                        dbias, a.inv_count, train);
     return mm_check_launch("conv3d_l1_bwd");
 }
 
 int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t st) {
-    MM_REQUIRE(src && dst && R > 0 && C > 0 && nrep >= 1, "transpose_add: null");
-    hipLaunchKernelGGL(transpose_add_kernel, dim3(ceil_div(R * C, 256)), dim3(256), 0, st, src, dst, R, C, nrep);
+    MM_REQUIRE(src && dst && R > 0 && C > 0, "transpose_add: null");
+    MM_REQUIRE(nrep == MM_ACC_REPL, "transpose_add: src is an accumulator workspace of %d replicas", MM_ACC_REPL);
+    hipLaunchKernelGGL(transpose_add_kernel, dim3(ceil_div(R * C, 256)), dim3(256), 0, st, src, dst, R, C);
     return mm_check_launch("transpose_add");
 }
 

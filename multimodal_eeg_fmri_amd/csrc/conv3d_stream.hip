@@ -314,13 +314,13 @@ __global__ __launch_bounds__(256) void conv3d_stream_kernel(Conv3dArgs a) {
             }
         }
         __syncthreads();
-        float* rep = a.stats + (size_t)((blockIdx.x + blockIdx.y) % MM_REPL) * 2 * COUT;
+        mm_acc_t* rep = acc_rep(a.stats, (blockIdx.x + blockIdx.y) % MM_ACC_REPL, 2 * COUT);
         if (tid < 2 * 32 * NW) {
             const int which = tid / (32 * NW), nl = tid % (32 * NW);           // nl: channel inside the workgroup's NW groups
             float tsum = 0.f;
 #pragma unroll
             for (int k = 0; k < WK; ++k) tsum += sstat[(((nl >> 5) + NW * k) * 2 + which) * 32 + (nl & 31)];
-            atomicAdd(&rep[which * COUT + blockIdx.y * NW * 32 + nl], tsum);
+            acc_add<MM_ACC_STAT>(&rep[which * COUT + blockIdx.y * NW * 32 + nl], tsum);
         }
     }
 }

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
     if (do_bias) {
         bsum += __shfl_xor(bsum, 32, 64);
         const int n = n0 + (lane & 31);
-        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(blockIdx.x % MM_REPL) * a.Cout + n, bsum);
+        if ((lane >> 5) == 0 && n < a.Cout) acc_add<MM_ACC_GRAD>(acc_rep(a.dbias, blockIdx.x % MM_ACC_REPL, a.Cout) + n, bsum);
     }
     // ---- the four K partials: every wave scatters its accumulators into its own [tap][n][c] image in LDS (row stride 36
     // floats), then all 256 threads sum the four images in wave order (fixed) and store 16-byte pieces.  (A wave's
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
     constexpr int PS = 36, IMG = 5 * 32 * PS;
     float* img = reinterpret_cast<float*>(smem);
     const int ec = lane & 31, en = 4 * (lane >> 5);            // register r of this lane: row en + (r & 3) + 8 (r >> 2), column ec
-    float* slot = a.dw + (size_t)(a.slot_mode ? blockIdx.x : blockIdx.x % a.nrep) * a.rep_stride;
-    const bool vec = a.sc == 1 && (a.stap & 3) == 0 && (a.sn & 3) == 0 && c0 + 32 <= a.Cin_real && a.slot_mode &&
+    float* slot = a.dw + (size_t)blockIdx.x * a.rep_stride;
+    const bool vec = a.sc == 1 && (a.stap & 3) == 0 && (a.sn & 3) == 0 && c0 + 32 <= a.Cin_real &&
                      ((size_t)slot & 15) == 0;                                               // (uniform)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -305,11 +305,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
                 const int cc = i & 31, n = (i >> 5) & 31, tt = i >> 10;
                 const float* src = img + (tt * 32 + n) * PS + cc;
                 const float v = ((src[0] + src[IMG]) + src[2 * IMG]) + src[3 * IMG];
-                if (n0 + n < a.Cout && c0 + cc < a.Cin_real) {
-                    float* o = slot + (long)(n0 + n) * a.sn + (long)(c0 + cc) * a.sc + (long)(kd * 9 + t_lo + tt) * a.stap;
-                    if (a.slot_mode) *o = v;
-                    else atomicAdd(o, v);
-                }
+                if (n0 + n < a.Cout && c0 + cc < a.Cin_real)
+                    slot[(long)(n0 + n) * a.sn + (long)(c0 + cc) * a.sc + (long)(kd * 9 + t_lo + tt) * a.stap] = v;
             }
         }
     }
@@ -350,7 +347,7 @@ int mm_conv3d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
                     int Cout, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep, int64_t rep_stride,
                     int slot_mode, hipStream_t st) {
     MM_REQUIRE(dy && x && dw && B > 0, "conv3d_wgrad: null/invalid");
-    MM_REQUIRE(nrep >= 1 && (slot_mode || nrep <= 64), "conv3d_wgrad: nrep");
+    MM_REQUIRE(slot_mode == 1 && nrep >= 1, "conv3d_wgrad: slot_mode must be 1 (the fp32-atomics mode is gone: results are order-free)");
     MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin_real > 0 && Cin_real <= Cin, "conv3d_wgrad: channels");
     const size_t vox = (size_t)B * D * H * W;
     MM_REQUIRE(vox * Cout * 2 < 0x7FFF0000ull && vox * Cin * 2 < 0x7FFF0000ull, "conv3d_wgrad: tensors past 2 GiB (32-bit buffer offsets)");

@@ -406,9 +406,9 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
             }
         }
         __syncthreads();
-        float* rep = a.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * BN;
+        mm_acc_t* rep = acc_rep(a.stats, blockIdx.x % MM_ACC_REPL, 2 * BN);
         if (tid < 2 * BN)
-            atomicAdd(&rep[tid], (sstat[tid] + sstat[2 * BN + tid]) + (sstat[4 * BN + tid] + sstat[6 * BN + tid]));
+            acc_add<MM_ACC_STAT>(&rep[tid], (sstat[tid] + sstat[2 * BN + tid]) + (sstat[4 * BN + tid] + sstat[6 * BN + tid]));
     }
 #undef WR_AB
 #undef WR_PF

@@ -20,8 +20,8 @@ __global__ void bn_finalize_kernel(const float* stats, const float* gamma, const
     if (n == 0 && tracked && mode == 0) tracked[0] += 1;
     float mean, var;
     if (mode == 0) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int r = 0; r < MM_REPL; ++r) { s1 += stats[(size_t)r * 2 * N + n]; s2 += stats[(size_t)r * 2 * N + N + n]; }
+        const float s1 = acc_val<MM_ACC_STAT>(acc_sum(stats, 2 * (size_t)N, n));
+        const float s2 = acc_val<MM_ACC_STAT>(acc_sum(stats, 2 * (size_t)N, (size_t)N + n));
         mean = s1 / count;
         var = fmaxf(s2 / count - mean * mean, 0.f);
         run_mean[n] = (1.f - momentum) * run_mean[n] + momentum * mean;
@@ -183,16 +183,8 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     if (APPLY && a.train) {
         // replica reduction in the prologue: a separate 5 us compaction launch sat between the two passes
         for (int i = threadIdx.x; i < 2 * a.N; i += 256) {
-            float s = 0.f;
-            if (a.sums_nrep == MM_REPL) {              // all 32 loads in flight at once, not a dependent chain
-                float v[MM_REPL];
-#pragma unroll
-                for (int r = 0; r < MM_REPL; ++r) v[r] = a.sums[(size_t)r * 2 * a.N + i];
-#pragma unroll
-                for (int r = 0; r < MM_REPL; ++r) s += v[r];
-            } else {
-                for (int r = 0; r < a.sums_nrep; ++r) s += a.sums[(size_t)r * 2 * a.N + i];
-            }
+            // the accumulator workspace as written by the reduce pass (all replica loads in flight at once), or compact fp32
+            const float s = a.sums_nrep == 1 ? a.sums[i] : acc_val<MM_ACC_GRAD>(acc_sum(a.sums, 2 * (size_t)a.N, i));
             csum[i] = s * a.inv_count;
         }
         __syncthreads();
@@ -266,11 +258,11 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
             *reinterpret_cast<float4*>(dst + a.N) = make_float4(s1[0], s1[1], s1[2], s1[3]);
         }
         __syncthreads();
-        float* rep = a.sums_out + (size_t)(blockIdx.x % MM_REPL) * 2 * a.N;
+        mm_acc_t* rep = acc_rep(a.sums_out, blockIdx.x % MM_ACC_REPL, 2 * (size_t)a.N);
         for (int i = threadIdx.x; i < 2 * a.N; i += 256) {
             float s = 0.f;
             for (int r = 0; r < rows_per_blk; ++r) s += part[r * 2 * a.N + i];
-            atomicAdd(&rep[i], s);
+            acc_add<MM_ACC_GRAD>(&rep[i], s);
         }
     }
 }
@@ -350,21 +342,20 @@ __global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const flo
             if (dx_bf16) dx_bf16[idx] = (bf16)(thresh ? o * dropout_scale(seed, (uint32_t)idx, thresh, inv_keep) : o);
         }
     }
-    __shared__ float red[2][1024];
-    for (int i = threadIdx.x; i < 2 * 1024; i += blockDim.x) (&red[0][0])[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        atomicAdd(&red[0][i * 64 + lane], ag[i]);
-        atomicAdd(&red[1][i * 64 + lane], ab[i]);
-    }
-    __syncthreads();
-    // dgb = replicated [MM_REPL][2][D] scratch (gamma row, beta row)
+    // dgb = accumulator workspace [MM_ACC_REPL][2][D] (gamma row, beta row).  Every wave parks its partials
+    // (plain stores) and the four rows are summed in wave order: no LDS atomics, a fixed summation order.
     if (dgb) {
-        float* rep = dgb + (size_t)(blockIdx.x % MM_REPL) * 2 * D;
-        for (int i = threadIdx.x; i < D; i += blockDim.x) {
-            atomicAdd(&rep[i], red[0][i]);
-            atomicAdd(&rep[D + i], red[1][i]);
+        __shared__ float red[4][2][D];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            red[wave][0][i * 64 + lane] = ag[i];
+            red[wave][1][i * 64 + lane] = ab[i];
+        }
+        __syncthreads();
+        mm_acc_t* rep = acc_rep(dgb, blockIdx.x % MM_ACC_REPL, 2 * D);
+        for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) {
+            const int which = i / D, col = i % D;
+            acc_add<MM_ACC_GRAD>(&rep[i], (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]));
         }
     }
 }
@@ -461,7 +452,7 @@ __global__ void layernorm128_bwd_kernel(const bf16* __restrict__ dy_bf16, const 
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += part[r][threadIdx.x];
-        atomicAdd(&dgb[(size_t)(blockIdx.x % MM_REPL) * 256 + threadIdx.x], s);
+        acc_add<MM_ACC_GRAD>(acc_rep(dgb, blockIdx.x % MM_ACC_REPL, 256) + threadIdx.x, s);
     }
 }
 
@@ -473,7 +464,7 @@ __global__ void colsum_kernel(const bf16* __restrict__ a_bf16, const float* __re
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.f;
         for (int m = m0; m < m1; ++m) s += a_bf16 ? (float)a_bf16[(size_t)m * N + n] : a_f32[(size_t)m * N + n];
-        atomicAdd(&out[(size_t)(blockIdx.x % MM_REPL) * N + n], s);
+        acc_add<MM_ACC_GRAD>(acc_rep(out, blockIdx.x % MM_ACC_REPL, N) + n, s);
     }
 }
 
@@ -608,7 +599,7 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
                          int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
                          const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t st) {
     MM_REQUIRE(y && out4 && (dout_bf16 || dout_f32), "bn_act_bwd: null");
-    MM_REQUIRE(sums_nrep >= 1 && sums_nrep <= 64, "bn_act_bwd: sums_nrep");
+    MM_REQUIRE(sums_nrep == 1 || sums_nrep == MM_REPL, "bn_act_bwd: sums_nrep = 1 (compact fp32) or %d (the reduce pass's workspace)", MM_REPL);
     MM_REQUIRE(N % 4 == 0 && N <= 1024 && (N / 4) <= 256, "bn_act_bwd: N");
     BnBwdArgs a;
     a.y = y; a.scale = out4; a.shift = out4 + N; a.mean = out4 + 2 * N; a.rstd = out4 + 3 * N;

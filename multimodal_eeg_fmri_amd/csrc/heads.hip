@@ -93,7 +93,10 @@ __global__ void colstats_kernel(const float* __restrict__ x, float* __restrict__
     if (n >= N) return;
     float s = 0.f, q = 0.f;
     for (int b = 0; b < B; ++b) { const float v = x[(size_t)b * N + n]; s += v; q += v * v; }
-    stats[n] = s; stats[N + n] = q;
+    // replica 0 of a statistics accumulator workspace (the input of mm_bn_finalize); the other replicas stay zero
+    mm_acc_t* acc = reinterpret_cast<mm_acc_t*>(stats);
+    acc[n] = __float2ll_rn(s * (float)(1ull << MM_ACC_STAT));
+    acc[N + n] = __float2ll_rn(q * (float)(1ull << MM_ACC_STAT));
 }
 
 // z = h / max(||h||, eps); one wave per row
@@ -202,43 +205,102 @@ __global__ __launch_bounds__(256) void proj_heads_fwd_kernel(HeadsArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void proj_heads_bwd_kernel(HeadsArgs a) {
-    __shared__ float xs[HEAD_MAXK], d1[HEAD_MAXN], red[4];
-    const int b = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+// Backward of both heads, bit-reproducible: no gradient element has more than one writer.  grid = (B, 2 heads),
+// 16 waves.  EVERY block recomputes d z1 of all rows (a wave per row: a few hundred flops each, the same bits in
+// every block), then block j writes dx of row j and the j-th slice of dW, each element summed over the rows in
+// order; block 0 adds the bias and LayerNorm-parameter gradients (per-wave partials combined in wave order).
+constexpr int HB_RC = 32;                                   // rows per LDS chunk
+__global__ __launch_bounds__(1024) void proj_heads_bwd_kernel(HeadsArgs a) {
+    __shared__ float d1[HB_RC][HEAD_MAXN];                  // 32 KB; re-used for the LayerNorm partials at the end
+    const int j = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const HeadSide s = a.s[m];
-    const int N = a.N, K = s.K;
-    const bool on = tid < N;
-    for (int k = tid; k < K; k += 256) xs[k] = s.x[(size_t)b * K + k];
-    const size_t o = ((size_t)m * a.B + b) * N + tid, oz = (size_t)b * 2 * N + m * N + tid;
-    const float dzv = on ? a.dz[oz] : 0.f, zv = on ? a.z[oz] : 0.f;
-    // F.normalize backward: da = (dz - z (z . dz)) / ||a||
-    const float dot = block_sum256(dzv * zv, red);
-    float dh = 0.f, xh = 0.f, gd = 0.f;
-    const float mean = a.stat[((size_t)m * a.B + b) * 2], rstd = a.stat[((size_t)m * a.B + b) * 2 + 1];
-    if (on) {
-        float g = (dzv - zv * dot) / a.nrm[m * a.B + b];
-        if (a.thresh) g *= dropout_scale(mm_eff_seed(s.seed, a.epoch), (uint32_t)(b * N + tid), a.thresh, a.inv_keep);
-        dh = g * gelu_erf_grad(a.hn[o]);
-        xh = (a.z1[o] - mean) * rstd;
-        gd = dh * s.gamma[tid];
-        if (s.dgamma) atomicAdd(&s.dgamma[tid], dh * xh);
-        if (s.dbeta) atomicAdd(&s.dbeta[tid], dh);
-    }
-    const float m1 = block_sum256(gd, red) / N, m2 = block_sum256(gd * xh, red) / N;
-    const float dz1 = on ? rstd * (gd - m1 - xh * m2) : 0.f;
-    if (on) {
-        d1[tid] = dz1;
-        if (s.dbias) atomicAdd(&s.dbias[tid], dz1);
-    }
-    __syncthreads();
-    if (s.dW)
-        for (int i = tid; i < N * K; i += 256) atomicAdd(&s.dW[i], d1[i / K] * xs[i % K]);    // contiguous fp32 atomics
-    if (s.dx)
-        for (int k = tid; k < K; k += 256) {
-            float acc = 0.f;
-            for (int n = 0; n < N; ++n) acc += d1[n] * s.W[(size_t)n * K + k];
-            s.dx[(size_t)b * K + k] = acc;
+    const int N = a.N, K = s.K, B = a.B, G = gridDim.x;
+    const int NK = N * K, S = (NK + G - 1) / G;
+    const uint32_t seed = mm_eff_seed(s.seed, a.epoch);
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = 0; b0 < B; b0 += HB_RC) {
+        const int nb = B - b0 < HB_RC ? B - b0 : HB_RC;
+        __syncthreads();                                    // the previous chunk is consumed
+        for (int r = wave; r < nb; r += 16) {
+            const int b = b0 + r;
+            const size_t o = ((size_t)m * B + b) * N, oz = (size_t)b * 2 * N + m * N;
+            float dzv[4], zv[4], dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = lane + 64 * e;
+                dzv[e] = n < N ? a.dz[oz + n] : 0.f;
+                zv[e] = n < N ? a.z[oz + n] : 0.f;
+                dot += dzv[e] * zv[e];
+            }
+            dot = wave_sum(dot);
+            const float mean = a.stat[((size_t)m * B + b) * 2], rstd = a.stat[((size_t)m * B + b) * 2 + 1];
+            const float nr = a.nrm[m * B + b];
+            float gd[4], xh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = lane + 64 * e;
+                gd[e] = 0.f; xh[e] = 0.f;
+                if (n < N) {
+                    // F.normalize backward: da = (dz - z (z . dz)) / ||a||
+                    float g = (dzv[e] - zv[e] * dot) / nr;
+                    if (a.thresh) g *= dropout_scale(seed, (uint32_t)(b * N + n), a.thresh, a.inv_keep);
+                    const float dh = g * gelu_erf_grad(a.hn[o + n]);
+                    xh[e] = (a.z1[o + n] - mean) * rstd;
+                    gd[e] = dh * s.gamma[n];
+                    ag[e] += dh * xh[e];
+                    ab[e] += dh;
+                }
+                s1 += gd[e]; s2 += gd[e] * xh[e];
+            }
+            const float m1 = wave_sum(s1) / N, m2 = wave_sum(s2) / N;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = lane + 64 * e;
+                if (n < N) d1[r][n] = rstd * (gd[e] - m1 - xh[e] * m2);
+            }
         }
+        __syncthreads();
+        if (s.dx)
+            for (int b = j; b < b0 + nb; b += G) {
+                if (b < b0) continue;
+                for (int k = tid; k < K; k += 1024) {
+                    float acc = 0.f;
+                    for (int n = 0; n < N; ++n) acc += d1[b - b0][n] * s.W[(size_t)n * K + k];
+                    s.dx[(size_t)b * K + k] = acc;
+                }
+            }
+        if (s.dW) {
+            const int hi = (j + 1) * S < NK ? (j + 1) * S : NK;
+            for (int i = j * S + tid; i < hi; i += 1024) {
+                const int n = i / K, k = i % K;
+                float acc = 0.f;
+                for (int r = 0; r < nb; ++r) acc += d1[r][n] * s.x[(size_t)(b0 + r) * K + k];
+                s.dW[i] += acc;
+            }
+        }
+        if (j == 0 && s.dbias && tid < N) {
+            float acc = 0.f;
+            for (int r = 0; r < nb; ++r) acc += d1[r][tid];
+            s.dbias[tid] += acc;
+        }
+    }
+    if (j == 0 && (s.dgamma || s.dbeta)) {
+        __syncthreads();
+        float (*pg)[2][HEAD_MAXN] = reinterpret_cast<float (*)[2][HEAD_MAXN]>(&d1[0][0]);     // [16 waves][dgamma | dbeta][N]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = lane + 64 * e;
+            if (n < N) { pg[wave][0][n] = ag[e]; pg[wave][1][n] = ab[e]; }
+        }
+        __syncthreads();
+        if (tid < 2 * N) {
+            const int which = tid / N, n = tid % N;
+            float acc = 0.f;
+            for (int w = 0; w < 16; ++w) acc += pg[w][which][n];
+            float* dst = which ? s.dbeta : s.dgamma;
+            if (dst) dst[n] += acc;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -677,18 +739,19 @@ __global__ void add_f32_kernel(const float* __restrict__ a, const float* __restr
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) o[i] = a[i] + b[i];
 }
 
-// backward of learned_fusion_kernel.  One wave per row; parameter gradients
-// (logits [M], temperature) are summed over rows with atomics into dlogits / dtemp.
-__global__ void learned_fusion_bwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+// backward of learned_fusion_kernel.  ONE block of 16 waves, a wave walks rows w, w + 16, ...; the parameter
+// gradients (logits [M], temperature) are per-wave partials summed in wave order (no atomics: bit-reproducible).
+__global__ __launch_bounds__(1024) void learned_fusion_bwd_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
                                           const float* __restrict__ f2, const float* __restrict__ dyn,
                                           const float* __restrict__ logits, const float* __restrict__ temp,
                                           const float* __restrict__ dfused, float* __restrict__ df0,
                                           float* __restrict__ df1, float* __restrict__ df2, float* __restrict__ ddyn,
                                           float* __restrict__ dlogits, float* __restrict__ dtemp, int B, int H, int M) {
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= B) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const float T = temp[0];
+    __shared__ float part[16][5];
+    float pl[4] = {0.f, 0.f, 0.f, 0.f}, pT = 0.f;
+    for (int row = wave; row < B; row += nwave) {
     float us[4], ud[4], st[4], dy[4], w[4], dw[4] = {0.f, 0.f, 0.f, 0.f};
     float ms = -INFINITY, md = -INFINITY;
     for (int m = 0; m < M; ++m) {
@@ -716,10 +779,23 @@ __global__ void learned_fusion_bwd_kernel(const float* __restrict__ f0, const fl
             const float gs = 0.5f * st[m] * (dw[m] - dots);      // d L / d (logits_m / T)
             const float gd = 0.5f * dy[m] * (dw[m] - dotd);      // d L / d (dyn_m / T)
             ddyn[(size_t)row * M + m] = gd / T;
-            atomicAdd(&dlogits[m], gs / T);
+            pl[m] += gs / T;
             dT -= (gs * us[m] + gd * ud[m]) / T;
         }
-        atomicAdd(dtemp, dT);
+        pT += dT;
+    }
+    }
+    if (lane == 0) {
+        for (int m = 0; m < 4; ++m) part[wave][m] = pl[m];
+        part[wave][4] = pT;
+    }
+    __syncthreads();
+    if (threadIdx.x <= M) {                              // threads 0..M-1: dlogits[m]; thread M: dtemp
+        const int j = (int)threadIdx.x == M ? 4 : (int)threadIdx.x;
+        float s = 0.f;
+        for (int wv = 0; wv < nwave; ++wv) s += part[wv][j];
+        if ((int)threadIdx.x == M) dtemp[0] += s;
+        else dlogits[threadIdx.x] += s;
     }
 }
 
@@ -871,22 +947,33 @@ __global__ void gate2_mix_bwd_kernel(const float* __restrict__ dcomb, const floa
 // out[0] += loss ; dlogits[b][c] = (softmax - (1-s)*onehot - s/C) / B
 __global__ void smoothed_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
                                    float* __restrict__ out, float* __restrict__ dlogits, int B, int C, float smoothing) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float* z = logits + (size_t)b * C;
-    float m = -INFINITY;
-    for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
-    float se = 0.f, sz = 0.f;
-    for (int c = 0; c < C; ++c) { se += __expf(z[c] - m); sz += z[c]; }
-    const float lse = m + __logf(se);
-    const int t = (int)target[b];
-    const float nll = lse - z[t], smooth = lse - sz / (float)C;
-    atomicAdd(out, ((1.f - smoothing) * nll + smoothing * smooth) / (float)B);
-    if (dlogits)
-        for (int c = 0; c < C; ++c) {
-            const float p = __expf(z[c] - lse);
-            dlogits[(size_t)b * C + c] = (p - (c == t ? 1.f - smoothing : 0.f) - smoothing / (float)C) / (float)B;
-        }
+    // one block (B is a batch size): per-thread partial sums over rows b = tid, tid + 256, ..., then a
+    // fixed-order tree over the 256 partials - the loss is bit-reproducible
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* z = logits + (size_t)b * C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, z[c]);
+        float se = 0.f, sz = 0.f;
+        for (int c = 0; c < C; ++c) { se += __expf(z[c] - m); sz += z[c]; }
+        const float lse = m + __logf(se);
+        const int t = (int)target[b];
+        const float nll = lse - z[t], smooth = lse - sz / (float)C;
+        acc += ((1.f - smoothing) * nll + smoothing * smooth) / (float)B;
+        if (dlogits)
+            for (int c = 0; c < C; ++c) {
+                const float p = __expf(z[c] - lse);
+                dlogits[(size_t)b * C + c] = (p - (c == t ? 1.f - smoothing : 0.f) - smoothing / (float)C) / (float)B;
+            }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += red[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -990,7 +1077,8 @@ __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restr
 // d pooled / L (the mean's gradient), optionally with a second, dropout-masked bf16 copy for the GEMM
 // that consumes it next.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pooled_head_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void pooled_head_fwd_kernel(const float* __restrict__ pooled, const mm_acc_t* __restrict__ pooled_acc,
+                                                             const float* __restrict__ W,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              bf16* __restrict__ z_pre, bf16* __restrict__ pooled_bf16,
                                                              int D, int N, int act, uint32_t thresh, float inv_keep,
@@ -998,7 +1086,7 @@ __global__ __launch_bounds__(256) void pooled_head_fwd_kernel(const float* __res
     __shared__ float xs[1024];
     const int b = blockIdx.x;
     for (int k = threadIdx.x; k < D; k += 256) {
-        const float v = pooled[(size_t)b * D + k];
+        const float v = pooled ? pooled[(size_t)b * D + k] : acc_val<MM_ACC_GRAD>(pooled_acc[(size_t)b * D + k]);
         xs[k] = v;
         if (pooled_bf16) pooled_bf16[(size_t)b * D + k] = (bf16)v;
     }
@@ -1176,7 +1264,7 @@ int mm_proj_heads_bwd(const float* dz, const float* z, const float* nrm, const f
     a.z1 = const_cast<float*>(z1); a.hn = const_cast<float*>(hn); a.stat = const_cast<float*>(stat);
     a.z = const_cast<float*>(z); a.nrm = const_cast<float*>(nrm); a.dz = dz; a.B = B; a.N = N;
     a.thresh = thresh_h(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.epoch = seed_epoch;
-    hipLaunchKernelGGL(proj_heads_bwd_kernel, dim3(B, 2), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(proj_heads_bwd_kernel, dim3(B, 2), dim3(1024), 0, st, a);
     return mm_check_launch("proj_heads_bwd");
 }
 
@@ -1268,7 +1356,7 @@ int mm_learned_fusion_bwd(const float* f0, const float* f1, const float* f2, con
     MM_REQUIRE(f0 && f1 && dyn && logits && temperature && dfused && df0 && df1 && ddyn && dlogits && dtemp,
                "learned_fusion_bwd: null");
     MM_REQUIRE(M >= 2 && M <= 3 && (M == 2 || (f2 && df2)), "learned_fusion_bwd: M=%d", M);
-    hipLaunchKernelGGL(learned_fusion_bwd_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, st, f0, f1, f2, dyn, logits,
+    hipLaunchKernelGGL(learned_fusion_bwd_kernel, dim3(1), dim3(1024), 0, st, f0, f1, f2, dyn, logits,
                        temperature, dfused, df0, df1, df2, ddyn, dlogits, dtemp, B, H, M);
     return mm_check_launch("learned_fusion_bwd");
 }
@@ -1313,7 +1401,7 @@ int mm_gate2_mix_bwd(const float* dcomb, const float* g, const float* erp, const
 int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out, float* dlogits, int B, int C,
                    float smoothing, hipStream_t st) {
     MM_REQUIRE(logits && target_i64 && loss_out && B > 0 && C > 0 && smoothing >= 0.f && smoothing < 1.f, "smoothed_ce: bad args");
-    hipLaunchKernelGGL(smoothed_ce_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, logits, (const long long*)target_i64,
+    hipLaunchKernelGGL(smoothed_ce_kernel, dim3(1), dim3(256), 0, st, logits, (const long long*)target_i64,
                        loss_out, dlogits, B, C, smoothing);
     return mm_check_launch("smoothed_ce");
 }
@@ -1369,14 +1457,14 @@ int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_
     return mm_check_launch("mul_f32");
 }
 
-int mm_pooled_head_fwd(const float* pooled, const float* W, const float* bias, float* out, void* z_pre_bf16,
+int mm_pooled_head_fwd(const float* pooled, const float* pooled_acc, const float* W, const float* bias, float* out, void* z_pre_bf16,
                        void* pooled_bf16, int B, int D, int N, int act, float drop_p, uint32_t seed,
                        const uint32_t* seed_epoch, hipStream_t st) {
-    MM_REQUIRE(pooled && W && out && B > 0, "pooled_head_fwd: null");
+    MM_REQUIRE((pooled != nullptr) != (pooled_acc != nullptr) && W && out && B > 0, "pooled_head_fwd: null (exactly one of pooled / pooled_acc)");
     MM_REQUIRE(D > 0 && D <= 1024 && D % 16 == 0 && N > 0, "pooled_head_fwd: D=%d (multiple of 16, <= 1024)", D);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "pooled_head_fwd: drop_p");
     const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    hipLaunchKernelGGL(pooled_head_fwd_kernel, dim3(B), dim3(256), 0, st, pooled, W, bias, out, (bf16*)z_pre_bf16,
+    hipLaunchKernelGGL(pooled_head_fwd_kernel, dim3(B), dim3(256), 0, st, pooled, reinterpret_cast<const mm_acc_t*>(pooled_acc), W, bias, out, (bf16*)z_pre_bf16,
                        (bf16*)pooled_bf16, D, N, act, thresh, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed, seed_epoch);
     return mm_check_launch("pooled_head_fwd");
 }

@@ -195,7 +195,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < RPP; ++r) s += part[r * BN + i];
-                atomicAdd(&e.pool_out[grp * N + n0 + i], s * e.pool_scale);
+                acc_add<MM_ACC_GRAD>(reinterpret_cast<mm_acc_t*>(e.pool_out) + grp * N + n0 + i, s * e.pool_scale);
             }
         if (EF_ON(EF_STATS, e.stats)) __syncthreads();
     }
@@ -208,14 +208,14 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
         *reinterpret_cast<float4*>(part + (rr * 2 + 0) * BN + cg * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
         *reinterpret_cast<float4*>(part + (rr * 2 + 1) * BN + cg * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
         __syncthreads();
-        float* rep = e.stats + (size_t)(blockIdx.x % MM_REPL) * 2 * N;
+        mm_acc_t* rep = acc_rep(e.stats, blockIdx.x % MM_ACC_REPL, 2 * (size_t)N);
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, col = i % BN;
             if (n0 + col < N) {
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < RPP; ++r) s += part[(r * 2 + which) * BN + col];
-                atomicAdd(&rep[which * N + n0 + col], s);
+                acc_add<MM_ACC_STAT>(&rep[which * N + n0 + col], s);
             }
         }
     }
@@ -288,7 +288,7 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += part[r * 256 + tid];
-        atomicAdd(&e.ln_dgb[(size_t)(blockIdx.x % MM_REPL) * 256 + tid], s);
+        acc_add<MM_ACC_GRAD>(acc_rep(e.ln_dgb, blockIdx.x % MM_ACC_REPL, 256) + tid, s);
     }
 #undef EF_ON
 }
@@ -671,24 +671,20 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
     }
     // D[i = n][j = c]: lane owns column c, rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int c = c0 + wc * 32 + (lane & 31);
-    float* dwr = a.dw + (size_t)(a.slot_mode ? bx : bx % a.nrep) * a.rep_stride;
+    float* dwr = a.dw + (size_t)bx * a.rep_stride;
     if (c < a.Cin_real) {
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < a.Cout) {
-                    float* o = dwr + n * a.sn + c * a.sc + tp * a.stap;
-                    if (a.slot_mode) *o = acc[tp][r];          // this (slot, tile) element has one writer
-                    else atomicAdd(o, acc[tp][r]);
-                }
+                if (n < a.Cout) dwr[n * a.sn + c * a.sc + tp * a.stap] = acc[tp][r];   // this (slot, tile) element has one writer
             }
     }
     if (a.dbias && bz == 0 && wc == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
         const int n = n0 + wn * 32 + (lane & 31);
-        if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(bx % MM_REPL) * a.Cout + n, bsum);
+        if ((lane >> 5) == 0 && n < a.Cout) acc_add<MM_ACC_GRAD>(acc_rep(a.dbias, bx % MM_ACC_REPL, a.Cout) + n, bsum);
     }
 }
 
@@ -788,7 +784,7 @@ __device__ __forceinline__ void linear_wgrad128_body(const WgradArgs& a, const i
         for (int i = 0; i < 2; ++i) {
             float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
             const int n = n0 + wn * 64 + i * 32 + (lane & 31);
-            if ((lane >> 5) == 0 && n < a.Cout) atomicAdd(a.dbias + (size_t)(bx % MM_REPL) * a.Cout + n, v);
+            if ((lane >> 5) == 0 && n < a.Cout) acc_add<MM_ACC_GRAD>(acc_rep(a.dbias, bx % MM_ACC_REPL, a.Cout) + n, v);
         }
 }
 
@@ -864,6 +860,22 @@ __global__ void reduce_replicas_kernel(const float* __restrict__ src, float* __r
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (k < K && r0 == 0) dst[k] += s;
+}
+
+// dst[k] += 2^-MM_ACC_GRAD * sum_rep acc[rep][k]: fixed-point accumulator workspace (common.h) -> fp32.
+// One replica per lane (16 lanes per output), integer shuffle reduction.
+__device__ __forceinline__ void acc_reduce_rows(const mm_acc_t* __restrict__ src, float* __restrict__ dst, long K,
+                                                long rep_stride, long kfirst, long kstep) {
+    const int r0 = threadIdx.x & 15;
+    for (long k = kfirst + (threadIdx.x >> 4); k < ((K + 15) / 16) * 16; k += kstep) {
+        mm_acc_t s = k < K ? src[r0 * rep_stride + k] : 0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (k < K && r0 == 0) dst[k] += acc_val<MM_ACC_GRAD>(s);
+    }
+}
+__global__ void acc_reduce_kernel(const mm_acc_t* __restrict__ src, float* __restrict__ dst, int K, long rep_stride) {
+    acc_reduce_rows(src, dst, K, rep_stride, (long)blockIdx.x * 16, (long)gridDim.x * 16);
 }
 
 template <int TAPS>
@@ -1096,7 +1108,7 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
                     int taps, int pad, int Cin_real, int64_t sn, int64_t sc, int64_t stap, int nrep,
                     int64_t rep_stride, int slot_mode, hipStream_t st) {
     MM_REQUIRE(dy && x && dw && B > 0 && T > 0, "conv1d_wgrad: null/invalid");
-    MM_REQUIRE(nrep >= 1 && (slot_mode || nrep <= 64), "conv1d_wgrad: nrep");
+    MM_REQUIRE(slot_mode == 1 && nrep >= 1, "conv1d_wgrad: slot_mode must be 1 (the fp32-atomics mode is gone: results are order-free)");
     MM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, "conv1d_wgrad: Cin=%d Cout=%d must be multiples of 8", Cin, Cout);
     MM_REQUIRE(Cin_real > 0 && Cin_real <= Cin, "conv1d_wgrad: Cin_real");
     WgradArgs a;
@@ -1150,22 +1162,21 @@ int mm_conv1d_wgrad_many(const void* desc_host, int n, hipStream_t st) {
     return 0;
 }
 
-// many independent replica reductions in one launch: desc[i] = {src, dst, K, nrep, stride}
-struct ReduceDesc { const float* src; float* dst; long K, nrep, stride; };
+// many independent reductions into parameter gradients in one launch: desc[i] = {src, dst, K, nrep, stride};
+// nrep = MM_ACC_REPL: src is a fixed-point accumulator workspace (stride in 64-bit elements);
+// nrep = 1: src is a compact fp32 vector (plain dst[k] += src[k])
+struct ReduceDesc { const void* src; float* dst; long K, nrep, stride; };
 constexpr int RM_MAX = 64;
 struct ReduceTable { ReduceDesc d[RM_MAX]; };      // passed BY VALUE (kernel argument): no memcpy node,
                                                    // so the launch can be recorded in a hipGraph
 __global__ void reduce_many_kernel(ReduceTable tab) {
     const ReduceDesc d = tab.d[blockIdx.y];
-    const int r0 = threadIdx.x & 31;
-    for (long k = blockIdx.x * 8 + (threadIdx.x >> 5); k < ((d.K + 7) / 8) * 8; k += (long)gridDim.x * 8) {
-        float s = 0.f;
-        if (k < d.K)
-            for (long r = r0; r < d.nrep; r += 32) s += d.src[r * d.stride + k];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (k < d.K && r0 == 0) d.dst[k] += s;
+    if (d.nrep == 1) {
+        const float* src = reinterpret_cast<const float*>(d.src);
+        for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < d.K; k += (long)gridDim.x * 256) d.dst[k] += src[k];
+        return;
     }
+    acc_reduce_rows(reinterpret_cast<const mm_acc_t*>(d.src), d.dst, d.K, d.stride, (long)blockIdx.x * 16, (long)gridDim.x * 16);
 }
 
 int mm_reduce_many(const void* desc_host, int ndesc, hipStream_t st) {
@@ -1174,7 +1185,12 @@ int mm_reduce_many(const void* desc_host, int ndesc, hipStream_t st) {
     for (int base = 0; base < ndesc; base += RM_MAX) {
         ReduceTable tab;
         const int n = ndesc - base < RM_MAX ? ndesc - base : RM_MAX;
-        for (int i = 0; i < n; ++i) tab.d[i] = src[base + i];
+        for (int i = 0; i < n; ++i) {
+            tab.d[i] = src[base + i];
+            MM_REQUIRE(tab.d[i].src && tab.d[i].dst && tab.d[i].K > 0 && tab.d[i].stride >= tab.d[i].K &&
+                           (tab.d[i].nrep == 1 || (tab.d[i].nrep == MM_ACC_REPL && ((uintptr_t)tab.d[i].src & 7) == 0)),
+                       "reduce_many: descriptor %d (nrep = 1 fp32 vector, or %d accumulator replicas)", base + i, MM_ACC_REPL);
+        }
         hipLaunchKernelGGL(reduce_many_kernel, dim3(16, n), dim3(256), 0, st, tab);
     }
     return mm_check_launch("reduce_many");
@@ -1184,6 +1200,14 @@ int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t re
     MM_REQUIRE(src && dst && K > 0 && nrep >= 1 && rep_stride >= K, "reduce_replicas: bad args");
     hipLaunchKernelGGL(reduce_replicas_kernel, dim3(ceil_div(K, 8)), dim3(256), 0, st, src, dst, K, nrep, (long)rep_stride);
     return mm_check_launch("reduce_replicas");
+}
+
+int mm_acc_reduce(const float* acc, float* dst, int K, int64_t rep_stride, hipStream_t st) {
+    MM_REQUIRE(acc && dst && K > 0 && rep_stride >= K, "acc_reduce: bad args");
+    MM_REQUIRE(((uintptr_t)acc & 7) == 0, "acc_reduce: workspace must be 8-byte aligned");
+    hipLaunchKernelGGL(acc_reduce_kernel, dim3(ceil_div(K, 16)), dim3(256), 0, st, reinterpret_cast<const mm_acc_t*>(acc), dst, K,
+                       (long)rep_stride);
+    return mm_check_launch("acc_reduce");
 }
 
 int mm_wgrad_scatter(const float* ws, float* dw, int Cout, int Cin, int taps, int Cinp, int nrep, hipStream_t st) {

@@ -46,8 +46,24 @@ def _empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
-REPL = 32          # replica count of every per-channel accumulator (csrc/common.h: MM_REPL)
+REPL = 32          # fp32-sized copies to allocate (and zero) per accumulator workspace (csrc/common.h: MM_REPL) ...
+AREPL = 16         # ... which the kernels use as 16 replicas of 64-bit fixed-point sums (MM_ACC_REPL): order-free adds
 WREP = 8           # replicas of the conv weight-gradient workspaces
+ACC_STAT, ACC_GRAD = 28, 40        # fixed-point fraction bits: activation statistics / gradient sums (csrc/common.h)
+
+
+def acc_decode(ws: torch.Tensor, k: int) -> torch.Tensor:
+    """accumulator workspace (REPL, ...) as the kernels left it -> its fp64 sums (...).  For tests and debugging:
+    the product reads workspaces on the device (mm_bn_finalize, mm_acc_reduce, ...)."""
+    i = ws.contiguous().flatten().view(torch.int64).view(AREPL, *ws.shape[1:])
+    return i.sum(0).double() * 2.0 ** -k
+
+
+def acc_encode(values: torch.Tensor, k: int) -> torch.Tensor:
+    """fp sums (...) -> an accumulator workspace (REPL, ...) holding them (replica 0), e.g. to feed mm_bn_finalize"""
+    i = torch.zeros((AREPL,) + tuple(values.shape), dtype=torch.int64, device=values.device)
+    i[0] = (values.double() * 2.0 ** k).round().long()
+    return i.flatten().view(torch.float32).view((REPL,) + tuple(values.shape))
 
 
 class _Arena:
@@ -446,8 +462,10 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
 def pooled_head_fwd(x: torch.Tensor, lin, *, act="gelu", training=False, drop_p=0.0,
                     need_dgrad=False, save=None, pooled_f32=None):
     """mean over L of fp32 (B, L, d) -> Linear -> act [-> dropout]: fp32 (B, out).
-    ``pooled_f32``: the mean, when the producer of ``x`` already accumulated it (transformer_block_fwd)."""
+    ``pooled_f32``: the mean, when the producer of ``x`` already accumulated it (transformer_block_fwd): a
+    (B, 2 d) buffer holding the 64-bit fixed-point accumulator the GEMM epilogue added into."""
     B, L, D = x.shape
+    pooled_acc = pooled_f32 is not None
     save = training if save is None else save
     p = drop_p if training else 0.0
     seed = _next_seed() if p > 0 else 0
@@ -459,8 +477,8 @@ def pooled_head_fwd(x: torch.Tensor, lin, *, act="gelu", training=False, drop_p=
         out = _empty((B, N), _F32, x)
         z = _empty((B, N), _BF, x) if save else None
         pooled = _empty((B, D), _BF, x) if save else None
-        _hip.call("mm_pooled_head_fwd", pooled_f32, lin.weight, lin.bias, out, z, pooled, B, D, N, ACT[act], float(p),
-                  int(seed), EP())
+        _hip.call("mm_pooled_head_fwd", None if pooled_acc else pooled_f32, pooled_f32 if pooled_acc else None,
+                  lin.weight, lin.bias, out, z, pooled, B, D, N, ACT[act], float(p), int(seed), EP())
         saved = dict(pooled=pooled, z=z, seed=seed, drop_p=p, B=B, L=L, D=D, lin=lin, act=act, fused=True) if save else None
         return out, saved
     pooled = _empty((B, D), _BF, x)
@@ -486,7 +504,8 @@ def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool):
     blocks = []
     B, L, D = h.shape
     nblk = len(m.transformer_layers)
-    pooled = _zeros((B, D), h) if nblk and L % 32 == 0 and D == 128 else None
+    # 64-bit fixed-point mean accumulator (one replica): the last block's GEMM epilogue adds into it
+    pooled = _zeros((B, 2 * D), h) if nblk and L % 32 == 0 and D == 128 else None
     layers = list(m.transformer_layers)
     prenorm = None
     for i, blk in enumerate(layers):

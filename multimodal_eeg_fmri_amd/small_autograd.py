@@ -218,9 +218,9 @@ class LayerNormFn(torch.autograd.Function):
         bag = GradBag()
         gw, gb = bag.target(ctx.g), bag.target(ctx.b)
         if gw is not None:
-            _hip.call("mm_reduce_replicas", dgb, gw, D, REPL, 2 * D)
+            _hip.call("mm_acc_reduce", dgb, gw, D, 2 * D)
         if gb is not None:
-            _hip.call("mm_reduce_replicas", dgb.data_ptr() + 4 * D, gb, D, REPL, 2 * D)
+            _hip.call("mm_acc_reduce", dgb.data_ptr() + 8 * D, gb, D, 2 * D)
         return dx, bag.result(ctx.g), bag.result(ctx.b), None
 
 

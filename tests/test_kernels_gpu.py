@@ -22,6 +22,18 @@ def _hip():
     return _hip
 
 
+def _stat(ws):
+    """activation-statistics accumulator workspace (32, ...) -> fp32 sums"""
+    from multimodal_eeg_fmri_amd.ops import ACC_STAT, acc_decode
+    return acc_decode(ws, ACC_STAT).float()
+
+
+def _grad(ws):
+    """gradient accumulator workspace (32, ...) -> fp32 sums"""
+    from multimodal_eeg_fmri_amd.ops import ACC_GRAD, acc_decode
+    return acc_decode(ws, ACC_GRAD).float()
+
+
 def _prep_w(hip, w, cinp, coutp=None):
     cout, cin, k = w.shape
     wf = torch.empty(cout, k, cinp, dtype=torch.bfloat16, device="cuda")
@@ -75,7 +87,7 @@ def test_conv1d_fwd_epilogue_bn_gelu_pool_stats():
     stats = torch.zeros(32, 2, Cout, device="cuda")
     hip.call("mm_conv1d_fwd", xg, wf, B, T, C, Cout, k, k // 2, scale.cuda(), shift.cuda(), 1, None, None, 2,
              stats, None, out, None, 0.0, 0, None, None, 0)
-    stats = stats.sum(0)
+    stats = _stat(stats)
     z = F.conv1d(_bf(x), _bf(w), None, padding=k // 2) * scale[None, :, None] + shift[None, :, None]
     want = F.max_pool1d(F.gelu(z), 2).transpose(1, 2)
     torch.testing.assert_close(out.float().cpu(), want, rtol=1e-2, atol=1e-2)
@@ -132,18 +144,21 @@ def test_conv1d_wgrad_matches_autograd(B, C, T, Cout, k):
     xg = torch.empty(B, T, cp, dtype=torch.bfloat16, device="cuda")
     hip.call("mm_pack_nct_bf16", x.cuda(), xg, B, C, T, cp)
     dyg = dy.transpose(1, 2).contiguous().cuda().to(torch.bfloat16)
-    dw = torch.zeros(2, Cout, C, k, device="cuda")
-    db = torch.zeros(32, Cout, device="cuda")
-    hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1, 2, Cout * C * k, 0)
-    dw, db = dw.sum(0), db.sum(0)
-    torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-2)
-    torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
-    # slot mode: one slot per row-chunk workgroup, plain stores into UNINITIALISED memory, summed by the scatter
+    # one slot per row-chunk workgroup, plain stores into UNINITIALISED memory; here with the strides of the PyTorch layout
     import ctypes
     n = ctypes.c_int(0)
     hip.call("mm_conv1d_wgrad_slots", B, T, cp, Cout, k, ctypes.addressof(n))
     slots = n.value
     assert slots >= 1
+    dw = torch.full((slots, Cout, C, k), float("nan"), device="cuda")
+    db = torch.zeros(32, Cout, device="cuda")
+    hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1, slots, Cout * C * k, 1)
+    dw, db = dw.sum(0), _grad(db)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
+    with pytest.raises(hip.HipLibraryError, match="slot_mode"):          # the fp32-atomics mode is gone
+        hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1, 2, Cout * C * k, 0)
+    # channel-contiguous slots, summed (in slot order) and moved to the parameter layout by the scatter
     ws = torch.full((slots, Cout, k, cp), float("nan"), device="cuda")
     hip.call("mm_conv1d_wgrad", dyg, xg, ws, None, B, T, cp, Cout, k, k // 2, cp, k * cp, 1, cp, slots, Cout * k * cp, 1)
     dw2 = torch.zeros(Cout, C, k, device="cuda")
@@ -188,7 +203,7 @@ def test_layernorm_fwd_bwd(M, D):
     dgb = torch.zeros(32, 2, D, device="cuda")
     hip.call("mm_layernorm_bwd", dy.cuda().to(torch.bfloat16), None, x.cuda(), stat, gam.cuda(), dres.cuda(), dx, None,
              dgb, M, D, 0.0, 0, None)
-    dg, db = dgb.sum(0)[0], dgb.sum(0)[1]
+    dg, db = _grad(dgb)[0], _grad(dgb)[1]
     torch.testing.assert_close(dx.cpu(), xr.grad + dres, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-3, atol=1e-3)
@@ -268,7 +283,8 @@ def test_grouped_linear_wgrads_equal_separate_launches():
     for ws_a, ws_b, db_a, db_b, dy, x in ref:
         assert not torch.isnan(ws_b).any()
         torch.testing.assert_close(ws_a.sum(0), ws_b.sum(0), rtol=1e-4, atol=1e-3)      # other chunking, same sums
-        torch.testing.assert_close(db_a.sum(0), db_b.sum(0), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(_grad(db_a), _grad(db_b), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(_grad(db_b), dy.float().sum(0), rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(ws_b.sum(0), dy.float().t() @ x.float(), rtol=2e-3, atol=2e-2)
     bad = struct.pack("<QQQQiiiiiiii", keep[0][0].data_ptr(), keep[0][1].data_ptr(), ref[0][1].data_ptr(), 0,
                       1, 512, 128, 384, 128, 1, 0, 0)                      # one slot is not enough
@@ -278,8 +294,8 @@ def test_grouped_linear_wgrads_equal_separate_launches():
 
 
 def test_linear_with_fused_mean_over_time_and_pooled_head():
-    """encoder tail: mm_linear_fwd_meanpool == mm_conv1d_fwd's rows + their per-group mean (fp32 atomics:
-    1e-5); mm_pooled_head_fwd / _bwd vs torch autograd of mean -> Linear -> GELU in fp32 (1e-5 / 1e-4; the saved
+    """encoder tail: mm_linear_fwd_meanpool == mm_conv1d_fwd's rows + their per-group mean (a 64-bit
+    fixed-point accumulator: 1e-5); mm_pooled_head_fwd / _bwd vs torch autograd of mean -> Linear -> GELU in fp32 (1e-5 / 1e-4; the saved
     pre-activation is bf16, so the backward's GELU' sees a rounded z: 1e-2 on d tokens)."""
     hip = _hip()
     g = torch.Generator().manual_seed(9)
@@ -291,15 +307,16 @@ def test_linear_with_fused_mean_over_time_and_pooled_head():
     xb = x.cuda().to(torch.bfloat16)
     out_a = torch.empty(B * L, D, device="cuda")
     out_b = torch.empty(B * L, D, device="cuda")
-    pooled = torch.zeros(B, D, device="cuda")
+    pooled_acc = torch.zeros(B, 2 * D, device="cuda")         # B x D 64-bit elements
     hip.call("mm_conv1d_fwd", xb, wf, 1, B * L, K, D, 1, 0, None, bias.cuda(), 0, res.cuda(), None, 1, None, out_a,
              None, None, 0.0, 0, None, None, 0)
-    hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, bias.cuda(), res.cuda(), out_b, 0.0, 0, None, pooled, L)
+    hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, bias.cuda(), res.cuda(), out_b, 0.0, 0, None, pooled_acc, L)
     assert torch.equal(out_a, out_b)
+    pooled = (pooled_acc.view(torch.int64).double() * 2.0 ** -40).float()
     torch.testing.assert_close(out_b.cpu(), x @ w.t() + bias + res, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(pooled, out_b.view(B, L, D).mean(1), rtol=1e-5, atol=1e-5)
     with pytest.raises(Exception):
-        hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, None, None, out_b, 0.0, 0, None, pooled, 96)
+        hip.call("mm_linear_fwd_meanpool", xb, wf, B * L, K, None, None, out_b, 0.0, 0, None, pooled_acc, 96)
     # head forward / backward
     W = torch.randn(N, D, generator=g) / math.sqrt(D)
     hb = torch.randn(N, generator=g)
@@ -311,8 +328,13 @@ def test_linear_with_fused_mean_over_time_and_pooled_head():
     out = torch.empty(B, N, device="cuda")
     z = torch.empty(B, N, dtype=torch.bfloat16, device="cuda")
     pb = torch.empty(B, D, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_pooled_head_fwd", pooled, W.cuda(), hb.cuda(), out, z, pb, B, D, N, 1, 0.0, 0, None)
+    hip.call("mm_pooled_head_fwd", pooled, None, W.cuda(), hb.cuda(), out, z, pb, B, D, N, 1, 0.0, 0, None)
     torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    out_acc = torch.empty(B, N, device="cuda")                # the same head, reading the accumulator itself
+    hip.call("mm_pooled_head_fwd", None, pooled_acc, W.cuda(), hb.cuda(), out_acc, None, None, B, D, N, 1, 0.0, 0, None)
+    assert torch.equal(out_acc, out)
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_pooled_head_fwd", pooled, pooled_acc, W.cuda(), hb.cuda(), out_acc, None, None, B, D, N, 1, 0.0, 0, None)
     torch.testing.assert_close(pb.float(), pooled, rtol=1e-2, atol=1e-2)
     dz = torch.empty(B, N, dtype=torch.bfloat16, device="cuda")
     dx = torch.empty(B, L, D, device="cuda")
@@ -365,7 +387,7 @@ def test_compiled_in_epilogues_equal_the_generic_one_bit_for_bit(monkeypatch):
         monkeypatch.delenv("MM_EPI_GENERIC", raising=False)
         for a_, b_ in zip(*outs):
             if a_.dtype == torch.float32 and a_.shape[0] == 32 and a_.dim() == 3 and a_.shape[1] == 2:
-                torch.testing.assert_close(a_.sum(0), b_.sum(0), rtol=1e-5, atol=1e-3)      # sums: atomic order differs run to run
+                assert torch.equal(_stat(a_), _stat(b_))       # fixed-point statistics: order-free, so bit-equal too
             else:
                 assert torch.equal(a_, b_)
 
@@ -432,7 +454,7 @@ def test_linear_dgrad_fused_with_layernorm_backward(M, K):
              dx, dxb, dgb, 0.0, 0, None)
     torch.testing.assert_close(dx.cpu(), xr.grad + dres, rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(dxb.float().cpu(), dx.cpu(), rtol=1e-2, atol=1e-2)
-    dg, db = dgb.sum(0)[0].cpu(), dgb.sum(0)[1].cpu()
+    dg, db = _grad(dgb)[0].cpu(), _grad(dgb)[1].cpu()
     torch.testing.assert_close(dg, gr.grad, rtol=2e-3, atol=2e-3 * gr.grad.abs().max().item())
     torch.testing.assert_close(db, br.grad, rtol=2e-3, atol=2e-3 * br.grad.abs().max().item())
     # dropout on the bf16 copy only: kept elements are dx / (1 - p), the fp32 output is untouched
@@ -467,9 +489,8 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     dout = _bf(torch.randn(R, S // pool, N, generator=g))
     a.backward(dout)
     yg = y.cuda()
-    stats = torch.zeros(32, 2, N)
-    stats[3] = torch.stack([y.sum(dim=(0, 1)), (y * y).sum(dim=(0, 1))])
-    stats = stats.cuda()
+    from multimodal_eeg_fmri_amd.ops import ACC_STAT, acc_encode
+    stats = acc_encode(torch.stack([y.sum(dim=(0, 1)), (y * y).sum(dim=(0, 1))]), ACC_STAT).cuda()
     rmg, rvg = rm.cuda(), rv.cuda()
     out4 = torch.empty(4, N, device="cuda")
     nbt = torch.full((), 7, dtype=torch.int64, device="cuda")
@@ -485,12 +506,12 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     sums = torch.zeros(32, 2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
     hip.call("mm_bn_act_bwd_reduce", yg, out4, dg, None, sums, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None)
-    torch.testing.assert_close(sums.sum(0)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(sums.sum(0)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(_grad(sums)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(_grad(sums)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
-    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums.sum(0).contiguous(), dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1, 1)
+    hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, _grad(sums).contiguous(), dy, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
-    dy2 = torch.empty_like(dy)                      # same, the kernel summing the 32 replicas itself
+    dy2 = torch.empty_like(dy)                      # same, the kernel summing the workspace's replicas itself
     hip.call("mm_bn_act_bwd_apply", yg, out4, dg, None, sums, dy2, None, R, S, N, 1, pool, 1, 0.0, 0, 0.0, 0, None, 1, 32)
     torch.testing.assert_close(dy2.float(), dy.float(), rtol=1e-2, atol=1e-3)
 
@@ -515,22 +536,25 @@ def test_conv3d_fwd_wgrad_dgrad(B, Cin, Cout, D, H, W):
     out = torch.empty(B, D, H, W, Cout, device="cuda")
     stats = torch.zeros(32, 2, Cout, device="cuda")
     hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, bias.detach().cuda(), stats, out, None)
-    stats = stats.sum(0)
+    stats = _stat(stats)
     want = y.detach().permute(0, 2, 3, 4, 1)
     torch.testing.assert_close(out.cpu(), want, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(stats[0].cpu(), want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(stats[1].cpu(), (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1e-2)
     dyg = _vol_cl(dy)
-    dw = torch.zeros(3, Cout, Cin, 27, device="cuda")
-    db = torch.zeros(32, Cout, device="cuda")
-    hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1, 3, Cout * Cin * 27, 0)
-    dw, db = dw.sum(0), db.sum(0)
-    torch.testing.assert_close(dw.cpu().view_as(w), w.grad, rtol=2e-3, atol=2e-2)
-    torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
-    # slot mode: plain stores into NaN-filled per-chunk slots, summed by the scatter
+    # plain stores into NaN-filled per-chunk slots; first with the strides of the PyTorch layout
     import ctypes
     n = ctypes.c_int(0)
     hip.call("mm_conv3d_wgrad_slots", B, D, H, W, Cin, Cout, ctypes.addressof(n))
+    dw = torch.full((n.value, Cout, Cin, 27), float("nan"), device="cuda")
+    db = torch.zeros(32, Cout, device="cuda")
+    hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1, n.value, Cout * Cin * 27, 1)
+    dw, db = dw.sum(0), _grad(db)
+    torch.testing.assert_close(dw.cpu().view_as(w), w.grad, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=2e-3, atol=2e-2)
+    with pytest.raises(hip.HipLibraryError, match="slot_mode"):          # the fp32-atomics mode is gone
+        hip.call("mm_conv3d_wgrad", dyg, xg, dw, db, B, D, H, W, Cin, Cout, Cin, Cin * 27, 27, 1, 3, Cout * Cin * 27, 0)
+    # channel-contiguous slots, summed by the scatter
     ws = torch.full((n.value, Cout, 27, Cin), float("nan"), device="cuda")
     hip.call("mm_conv3d_wgrad", dyg, xg, ws, None, B, D, H, W, Cin, Cout, Cin, 27 * Cin, 1, Cin, n.value, Cout * 27 * Cin, 1)
     dw2 = torch.zeros(Cout, Cin, 27, device="cuda")
@@ -563,7 +587,7 @@ def test_conv3d_weight_resident_kernel_vs_torch(B, D, H, W):
     stats = torch.zeros(32, 2, Cout, device="cuda")
     hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, bias.cuda(), stats, None, out)
     torch.testing.assert_close(out.float().cpu(), want, rtol=1e-2, atol=1e-2)
-    st = stats.sum(0).cpu()
+    st = _stat(stats).cpu()
     torch.testing.assert_close(st[0], want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
     torch.testing.assert_close(st[1], (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
     out2 = torch.empty_like(out)                                        # no bias, no statistics (eval form)
@@ -592,7 +616,7 @@ def test_conv3d_weight_streaming_kernel_vs_torch(B, Cin, Cout, D, H, W):
     hip.call("mm_conv3d_fwd", xg, wf, B, D, H, W, Cin, Cout, bias.cuda(), stats, out, outb)
     torch.testing.assert_close(out.cpu(), want, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(outb.float().cpu(), want, rtol=1e-2, atol=1e-2)
-    st = stats.sum(0).cpu()
+    st = _stat(stats).cpu()
     torch.testing.assert_close(st[0], want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
     torch.testing.assert_close(st[1], (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=5e-2)
     out2 = torch.full_like(outb, float("nan"))                         # the data-gradient form: no bias, no statistics, bf16 out
@@ -614,9 +638,8 @@ def test_pool3d_bn_act_train_fwd_bwd():
     a.backward(dout)
     yg = y.cuda().to(torch.bfloat16)
     flat = y.reshape(-1, N)
-    stats = torch.zeros(32, 2, N)
-    stats[0] = torch.stack([flat.sum(0), (flat * flat).sum(0)])
-    stats = stats.cuda()
+    from multimodal_eeg_fmri_amd.ops import ACC_STAT, acc_encode
+    stats = acc_encode(torch.stack([flat.sum(0), (flat * flat).sum(0)]), ACC_STAT).cuda()
     out4 = torch.empty(4, N, device="cuda")
     hip.call("mm_bn_finalize", stats, gam.cuda(), bet.cuda(), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"),
              None, out4, N, float(flat.shape[0]), 0.1, 1e-5, 0, None)
@@ -638,12 +661,19 @@ def test_pool3d_bn_act_train_fwd_bwd():
     sums = torch.zeros(32, 2, N, device="cuda")
     dg = dout.cuda().to(torch.bfloat16)
     hip.call("mm_pool3d_bn_act_bwd_reduce", ysel, out4, dg, sums, B, D, H, W, N, 1, 0.0, 0, None)
-    torch.testing.assert_close(sums.sum(0)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(sums.sum(0)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(_grad(sums)[0].cpu(), br.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(_grad(sums)[1].cpu(), gr.grad, rtol=1e-3, atol=1e-3)
     dy = torch.empty(B, D, H, W, N, dtype=torch.bfloat16, device="cuda")
     sc = torch.zeros(2 * N, device="cuda")
-    hip.call("mm_reduce_replicas", sums, sc, 2 * N, 32, 2 * N)
-    torch.testing.assert_close(sc.cpu(), sums.sum(0).flatten().cpu(), rtol=1e-5, atol=1e-5)
+    hip.call("mm_acc_reduce", sums, sc, 2 * N, 2 * N)
+    torch.testing.assert_close(sc.cpu(), _grad(sums).flatten().cpu(), rtol=1e-6, atol=1e-7)
+    sc2 = torch.ones(N, device="cuda")                      # offset e of a workspace = byte offset 8 e; dst is ADDED to
+    hip.call("mm_acc_reduce", sums.data_ptr() + 8 * N, sc2, N, 2 * N)
+    torch.testing.assert_close(sc2.cpu(), 1 + _grad(sums)[1].cpu(), rtol=1e-6, atol=1e-6)
+    fl = torch.arange(3 * 5, dtype=torch.float32, device="cuda").view(3, 5)      # the fp32 form: replicas summed in order
+    d3 = torch.zeros(5, device="cuda")
+    hip.call("mm_reduce_replicas", fl, d3, 5, 3, 5)
+    assert torch.equal(d3, fl.sum(0))
     hip.call("mm_pool3d_bn_act_bwd_apply", yg, arg, out4, dg, sc, dy, B, D, H, W, N, 1, 0.0, 0, None, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
 
