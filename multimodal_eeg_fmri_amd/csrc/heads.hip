@@ -206,47 +206,70 @@ __global__ __launch_bounds__(256) void proj_heads_fwd_kernel(HeadsArgs a) {
 }
 
 // Backward of both heads, bit-reproducible: no gradient element has more than one writer.  grid = (B, 2 heads),
-// 16 waves.  EVERY block recomputes d z1 of all rows (a wave per row: a few hundred flops each, the same bits in
-// every block), then block j writes dx of row j and the j-th slice of dW, each element summed over the rows in
-// order; block 0 adds the bias and LayerNorm-parameter gradients (per-wave partials combined in wave order).
-constexpr int HB_RC = 32;                                   // rows per LDS chunk
+// 16 waves.  EVERY block recomputes d z1 of all rows (a wave per row, two rows in flight per wave: a few hundred
+// flops each, the same bits in every block), then block j writes dx of row j and the j-th slice of dW, each element
+// summed over the rows in order; block 0 adds the bias and LayerNorm-parameter gradients (per-wave partials combined
+// in wave order).  NE = ceil(N / 64) elements per lane.
+constexpr int HB_RC = 32;                                   // rows per LDS chunk (= 2 per wave)
+template <int NE>
 __global__ __launch_bounds__(1024) void proj_heads_bwd_kernel(HeadsArgs a) {
     __shared__ float d1[HB_RC][HEAD_MAXN];                  // 32 KB; re-used for the LayerNorm partials at the end
+    __shared__ float px[1024];                              // dx partials [part][k]
     const int j = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const HeadSide s = a.s[m];
     const int N = a.N, K = s.K, B = a.B, G = gridDim.x;
     const int NK = N * K, S = (NK + G - 1) / G;
     const uint32_t seed = mm_eff_seed(s.seed, a.epoch);
-    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    float ag[NE], ab[NE], gam[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        ag[e] = 0.f; ab[e] = 0.f;
+        gam[e] = lane + 64 * e < N ? s.gamma[lane + 64 * e] : 0.f;
+    }
     for (int b0 = 0; b0 < B; b0 += HB_RC) {
         const int nb = B - b0 < HB_RC ? B - b0 : HB_RC;
         __syncthreads();                                    // the previous chunk is consumed
-        for (int r = wave; r < nb; r += 16) {
-            const int b = b0 + r;
+        // rows wave and wave + 16 of the chunk: every load of both rows is issued before the first use
+        float dzv[2][NE], zv[2][NE], hnv[2][NE], z1v[2][NE], mean[2], rstd[2], nr[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = wave + 16 * q;
+            const bool row_on = r < nb;
+            const int b = row_on ? b0 + r : b0;
             const size_t o = ((size_t)m * B + b) * N, oz = (size_t)b * 2 * N + m * N;
-            float dzv[4], zv[4], dot = 0.f;
+            mean[q] = a.stat[((size_t)m * B + b) * 2]; rstd[q] = a.stat[((size_t)m * B + b) * 2 + 1];
+            nr[q] = a.nrm[m * B + b];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 const int n = lane + 64 * e;
-                dzv[e] = n < N ? a.dz[oz + n] : 0.f;
-                zv[e] = n < N ? a.z[oz + n] : 0.f;
-                dot += dzv[e] * zv[e];
+                const bool on = row_on && n < N;
+                dzv[q][e] = on ? a.dz[oz + n] : 0.f;
+                zv[q][e] = on ? a.z[oz + n] : 0.f;
+                hnv[q][e] = on ? a.hn[o + n] : 0.f;
+                z1v[q][e] = on ? a.z1[o + n] : 0.f;
             }
-            dot = wave_sum(dot);
-            const float mean = a.stat[((size_t)m * B + b) * 2], rstd = a.stat[((size_t)m * B + b) * 2 + 1];
-            const float nr = a.nrm[m * B + b];
-            float gd[4], xh[4], s1 = 0.f, s2 = 0.f;
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+        for (int q = 0; q < 2; ++q) {
+            const int r = wave + 16 * q;
+            if (r >= nb) continue;                          // (wave-uniform)
+            const int b = b0 + r;
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) dot += dzv[q][e] * zv[q][e];
+            dot = wave_sum(dot);
+            float gd[NE], xh[NE], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
                 const int n = lane + 64 * e;
                 gd[e] = 0.f; xh[e] = 0.f;
                 if (n < N) {
                     // F.normalize backward: da = (dz - z (z . dz)) / ||a||
-                    float g = (dzv[e] - zv[e] * dot) / nr;
+                    float g = (dzv[q][e] - zv[q][e] * dot) / nr[q];
                     if (a.thresh) g *= dropout_scale(seed, (uint32_t)(b * N + n), a.thresh, a.inv_keep);
-                    const float dh = g * gelu_erf_grad(a.hn[o + n]);
-                    xh[e] = (a.z1[o + n] - mean) * rstd;
-                    gd[e] = dh * s.gamma[n];
+                    const float dh = g * gelu_erf_grad(hnv[q][e]);
+                    xh[e] = (z1v[q][e] - mean[q]) * rstd[q];
+                    gd[e] = dh * gam[e];
                     ag[e] += dh * xh[e];
                     ab[e] += dh;
                 }
@@ -254,27 +277,41 @@ __global__ __launch_bounds__(1024) void proj_heads_bwd_kernel(HeadsArgs a) {
             }
             const float m1 = wave_sum(s1) / N, m2 = wave_sum(s2) / N;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 const int n = lane + 64 * e;
-                if (n < N) d1[r][n] = rstd * (gd[e] - m1 - xh[e] * m2);
+                if (n < N) d1[r][n] = rstd[q] * (gd[e] - m1 - xh[e] * m2);
             }
         }
         __syncthreads();
-        if (s.dx)
+        // dx of the rows this block owns: 1024 / K threads share one output (strided over n), partials summed in order
+        if (s.dx) {
+            const int nparts = 1024 / K > 0 ? 1024 / K : 1;                 // K <= 1024 (host-checked)
             for (int b = j; b < b0 + nb; b += G) {
                 if (b < b0) continue;
-                for (int k = tid; k < K; k += 1024) {
+                const int k = tid % K, part = tid / K;
+                if (part < nparts) {
                     float acc = 0.f;
-                    for (int n = 0; n < N; ++n) acc += d1[b - b0][n] * s.W[(size_t)n * K + k];
-                    s.dx[(size_t)b * K + k] = acc;
+#pragma unroll 4
+                    for (int n = part; n < N; n += nparts) acc += d1[b - b0][n] * s.W[(size_t)n * K + k];
+                    px[part * K + k] = acc;
                 }
+                __syncthreads();
+                if (tid < K) {
+                    float acc = 0.f;
+                    for (int q = 0; q < nparts; ++q) acc += px[q * K + tid];
+                    s.dx[(size_t)b * K + tid] = acc;
+                }
+                __syncthreads();
             }
+        }
         if (s.dW) {
             const int hi = (j + 1) * S < NK ? (j + 1) * S : NK;
             for (int i = j * S + tid; i < hi; i += 1024) {
                 const int n = i / K, k = i % K;
+                const float* xc = s.x + (size_t)b0 * K + k;
                 float acc = 0.f;
-                for (int r = 0; r < nb; ++r) acc += d1[r][n] * s.x[(size_t)(b0 + r) * K + k];
+#pragma unroll 8
+                for (int r = 0; r < nb; ++r) acc += d1[r][n] * xc[(size_t)r * K];
                 s.dW[i] += acc;
             }
         }
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(1024) void proj_heads_bwd_kernel(HeadsArgs a) {
         __syncthreads();
         float (*pg)[2][HEAD_MAXN] = reinterpret_cast<float (*)[2][HEAD_MAXN]>(&d1[0][0]);     // [16 waves][dgamma | dbeta][N]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int n = lane + 64 * e;
             if (n < N) { pg[wave][0][n] = ag[e]; pg[wave][1][n] = ab[e]; }
         }
@@ -1264,7 +1301,12 @@ int mm_proj_heads_bwd(const float* dz, const float* z, const float* nrm, const f
     a.z1 = const_cast<float*>(z1); a.hn = const_cast<float*>(hn); a.stat = const_cast<float*>(stat);
     a.z = const_cast<float*>(z); a.nrm = const_cast<float*>(nrm); a.dz = dz; a.B = B; a.N = N;
     a.thresh = thresh_h(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; a.epoch = seed_epoch;
-    hipLaunchKernelGGL(proj_heads_bwd_kernel, dim3(B, 2), dim3(1024), 0, st, a);
+    switch (ceil_div(N, 64)) {
+        case 1: hipLaunchKernelGGL(proj_heads_bwd_kernel<1>, dim3(B, 2), dim3(1024), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(proj_heads_bwd_kernel<2>, dim3(B, 2), dim3(1024), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(proj_heads_bwd_kernel<3>, dim3(B, 2), dim3(1024), 0, st, a); break;
+        default: hipLaunchKernelGGL(proj_heads_bwd_kernel<4>, dim3(B, 2), dim3(1024), 0, st, a); break;
+    }
     return mm_check_launch("proj_heads_bwd");
 }
 
