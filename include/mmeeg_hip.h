@@ -119,6 +119,10 @@ int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t stream);
  * aligned; element e of it is at byte offset 8 e; rep_stride in 64-bit elements), dst[k] += its sum in fp32;
  * nrep = 1: src = compact fp32 vector, dst[k] += src[k]. */
 int mm_reduce_many(const void* desc_host, int ndesc, hipStream_t stream);
+/* mm_scatter_many(scatter_desc_host, nscatter) and mm_reduce_many(reduce_desc_host, nreduce) in ONE launch (per 48
+ * descriptors of each kind): the two are independent, and a graph node costs ~5 us on the stream that flushes */
+int mm_flush_many(const void* scatter_desc_host, int nscatter, const void* reduce_desc_host, int nreduce,
+                  hipStream_t stream);
 /* dst[k] += fp32(sum over the 16 replicas of acc[rep * rep_stride + k]),  k < K: gradient accumulator workspace
  * (64-bit elements: offset e is byte offset 8 e) -> fp32 */
 int mm_acc_reduce(const float* acc, float* dst, int K, int64_t rep_stride, hipStream_t stream);
@@ -217,7 +221,8 @@ int mm_conv3d_wgrad_slots(int B, int D, int H, int W, int Cin, int Cout, int* sl
  * bf16 [B][D/2][H/2][W/2][N].  N % 8 == 0.  Training also keeps, per pooled element, the winner's pre-BN
  * value (ysel bf16) and its index in the 2x2x2 window (arg, one byte: 4 d + 2 h + w); both null in eval.
  * The reduction of the BatchNorm gradient sums then reads only pooled data (gradients vanish off the
- * winners) and the apply pass (dy bf16, full volume) takes the argmax from `arg`. */
+ * winners) and the apply pass (dy bf16, full volume) takes the argmax from `arg`; its `sums` is the reduce pass's
+ * accumulator workspace (sums_nrep = 32) or a compact fp32 [2][N] (sums_nrep = 1), as for mm_bn_act_bwd_apply. */
 int mm_pool3d_bn_act_fwd(const void* y, const float* out4, void* out_bf16, void* ysel, void* arg, int B, int D,
                          int H, int W, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                          hipStream_t stream);
@@ -226,7 +231,7 @@ int mm_pool3d_bn_act_bwd_reduce(const void* ysel, const float* out4, const void*
                                 const uint32_t* seed_epoch, hipStream_t stream);
 int mm_pool3d_bn_act_bwd_apply(const void* y, const void* arg, const float* out4, const void* dout_bf16,
                                const float* sums, void* dy, int B, int D, int H, int W, int N, int act,
-                               float drop_p, uint32_t seed, const uint32_t* seed_epoch, int train,
+                               float drop_p, uint32_t seed, const uint32_t* seed_epoch, int train, int sums_nrep,
                                hipStream_t stream);
 
 /* Fused first voxel layer Conv3d(1->32,k3,p1)+BatchNorm3d+GELU+MaxPool3d(2)[+Dropout]

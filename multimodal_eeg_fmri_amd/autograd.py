@@ -171,17 +171,16 @@ class GradBag:
             host = ctypes.create_string_buffer(raw, len(raw))
             _hip.call("mm_conv1d_wgrad_many", ctypes.addressof(host), len(self.wgrads))
             self.wgrads = []
-        if self.scatters:
-            raw = b"".join(struct.pack("<QQiiiiii", *d, 0) for d in self.scatters)
-            host = ctypes.create_string_buffer(raw, len(raw))
-            _hip.call("mm_scatter_many", ctypes.addressof(host), len(self.scatters))
-            self.scatters = []
-        if not self.pending:
+        if not self.scatters and not self.pending:
             return
-        raw = b"".join(struct.pack("<QQqqq", *d) for d in self.pending)
-        host = ctypes.create_string_buffer(raw, len(raw))      # descriptors travel as kernel arguments
-        _hip.call("mm_reduce_many", ctypes.addressof(host), len(self.pending))
-        self.pending = []
+        # slot sums (weight gradients) and accumulator reductions (bias / norm-parameter gradients): one launch
+        sraw = b"".join(struct.pack("<QQiiiiii", *d, 0) for d in self.scatters)
+        rraw = b"".join(struct.pack("<QQqqq", *d) for d in self.pending)
+        shost = ctypes.create_string_buffer(sraw, max(len(sraw), 1))      # descriptors travel as kernel arguments
+        rhost = ctypes.create_string_buffer(rraw, max(len(rraw), 1))
+        _hip.call("mm_flush_many", ctypes.addressof(shost) if self.scatters else None, len(self.scatters),
+                  ctypes.addressof(rhost) if self.pending else None, len(self.pending))
+        self.scatters, self.pending = [], []
 
     def target(self, p: torch.Tensor) -> Optional[torch.Tensor]:
         """fp32 buffer (PyTorch layout of ``p``) the kernels accumulate into."""
@@ -539,15 +538,14 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
     if s["pool"]:
         _hip.call("mm_pool3d_bn_act_bwd_reduce", s["ysel"], out4, dout, sums, B, D, H, W, N, gelu,
                   float(s["drop_p"]), int(s["seed"]), ops.EP())
-        sc = _compact(sums, 2 * N)
-        _hip.call("mm_pool3d_bn_act_bwd_apply", y, s["arg"], out4, dout, sc, dy, B, D, H, W, N, gelu,
-                  float(s["drop_p"]), int(s["seed"]), ops.EP(), 1)
+        # the apply passes sum the workspace's replicas themselves (no compaction launch between the two passes)
+        _hip.call("mm_pool3d_bn_act_bwd_apply", y, s["arg"], out4, dout, sums, dy, B, D, H, W, N, gelu,
+                  float(s["drop_p"]), int(s["seed"]), ops.EP(), 1, REPL)
     else:
         args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
-        sc = _compact(sums, 2 * N)
-        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sc, dy, None, *args, 1, 1)
-    _bn_param_grads(bag, bn, sc, N)
+        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, None, *args, 1, REPL)
+    _bn_param_grads(bag, bn, sums, N, nrep=REPL)
     cin = conv.in_channels
     dw = bag.target(conv.weight)
     if dw is not None:

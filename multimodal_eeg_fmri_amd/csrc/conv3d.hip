@@ -271,6 +271,7 @@ struct Pool3Args {
     int B, D, H, W, N, act, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
     const uint32_t* epoch;
+    int sums_nrep;                             // apply: 1 = compact fp32 sums, MM_REPL = the reduce pass's accumulator workspace
 };
 
 // One thread = 8 channels of one pooled voxel: eight 16-byte loads of the bf16 pre-BatchNorm volume.
@@ -283,6 +284,13 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
     const size_t nrows = (size_t)a.B * Do * Ho * Wo;
     const int rows_per_blk = 256 / nv > 0 ? 256 / nv : 1;
     const int vi = threadIdx.x % nv, ri = threadIdx.x / nv;
+    __shared__ float csum[MODE == 2 ? 2048 : 1];       // sum dz | sum dz * xhat per channel (N <= 1024)
+    if (MODE == 2 && a.train) {
+        // the workspace's replicas are summed here (a separate compaction launch sat between the two passes)
+        for (int i = threadIdx.x; i < 2 * a.N; i += 256)
+            csum[i] = a.sums_nrep == 1 ? a.sums[i] : acc_val<MM_ACC_GRAD>(acc_sum(a.sums, 2 * (size_t)a.N, i));
+        __syncthreads();
+    }
     if (ri >= rows_per_blk) return;
     const int n8 = vi * 8;
     float sc[8], sh[8], mu[8], rs[8], c0[8], c1[8];
@@ -290,8 +298,8 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
     for (int q = 0; q < 8; ++q) {
         sc[q] = a.out4[n8 + q]; sh[q] = a.out4[a.N + n8 + q];
         mu[q] = a.out4[2 * a.N + n8 + q]; rs[q] = a.out4[3 * a.N + n8 + q];
-        c0[q] = (MODE == 2 && a.train) ? a.sums[n8 + q] * a.inv_count : 0.f;    // compact [2][N] sums
-        c1[q] = (MODE == 2 && a.train) ? a.sums[a.N + n8 + q] * a.inv_count : 0.f;
+        c0[q] = (MODE == 2 && a.train) ? csum[n8 + q] * a.inv_count : 0.f;
+        c1[q] = (MODE == 2 && a.train) ? csum[a.N + n8 + q] * a.inv_count : 0.f;
     }
     for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
         unsigned q = (unsigned)row;                                 // 32-bit divisions (rows < 2^31: checked on the host)
@@ -503,12 +511,14 @@ int mm_pool3d_bn_act_bwd_reduce(const void* ysel, const float* out4, const void*
 
 int mm_pool3d_bn_act_bwd_apply(const void* y, const void* arg, const float* out4, const void* dout_bf16,
                                const float* sums, void* dy, int B, int D, int H, int W, int N, int act, float drop_p,
-                               uint32_t seed, const uint32_t* seed_epoch, int train, hipStream_t st) {
+                               uint32_t seed, const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t st) {
     MM_REQUIRE(y && arg && dout_bf16 && dy && (!train || sums), "pool3d_bn_act_bwd_apply: null");
+    MM_REQUIRE(sums_nrep == 1 || sums_nrep == MM_REPL, "pool3d_bn_act_bwd_apply: sums_nrep = 1 (compact fp32) or %d (the reduce pass's workspace)", MM_REPL);
+    MM_REQUIRE(N <= 1024, "pool3d_bn_act_bwd_apply: N=%d > 1024", N);
     Pool3Args a{};
     a.y = (const bf16*)y; a.arg = (uint8_t*)const_cast<void*>(arg); a.out4 = out4; a.dout = (const bf16*)dout_bf16; a.sums = sums;
     a.dy = (bf16*)dy; a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch;
-    a.train = train;
+    a.train = train; a.sums_nrep = sums_nrep;
     return pool3_launch(2, a, drop_p, st);
 }
 

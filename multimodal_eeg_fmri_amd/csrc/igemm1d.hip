@@ -823,12 +823,11 @@ __global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __rest
 struct ScatterDesc { const float* ws; float* dw; int Cout, Cin, taps, Cinp, nrep, pad_; };
 constexpr int SM_MAX = 64;
 struct ScatterTable { ScatterDesc d[SM_MAX]; };
-__global__ void scatter_many_kernel(ScatterTable tab) {
-    const ScatterDesc d = tab.d[blockIdx.y];
+__device__ __forceinline__ void scatter_body(const ScatterDesc& d, int blk, int nblk) {
     // walk the workspace in ITS order (channel-contiguous: the nrep replica reads coalesce) and
     // scatter one strided write per element, not nrep strided reads
     const size_t rstride = (size_t)d.Cout * d.taps * d.Cinp;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rstride; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < rstride; i += (size_t)nblk * blockDim.x) {
         const int c = (int)(i % d.Cinp);
         if (c >= d.Cin) continue;
         const int tap = (int)((i / d.Cinp) % d.taps);
@@ -846,6 +845,7 @@ __global__ void scatter_many_kernel(ScatterTable tab) {
         d.dw[((size_t)n * d.Cin + c) * d.taps + tap] += s;
     }
 }
+__global__ void scatter_many_kernel(ScatterTable tab) { scatter_body(tab.d[blockIdx.y], blockIdx.x, gridDim.x); }
 
 // dst[k] += sum_rep src[rep][k]
 // one replica per lane (32 lanes per output), one shuffle reduction: a single
@@ -1169,14 +1169,24 @@ struct ReduceDesc { const void* src; float* dst; long K, nrep, stride; };
 constexpr int RM_MAX = 64;
 struct ReduceTable { ReduceDesc d[RM_MAX]; };      // passed BY VALUE (kernel argument): no memcpy node,
                                                    // so the launch can be recorded in a hipGraph
-__global__ void reduce_many_kernel(ReduceTable tab) {
-    const ReduceDesc d = tab.d[blockIdx.y];
+__device__ __forceinline__ void reduce_body(const ReduceDesc& d, int blk, int nblk) {
     if (d.nrep == 1) {
         const float* src = reinterpret_cast<const float*>(d.src);
-        for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < d.K; k += (long)gridDim.x * 256) d.dst[k] += src[k];
+        for (long k = (long)blk * 256 + threadIdx.x; k < d.K; k += (long)nblk * 256) d.dst[k] += src[k];
         return;
     }
-    acc_reduce_rows(reinterpret_cast<const mm_acc_t*>(d.src), d.dst, d.K, d.stride, (long)blockIdx.x * 16, (long)gridDim.x * 16);
+    acc_reduce_rows(reinterpret_cast<const mm_acc_t*>(d.src), d.dst, d.K, d.stride, (long)blk * 16, (long)nblk * 16);
+}
+__global__ void reduce_many_kernel(ReduceTable tab) { reduce_body(tab.d[blockIdx.y], blockIdx.x, gridDim.x); }
+
+// the slot sums AND the accumulator reductions of one gradient flush in ONE launch (they are independent; two graph
+// nodes cost ~5 us of latency each on the stream that flushes): blocks [0, 256 ns) scatter, the rest reduce
+constexpr int FM_MAX = 48, FM_SB = 256, FM_RB = 16;
+struct FlushTable { ScatterDesc s[FM_MAX]; ReduceDesc r[FM_MAX]; int ns, nr; };
+__global__ void flush_many_kernel(FlushTable tab) {
+    const int b = blockIdx.x;
+    if (b < tab.ns * FM_SB) scatter_body(tab.s[b / FM_SB], b % FM_SB, FM_SB);
+    else reduce_body(tab.r[(b - tab.ns * FM_SB) / FM_RB], (b - tab.ns * FM_SB) % FM_RB, FM_RB);
 }
 
 int mm_reduce_many(const void* desc_host, int ndesc, hipStream_t st) {
@@ -1200,6 +1210,33 @@ int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t re
     MM_REQUIRE(src && dst && K > 0 && nrep >= 1 && rep_stride >= K, "reduce_replicas: bad args");
     hipLaunchKernelGGL(reduce_replicas_kernel, dim3(ceil_div(K, 8)), dim3(256), 0, st, src, dst, K, nrep, (long)rep_stride);
     return mm_check_launch("reduce_replicas");
+}
+
+int mm_flush_many(const void* scatter_desc_host, int nscatter, const void* reduce_desc_host, int nreduce, hipStream_t st) {
+    MM_REQUIRE(nscatter >= 0 && nreduce >= 0 && nscatter + nreduce > 0 && (scatter_desc_host || !nscatter) &&
+                   (reduce_desc_host || !nreduce), "flush_many: bad args");
+    const ScatterDesc* sd = (const ScatterDesc*)scatter_desc_host;
+    const ReduceDesc* rd = (const ReduceDesc*)reduce_desc_host;
+    static_assert(sizeof(FlushTable) <= 4096, "kernel arguments");
+    for (int sb = 0, rb = 0; sb < nscatter || rb < nreduce; sb += FM_MAX, rb += FM_MAX) {
+        FlushTable tab;
+        tab.ns = nscatter - sb > FM_MAX ? FM_MAX : (nscatter - sb > 0 ? nscatter - sb : 0);
+        tab.nr = nreduce - rb > FM_MAX ? FM_MAX : (nreduce - rb > 0 ? nreduce - rb : 0);
+        for (int i = 0; i < tab.ns; ++i) {
+            const ScatterDesc& d = sd[sb + i];
+            MM_REQUIRE(d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.Cinp >= d.Cin && d.nrep >= 1,
+                       "flush_many: scatter descriptor %d", sb + i);
+            tab.s[i] = d;
+        }
+        for (int i = 0; i < tab.nr; ++i) {
+            const ReduceDesc& d = rd[rb + i];
+            MM_REQUIRE(d.src && d.dst && d.K > 0 && d.stride >= d.K && (d.nrep == 1 || (d.nrep == MM_ACC_REPL && ((uintptr_t)d.src & 7) == 0)),
+                       "flush_many: reduce descriptor %d (nrep = 1 fp32 vector, or %d accumulator replicas)", rb + i, MM_ACC_REPL);
+            tab.r[i] = d;
+        }
+        hipLaunchKernelGGL(flush_many_kernel, dim3(tab.ns * FM_SB + tab.nr * FM_RB), dim3(256), 0, st, tab);
+    }
+    return mm_check_launch("flush_many");
 }
 
 int mm_acc_reduce(const float* acc, float* dst, int K, int64_t rep_stride, hipStream_t st) {

@@ -674,8 +674,11 @@ def test_pool3d_bn_act_train_fwd_bwd():
     d3 = torch.zeros(5, device="cuda")
     hip.call("mm_reduce_replicas", fl, d3, 5, 3, 5)
     assert torch.equal(d3, fl.sum(0))
-    hip.call("mm_pool3d_bn_act_bwd_apply", yg, arg, out4, dg, sc, dy, B, D, H, W, N, 1, 0.0, 0, None, 1)
+    hip.call("mm_pool3d_bn_act_bwd_apply", yg, arg, out4, dg, sc, dy, B, D, H, W, N, 1, 0.0, 0, None, 1, 1)
     torch.testing.assert_close(dy.float().cpu(), yr.grad, rtol=2e-2, atol=2e-3)
+    dy2 = torch.empty_like(dy)                      # same, the kernel summing the workspace's replicas itself
+    hip.call("mm_pool3d_bn_act_bwd_apply", yg, arg, out4, dg, sums, dy2, B, D, H, W, N, 1, 0.0, 0, None, 1, 32)
+    assert torch.equal(dy2, dy)
 
 
 
