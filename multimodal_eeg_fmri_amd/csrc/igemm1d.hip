@@ -549,12 +549,20 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, bf16* __restrict
 // path of the step's graph
 struct PrepDesc { const float* w; bf16* wf; bf16* wd; int Cout, Cin, k, Cinp, Coutp, pad_; };
 constexpr int PM_MAX = 64;
-struct PrepTable { PrepDesc d[PM_MAX]; };          // by value, as ReduceTable
-__global__ void prep_many_kernel(PrepTable tab) {
-    const PrepDesc d = tab.d[blockIdx.y];
+// first[t] = first workgroup of tensor t: workgroups are dealt out in proportion to the elements (PM_EPB per
+// workgroup).  128 workgroups per tensor left the step's two largest images (13 elements per thread, gathered with
+// a stride of k floats) as a 12 us tail on the chain while the small ones idled.
+constexpr int PM_EPB = 1024;
+struct PrepTable { PrepDesc d[PM_MAX]; int first[PM_MAX + 1]; };          // by value, as ReduceTable
+__global__ void prep_many_kernel(PrepTable tab, int ndesc) {
+    int t = 0;
+    while (t + 1 < ndesc && (int)blockIdx.x >= tab.first[t + 1]) ++t;      // (uniform: <= 64 scalar compares)
+    const PrepDesc d = tab.d[t];
+    const int blk = blockIdx.x - tab.first[t], nblk = tab.first[t + 1] - tab.first[t];
     const int total_f = d.Cout * d.k * d.Cinp;
     const int total_d = d.wd ? d.Cinp * d.k * d.Coutp : 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_f + total_d; i += gridDim.x * blockDim.x) {
+#pragma unroll 4
+    for (int i = blk * blockDim.x + threadIdx.x; i < total_f + total_d; i += nblk * blockDim.x) {
         if (i < total_f) {
             const int c = i % d.Cinp, tap = (i / d.Cinp) % d.k, n = i / (d.Cinp * d.k);
             d.wf[conv_image_index(d.Cout, d.k, d.Cinp, n, tap, c)] = (bf16)(c < d.Cin ? d.w[((size_t)n * d.Cin + c) * d.k + tap] : 0.f);
@@ -929,7 +937,17 @@ int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) {
                        (!d.wd || (d.Coutp % 16 == 0 && d.Coutp >= d.Cout)), "prep_many: descriptor %d", base + i);
             tab.d[i] = d;
         }
-        hipLaunchKernelGGL(prep_many_kernel, dim3(128, n), dim3(256), 0, st, tab);
+        static_assert(sizeof(PrepTable) + 8 <= 4096, "kernel arguments");
+        int nblocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const PrepDesc& d = tab.d[i];
+            const long total = (long)d.Cout * d.k * d.Cinp + (d.wd ? (long)d.Cinp * d.k * d.Coutp : 0);
+            MM_REQUIRE(total < (1l << 31), "prep_many: descriptor %d too large", base + i);
+            tab.first[i] = nblocks;
+            nblocks += (int)((total + PM_EPB - 1) / PM_EPB);
+        }
+        tab.first[n] = nblocks;
+        hipLaunchKernelGGL(prep_many_kernel, dim3(nblocks), dim3(256), 0, st, tab, n);
     }
     return mm_check_launch("prep_many");
 }
