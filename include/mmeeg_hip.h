@@ -110,6 +110,9 @@ int mm_debug_stamp(void* buf, int idx, hipStream_t stream);
  * of {const float* w; void* w_fwd; void* w_dgrad /*nullable*/; int32 Cout, Cin, k, Cinp, Coutp, 0}
  * (48 bytes each), copied into the kernel arguments (capturable in a hipGraph) */
 int mm_prep_many(const void* desc_host, int ndesc, hipStream_t stream);
+/* the same, and the launch also zeroes `nzero` floats at `zero` (16-byte aligned, nzero % 4 == 0): a training step's
+ * accumulator workspaces, which would otherwise be one more fill node in front of the first kernel */
+int mm_prep_many_zero(const void* desc_host, int ndesc, float* zero, int64_t nzero, hipStream_t stream);
 /* mm_wgrad_scatter for ndesc workspaces in one launch per 64 descriptors; desc_host = HOST array of
  * {const float* ws; float* dw; int32 Cout, Cin, taps, Cinp, nrep, 0} (40 bytes each) */
 int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t stream);

@@ -133,9 +133,12 @@ class BridgeTrainer(nn.Module):
         self._stamp(0)
         # one memset of what the step's accumulators actually use (high-water mark of the first
         # step + slack); the gradient bucket is cleared by the previous step's AdamW kernel
-        ops.arena.begin(eeg.device, clear=self._arena_need)
         if self._weight_list is not None:
-            ops.weights.prepare_all(self._weight_list)   # every bf16 weight image of the step, one launch
+            # every bf16 weight image of the step AND the clearing of its accumulators: one launch
+            ops.arena.begin(eeg.device, clear=self._arena_need, defer_zero=True)
+            ops.weights.prepare_all(self._weight_list, zero=ops.arena.zero_range())
+        else:
+            ops.arena.begin(eeg.device, clear=self._arena_need)
         self._stamp(1)
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)                 # fork point: recorded before any encoder kernel

@@ -554,7 +554,13 @@ constexpr int PM_MAX = 64;
 // a stride of k floats) as a 12 us tail on the chain while the small ones idled.
 constexpr int PM_EPB = 1024;
 struct PrepTable { PrepDesc d[PM_MAX]; int first[PM_MAX + 1]; };          // by value, as ReduceTable
-__global__ void prep_many_kernel(PrepTable tab, int ndesc) {
+__global__ void prep_many_kernel(PrepTable tab, int ndesc, float4* __restrict__ zero, long nzero4) {
+    if ((int)blockIdx.x >= tab.first[ndesc]) {
+        // the step's accumulator arena is zeroed by the same launch (a fill node of its own cost ~5 us on the chain)
+        const long b = blockIdx.x - tab.first[ndesc], nb = gridDim.x - tab.first[ndesc];
+        for (long i = b * blockDim.x + threadIdx.x; i < nzero4; i += nb * blockDim.x) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     int t = 0;
     while (t + 1 < ndesc && (int)blockIdx.x >= tab.first[t + 1]) ++t;      // (uniform: <= 64 scalar compares)
     const PrepDesc d = tab.d[t];
@@ -925,8 +931,10 @@ int mm_prep_conv_weight(const float* w, void* w_fwd, void* w_dgrad, int Cout, in
     return mm_check_launch("prep_conv_weight");
 }
 
-int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) {
+int mm_prep_many_zero(const void* desc_host, int ndesc, float* zero, int64_t nzero, hipStream_t st) {
     MM_REQUIRE(desc_host && ndesc > 0, "prep_many: bad args");
+    MM_REQUIRE(nzero >= 0 && (zero || !nzero) && nzero % 4 == 0 && ((uintptr_t)zero & 15) == 0,
+               "prep_many_zero: the zeroed range must be 16-byte aligned and a multiple of 4 floats");
     const PrepDesc* src = (const PrepDesc*)desc_host;
     for (int base = 0; base < ndesc; base += PM_MAX) {
         PrepTable tab;
@@ -947,10 +955,15 @@ int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) {
             nblocks += (int)((total + PM_EPB - 1) / PM_EPB);
         }
         tab.first[n] = nblocks;
-        hipLaunchKernelGGL(prep_many_kernel, dim3(nblocks), dim3(256), 0, st, tab, n);
+        const bool last = base + PM_MAX >= ndesc;                     // the fill rides in the last launch
+        const long nz4 = last ? nzero / 4 : 0;
+        const int zblocks = (int)((nz4 + 2047) / 2048 < 1024 ? (nz4 + 2047) / 2048 : 1024);
+        hipLaunchKernelGGL(prep_many_kernel, dim3(nblocks + zblocks), dim3(256), 0, st, tab, n, reinterpret_cast<float4*>(zero), nz4);
     }
     return mm_check_launch("prep_many");
 }
+
+int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) { return mm_prep_many_zero(desc_host, ndesc, nullptr, 0, st); }
 
 // Generic forward implicit GEMM.  See include/mmeeg_hip.h for the contract.
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,

@@ -78,18 +78,25 @@ class _Arena:
         self.cleared = 0
         self.high = 0                     # largest offset any step has reached
 
-    def begin(self, device, nfloats: int = 6 << 20, clear: Optional[int] = None):
+    def begin(self, device, nfloats: int = 6 << 20, clear: Optional[int] = None, defer_zero: bool = False):
         """``clear``: zero only the first ``clear`` floats (a caller that knows its step's high-water
-        mark; slices beyond it fall back to torch.zeros)."""
+        mark; slices beyond it fall back to torch.zeros).  ``defer_zero``: the caller zeroes
+        ``zero_range()`` itself before the first kernel that uses a slice (the trainer's weight-image launch does)."""
         if self.buf is None or self.buf.device != device or self.buf.numel() < nfloats:
             self.buf = torch.empty(nfloats, dtype=_F32, device=device)
         self.cleared = self.buf.numel() if clear is None else min(int(clear), self.buf.numel())
-        self.buf[:self.cleared].zero_()
+        self.cleared -= self.cleared % 4
+        if not defer_zero:
+            self.buf[:self.cleared].zero_()
         self.off = 0
         self.active = True
 
     def end(self):
         self.active = False
+
+    def zero_range(self):
+        """(tensor, floats) a ``begin(defer_zero=True)`` left for the caller to clear"""
+        return self.buf, self.cleared
 
     def take(self, shape, device):
         n = 1
@@ -209,8 +216,9 @@ class _WeightCache:
             wd3 = wd3.reshape(wd3.shape[0], wd3.shape[1], -1)
         return wd3.contiguous()
 
-    def prepare_all(self, recorded):
-        """rebuild every recorded image that is out of date with one mm_prep_many launch"""
+    def prepare_all(self, recorded, zero=None):
+        """rebuild every recorded image that is out of date with one mm_prep_many launch; ``zero`` = (fp32 tensor,
+        floats): the same launch clears that range (the step's accumulator arena)"""
         import ctypes
         import struct
         raw, keep = [], []
@@ -232,7 +240,12 @@ class _WeightCache:
         if raw:
             buf = b"".join(raw)
             host = ctypes.create_string_buffer(buf, len(buf))
-            _hip.call("mm_prep_many", ctypes.addressof(host), len(raw))
+            if zero is not None:
+                _hip.call("mm_prep_many_zero", ctypes.addressof(host), len(raw), zero[0], int(zero[1]))
+            else:
+                _hip.call("mm_prep_many", ctypes.addressof(host), len(raw))
+        elif zero is not None:
+            zero[0][:int(zero[1])].zero_()
 
     def get(self, w: torch.Tensor, need_dgrad: bool, key=None):
         owner = w if key is None else key          # the nn.Parameter the image belongs to
