@@ -45,14 +45,29 @@ __device__ __forceinline__ int vperm(int key) {       // swap bits 2 and 3 of th
 
 // attention-probability dropout (nn.MultiheadAttention(dropout=p)): the softmax
 // row sum uses the un-dropped probabilities, only the P operand of P.V is masked.
-// lighter index hash than common.h's (the softmax loops are VALU-bound: one Weyl multiply,
-// one xorshift-multiply round; the high bits feed the threshold compare)
-__device__ __forceinline__ float attn_keep(uint32_t seed, int bh, int q, int key, int L, uint32_t thresh, float inv_keep) {
-    uint32_t x = (((uint32_t)bh * (uint32_t)L + (uint32_t)q) * (uint32_t)L + (uint32_t)key) * 0x9E3779B1u + seed;
+// The mask costs a quarter of these kernels (the hash is ~9 of ~20 VALU instructions per score, its multiply
+// quarter-rate), so ONE hash serves a PAIR of adjacent keys (2j, 2j + 1) of a query row: its low / high 16 bits
+// decide the even / odd key (keep iff half >= p * 2^16; p is honoured to 2^-17).  Pair index =
+// (bh * L + q) * ceil(L / 2) + key / 2; same hash as common.h's mm_hash.  The forward and dq kernels hold the two
+// keys of a pair in one lane (registers r, r + 1); the dkv kernel, whose registers run along q, hashes per score.
+__device__ __forceinline__ uint32_t attn_pair_hash(uint32_t seed, int bh, int q, int key, int L) {
+    const uint32_t Lh = ((uint32_t)L + 1u) >> 1;
+    uint32_t x = (((uint32_t)bh * (uint32_t)L + (uint32_t)q) * Lh + ((uint32_t)key >> 1)) * 0x9E3779B1u + seed;
     x ^= x >> 15;
     x *= 0x2C1B3C6Du;
     x ^= x >> 13;
-    return x >= thresh ? inv_keep : 0.f;
+    return x;
+}
+__device__ __forceinline__ float attn_keep(uint32_t seed, int bh, int q, int key, int L, uint32_t thresh16, float inv_keep) {
+    const uint32_t x = attn_pair_hash(seed, bh, q, key, L);
+    return __builtin_amdgcn_ubfe(x, (key & 1) * 16, 16) >= thresh16 ? inv_keep : 0.f;
+}
+// both keys of the pair that starts at the EVEN key `key`
+__device__ __forceinline__ void attn_keep2(uint32_t seed, int bh, int q, int key, int L, uint32_t thresh16, float inv_keep,
+                                           float& k0, float& k1) {
+    const uint32_t x = attn_pair_hash(seed, bh, q, key, L);
+    k0 = (x & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
+    k1 = (x >> 16) >= thresh16 ? inv_keep : 0.f;
 }
 
 // v_exp_f32 as is: arguments are <= 0 here and a result below 2^-126 may flush to zero (softmax
@@ -146,11 +161,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             float ps = 0.f;
             bf16x8 pf[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = fast_exp2(sacc[r] - m_sub);
-                ps += p;
-                if (DROP) p *= attn_keep(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv);
-                pf[r >> 3][r & 7] = (bf16)p;
+            for (int r = 0; r < 16; r += 2) {                    // registers r, r + 1: keys 2j, 2j + 1
+                float p0 = fast_exp2(sacc[r] - m_sub), p1 = fast_exp2(sacc[r + 1] - m_sub);
+                ps += p0;
+                ps += p1;
+                if (DROP) {
+                    float kp0, kp1;
+                    attn_keep2(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv, kp0, kp1);
+                    p0 *= kp0; p1 *= kp1;
+                }
+                pf[r >> 3][r & 7] = (bf16)p0;
+                pf[r >> 3][(r & 7) + 1] = (bf16)p1;
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
@@ -269,6 +290,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
             }
             bf16x8 dsf[2];
+            float kp[16];
+            if (DROP)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2)                  // registers r, r + 1: keys 2j, 2j + 1 share one hash
+                    attn_keep2(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv, kp[r], kp[r + 1]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                 if (MASK && key < kn) sc += amask[(size_t)min(q, L - 1) * L + k0 + key] * 1.4426950408889634f;
                 const float p = (FULL || key < kn) ? fast_exp2(sc) : 0.f;
                 float dpr = dp[r];
-                if (DROP) dpr *= attn_keep(dseed, b * H + h, q, k0 + key, L, dthresh, dinv);
+                if (DROP) dpr *= kp[r];
                 dsf[r >> 3][r & 7] = (bf16)(p * (dpr - dl));
             }
 #pragma unroll
@@ -415,7 +441,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 
 extern "C" {
 
-static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+// 16-bit drop threshold of a half hash word (0 = dropout off: p < 2^-17)
+static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u; }
 
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, float scale,
                 float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
@@ -424,11 +451,12 @@ int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int
     MM_REQUIRE(head_dim == DH, "attn_fwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
     const bool full = L % KCH == 0;
-    auto kern = drop_p > 0.f ? (full ? attn_fwd_kernel<true, true> : attn_fwd_kernel<true, false>)
-                             : (full ? attn_fwd_kernel<false, true> : attn_fwd_kernel<false, false>);
-    if (attn_mask) kern = drop_p > 0.f ? attn_fwd_kernel<true, false, true> : attn_fwd_kernel<false, false, true>;
+    const uint32_t dth = attn_thresh(drop_p);
+    auto kern = dth ? (full ? attn_fwd_kernel<true, true> : attn_fwd_kernel<true, false>)
+                    : (full ? attn_fwd_kernel<false, true> : attn_fwd_kernel<false, false>);
+    if (attn_mask) kern = dth ? attn_fwd_kernel<true, false, true> : attn_fwd_kernel<false, false, true>;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
-                       scale * 1.4426950408889634f, attn_thresh(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
+                       scale * 1.4426950408889634f, dth, seed, dth ? 1.f / (1.f - drop_p) : 1.f,
                        seed_epoch, attn_mask);
     return mm_check_launch("attn_fwd");
 }
@@ -437,7 +465,7 @@ int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
                 int B, int L, int H, int head_dim, float scale, float drop_p, uint32_t seed,
                 const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
     const uint32_t dth = attn_thresh(drop_p);
-    const float dinv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float dinv = dth ? 1.f / (1.f - drop_p) : 1.f;
     MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_bwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);

@@ -31,6 +31,23 @@ def keep_scale(seed: int, n: int, p: float) -> torch.Tensor:
     return (x >= int(p * 4294967296.0)).float() / (1.0 - p)
 
 
+def attn_keep_scale(seed: int, bh: int, L: int, p: float) -> torch.Tensor:
+    """[bh, L, L] float32 attention-probability mask (attention.hip: attn_pair_hash / attn_keep): one hash per pair of
+    adjacent keys of a query row, pair index (bh * L + q) * ceil(L / 2) + key // 2; its low / high 16 bits decide the
+    even / odd key, keep iff half >= round(p * 2^16)."""
+    t16 = int(p * 65536.0 + 0.5)
+    if t16 == 0:
+        return torch.ones(bh, L, L)
+    Lh = (L + 1) // 2
+    idx = torch.arange(bh * L * Lh, dtype=torch.int64)
+    x = (idx * 0x9E3779B1 + int(seed)) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 13
+    keep = torch.stack([(x & 0xFFFF) >= t16, (x >> 16) >= t16], dim=-1).view(bh, L, 2 * Lh)[:, :, :L]
+    return keep.float() / (1.0 - p)
+
+
 def erp_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int], p: float, p_attn: float,
                                  p_pe: float, nhead: int = 4):
     """``seeds``: the dropout seeds in the order the product path draws them (ops._next_seed):
@@ -63,7 +80,7 @@ def erp_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int
         dh = D // nhead
         qh, kh, vh = (u.view(B, L, nhead, dh).transpose(1, 2) for u in qkv.split(D, dim=2))
         a = torch.softmax((qh @ kh.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
-        a = a * keep_scale(sa, B * nhead * L * L, p_attn).view(B, nhead, L, L)
+        a = a * attn_keep_scale(sa, B * nhead, L, p_attn).view(B, nhead, L, L)
         o = (a @ vh).transpose(1, 2).reshape(B, L, D)
         o = F.linear(o, sd[q + "self_attn.out_proj.weight"], sd[q + "self_attn.out_proj.bias"])
         t = t + o * keep_scale(s1, B * L * D, p).view(B, L, D)

@@ -682,7 +682,7 @@ def test_pool3d_bn_act_train_fwd_bwd():
 
 
 
-@pytest.mark.parametrize("L", [64, 256])      # 256: the full-tile specialisation (L % 256 == 0) of all three kernels
+@pytest.mark.parametrize("L", [64, 77, 256])      # 77: ragged tiles, odd row length (pairs do not straddle rows); 256: the full-tile specialisation (L % 256 == 0) of all three kernels
 def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     """attention-probability dropout: forward equals softmax(S) * mask / keep @ V for the
     kernel's own hash mask, and backward differentiates exactly that function
@@ -700,13 +700,8 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
     # recover the mask from V = identity-like probe: compare row sums of kept probabilities
     # host replica of the attention kernels' index hash (attention.hip: attn_keep)
-    def keep_mask():
-        idx = torch.arange(B * H * L * L, dtype=torch.int64)
-        x = (idx * 0x9E3779B1 + seed) & 0xFFFFFFFF
-        x ^= x >> 15; x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
-        x ^= x >> 13
-        return (x >= int(p * 4294967296.0)).view(B, H, L, L).double() / (1 - p)
-    m = keep_mask()
+    from oracle.dropout_replica import attn_keep_scale
+    m = attn_keep_scale(seed, B * H, L, p).view(B, H, L, L).double()
     q, k, v = (t.view(B, L, H, 32).transpose(1, 2).double() for t in qkv.split(E, dim=2))
     q.requires_grad_(True)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(32)
