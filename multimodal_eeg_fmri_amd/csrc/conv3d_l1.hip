@@ -164,26 +164,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                     const int oh = (h0 >> 1) + 2 * ip + ra, ow = (w0 >> 1) + 4 * wave + rb + 2 * lh, od = d0 >> 1;
                     const bool ok = oh < Ho && ow < Wo;
                     float y[8], z[8];
-                    float zmax = -INFINITY;
-                    int jmax = 0;
+                    float zmax = -INFINITY, zmin = INFINITY;
+                    int jmax = 0, jmin = 0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {           // j = (dd << 2) | (hh << 1) | ww
                         const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
                         y[j] = acc[ti][r] + bias;
                         z[j] = y[j] * sc + sh;
-                        if (z[j] > zmax) { zmax = z[j]; jmax = j; }
+                        if (z[j] > zmax) { zmax = z[j]; jmax = j; }       // strict: the first occurrence wins, as PyTorch
+                        if (z[j] < zmin) { zmin = z[j]; jmin = j; }
                     }
-                    float best;
-                    if (zmax >= 0.f) {
-                        best = gelu_erf(zmax);
-                    } else {
-                        best = -INFINITY;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float g = gelu_erf(z[j]);
-                            if (g > best) { best = g; jmax = j; }
-                        }
-                    }
+                    // GELU falls on (-inf, -0.75] and rises after it, so the window's largest activation sits at its largest
+                    // or at its smallest pre-activation: two evaluations, no divergent eight-way fallback (as pool3_bn_act)
+                    float best = gelu_erf(zmax);
+                    const float amin = gelu_erf(zmin);
+                    if (amin > best) { best = amin; jmax = jmin; }
                     const size_t oidx = ((((size_t)b * Do + od) * Ho + oh) * Wo + ow) * 32 + lr;
                     if (MODE == 1) {
                         if (ok) {
