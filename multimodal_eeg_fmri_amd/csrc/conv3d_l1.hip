@@ -53,7 +53,9 @@ __device__ __forceinline__ int tap_off(int tap) {          // halo offset of tap
     return kd * 10 * HP + kh * HP + kw;
 }
 
-template <int MODE>
+// FULLT: H % 8 == 0 and W % 32 == 0, i.e. every 2 x 8 x 32 tile lies inside the volume: the per-voxel bounds tests
+// (three compares and the index arithmetic behind them, per voxel and channel) are compiled out
+template <int MODE, bool FULLT = false>
 __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // two waves per SIMD: <= 256 registers
     a.seed = mm_eff_seed(a.seed, a.epoch);
     __shared__ __attribute__((aligned(16))) unsigned short halo[HSZ];
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int d = d0 + (i >> 1), h = h0 + 4 * (i & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
-                    if (d < a.D && h < a.H && w < a.W) {
+                    if (FULLT || (d < a.D && h < a.H && w < a.W)) {
                         const float y = acc[i][r] + bias;
                         acc1 += y; acc2 += y * y;
                     }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                 for (int rb = 0; rb < 2; ++rb) {
                     const int r0 = 8 * ra + 2 * rb;
                     const int oh = (h0 >> 1) + 2 * ip + ra, ow = (w0 >> 1) + 4 * wave + rb + 2 * lh, od = d0 >> 1;
-                    const bool ok = oh < Ho && ow < Wo;
+                    const bool ok = FULLT || (oh < Ho && ow < Wo);
                     float y[8], z[8];
                     float zmax = -INFINITY, zmin = INFINITY;
                     int jmax = 0, jmin = 0;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                             for (int j = 0; j < 8; ++j) {
                                 const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
                                 const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
-                                const bool in = d < a.D && h < a.H && w < a.W;
+                                const bool in = FULLT || (d < a.D && h < a.H && w < a.W);
                                 dyf[ti >> 1][r >> 3][r & 7] = (bf16)((in && j == jmax) ? dzs : 0.f);
                                 xhf[ti >> 1][r >> 3][r & 7] = (bf16)(in ? (y[j] - mu) * rs : 0.f);
                             }
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                                 const float dzj = (j == jmax) ? dzs : 0.f;
                                 float dy = a.train ? sc * (dzj - c0 - (y[j] - mu) * rs * c1) : sc * dzj;
                                 const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
-                                if (!(d < a.D && h < a.H && w < a.W)) dy = 0.f;
+                                if (!FULLT && !(d < a.D && h < a.H && w < a.W)) dy = 0.f;
                                 acc1 += dy;
                                 dyf[ti >> 1][r >> 3][r & 7] = (bf16)dy;
                             }
@@ -384,11 +386,16 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     a.epoch = seed_epoch;
     const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
     const int grid = ntiles < 1024 ? ntiles : 1024;
-    switch (mode) {
-        case 0: hipLaunchKernelGGL(conv3d_l1_kernel<0>, dim3(grid), dim3(256), 0, st, a); break;
-        case 1: hipLaunchKernelGGL(conv3d_l1_kernel<1>, dim3(grid), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(conv3d_l1_kernel<2>, dim3(grid), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(conv3d_l1_kernel<3>, dim3(grid), dim3(256), 0, st, a); break;
+    const bool full = H % 8 == 0 && W % 32 == 0;
+    switch (mode * 2 + (full ? 1 : 0)) {
+        case 0: hipLaunchKernelGGL((conv3d_l1_kernel<0, false>), dim3(grid), dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((conv3d_l1_kernel<0, true>), dim3(grid), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((conv3d_l1_kernel<1, false>), dim3(grid), dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((conv3d_l1_kernel<1, true>), dim3(grid), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((conv3d_l1_kernel<2, false>), dim3(grid), dim3(256), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((conv3d_l1_kernel<2, true>), dim3(grid), dim3(256), 0, st, a); break;
+        case 6: hipLaunchKernelGGL((conv3d_l1_kernel<3, false>), dim3(grid), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv3d_l1_kernel<3, true>), dim3(grid), dim3(256), 0, st, a); break;
     }
     return mm_check_launch("conv3d_l1");
 }
@@ -417,7 +424,8 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
     if (!tapsum_ready)
         hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0,
                            st, x, tapsum, B, D, H, W);
-    hipLaunchKernelGGL(conv3d_l1_kernel<4>, dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
+    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<4, true>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3d_l1_kernel<4, false>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
     hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 16, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
                        dbias, a.inv_count, train);
     return mm_check_launch("conv3d_l1_bwd");
