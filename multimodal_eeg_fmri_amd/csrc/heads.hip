@@ -789,38 +789,38 @@ __global__ __launch_bounds__(1024) void learned_fusion_bwd_kernel(const float* _
     __shared__ float part[16][5];
     float pl[4] = {0.f, 0.f, 0.f, 0.f}, pT = 0.f;
     for (int row = wave; row < B; row += nwave) {
-    float us[4], ud[4], st[4], dy[4], w[4], dw[4] = {0.f, 0.f, 0.f, 0.f};
-    float ms = -INFINITY, md = -INFINITY;
-    for (int m = 0; m < M; ++m) {
-        us[m] = logits[m] / T; ud[m] = dyn[(size_t)row * M + m] / T;
-        ms = fmaxf(ms, us[m]); md = fmaxf(md, ud[m]);
-    }
-    float ss = 0.f, sd = 0.f;
-    for (int m = 0; m < M; ++m) { st[m] = __expf(us[m] - ms); dy[m] = __expf(ud[m] - md); ss += st[m]; sd += dy[m]; }
-    for (int m = 0; m < M; ++m) { st[m] /= ss; dy[m] /= sd; w[m] = 0.5f * st[m] + 0.5f * dy[m]; }
-    const float* fs[3] = {f0, f1, f2};
-    float* dfs[3] = {df0, df1, df2};
-    for (int h = lane; h < H; h += 64) {
-        const float g = dfused[(size_t)row * H + h];
+        float us[4], ud[4], st[4], dy[4], w[4], dw[4] = {0.f, 0.f, 0.f, 0.f};
+        float ms = -INFINITY, md = -INFINITY;
         for (int m = 0; m < M; ++m) {
-            dw[m] += g * fs[m][(size_t)row * H + h];
-            dfs[m][(size_t)row * H + h] = w[m] * g;
+            us[m] = logits[m] / T; ud[m] = dyn[(size_t)row * M + m] / T;
+            ms = fmaxf(ms, us[m]); md = fmaxf(md, ud[m]);
         }
-    }
-    for (int m = 0; m < M; ++m) dw[m] = wave_sum(dw[m]);
-    if (lane == 0) {
-        float dots = 0.f, dotd = 0.f;
-        for (int m = 0; m < M; ++m) { dots += st[m] * dw[m]; dotd += dy[m] * dw[m]; }
-        float dT = 0.f;
-        for (int m = 0; m < M; ++m) {
-            const float gs = 0.5f * st[m] * (dw[m] - dots);      // d L / d (logits_m / T)
-            const float gd = 0.5f * dy[m] * (dw[m] - dotd);      // d L / d (dyn_m / T)
-            ddyn[(size_t)row * M + m] = gd / T;
-            pl[m] += gs / T;
-            dT -= (gs * us[m] + gd * ud[m]) / T;
+        float ss = 0.f, sd = 0.f;
+        for (int m = 0; m < M; ++m) { st[m] = __expf(us[m] - ms); dy[m] = __expf(ud[m] - md); ss += st[m]; sd += dy[m]; }
+        for (int m = 0; m < M; ++m) { st[m] /= ss; dy[m] /= sd; w[m] = 0.5f * st[m] + 0.5f * dy[m]; }
+        const float* fs[3] = {f0, f1, f2};
+        float* dfs[3] = {df0, df1, df2};
+        for (int h = lane; h < H; h += 64) {
+            const float g = dfused[(size_t)row * H + h];
+            for (int m = 0; m < M; ++m) {
+                dw[m] += g * fs[m][(size_t)row * H + h];
+                dfs[m][(size_t)row * H + h] = w[m] * g;
+            }
         }
-        pT += dT;
-    }
+        for (int m = 0; m < M; ++m) dw[m] = wave_sum(dw[m]);
+        if (lane == 0) {
+            float dots = 0.f, dotd = 0.f;
+            for (int m = 0; m < M; ++m) { dots += st[m] * dw[m]; dotd += dy[m] * dw[m]; }
+            float dT = 0.f;
+            for (int m = 0; m < M; ++m) {
+                const float gs = 0.5f * st[m] * (dw[m] - dots);      // d L / d (logits_m / T)
+                const float gd = 0.5f * dy[m] * (dw[m] - dotd);      // d L / d (dyn_m / T)
+                ddyn[(size_t)row * M + m] = gd / T;
+                pl[m] += gs / T;
+                dT -= (gs * us[m] + gd * ud[m]) / T;
+            }
+            pT += dT;
+        }
     }
     if (lane == 0) {
         for (int m = 0; m < 4; ++m) part[wave][m] = pl[m];
