@@ -715,3 +715,65 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None)
     dq_got = dqkv.float().cpu()[:, :, :E].view(B, L, H, 32).transpose(1, 2)
     assert ((dq_got - q.grad.float()).norm() / q.grad.float().norm()).item() < 3e-2
+
+
+def test_batched_launches_equal_their_single_forms():
+    """mm_prep_many_zero == one mm_prep_conv_weight per tensor (workgroups dealt out by tensor size; 70 tensors also
+    exercise the split into tables of 64) + a cleared range; mm_flush_many == mm_scatter_many + mm_reduce_many."""
+    import ctypes
+    import struct
+    hip = _hip()
+    g = torch.Generator().manual_seed(8)
+    shapes = [(128, 64, 27), (64, 32, 27), (512, 128, 1), (128, 512, 1), (384, 128, 1), (64, 7, 7), (32, 1, 27)] + [(24, 40, 3)] * 63
+    keep, raw, want = [], [], []
+    for cout, cin, k in shapes:
+        cinp, coutp = _cpad(cin), _cpad(cout)
+        w = torch.randn(cout, cin, k, generator=g).cuda()
+        wf_a = torch.empty(cout, k, cinp, dtype=torch.bfloat16, device="cuda")
+        wd_a = torch.empty(cinp, k, coutp, dtype=torch.bfloat16, device="cuda")
+        hip.call("mm_prep_conv_weight", w, wf_a, wd_a, cout, cin, k, cinp, coutp)
+        wf_b, wd_b = torch.full_like(wf_a, float("nan")), torch.full_like(wd_a, float("nan"))
+        raw.append(struct.pack("<QQQiiiiii", w.data_ptr(), wf_b.data_ptr(), wd_b.data_ptr(), cout, cin, k, cinp, coutp, 0))
+        keep.append(w)
+        want.append((wf_a, wd_a, wf_b, wd_b))
+    arena = torch.full((4096 + 8,), 7.0, device="cuda")
+    buf = b"".join(raw)
+    host = ctypes.create_string_buffer(buf, len(buf))
+    hip.call("mm_prep_many_zero", ctypes.addressof(host), len(shapes), arena, 4096)
+    torch.cuda.synchronize()
+    for wf_a, wd_a, wf_b, wd_b in want:
+        assert torch.equal(wf_a.view(torch.int16), wf_b.view(torch.int16)) and torch.equal(wd_a.view(torch.int16), wd_b.view(torch.int16))
+    assert (arena[:4096] == 0).all() and (arena[4096:] == 7.0).all()
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_prep_many_zero", ctypes.addressof(host), len(shapes), arena, 4095)      # not a multiple of 4 floats
+    # gradient flush: three slot workspaces + five reductions (accumulator workspaces and one compact fp32 vector)
+    from multimodal_eeg_fmri_amd.ops import ACC_GRAD, acc_encode
+    sdesc, rdesc, ref = [], [], []
+    for cout, cin, k, slots in [(64, 48, 5, 7), (128, 128, 1, 3), (32, 20, 3, 1)]:
+        cinp = _cpad(cin)
+        ws = torch.randn(slots, cout, k, cinp, generator=g).cuda()
+        dw_a, dw_b = torch.ones(cout, cin, k, device="cuda"), torch.ones(cout, cin, k, device="cuda")
+        hip.call("mm_wgrad_scatter", ws, dw_a, cout, cin, k, cinp, slots)
+        sdesc.append(struct.pack("<QQiiiiii", ws.data_ptr(), dw_b.data_ptr(), cout, cin, k, cinp, slots, 0))
+        keep.append(ws)
+        ref.append((dw_a, dw_b))
+    for K in (128, 64, 1, 300):
+        acc = acc_encode(torch.randn(2, K, generator=g) * 1e-2, ACC_GRAD).cuda()
+        d_a, d_b = torch.ones(K, device="cuda"), torch.ones(K, device="cuda")
+        hip.call("mm_acc_reduce", acc.data_ptr() + 8 * K, d_a, K, 2 * K)
+        rdesc.append(struct.pack("<QQqqq", acc.data_ptr() + 8 * K, d_b.data_ptr(), K, 16, 2 * K))
+        keep.append(acc)
+        ref.append((d_a, d_b))
+    vec = torch.randn(77, generator=g).cuda()
+    d_a, d_b = torch.ones(77, device="cuda"), torch.ones(77, device="cuda")
+    d_a += vec
+    rdesc.append(struct.pack("<QQqqq", vec.data_ptr(), d_b.data_ptr(), 77, 1, 77))
+    ref.append((d_a, d_b))
+    sb, rb = b"".join(sdesc), b"".join(rdesc)
+    sh, rh = ctypes.create_string_buffer(sb, len(sb)), ctypes.create_string_buffer(rb, len(rb))
+    hip.call("mm_flush_many", ctypes.addressof(sh), len(sdesc), ctypes.addressof(rh), len(rdesc))
+    torch.cuda.synchronize()
+    for a_, b_ in ref:
+        assert torch.equal(a_, b_)
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_flush_many", None, 0, None, 0)
