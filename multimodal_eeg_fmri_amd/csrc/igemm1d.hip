@@ -1107,11 +1107,12 @@ static int wgrad_rows_per_wg(int B, int T, int Cin, int Cout, int taps, int slot
 }
 
 // grouped launches (mm_conv1d_wgrad_many) get their parallelism from the number of problems, so each
-// problem is cut into far fewer row chunks: ~64 workgroups per problem instead of 384 (sweep: 384 1.127, 128 1.124,
-// 64 1.120, 32 1.158 ms/step), i.e. 6x less
+// problem is cut into far fewer row chunks: ~32 workgroups per problem instead of 384 (round-1 sweep: 384 1.127, 128 1.124,
+// 64 1.120, 32 1.158 ms/step; end of round 2, with the launch on the side stream beside the chain: 128 0.880, 96 0.873,
+// 64 0.870, 48 0.866, 32 0.865, 24 0.864, 16 0.887 - fewer workgroups also leave more of the chip to the chain), i.e. 12x less
 // slot memory to write and to sum afterwards
 static int wgrad_many_target() {
-    static const int t = getenv("MM_WGM_TARGET") ? atoi(getenv("MM_WGM_TARGET")) : 64;
+    static const int t = getenv("MM_WGM_TARGET") ? atoi(getenv("MM_WGM_TARGET")) : 32;
     return t;
 }
 static int wgrad_many_rows_per_wg(int T, int Cin, int Cout) {
