@@ -198,10 +198,11 @@ int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, 
 int mm_meanpool_fwd(const float* x, float* out_f32, void* out_bf16, int B, int L, int D, hipStream_t stream);
 int mm_meanpool_bwd(const float* g, float* dx, int B, int L, int D, hipStream_t stream);
 int mm_cast_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
-/* two fp32 device-to-device copies in ONE launch (16-byte aligned, counts multiples of 4): a step's two input tensors
- * into the static buffers a captured step reads */
-int mm_copy2_f32(float* dst0, const float* src0, int64_t n0, float* dst1, const float* src1, int64_t n1,
-                 hipStream_t stream);
+/* A training step's inputs into the static buffers a captured step reads, ONE launch: mm_pack_nct_bf16(eeg ->
+ * eeg_packed_bf16) [+ an fp32 copy of the EEG batch into eeg_copy, nullable] + an fp32 copy of the fMRI batch
+ * (fmri_n floats, a multiple of 4, 16-byte aligned).  The captured step then starts at the first convolution. */
+int mm_stage_inputs(const float* eeg, void* eeg_packed_bf16, float* eeg_copy, int B, int C, int T, int Cp,
+                    float* fmri_dst, const float* fmri_src, int64_t fmri_n, hipStream_t stream);
 int mm_cast_f32(const void* x, float* y, int64_t n, hipStream_t stream);
 /* out = bf16( g * dropout_mask * act'(z) ) */
 int mm_act_bwd(const float* g_f32, const void* g_bf16, const void* z, void* out, int64_t n, int act,

@@ -129,7 +129,9 @@ class BridgeTrainer(nn.Module):
         if self.stamps is not None:
             _hip.call("mm_debug_stamp", self.stamps, i)
 
-    def _seg_forward(self, eeg, fmri):
+    def _seg_forward(self, eeg, fmri, xb=None):
+        """``xb``: the EEG batch already packed (B, T, Cp) bf16 (the captured step reads its static packed buffer, which
+        the trainer fills outside the graph together with the input copies)"""
         self._stamp(0)
         # one memset of what the step's accumulators actually use (high-water mark of the first
         # step + slack); the gradient bucket is cleared by the previous step's AdamW kernel
@@ -145,7 +147,7 @@ class BridgeTrainer(nn.Module):
         # The EEG branch is the longer chain, so it is issued FIRST: a hipGraph replay writes its
         # kernel packets in capture order at ~4.6 us per node, and the branch captured second
         # cannot start before the host has written every packet of the first (profiles/README.md).
-        fe, sv_e = ops._erp_forward_impl(self.eeg_encoder, eeg, True, True)
+        fe, sv_e = ops._erp_forward_impl(self.eeg_encoder, eeg, True, True, xb=xb)
         self._stamp(2)
         with torch.cuda.stream(self._side):
             self._stamp(3)
@@ -249,6 +251,7 @@ class BridgeTrainer(nn.Module):
         dev = eeg.device
         world = self.world
         c = {"eeg": eeg.clone(), "fmri": fmri.clone(), "epoch": torch.zeros(1, dtype=torch.int32, device=dev)}
+        c["xb"] = ops.pack_nct(c["eeg"])                         # static packed EEG operand: refilled before every replay
         ops.set_seed_epoch(c["epoch"])
         # warm-up outside capture (lazy inits, allocator priming) on a snapshot of the
         # training state, so that the first replay is really step 1
@@ -283,7 +286,7 @@ class BridgeTrainer(nn.Module):
         c["scal"] = self._scal
         if world == 1 and not (self.force_segments and self.group is not None):
             def whole():
-                z, saved = self._seg_forward(c["eeg"], c["fmri"])
+                z, saved = self._seg_forward(c["eeg"], c["fmri"], xb=c["xb"])
                 c["dz"] = ops._empty(tuple(z.shape), torch.float32, z)
                 self._seg_loss(z, c["scal"], c["dz"])
                 self._seg_backward(saved, c["dz"], c["scal"])
@@ -291,7 +294,7 @@ class BridgeTrainer(nn.Module):
             record(whole)
         else:
             def seg1():
-                c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"])
+                c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"], xb=c["xb"])
                 c["dz"] = ops._empty((B, N2), torch.float32, c["z"])
             record(seg1)
             c["z_all"] = torch.empty(world * B, N2, device=dev)
@@ -312,12 +315,16 @@ class BridgeTrainer(nn.Module):
         if (ce and cf and eeg.dtype == torch.float32 and fmri.dtype == torch.float32 and eeg.is_cuda and fmri.is_cuda
                 and eeg.is_contiguous() and fmri.is_contiguous() and eeg.numel() % 4 == 0 and fmri.numel() % 4 == 0
                 and (eeg.data_ptr() | fmri.data_ptr()) % 16 == 0):
-            _hip.call("mm_copy2_f32", c["eeg"], eeg, eeg.numel(), c["fmri"], fmri, fmri.numel())    # both in one launch
+            # ONE launch: EEG batch packed into the first convolution's bf16 operand (+ its fp32 copy), fMRI batch copied
+            Bx, Cx, Tx = eeg.shape
+            _hip.call("mm_stage_inputs", eeg, c["xb"], c["eeg"], Bx, Cx, Tx, c["xb"].shape[2], c["fmri"], fmri, fmri.numel())
         else:                                               # each input on its own: a loader may fill only one in place
             if ce:
                 c["eeg"].copy_(eeg)
             if cf:
                 c["fmri"].copy_(fmri)
+            Bx, Cx, Tx = c["eeg"].shape
+            _hip.call("mm_pack_nct_bf16", c["eeg"], c["xb"], Bx, Cx, Tx, c["xb"].shape[2])
         g = c["graphs"]
         if len(g) == 1:
             g[0].replay()

@@ -558,17 +558,6 @@ __global__ void add_pe_kernel(const float* __restrict__ x, const float* __restri
     }
 }
 
-// two fp32 device-to-device copies in one launch (a step's EEG and fMRI batch into the captured step's static inputs:
-// two runtime copy kernels cost ~5.5 us each, mostly launch latency in front of the graph)
-__global__ void copy2_kernel(float4* __restrict__ d0, const float4* __restrict__ s0, size_t n0,
-                             float4* __restrict__ d1, const float4* __restrict__ s1, size_t n1) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += stride) {
-        if (i < n0) d0[i] = s0[i];
-        else d1[i - n0] = s1[i - n0];
-    }
-}
-
 inline int grid_for(size_t n, int block = 256, int cap = 4096) {
     size_t g = (n + block - 1) / block;
     return (int)(g < (size_t)cap ? (g ? g : 1) : cap);
@@ -716,15 +705,6 @@ int mm_meanpool_bwd(const float* g, float* dx, int B, int L, int D, hipStream_t 
     MM_REQUIRE(g && dx, "meanpool_bwd: null");
     hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(grid_for((size_t)B * L * D)), dim3(256), 0, st, g, dx, B, L, D);
     return mm_check_launch("meanpool_bwd");
-}
-
-int mm_copy2_f32(float* dst0, const float* src0, int64_t n0, float* dst1, const float* src1, int64_t n1, hipStream_t st) {
-    MM_REQUIRE(dst0 && src0 && dst1 && src1 && n0 > 0 && n1 > 0 && n0 % 4 == 0 && n1 % 4 == 0, "copy2_f32: null / counts must be multiples of 4");
-    MM_REQUIRE((((uintptr_t)dst0 | (uintptr_t)src0 | (uintptr_t)dst1 | (uintptr_t)src1) & 15) == 0, "copy2_f32: 16-byte alignment");
-    hipLaunchKernelGGL(copy2_kernel, dim3(grid_for((size_t)(n0 + n1) / 4, 256, 2048)), dim3(256), 0, st, reinterpret_cast<float4*>(dst0),
-                       reinterpret_cast<const float4*>(src0), (size_t)n0 / 4, reinterpret_cast<float4*>(dst1),
-                       reinterpret_cast<const float4*>(src1), (size_t)n1 / 4);
-    return mm_check_launch("copy2_f32");
 }
 
 int mm_cast_bf16(const float* x, void* y, int64_t n, hipStream_t st) {

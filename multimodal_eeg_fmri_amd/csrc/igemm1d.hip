@@ -506,6 +506,34 @@ __global__ void pack_nct_kernel(const float* __restrict__ x, bf16* __restrict__ 
     }
 }
 
+// A step's inputs into the static buffers of a captured step, ONE launch: the EEG batch (B, C, T) fp32 is packed straight
+// into the channels-last bf16 operand (B, T, Cp) of the first convolution (and, optionally, copied as fp32), the fMRI
+// batch is copied.  Workgroups [0, npack) are pack_nct tiles, the rest copy.
+__global__ void stage_inputs_kernel(const float* __restrict__ x, bf16* __restrict__ y, float* __restrict__ x_copy, int B, int C,
+                                    int T, int Cp, int npack, float4* __restrict__ d1, const float4* __restrict__ s1, size_t n1) {
+    __shared__ float tile[32][33];
+    if ((int)blockIdx.x >= npack) {
+        const size_t nb = gridDim.x - npack;
+        for (size_t i = (size_t)(blockIdx.x - npack) * blockDim.x + threadIdx.x; i < n1; i += nb * blockDim.x) d1[i] = s1[i];
+        return;
+    }
+    const int tt = (T + 31) / 32, tc = (Cp + 31) / 32;
+    const int b = blockIdx.x / (tt * tc), rem = blockIdx.x % (tt * tc);
+    const int t0 = (rem % tt) * 32, c0 = (rem / tt) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, t = t0 + tx;
+        const float v = (c < C && t < T) ? x[((size_t)b * C + c) * T + t] : 0.f;
+        tile[i][tx] = v;
+        if (x_copy && c < C && t < T) x_copy[((size_t)b * C + c) * T + t] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, c = c0 + tx;
+        if (t < T && c < Cp) y[((size_t)b * T + t) * Cp + c] = (bf16)tile[tx][i];
+    }
+}
+
 // (B, T, Cp) (bf16 grads) -> (B, C, T) fp32  (input-gradient un-pack)
 __global__ void unpack_ntc_kernel(const bf16* __restrict__ g, float* __restrict__ dx, int C, int T, int Cp) {
     __shared__ float tile[32][33];
@@ -912,6 +940,19 @@ int mm_pack_nct_bf16(const float* x, void* y, int B, int C, int T, int Cp, hipSt
     dim3 grid(ceil_div(T, 32), ceil_div(Cp, 32), B);
     hipLaunchKernelGGL(pack_nct_kernel, grid, dim3(256), 0, st, x, (bf16*)y, C, T, Cp);
     return mm_check_launch("pack_nct");
+}
+
+int mm_stage_inputs(const float* eeg, void* eeg_packed_bf16, float* eeg_copy, int B, int C, int T, int Cp, float* fmri_dst,
+                    const float* fmri_src, int64_t fmri_n, hipStream_t st) {
+    MM_REQUIRE(eeg && eeg_packed_bf16 && B > 0 && C > 0 && T > 0 && Cp >= C && Cp % 16 == 0, "stage_inputs: bad EEG args");
+    MM_REQUIRE(fmri_dst && fmri_src && fmri_n > 0 && fmri_n % 4 == 0 && (((uintptr_t)fmri_dst | (uintptr_t)fmri_src) & 15) == 0,
+               "stage_inputs: fMRI copy needs 16-byte alignment and a multiple of 4 floats");
+    const int npack = B * ceil_div(T, 32) * ceil_div(Cp, 32);
+    const long n4 = fmri_n / 4;
+    const int ncopy = (int)((n4 + 1023) / 1024 < 1024 ? (n4 + 1023) / 1024 : 1024);
+    hipLaunchKernelGGL(stage_inputs_kernel, dim3(npack + ncopy), dim3(256), 0, st, eeg, (bf16*)eeg_packed_bf16, eeg_copy, B, C, T, Cp,
+                       npack, reinterpret_cast<float4*>(fmri_dst), reinterpret_cast<const float4*>(fmri_src), (size_t)n4);
+    return mm_check_launch("stage_inputs");
 }
 
 int mm_unpack_ntc_f32(const void* g, float* dx, int B, int C, int T, int Cp, hipStream_t st) {

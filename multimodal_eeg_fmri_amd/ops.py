@@ -533,13 +533,15 @@ def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool):
     return out, blocks, s, h
 
 
-def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None):
+def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None, xb=None):
     """EnhancedERPEncoder forward; returns (features fp32 (B, H), saved list).
-    ``save`` (default = training): keep what a backward needs (eval + save = frozen BatchNorm)."""
+    ``save`` (default = training): keep what a backward needs (eval + save = frozen BatchNorm).
+    ``xb``: ``pack_nct(x)`` when the caller already holds it (a trainer stages its inputs packed)."""
     cl = m.conv_layers
     save = training if save is None else save
     p = m.drop_p if training else 0.0
-    xb = pack_nct(x)
+    if xb is None:
+        xb = pack_nct(x)
     saved = []
     r, s = conv_bn_act(xb, cl[0], cl[1], training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
