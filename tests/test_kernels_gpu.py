@@ -777,3 +777,25 @@ def test_batched_launches_equal_their_single_forms():
         assert torch.equal(a_, b_)
     with pytest.raises(hip.HipLibraryError):
         hip.call("mm_flush_many", None, 0, None, 0)
+
+
+@pytest.mark.parametrize("B,C,T", [(3, 64, 1024), (2, 20, 77), (1, 16, 32)])
+def test_stage_inputs_equals_pack_plus_copies(B, C, T):
+    """mm_stage_inputs (one launch in front of a captured step) == mm_pack_nct_bf16 of the EEG batch + an fp32 copy of
+    it + an fp32 copy of the fMRI batch, bit for bit; ragged channel / time counts hit the partial 32 x 32 tiles."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(B * 100 + C + T)
+    eeg = torch.randn(B, C, T, generator=g).cuda()
+    fmri = torch.randn(B, 1, 8, 8, 12, generator=g).cuda()
+    cp = _cpad(C)
+    want = torch.empty(B, T, cp, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_pack_nct_bf16", eeg, want, B, C, T, cp)
+    xb = torch.full((B, T, cp), float("nan"), dtype=torch.bfloat16, device="cuda")
+    e2, f2 = torch.full_like(eeg, float("nan")), torch.full_like(fmri, float("nan"))
+    hip.call("mm_stage_inputs", eeg, xb, e2, B, C, T, cp, f2, fmri, fmri.numel())
+    assert torch.equal(xb.view(torch.int16), want.view(torch.int16)) and torch.equal(e2, eeg) and torch.equal(f2, fmri)
+    xb2 = torch.full_like(xb, float("nan"))
+    hip.call("mm_stage_inputs", eeg, xb2, None, B, C, T, cp, f2, fmri, fmri.numel())      # without the fp32 EEG copy
+    assert torch.equal(xb2.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_stage_inputs", eeg, xb2, None, B, C, T, cp, f2, fmri, fmri.numel() - 2)
