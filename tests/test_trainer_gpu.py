@@ -224,11 +224,10 @@ def test_two_rank_data_parallel_step_on_one_gpu():
     from tools import dp_rehearsal as mod
     r = mod.run(2)
     assert r["same_params_across_ranks"], r
-    # Adam turns float-atomic ordering noise on near-zero gradients into +-lr steps, so six
-    # steps at lr 1e-3 leave ~2e-3 relative parameter distance between two runs of the SAME tape
-    assert r["graph_vs_manual_rel"] < 1e-2, r
-    for i, (a, b) in enumerate(zip(r["losses"]["graph"], r["losses"]["manual"])):
-        assert abs(a - b) <= (5e-3 if i < 3 else 3e-2) * abs(b), r
+    # the step is bit-reproducible (no floating-point atomics): the segmented graph replay and the eager tape, six steps
+    # each from the same state, end on IDENTICAL parameters and report identical losses
+    assert r["graph_vs_manual_rel"] == 0.0, r
+    assert r["losses"]["graph"] == r["losses"]["manual"], r
     assert r["losses"]["graph"][-1] < r["losses"]["graph"][0], r
 
 
