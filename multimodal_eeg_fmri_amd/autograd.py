@@ -527,11 +527,12 @@ class TransformerBlockFn(_ModuleFn):
 
 
 def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
-    """backward of ops.conv3d_bn_act (train). dout: bf16 pooled volume, or fp32
-    (B, V, N) for the un-pooled last stage.  returns dx bf16 (B,D,H,W,Cinp)."""
+    """backward of ops.conv3d_bn_act (train, or eval with frozen BatchNorm: ``s["train"]`` False). dout: bf16 pooled
+    volume, or fp32 (B, V, N) for the un-pooled last stage.  returns dx bf16 (B,D,H,W,Cinp)."""
     conv, bn = s["conv"], s["bn"]
     y, out4, xv = s["y"], s["out4"], s["xv"]
     B, D, H, W, N = y.shape
+    train = 1 if s.get("train", True) else 0
     sums = _zeros((REPL, 2, N), y)
     dy = _empty((B, D, H, W, N), _BF, y)
     gelu = ACT["gelu"]
@@ -540,11 +541,11 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
                   float(s["drop_p"]), int(s["seed"]), ops.EP())
         # the apply passes sum the workspace's replicas themselves (no compaction launch between the two passes)
         _hip.call("mm_pool3d_bn_act_bwd_apply", y, s["arg"], out4, dout, sums, dy, B, D, H, W, N, gelu,
-                  float(s["drop_p"]), int(s["seed"]), ops.EP(), 1, REPL)
+                  float(s["drop_p"]), int(s["seed"]), ops.EP(), train, REPL)
     else:
         args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
-        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, None, *args, 1, REPL)
+        _hip.call("mm_bn_act_bwd_apply", y, out4, None, dout, sums, dy, None, *args, train, REPL)
     _bn_param_grads(bag, bn, sums, N, nrep=REPL)
     cin = conv.in_channels
     dw = bag.target(conv.weight)
@@ -575,9 +576,11 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
 
 
 def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
-    """backward of ops.conv3d_l1_bn_act (no input gradient: the volume is data)."""
+    """backward of ops.conv3d_l1_bn_act (no input gradient: the volume is data; a caller that wants one runs
+    layer 1 through conv3d_bn_act, ops._vol_forward_impl(need_dx=True))."""
     conv, bn, x = s["conv"], s["bn"], s["x"]
     B, _, D, H, W = x.shape
+    train = 1 if s.get("train", True) else 0
     # one recompute pass: S1/S2, A1 = x^T dz, A3 = x^T xhat; BatchNorm's backward is linear in S1, S2
     sums = _zeros((REPL, 2, 32), x)
     a1 = _zeros((REPL, 27, 32), x)
@@ -589,32 +592,43 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
     dw = bag.target(conv.weight)
     if dw is None:                                   # frozen conv weight: the sums alone (BatchNorm gradients)
         _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
-                  B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
+                  B, D, H, W, train, float(s["drop_p"]), int(s["seed"]), ops.EP())
     else:
         _hip.call("mm_conv3d_l1_bwd", x, s["wimg"], conv.bias, s["out4"], dout, sums, a1, a3, tapsum, 1 if ready else 0,
-                  dw, bag.target(conv.bias), B, D, H, W, 1, float(s["drop_p"]), int(s["seed"]), ops.EP())
+                  dw, bag.target(conv.bias), B, D, H, W, train, float(s["drop_p"]), int(s["seed"]), ops.EP())
     _bn_param_grads(bag, bn, sums, 32, nrep=REPL)
 
 
 def volume_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor):
-    """backward of ops._vol_forward_impl (train mode); dout fp32 (B, out_dim)."""
+    """backward of ops._vol_forward_impl (train mode, or eval with frozen BatchNorm); dout fp32 (B, out_dim).
+    Returns d / d volume (fp32, the input's shape) when the forward was run with need_dx, else None."""
     d = pooled_head_bwd(bag, sv["head"], dout)                # fp32 (B, V, N)
     g = conv3d_bn_act_bwd(bag, sv["convs"][2], d)
     g = conv3d_bn_act_bwd(bag, sv["convs"][1], g)
     if sv["convs"][0].get("l1"):
         conv3d_l1_bwd(bag, sv["convs"][0], g)
-    else:
-        conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=False)
+        return None
+    need_dx = bool(sv.get("need_dx"))
+    dxp = conv3d_bn_act_bwd(bag, sv["convs"][0], g, need_dx=need_dx)
+    if not need_dx:
+        return None
+    Bx, C, D, H, W = sv["x_shape"]
+    return dxp[..., :C].permute(0, 4, 1, 2, 3).float().contiguous()      # (B, D, H, W, Cp) bf16 -> (B, C, D, H, W) fp32
 
 
 class VolumeEncoderFn(_ModuleFn):
+    """train mode, or eval mode with a backward to follow (frozen BatchNorm: running statistics, no dropout, no
+    statistic update) - fine-tuning on a frozen voxel encoder and gradient saliency / integrated gradients on an
+    end-to-end voxel path (the protocol of bridge_utils.py:158-229)."""
+
     @staticmethod
     def run(m, x):
         return VolumeEncoderFn.apply(m, x, *_module_params(m))
 
     @staticmethod
     def forward(ctx, m, x, *params):
-        out, saved = ops._vol_forward_impl(m, x.float(), True, True)
+        ctx.need_dx = bool(x.requires_grad)
+        out, saved = ops._vol_forward_impl(m, x.float(), m.training, True, save=True, need_dx=ctx.need_dx)
         ctx.saved, ctx.params = saved, params
         return out
 
@@ -622,8 +636,8 @@ class VolumeEncoderFn(_ModuleFn):
     def backward(ctx, dout):
         bag = GradBag()
         with deferred(bag, dout.device):
-            volume_encoder_bwd(bag, ctx.saved, dout)
-        return _ModuleFn._finish(ctx, bag, ctx.params, None)
+            dx = volume_encoder_bwd(bag, ctx.saved, dout)
+        return _ModuleFn._finish(ctx, bag, ctx.params, dx)
 
 
 # ------------------------------------------------ projection bridge / loss

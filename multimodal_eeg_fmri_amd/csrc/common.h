@@ -115,8 +115,8 @@ __device__ __forceinline__ uint32_t mm_eff_seed(uint32_t base, const uint32_t* e
 // depend on the order the workgroups arrive in and a training step is bit-reproducible (fp32 atomics
 // are not).  A contribution v (already a block-level partial sum, formed in a fixed order) is added as
 // rint(v * 2^K); the consumer converts sum * 2^-K back to fp32 once.
-//   K = MM_ACC_STAT (28) for sums of activations / their squares: resolution 3.7e-9, range +-3.4e10
-//   K = MM_ACC_GRAD (40) for sums of gradients:                     resolution 9.1e-13, range +-8.4e6
+//   K = MM_ACC_STAT (28) for sums of activations / their squares: resolution 3.7e-9, range +-8.6e9
+//   K = MM_ACC_GRAD (40) for sums of gradients:                     resolution 9.1e-13, range +-2.1e6
 // Hundreds of workgroups adding to the SAME address serialise in L2 (~25 ns each), so every such
 // accumulator is replicated: callers allocate (and zero) MM_REPL fp32-sized copies = MM_ACC_REPL
 // 64-bit ones; a workgroup adds into replica (blockIdx.x % MM_ACC_REPL) and the consumer sums the
@@ -127,23 +127,62 @@ __device__ __forceinline__ uint32_t mm_eff_seed(uint32_t base, const uint32_t* e
 #define MM_ACC_STAT 28
 #define MM_ACC_GRAD 40
 typedef long long mm_acc_t;
+// Overflow / non-finite contract (fp32 atomics degraded to inf / NaN by themselves; integers wrap): a contribution
+// whose fixed-point image is not below 2^55 in magnitude (|v| >= 1.3e8 for STAT, 32 768 for GRAD - or NaN / Inf)
+// does not add: it EXCHANGES the accumulator for the poison value 2^62, which no run of in-range contributions can
+// move out of the poisoned band (64 full-size ones of one sign per replica would be needed - 1 024 workgroups each
+// at the limit, whose true sum is out of range anyway; a wrap would need 256 per replica).  A consumer sums the replicas as
+// integers and, beside that, their magnitudes in units of 2^36: when those reach 2^61 a replica is poisoned or the
+// integer sum may have wrapped, and the consumer's value is NaN (acc_val of MM_ACC_BAD) - BatchNorm statistics,
+// gradients and the loss then go NaN exactly as they would have with floating-point sums, never to wrapped
+// garbage.  Exact range of a sum: +-8.6e9 (STAT), +-2.1e6 (GRAD).  tests/test_kernels_gpu.py::test_accumulator_*.
+#define MM_ACC_POISON (1ll << 62)
+#define MM_ACC_BAD ((mm_acc_t)0x8000000000000000ull)
+#define MM_ACC_MAG_LIMIT ((1u << 25) - 16u)
 #ifdef __HIPCC__
 template <int K> __device__ __forceinline__ void acc_add(mm_acc_t* p, float v) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(v * (float)(1ull << K)));
+    const float f = v * (float)(1ull << K);
+    if (fabsf(f) < 36028797018963968.f)                 // 2^55; false for NaN
+        atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__float2ll_rn(f));
+    else
+        atomicExch(reinterpret_cast<unsigned long long*>(p), (unsigned long long)MM_ACC_POISON);
 }
-template <int K> __device__ __forceinline__ float acc_val(mm_acc_t s) { return (float)s * (1.0f / (float)(1ull << K)); }
+// a whole value written by one thread (no accumulation): same contract
+template <int K> __device__ __forceinline__ mm_acc_t acc_encode(float v) {
+    const float f = v * (float)(1ull << K);
+    return fabsf(f) < 2305843009213693952.f ? __float2ll_rn(f) : MM_ACC_POISON;      // 2^61
+}
+// magnitude of one replica in units of 2^36 (floor), for the guard sums
+__device__ __forceinline__ unsigned acc_mag(mm_acc_t v) {
+    const int hi = (int)(v >> 32);
+    return (unsigned)(hi < 0 ? ~hi : hi) >> 4;
+}
+__device__ __forceinline__ mm_acc_t acc_guard(mm_acc_t s, unsigned mag_sum) { return mag_sum >= MM_ACC_MAG_LIMIT ? MM_ACC_BAD : s; }
+template <int K> __device__ __forceinline__ float acc_val(mm_acc_t s) {
+    // a single accumulator (or a guarded sum): outside [-2^61, 2^61) = poisoned / flagged
+    const bool bad = (unsigned long long)(s + (1ll << 61)) >= (1ull << 62);
+    return bad ? __builtin_nanf("") : (float)s * (1.0f / (float)(1ull << K));
+}
 // replica r of an accumulator workspace of n values per replica
 __device__ __forceinline__ mm_acc_t* acc_rep(float* ws, int r, size_t n) { return reinterpret_cast<mm_acc_t*>(ws) + (size_t)r * n; }
-// sum over the MM_ACC_REPL replicas of element i (all loads in flight at once)
+// sum over the MM_ACC_REPL replicas of element i (all loads in flight at once); MM_ACC_BAD if poisoned / out of range
 __device__ __forceinline__ mm_acc_t acc_sum(const float* ws, size_t n, size_t i) {
     const mm_acc_t* p = reinterpret_cast<const mm_acc_t*>(ws) + i;
     mm_acc_t v[MM_ACC_REPL];
 #pragma unroll
     for (int r = 0; r < MM_ACC_REPL; ++r) v[r] = p[(size_t)r * n];
     mm_acc_t s = 0;
+    unsigned g = 0;
 #pragma unroll
-    for (int r = 0; r < MM_ACC_REPL; ++r) s += v[r];
-    return s;
+    for (int r = 0; r < MM_ACC_REPL; ++r) { s += v[r]; g += acc_mag(v[r]); }
+    return acc_guard(s, g);
+}
+// the same sum with one replica per lane: 16 adjacent lanes hold the 16 replicas of one element
+__device__ __forceinline__ mm_acc_t acc_sum_lanes16(mm_acc_t v) {
+    unsigned g = acc_mag(v);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); g += __shfl_xor(g, o, 64); }
+    return acc_guard(v, g);
 }
 #endif
 

@@ -336,11 +336,8 @@ __global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __r
                    *qt = reinterpret_cast<const mm_acc_t*>(tapsum), *qs = reinterpret_cast<const mm_acc_t*>(sums);
     mm_acc_t iA1 = q1[(size_t)r * 864 + tap * 32 + n], iA3 = q3[(size_t)r * 864 + tap * 32 + n];
     mm_acc_t iSt = qt[r * 32 + tap], is0 = qs[r * 64 + n], is1 = qs[r * 64 + 32 + n];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        iA1 += __shfl_xor(iA1, o, 64); iA3 += __shfl_xor(iA3, o, 64); iSt += __shfl_xor(iSt, o, 64);
-        is0 += __shfl_xor(is0, o, 64); is1 += __shfl_xor(is1, o, 64);
-    }
+    iA1 = acc_sum_lanes16(iA1); iA3 = acc_sum_lanes16(iA3); iSt = acc_sum_lanes16(iSt);
+    is0 = acc_sum_lanes16(is0); is1 = acc_sum_lanes16(is1);
     if (r) return;
     const float A1 = acc_val<MM_ACC_GRAD>(iA1), A3 = acc_val<MM_ACC_GRAD>(iA3), St = acc_val<MM_ACC_STAT>(iSt);
     const float s0 = acc_val<MM_ACC_GRAD>(is0), s1 = acc_val<MM_ACC_GRAD>(is1);

@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     const int lo = xlo + slot_ * per + (slot_ < rem ? slot_ : rem), hi = lo + per + (slot_ < rem ? 1 : 0);
     const bool has_work = lo < hi;                                  // (uniform) a workgroup without tiles still drains its DMA
     auto coords = [&](int t) __attribute__((always_inline)) {       // divisions by host-made reciprocals (t < 2^24)
-        Tile c;
-        int q = (int)__umulhi((unsigned)t, a.mtd); c.d = t - q * td; t = q;
-        q = (int)__umulhi((unsigned)t, a.mtw); c.w0 = (t - q * tw) * 8; t = q;
-        q = (int)__umulhi((unsigned)t, a.mth); c.h0 = (t - q * th) * 8;
+        Tile c;                                                      // a divisor of 1 has no 32-bit reciprocal (2^32 + 1): q = t
+        int q = td == 1 ? t : (int)__umulhi((unsigned)t, a.mtd); c.d = t - q * td; t = q;
+        q = tw == 1 ? t : (int)__umulhi((unsigned)t, a.mtw); c.w0 = (t - q * tw) * 8; t = q;
+        q = th == 1 ? t : (int)__umulhi((unsigned)t, a.mth); c.h0 = (t - q * th) * 8;
         c.b = q;
         return c;
     };
@@ -436,7 +436,8 @@ int launch3d_wres(const Conv3dArgs& a, hipStream_t st) {
     if (grid < 8) return mm_fail(MM_ERR_UNSUPPORTED, "conv3d_fwd_wres: %d tiles", ntiles);
     if (ntiles >= (1 << 24)) return mm_fail(MM_ERR_UNSUPPORTED, "conv3d_fwd_wres: %d tiles", ntiles);
     Conv3dArgs k = a;
-    auto magic = [](int d) { return (unsigned)(0x100000000ull / (unsigned)d) + 1u; };
+    // floor(2^32 / d) + 1; d = 1 would need 2^32 + 1 and is special-cased in the kernel's coords() (the value is unused)
+    auto magic = [](int d) { return d == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; };
     k.mtw = magic(ceil_div(a.W, 8)); k.mth = magic(ceil_div(a.H, 8)); k.mtd = magic(ceil_div(a.D, TD));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, st, k);
     return mm_check_launch("conv3d_fwd_wres");

@@ -23,7 +23,8 @@ __global__ void bn_finalize_kernel(const float* stats, const float* gamma, const
         const float s1 = acc_val<MM_ACC_STAT>(acc_sum(stats, 2 * (size_t)N, n));
         const float s2 = acc_val<MM_ACC_STAT>(acc_sum(stats, 2 * (size_t)N, (size_t)N + n));
         mean = s1 / count;
-        var = fmaxf(s2 / count - mean * mean, 0.f);
+        var = s2 / count - mean * mean;
+        var = var < 0.f ? 0.f : var;                     // (not fmaxf: a NaN sum - an accumulator out of range - must stay NaN)
         run_mean[n] = (1.f - momentum) * run_mean[n] + momentum * mean;
         const float unb = count > 1.f ? var * count / (count - 1.f) : var;
         run_var[n] = (1.f - momentum) * run_var[n] + momentum * unb;

@@ -95,8 +95,8 @@ __global__ void colstats_kernel(const float* __restrict__ x, float* __restrict__
     for (int b = 0; b < B; ++b) { const float v = x[(size_t)b * N + n]; s += v; q += v * v; }
     // replica 0 of a statistics accumulator workspace (the input of mm_bn_finalize); the other replicas stay zero
     mm_acc_t* acc = reinterpret_cast<mm_acc_t*>(stats);
-    acc[n] = __float2ll_rn(s * (float)(1ull << MM_ACC_STAT));
-    acc[N + n] = __float2ll_rn(q * (float)(1ull << MM_ACC_STAT));
+    acc[n] = acc_encode<MM_ACC_STAT>(s);
+    acc[N + n] = acc_encode<MM_ACC_STAT>(q);
 }
 
 // z = h / max(||h||, eps); one wave per row

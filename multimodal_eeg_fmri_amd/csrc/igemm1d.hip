@@ -911,8 +911,7 @@ __device__ __forceinline__ void acc_reduce_rows(const mm_acc_t* __restrict__ src
     const int r0 = threadIdx.x & 15;
     for (long k = kfirst + (threadIdx.x >> 4); k < ((K + 15) / 16) * 16; k += kstep) {
         mm_acc_t s = k < K ? src[r0 * rep_stride + k] : 0;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s = acc_sum_lanes16(s);
         if (k < K && r0 == 0) dst[k] += acc_val<MM_ACC_GRAD>(s);
     }
 }

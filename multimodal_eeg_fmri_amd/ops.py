@@ -56,7 +56,10 @@ def acc_decode(ws: torch.Tensor, k: int) -> torch.Tensor:
     """accumulator workspace (REPL, ...) as the kernels left it -> its fp64 sums (...).  For tests and debugging:
     the product reads workspaces on the device (mm_bn_finalize, mm_acc_reduce, ...)."""
     i = ws.contiguous().flatten().view(torch.int64).view(AREPL, *ws.shape[1:])
-    return i.sum(0).double() * 2.0 ** -k
+    out = i.sum(0).double() * 2.0 ** -k
+    # csrc/common.h's overflow contract: a poisoned replica (2^62) or replica magnitudes summing to 2^61 read as NaN
+    bad = i.double().abs().sum(0) >= 2.0 ** 61
+    return torch.where(bad, torch.full_like(out, float("nan")), out)
 
 
 def acc_encode(values: torch.Tensor, k: int) -> torch.Tensor:
@@ -620,11 +623,14 @@ def pack_volume(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, drop_p: float,
-                  need_dgrad: bool):
+                  need_dgrad: bool, save=None):
     """Conv3d(k3,p1) -> BatchNorm3d -> GELU [-> MaxPool3d(2)] [-> Dropout] on
     channels-last bf16 volumes.  Returns (out, saved).  A pooled layer keeps its pre-BatchNorm
     tensor in bf16 (half the traffic of the conv's output, the pooling pass and the backward; the
-    statistics come from the fp32 accumulators); the un-pooled last layer keeps fp32."""
+    statistics come from the fp32 accumulators); the un-pooled last layer keeps fp32.
+    eval with ``save`` (a backward will follow: frozen BatchNorm - fine-tuning on a frozen encoder, saliency):
+    the train-shaped pipeline with the RUNNING statistics, no statistic update, no dropout."""
+    save = training if save is None else save
     B, D, H, W, cinp = xv.shape
     cout = conv.out_channels
     wf, _, cp, _ = weights.get(conv.weight, need_dgrad)
@@ -641,6 +647,9 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
         if end is not None:
             end.record()
         out4 = bn_finalize_train(bn, stats, B * D * H * W)
+    elif save:
+        _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, None, yf, yb)
+        out4 = bn_fold_eval(bn, None)
     else:
         _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, None, None, yf, yb)
         out4 = bn_fold_eval(bn, conv.bias)
@@ -649,7 +658,7 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     ysel = arg = None
     if pool:
         out = _empty((B, D // 2, H // 2, W // 2, cout), _BF, xv)
-        if training:                                   # the window winners: all that BN-backward's reduction needs
+        if save:                                       # the window winners: all that BN-backward's reduction needs
             ysel = _empty(out.shape, _BF, xv)
             arg = _empty(out.shape, torch.uint8, xv)
         _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, ysel, arg, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
@@ -658,12 +667,14 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
         _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], None, None, out, B, D * H * W, cout,
                   ACT["gelu"], 1, 1, float(p), seed, 0.0, 0, EP())
     saved = dict(xv=xv, y=y, out4=out4, pool=pool, drop_p=p, seed=seed, conv=conv, bn=bn,
-                 ysel=ysel, arg=arg) if training else None
+                 ysel=ysel, arg=arg, train=training) if save else None
     return out, saved
 
 
-def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float):
-    """fused first layer on the raw fp32 volume (B, 1, D, H, W); see conv3d_l1.hip."""
+def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float, save=None):
+    """fused first layer on the raw fp32 volume (B, 1, D, H, W); see conv3d_l1.hip.  ``save`` without ``training``:
+    frozen BatchNorm (running statistics), a backward will follow."""
+    save = training if save is None else save
     B, _, D, H, W = x.shape
     wimg = weights.get(conv.weight.view(32, 27, 1), False, key=conv.weight)[0]
     out = _empty((B, D // 2, H // 2, W // 2, 32), _BF, x)
@@ -675,43 +686,50 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
                   B, D, H, W, 1, 0.0, 0, None)
         out4 = bn_finalize_train(bn, stats, B * D * H * W)
         bias = conv.bias
+    elif save:
+        out4 = bn_fold_eval(bn, None)                  # the backward recomputes conv + bias and needs mean / rstd apart
+        bias = conv.bias
     else:
         out4 = bn_fold_eval(bn, conv.bias)
         bias = None
     _hip.call("mm_conv3d_l1", 1, x, wimg, bias, out4, None, None, None, out, None, None,
               B, D, H, W, 1 if training else 0, float(p), seed, EP())
-    saved = dict(l1=True, x=x, wimg=wimg, out4=out4, drop_p=p, seed=seed, conv=conv, bn=bn) if training else None
+    saved = dict(l1=True, x=x, wimg=wimg, out4=out4, drop_p=p, seed=seed, conv=conv, bn=bn, train=training) if save else None
     return out, saved
 
 
-def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool):
+def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None, need_dx: bool = False):
+    """``save`` (default = training): keep what a backward needs; eval + save = frozen BatchNorm.  ``need_dx``: the
+    caller wants d / d volume - layer 1 then runs as an ordinary implicit GEMM on the channel-padded volume (the
+    fused layer-1 kernels never form its data gradient)."""
+    save = training if save is None else save
     cl = m.conv_layers
     p = m.drop_p
     saved = []
     B, C, D, H, W = x.shape
     x = x.contiguous()
-    if C == 1 and cl[0].out_channels == 32 and D % 2 == 0 and H % 2 == 0 and W % 2 == 0:
-        h, s = conv3d_l1_bn_act(x, cl[0], cl[1], training=training, drop_p=p)
+    if C == 1 and cl[0].out_channels == 32 and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and not need_dx:
+        h, s = conv3d_l1_bn_act(x, cl[0], cl[1], training=training, drop_p=p, save=save)
     else:
         h, s = conv3d_bn_act(pack_volume(x), cl[0], cl[1], pool=True, training=training, drop_p=p,
-                             need_dgrad=need_dgrad)
+                             need_dgrad=need_dgrad or need_dx, save=save)
     saved.append(s)
-    h, s = conv3d_bn_act(h, cl[5], cl[6], pool=True, training=training, drop_p=p, need_dgrad=need_dgrad)
+    h, s = conv3d_bn_act(h, cl[5], cl[6], pool=True, training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
-    h, s = conv3d_bn_act(h, cl[10], cl[11], pool=False, training=training, drop_p=p, need_dgrad=need_dgrad)
+    h, s = conv3d_bn_act(h, cl[10], cl[11], pool=False, training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
-    out, hs = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad)
-    if saved[0] is not None and saved[0].get("l1") and cl[0].weight.requires_grad:
+    out, hs = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
+    if training and saved[0] is not None and saved[0].get("l1") and cl[0].weight.requires_grad:
         # per-tap input sums of the layer-1 weight gradient depend on the volume alone: taken here, where the
         # fMRI stream has slack, instead of at the head of the layer-1 backward
         saved[0]["tapsum"] = _zeros((REPL, 32), x)
         _hip.call("mm_conv3d_l1_tapsum", x, saved[0]["tapsum"], B, D, H, W)
-    return out, dict(convs=saved, head=hs)
+    return out, dict(convs=saved, head=hs, x_shape=tuple(x.shape), need_dx=need_dx)
 
 
 def volume_encoder_forward(m, x: torch.Tensor) -> torch.Tensor:
     _need_gpu(x)
-    if m.training:
+    if m.training or _wants_grad(m, x):
         from .autograd import VolumeEncoderFn
         return VolumeEncoderFn.run(m, x)
     with torch.no_grad():

@@ -24,6 +24,9 @@ def _r(t):
 
 
 class _RoundedF:
+    def __init__(self, stored_bf16=((64, 32),)):
+        self.stored = tuple(stored_bf16)          # (Cout, Cin) of the conv3d layers whose pre-BatchNorm output the HIP path keeps in bf16
+
     def __getattr__(self, name):
         fn = getattr(TF, name)
         if name in ("conv1d", "linear"):
@@ -33,15 +36,17 @@ class _RoundedF:
         if name == "conv3d":
             def wrapped3(x, w, b=None, *a, **k):
                 out = fn(_r(x), _r(w), b, *a, **k)
-                return _r(out) if tuple(w.shape[:2]) == (64, 32) else out     # layer 2: stored in bf16
+                return _r(out) if tuple(w.shape[:2]) in self.stored else out   # layer 2 (and the implicit-GEMM layer 1): stored in bf16
             return wrapped3
         return fn
 
 
 @contextlib.contextmanager
-def bf16_operands():
+def bf16_operands(l1_as_gemm: bool = False):
+    """``l1_as_gemm``: the voxel encoder's first layer ran as an ordinary implicit GEMM (a caller asked for d / d volume,
+    ops._vol_forward_impl(need_dx=True)); that form keeps its pooled layer's pre-BatchNorm output in bf16 too."""
     saved = RF.F
-    RF.F = _RoundedF()
+    RF.F = _RoundedF(((64, 32), (32, 1)) if l1_as_gemm else ((64, 32),))
     try:
         yield
     finally:

@@ -565,13 +565,122 @@ def test_conv3d_fwd_wgrad_dgrad(B, Cin, Cout, D, H, W):
     torch.testing.assert_close(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1), rtol=1e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("B,D,H,W", [(4, 16, 16, 16), (32, 16, 16, 16), (8, 32, 32, 24), (24, 14, 16, 20), (2, 16, 24, 20)])
+@pytest.mark.parametrize("scale,expect", [(30.0, "exact"), (3e3, "flagged"), (float("nan"), "flagged"), (float("inf"), "flagged")])
+def test_accumulator_overflow_is_reported_not_wrapped(scale, expect):
+    """csrc/common.h: the 64-bit fixed-point accumulators either hold the exact sum or read as NaN (a contribution
+    out of range / non-finite poisons its replica; replica magnitudes reaching 2^61 flag the sum) - never a wrapped
+    integer.  Through a real producer / consumer pair: the weight-resident conv3d's BatchNorm sums -> mm_bn_finalize.
+    scale 30: sum of squares ~1.5e7, in range -> statistics to 1e-3; scale 3e3: ~1.5e11 > 8.6e9 -> NaN mean / rstd
+    and untouched-by-garbage running statistics are not required, only non-finite ones; NaN / Inf inputs -> NaN."""
+    from multimodal_eeg_fmri_amd.ops import ACC_STAT, acc_decode
+    hip = _hip()
+    B, Cin, Cout, D, H, W = 4, 32, 64, 16, 16, 16
+    g = torch.Generator().manual_seed(5)
+    x = _bf(torch.randn(B, Cin, D, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, 3, generator=g) / math.sqrt(27 * Cin))
+    if math.isfinite(scale):
+        x = _bf(x * scale)
+    else:
+        x[1, 3, 4, 5, 6] = scale
+    wf, _ = _prep_w(hip, w.reshape(Cout, Cin, 27), Cin)
+    out = torch.empty(B, D, H, W, Cout, dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
+    hip.call("mm_conv3d_fwd", _vol_cl(x), wf, B, D, H, W, Cin, Cout, None, stats, None, out)
+    dec = acc_decode(stats, ACC_STAT).cpu()
+    gam, bet = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    out4 = torch.empty(4, Cout, device="cuda")
+    hip.call("mm_bn_finalize", stats, gam, bet, rm, rv, None, out4, Cout, float(B * D * H * W), 0.1, 1e-5, 0, None)
+    if expect == "exact":
+        want = F.conv3d(x, w, None, padding=1).permute(0, 2, 3, 4, 1).double()
+        torch.testing.assert_close(dec[0], want.sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1.0)
+        torch.testing.assert_close(dec[1], (want * want).sum(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1.0)
+        assert torch.isfinite(out4).all().item()
+        torch.testing.assert_close(out4[2].cpu().double(), want.mean(dim=(0, 1, 2, 3)), rtol=1e-3, atol=1e-3)
+    else:
+        assert torch.isnan(dec[1]).any().item()                       # the sum of squares is out of range / poisoned ...
+        bad = torch.isnan(dec).any(dim=0)
+        assert torch.isnan(out4[:2].cpu())[:, bad].all().item()       # ... and the consumer says so: scale / shift are NaN
+        good = ~bad
+        assert torch.isfinite(out4[:, good]).all().item()             # channels whose sums are in range stay exact
+
+
+def test_accumulator_single_writer_and_lane_sums_report_overflow():
+    """the other consumer forms: mm_colstats (one writer, acc_encode) -> mm_bn_finalize, and mm_acc_reduce
+    (one replica per lane, acc_sum_lanes16) on a hand-made workspace holding a poisoned replica, a wrapped-range
+    sum and an in-range sum."""
+    from multimodal_eeg_fmri_amd.ops import ACC_GRAD
+    hip = _hip()
+    N = 16
+    x = torch.randn(8, N)
+    x[:, 3] *= 1e6
+    x[2, 5] = float("nan")
+    stats = torch.zeros(32, 2, N, device="cuda")
+    hip.call("mm_colstats", x.cuda(), stats, 8, N)
+    out4 = torch.empty(4, N, device="cuda")
+    rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    hip.call("mm_bn_finalize", stats, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), rm, rv, None, out4, N, 8.0, 0.1,
+             1e-5, 0, None)
+    o = out4.cpu()
+    assert torch.isnan(o[0, 3]).item() and torch.isnan(o[0, 5]).item()
+    keep = [i for i in range(N) if i not in (3, 5)]
+    assert torch.isfinite(o[:, keep]).all().item()
+    torch.testing.assert_close(o[2, keep], x[:, keep].mean(0), rtol=1e-5, atol=1e-6)
+    ws = torch.zeros(16, 4, dtype=torch.int64)
+    ws[:, 0] = int(1.5 * 2 ** ACC_GRAD)                      # 16 x 1.5 = 24
+    ws[5, 1] = 1 << 62                                        # poisoned replica
+    ws[:, 2] = 1 << 58                                        # 16 x 2^58 = 2^62: over the flagged range
+    ws[:, 3] = -(1 << 57) + 12345                             # 16 x -2^57 = -2^61: flagged (boundary)
+    dst = torch.zeros(4, device="cuda")
+    hip.call("mm_acc_reduce", ws.view(torch.float32).view(32, 4).cuda(), dst, 4, 4)
+    d = dst.cpu()
+    assert d[0].item() == 24.0 and torch.isnan(d[1:]).all().item(), d
+
+
+@pytest.mark.parametrize("B,Cin,Cout,D,H,W", [(32, 32, 64, 16, 16, 16), (32, 64, 128, 8, 8, 8), (8, 32, 64, 32, 32, 24),
+                                              (3, 32, 64, 14, 16, 20)])
+def test_conv3d_wgrad_at_training_shapes(B, Cin, Cout, D, H, W):
+    """csrc/conv3d_wgrad.hip at the shapes the training step runs it at - layer 2 and layer 3 of the C2 step (41 / 25
+    slot counts, the 4-way K split, the LDS-DMA ring at full depth), layer 2 at BASELINE config #4 volumes, one ragged
+    volume - against F.conv3d's weight gradient on the same bf16-rounded operands: rel-L2 <= 2e-3 and element-wise 2e-3
+    of the tensor's scale; per-chunk slots are NaN-filled before the launch (every element of every slot is written)."""
+    import ctypes
+    hip = _hip()
+    g = torch.Generator().manual_seed(B + Cin + D + W)
+    x = _bf(torch.randn(B, Cin, D, H, W, generator=g))
+    dy = _bf(torch.randn(B, Cout, D, H, W, generator=g))
+    want = torch.nn.grad.conv3d_weight(x, (Cout, Cin, 3, 3, 3), dy, padding=1).reshape(Cout, Cin, 27)
+    want_db = dy.sum(dim=(0, 2, 3, 4))
+    xg, dyg = _vol_cl(x), _vol_cl(dy)
+    n = ctypes.c_int(0)
+    hip.call("mm_conv3d_wgrad_slots", B, D, H, W, Cin, Cout, ctypes.addressof(n))
+    ws = torch.full((n.value, Cout, 27, Cin), float("nan"), device="cuda")
+    db = torch.zeros(32, Cout, device="cuda")
+    hip.call("mm_conv3d_wgrad", dyg, xg, ws, db, B, D, H, W, Cin, Cout, Cin, 27 * Cin, 1, Cin, n.value, Cout * 27 * Cin, 1)
+    assert torch.isfinite(ws).all().item()
+    dw = torch.zeros(Cout, Cin, 27, device="cuda")
+    hip.call("mm_wgrad_scatter", ws, dw, Cout, Cin, 27, Cin, n.value)
+    got = dw.cpu()
+    rel = ((got - want).norm() / want.norm()).item()
+    assert rel <= 2e-3, rel
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-3 * scale
+    torch.testing.assert_close(_grad(db).cpu(), want_db, rtol=2e-3, atol=2e-3 * want_db.abs().max().item())
+    ws2 = torch.full_like(ws, float("nan"))                     # bit-reproducible: slots are plain stores in a fixed order
+    hip.call("mm_conv3d_wgrad", dyg, xg, ws2, None, B, D, H, W, Cin, Cout, Cin, 27 * Cin, 1, Cin, n.value, Cout * 27 * Cin, 1)
+    assert torch.equal(ws, ws2)
+
+
+@pytest.mark.parametrize("B,D,H,W", [(4, 16, 16, 16), (32, 16, 16, 16), (8, 32, 32, 24), (24, 14, 16, 20), (2, 16, 24, 20),
+                                     (32, 8, 8, 8), (64, 8, 8, 8), (8, 4, 32, 32), (64, 4, 8, 8), (70, 3, 7, 5)])
 def test_conv3d_weight_resident_kernel_vs_torch(B, D, H, W):
     """csrc/conv3d_wres.hip (Cin 32 -> Cout 64, bf16 out + BatchNorm sums; layer 2 of the voxel encoder,
     bench.py's roofline kernel) against F.conv3d on bf16-rounded operands: one tile per workgroup (64 tiles),
     the C2 shape (512 tiles: two per workgroup, the second one's K loop carries the first one's stores), the
     config-#4 shape (768 tiles), ragged tiles (14 = 3.5 tiles deep, 20 = 2.5 wide; stored by the predicated
-    path) mixed with interior ones, and the XCD-aware tile lists.  bf16 output: 1e-2; statistics come from the
+    path) mixed with interior ones, the XCD-aware tile lists, and volumes that are ONE tile wide / high / deep
+    (8^3 = layer 2 of a 16^3 volume at B >= 32; 4 x 32 x 32; a single ragged tile per sample: the tile-index
+    division by 1 has no 32-bit reciprocal).  bf16 output: 1e-2; statistics come from the
     fp32 accumulators: 1e-3."""
     hip = _hip()
     Cin, Cout = 32, 64

@@ -167,6 +167,57 @@ def test_volume_encoder_train_grads_at_config4_size_vs_oracle():
     assert w32[1] <= 2e-1, ("vs fp32 oracle", w32)
 
 
+def test_volume_encoder_frozen_bn_backward_vs_oracle():
+    """eval-mode voxel encoder with a backward to follow (frozen BatchNorm: running statistics, no dropout, no
+    statistic update): parameter gradients through the fused layer-1 kernels, and - when the volume itself asks
+    for a gradient (saliency / integrated gradients on an end-to-end voxel path, the protocol of
+    bridge_utils.py:158-229) - d / d volume through the implicit-GEMM form of layer 1.  Against the oracle's
+    eval-mode autograd with bf16-rounded operands; the running statistics must not move."""
+    from oracle.bf16_emulation import bf16_operands
+    m = build(Fm.fMRIVolumeEncoder3D, 36, dropout=0.3).eval()
+    with torch.no_grad():                              # non-trivial running statistics
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm3d):
+                mod.running_mean.copy_(seeded_randn(17, *mod.running_mean.shape) * 0.1)
+                mod.running_var.copy_(1.0 + 0.2 * seeded_randn(18, *mod.running_var.shape).abs())
+    x = seeded_randn(136, 3, 1, 16, 16, 16)
+    gy = seeded_randn(137, 3, 64)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    with bf16_operands():
+        out = RF.volume_encoder3d(sd, xo, train=False)
+        out.backward(gy)
+    want = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    mg = m.cuda()
+    # (1) parameters only: the fused layer-1 path
+    y = mg(x.cuda())
+    assert y.requires_grad
+    y.backward(gy.cuda())
+    assert cos_min(y.detach().cpu(), out.detach()) >= 1 - COS_TOL
+    w = _worst(mg.named_parameters(), want)
+    assert w[1] <= 6e-2, w
+    assert mg.conv_layers[0].bias.grad is not None and mg.conv_layers[0].bias.grad.abs().max().item() > 0   # not zero with a frozen BN
+    # (2) the volume wants a gradient too: layer 1 as an implicit GEMM, its pre-BatchNorm tensor kept in bf16
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    with bf16_operands(l1_as_gemm=True):
+        out = RF.volume_encoder3d(sd, xo, train=False)
+        out.backward(gy)
+    want = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    mg.zero_grad(set_to_none=True)
+    xg = x.cuda().requires_grad_(True)
+    y2 = mg(xg)
+    y2.backward(gy.cuda())
+    assert cos_min(y2.detach().cpu(), out.detach()) >= 1 - COS_TOL
+    assert xg.grad is not None and xg.grad.shape == x.shape
+    assert rel_err(xg.grad.cpu(), xo.grad) <= 8e-2, rel_err(xg.grad.cpu(), xo.grad)
+    w = _worst(mg.named_parameters(), want)
+    assert w[1] <= 6e-2, w
+    for k, v in before.items():
+        assert torch.equal(mg.state_dict()[k].cpu(), v), k
+
+
 import multimodal_eeg_fmri_amd.bridge_utils as Bu
 import multimodal_eeg_fmri_amd.crossmodal_v4_enhancements as Cv
 

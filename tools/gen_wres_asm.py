@@ -239,8 +239,9 @@ def kloop(cur, prev=None, march=True):
             if march and t in (8, 17, 26) and g == 8:
                 # end of a kd phase.  Every fragment of this tap has landed (so no wave still reads the dying plane
                 # once all have passed the barrier); the new plane's loads have landed; then overwrite.
-                last = max(i_ for i_, e in enumerate(st.ds) if e != "W" and e[0] == t)
-                st.wait_ds(last)
+                mine = [i_ for i_, e in enumerate(st.ds) if e != "W" and e[0] == t]
+                if mine:                             # (none in the no-ds_read ablation build)
+                    st.wait_ds(max(mine))
                 planes = {8: [0], 17: [1], 26: [2, 3]}[t]
                 if not (ABL & 64) and not (ABL & 256):
                     st.need_vm(is_plane_load(planes[-1]))
