@@ -28,27 +28,41 @@ EEG_CH, EEG_T, VOL = 64, 1024, (32, 32, 32)
 
 
 PMC_SUMMARY = "profiles/r02_pmc_wres_c2.summary.txt"
+PMC_SUMMARY_C4 = "profiles/r02_pmc_wres_c4.summary.txt"
+# rocprofv3 --kernel-trace of this command (profiles/run_prof.sh): the kernel's mean duration inside the replayed step
+PROFILE_IN_STEP = {"source": "profiles/r02_step_kernel_summary.txt", "avg_launch_ms": 0.0242}
 
 
-def pmc_traffic_bytes():
+def pmc_traffic_bytes(path=None):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC summary (None if absent)"""
     import re
     try:
-        text = open(os.path.join(ROOT, PMC_SUMMARY)).read()
+        text = open(os.path.join(ROOT, path or PMC_SUMMARY)).read()
     except OSError:
         return None
     m = re.search(r"=\s*([0-9.]+)\s*MB\s*$", text, re.M)
     return float(m.group(1)) * 1e6 if m else None
 
 
-def cpu_baseline(pairs: int, steps: int = 2):
-    """oracle/ training step on the host (checker code, reported baseline only)."""
+def cpu_model() -> str:
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
+    """oracle/ training step on the host (checker code, reported baseline only): every core of the affinity mask,
+    2 warm-up + 5 timed steps, CPU model stated."""
     import torch.nn.functional as F
     from oracle import ref_functional as RF
     import multimodal_eeg_fmri_amd.enhanced_models_v4 as E
     import multimodal_eeg_fmri_amd.fmri_utils as Fm
     import multimodal_eeg_fmri_amd.bridge_utils as Bu
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     mods = {"e.": E.EnhancedERPEncoder(EEG_CH, 128, 2, 4, 0.0), "f.": Fm.fMRIVolumeEncoder3D(1, 64, dropout=0.0),
@@ -72,7 +86,8 @@ def cpu_baseline(pairs: int, steps: int = 2):
         loss.backward()
         torch.nn.utils.clip_grad_norm_([p for p in leaves if p.grad is not None], 1.0)
         opt.step()
-    step()                                    # warm-up
+    for _ in range(warmup):
+        step()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -83,9 +98,9 @@ def cpu_baseline(pairs: int, steps: int = 2):
     dt1 = time.perf_counter() - t0
     torch.set_num_threads(cores)
     c1 = cpu_baseline_c1_lite()
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} timed + 1 warm-up full training steps of {pairs} pairs "
-                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step",
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{steps} timed + {warmup} warm-up full training steps of {pairs} pairs "
+                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step, torch threads = {cores} (all affinity cores)",
             "one_thread": {"value": pairs / dt1, "unit": "pairs/s", "sample": f"1 step, {dt1:.1f} s"},
             "c1_lite": c1}
 
@@ -119,6 +134,45 @@ def cpu_baseline_c1_lite(steps: int = 20):
     dt = (time.perf_counter() - t0) / steps
     return {"value": 8 / dt, "unit": "samples/s", "sample": f"{steps} timed + 2 warm-up V4-Lite training steps of 8 "
             f"samples, fp32 torch CPU oracle, {dt * 1e3:.1f} ms/step"}
+
+
+def standalone_wres(B: int, D: int, H: int, W: int, launches: int = 20, rounds: int = 7):
+    """the roofline kernel alone (layer 2 of the voxel encoder, 32 -> 64 channels, bf16 out + BatchNorm sums) at volume
+    (B, D, H, W): `launches` back-to-back launches between two HIP events on the launch stream, behind a device-side
+    sleep so that the host's enqueue time is not in the bracket; per-launch mean of each round -> min / mean / max."""
+    import math
+    from multimodal_eeg_fmri_amd import _hip
+    Cin, Cout = 32, 64
+    x = torch.randn(B, D, H, W, Cin, device="cuda").to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
+    wf = torch.empty(Cout, 27, Cin, dtype=torch.bfloat16, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
+    out = torch.empty(B, D, H, W, Cout, dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(32, 2, Cout, device="cuda")
+    bias = torch.randn(Cout, device="cuda")
+
+    def fn():
+        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, bias, stats, None, out)
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    per = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(4.0e6))
+        a.record()
+        for _ in range(launches):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        per.append(a.elapsed_time(b) / launches)
+    flops = 2.0 * B * D * H * W * Cin * Cout * 27
+    mean = sum(per) / len(per)
+    return {"flops_per_launch": flops, "avg_launch_ms": mean, "min_launch_ms": min(per), "max_launch_ms": max(per),
+            "achieved": flops / (mean * 1e-3) / 1e12, "frac": flops / (mean * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+            "launches": launches * rounds,
+            "method": f"{rounds} rounds of {launches} back-to-back launches between two HIP events on the launch stream "
+                      "(launch-to-launch gaps included), inputs resident"}
 
 
 def fit_and_retrieve(steps: int, lr: float = 3e-4, dropout: float = 0.1, held_out_batches: int = 8):
@@ -247,15 +301,19 @@ def main():
                 ready[b].record(copy_s)
         for b in range(2):
             consumed[b].record()
-        upload(0)
-        sync()
+
+        def h2d_loop(n):
+            upload(0)
+            for i in range(n):
+                if i + 1 < n:
+                    upload(i + 1)
+                torch.cuda.current_stream().wait_event(ready[i % 2])
+                tr.train_step(*stage[i % 2])
+                consumed[i % 2].record()
+        h2d_loop(max(6, min(args.warmup, 20)))        # its own warm-up: copy stream, pinned copies, event pool (first use
+        sync()                                          # of each costs milliseconds - more than a 20-step timed region)
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            if i + 1 < args.steps:
-                upload(i + 1)
-            torch.cuda.current_stream().wait_event(ready[i % 2])
-            tr.train_step(*stage[i % 2])
-            consumed[i % 2].record()
+        h2d_loop(args.steps)
         sync()
         dt_h2d = time.perf_counter() - t0
         t = torch.tensor([dt_h2d], device="cuda")
@@ -281,18 +339,25 @@ def main():
     # (~30 us of Python per launch against ~10 us kernels): each step is queued behind a device-side sleep, so that
     # the whole step sits in the stream queues before the GPU starts and the events see device time, not host gaps.
     kt = kt_raw = kt_pair = None
+    kt_all = []
+    rf_c2 = rf_c4 = None
     if not args.profile:
         tr.mode = "manual"
         tr.train_step(eeg, fmri)
         ops.kernel_timer.reset("conv3d_fwd_c32")
         ops.kernel_timer.reset("event_pair_c32")
-        for _ in range(8):
+        for _ in range(16):
             torch.cuda._sleep(int(2.0e7))                    # ~10 ms of device spin: covers the host's enqueue time
             tr.train_step(eeg, fmri)
             torch.cuda.synchronize()
-        kt_raw = ops.kernel_timer.mean_ms("conv3d_fwd_c32")
+        kt_all = ops.kernel_timer.all_ms("conv3d_fwd_c32")
+        kt_raw = sum(kt_all) / len(kt_all)
         kt_pair = ops.kernel_timer.mean_ms("event_pair_c32")      # an empty event bracket on the same stream, same steps
         kt = kt_raw - kt_pair                                     # the kernel's share of its bracket
+        if rank == 0:
+            # the same kernel alone: the C2 shape, and BASELINE config #4 (64 x 64 x 48 volumes -> layer 2 at 32 x 32 x 24)
+            rf_c2 = standalone_wres(PAIRS_PER_GPU, 16, 16, 16)
+            rf_c4 = standalone_wres(PAIRS_PER_GPU, 32, 32, 24)
     ev = tr.evaluate(eeg, fmri)
     fit = None
     if world == 1 and args.fit_steps > 0 and not args.profile:
@@ -325,12 +390,28 @@ def main():
                      "frac": (achieved / PEAK_BF16_MFMA_TFLOPS) if achieved else None,
                      "flops_per_launch": flops, "avg_launch_ms": kt,
                      "event_bracket_ms": kt_raw if kt else None, "empty_event_bracket_ms": kt_pair if kt else None,
+                     # spread over the bracketed launches (each minus the mean empty bracket), and the uncorrected bound:
+                     # frac_raw_bracket counts the event pair's own ~5 us as kernel time (a lower bound on the fraction)
+                     "min_launch_ms": (min(kt_all) - kt_pair) if kt else None,
+                     "max_launch_ms": (max(kt_all) - kt_pair) if kt else None,
+                     "launches_bracketed": len(kt_all),
+                     "frac_raw_bracket": (flops / (kt_raw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if kt else None,
+                     "profile_in_step": PROFILE_IN_STEP,
                      # HBM bytes per launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2 gfx950 correction
                      # and WRITE_SIZE in separate passes, profiles/run_pmc_wres.sh); algorithmic = 8.4 + 16.8 + 0.1 MB
                      "traffic": pmc_traffic_bytes(), "traffic_source": PMC_SUMMARY, "algorithmic_bytes": 25.3e6,
                      "note": "measured inside the training step (other stream busy); stand-alone and config-#4 figures: "
                              "profiles/README.md"},
     }
+    if rf_c2:
+        line["roofline_c2_standalone"] = dict(rf_c2, kernel="conv3d_wres_kernel alone at the C2 shape (B=32, 16^3)", bound="mfma",
+                                              peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", traffic=pmc_traffic_bytes(),
+                                              traffic_source=PMC_SUMMARY, algorithmic_bytes=25.3e6)
+    if rf_c4:
+        line["roofline_c4"] = dict(rf_c4, kernel="conv3d_wres_kernel at BASELINE config #4: 64x64x48 volumes -> layer 2 (32->64 ch) "
+                                                 "@32x32x24, B=32, implicit GEMM M=786432 N=64 K=864", bound="mfma",
+                                   peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", traffic=pmc_traffic_bytes(PMC_SUMMARY_C4),
+                                   traffic_source=PMC_SUMMARY_C4, algorithmic_bytes=151.1e6)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(PAIRS_PER_GPU)
     print(json.dumps(line))

@@ -45,29 +45,38 @@ __device__ __forceinline__ int vperm(int key) {       // swap bits 2 and 3 of th
 
 // attention-probability dropout (nn.MultiheadAttention(dropout=p)): the softmax
 // row sum uses the un-dropped probabilities, only the P operand of P.V is masked.
-// The mask costs a quarter of these kernels (the hash is ~9 of ~20 VALU instructions per score, its multiply
-// quarter-rate), so ONE hash serves a PAIR of adjacent keys (2j, 2j + 1) of a query row: its low / high 16 bits
-// decide the even / odd key (keep iff half >= p * 2^16; p is honoured to 2^-17).  Pair index =
-// (bh * L + q) * ceil(L / 2) + key / 2; same hash as common.h's mm_hash.  The forward and dq kernels hold the two
-// keys of a pair in one lane (registers r, r + 1); the dkv kernel, whose registers run along q, hashes per score.
-__device__ __forceinline__ uint32_t attn_pair_hash(uint32_t seed, int bh, int q, int key, int L) {
+// The mask used to cost a quarter of these kernels (hash ~9 of ~20 VALU instructions per score, its 32-bit multiply
+// quarter-rate; the dkv kernel, whose registers run along the queries, could not share the per-key-pair hash of the
+// other two and hashed per score).  Now ONE hash serves the 2 x 2 block (queries 2i, 2i + 1) x (keys 2j, 2j + 1): byte
+// 2 (q & 1) + (key & 1) of the word decides the score (keep iff byte >= round(p * 256): p is honoured to 1/256 and
+// the keep scale is 256 / (256 - t), so the mask stays unbiased for the quantised p).  Every kernel then spends one
+// hash per two scores whichever way its registers run: forward / dq lanes own a query and hold the two keys of a
+// block in registers r, r + 1; dkv lanes own a key and hold the two queries.  The mixer's multiply is the full-rate
+// 24-bit one (v_mul_u32_u24; constants chosen on the mask statistics: keep rate to 7e-4, lag / diagonal / head
+// correlations <= 0.0022, row- and column-sum variance 0.97-1.04 of binomial; oracle/dropout_replica.py is the host
+// replica).  Block index = (bh * ceil(L / 2) + q / 2) * ceil(L / 2) + key / 2.
+__device__ __forceinline__ uint32_t attn_block_hash(uint32_t seed, int bh, int q, int key, int L) {
     const uint32_t Lh = ((uint32_t)L + 1u) >> 1;
-    uint32_t x = (((uint32_t)bh * (uint32_t)L + (uint32_t)q) * Lh + ((uint32_t)key >> 1)) * 0x9E3779B1u + seed;
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
+    uint32_t x = (((uint32_t)bh * Lh + ((uint32_t)q >> 1)) * Lh + ((uint32_t)key >> 1)) * 0x9E3779B1u + seed;
     x ^= x >> 13;
+    x = __umul24(x, 0xB5297Bu);
+    x ^= x >> 15;
     return x;
 }
-__device__ __forceinline__ float attn_keep(uint32_t seed, int bh, int q, int key, int L, uint32_t thresh16, float inv_keep) {
-    const uint32_t x = attn_pair_hash(seed, bh, q, key, L);
-    return __builtin_amdgcn_ubfe(x, (key & 1) * 16, 16) >= thresh16 ? inv_keep : 0.f;
-}
-// both keys of the pair that starts at the EVEN key `key`
-__device__ __forceinline__ void attn_keep2(uint32_t seed, int bh, int q, int key, int L, uint32_t thresh16, float inv_keep,
-                                           float& k0, float& k1) {
-    const uint32_t x = attn_pair_hash(seed, bh, q, key, L);
-    k0 = (x & 0xFFFFu) >= thresh16 ? inv_keep : 0.f;
-    k1 = (x >> 16) >= thresh16 ? inv_keep : 0.f;
+// the two scores of a block that ONE lane owns: `mine` = the lane's own index (query in forward / dq, key in dkv),
+// `other` = the EVEN index of the register pair (keys 2j, 2j + 1 resp. queries 2i, 2i + 1).  along_keys: the pair runs
+// along the keys (forward, dq) or along the queries (dkv).
+template <bool ALONG_KEYS>
+__device__ __forceinline__ void attn_keep2(uint32_t seed, int bh, int mine, int other, int L, uint32_t thresh8, bool& k0, bool& k1) {
+    if (ALONG_KEYS) {
+        const uint32_t x = attn_block_hash(seed, bh, mine, other, L) >> (16 * (mine & 1));
+        k0 = (x & 0xFFu) >= thresh8;
+        k1 = ((x >> 8) & 0xFFu) >= thresh8;
+    } else {
+        const uint32_t x = attn_block_hash(seed, bh, other, mine, L) >> (8 * (mine & 1));
+        k0 = (x & 0xFFu) >= thresh8;
+        k1 = ((x >> 16) & 0xFFu) >= thresh8;
+    }
 }
 
 // v_exp_f32 as is: arguments are <= 0 here and a result below 2^-126 may flush to zero (softmax
@@ -143,40 +152,52 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt + lr) * KS + 16 * s + 8 * lh);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
             }
-            // scaled scores in log2 units; mask padded keys
+            // scores: raw MFMA output (the softmax scale rides in the exp's FMA: exp2(s * scale - m * scale)); with an additive
+            // mask they are formed in scaled log2 units instead (sc2 = 1).  Padded keys -> -inf.
+            const float sc2 = MASK ? 1.f : scale_log2;
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float sc = sacc[r] * scale_log2;
-                if (MASK && key < kn) sc += amask[(size_t)min(q, L - 1) * L + k0 + key] * 1.4426950408889634f;
+                float sc = sacc[r];
+                if (MASK) {
+                    sc *= scale_log2;
+                    if (key < kn) sc += amask[(size_t)min(q, L - 1) * L + k0 + key] * 1.4426950408889634f;
+                }
                 sacc[r] = (FULL || key < kn) ? sc : -INFINITY;
                 mx = fmaxf(mx, sacc[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            // a row whose keys so far are all masked out keeps m = -inf: subtract 0 instead (exp2(-inf) = 0)
-            const float m_sub = (MASK && m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run - m_sub);  // m_run = -inf first time -> 0
+            // lazy running maximum: the accumulators are rescaled only when some row's maximum grew by more than 2^8 (in the
+            // exp's units) - p <= 256 is as exact in bf16 / fp32 as p <= 1 - so after the first tile of a row the 16
+            // accumulator reads, multiplies and writes per tile are skipped (wave-uniform branch)
+            if (__builtin_amdgcn_ballot_w64(mx * sc2 > m_run + 8.f)) {
+                const float m_new = fmaxf(m_run, mx * sc2);
+                // a row whose keys so far are all masked out keeps m = -inf: subtract 0 instead (exp2(-inf) = 0)
+                const float alpha = fast_exp2(m_run - ((MASK && m_new == -INFINITY) ? 0.f : m_new));  // m_run = -inf first time -> 0
+                l_run *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            }
+            const float m_neg = (MASK && m_run == -INFINITY) ? 0.f : -m_run;
             float ps = 0.f;
-            bf16x8 pf[2];
+            union { bf16x8 v[2]; bf16x2 h[8]; } pu;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {                    // registers r, r + 1: keys 2j, 2j + 1
-                float p0 = fast_exp2(sacc[r] - m_sub), p1 = fast_exp2(sacc[r + 1] - m_sub);
+                float p0 = fast_exp2(fmaf(sacc[r], sc2, m_neg)), p1 = fast_exp2(fmaf(sacc[r + 1], sc2, m_neg));
                 ps += p0;
                 ps += p1;
-                if (DROP) {
-                    float kp0, kp1;
-                    attn_keep2(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv, kp0, kp1);
-                    p0 *= kp0; p1 *= kp1;
+                if (DROP) {                                      // 0 / 1 mask; the keep scale multiplies the final normaliser
+                    bool kp0, kp1;
+                    attn_keep2<true>(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, kp0, kp1);
+                    p0 = kp0 ? p0 : 0.f; p1 = kp1 ? p1 : 0.f;
                 }
-                pf[r >> 3][r & 7] = (bf16)p0;
-                pf[r >> 3][(r & 7) + 1] = (bf16)p1;
+                typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+                pu.h[r >> 1] = __builtin_convertvector((f32x2_t){p0, p1}, bf16x2);      // one v_cvt_pk_bf16_f32
             }
-            l_run = l_run * alpha + ps;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            l_run += ps;
+            const bf16x8* pf = pu.v;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 vf = tr_frag32(Vs, kt + 16 * s, lane);
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
+    const float inv = (DROP ? dinv : 1.f) / l_tot;
     if (q < L) {
         bf16* orow = out + ((size_t)b * L + q) * E + h * DH;
 #pragma unroll
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             bf16x4 v = {(bf16)(o[4 * g] * inv), (bf16)(o[4 * g + 1] * inv), (bf16)(o[4 * g + 2] * inv), (bf16)(o[4 * g + 3] * inv)};
             *reinterpret_cast<bf16x4*>(orow + 8 * g + 4 * lh) = v;
         }
-        if (lse && lh == 0) lse[((size_t)b * H + h) * L + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+        if (lse && lh == 0) lse[((size_t)b * H + h) * L + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;    // m_run is in scaled log2 units
     }
 }
 
@@ -290,20 +311,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
             }
             bf16x8 dsf[2];
-            float kp[16];
+            bool kp[16];
             if (DROP)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2)                  // registers r, r + 1: keys 2j, 2j + 1 share one hash
-                    attn_keep2(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, dinv, kp[r], kp[r + 1]);
+                for (int r = 0; r < 16; r += 2)                  // registers r, r + 1: keys 2j, 2j + 1 of one block
+                    attn_keep2<true>(dseed, b * H + h, q, k0 + kt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, kp[r], kp[r + 1]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float sc = sacc[r] * scale_log2 - lse2;
+                float sc = fmaf(sacc[r], scale_log2, -lse2);
                 if (MASK && key < kn) sc += amask[(size_t)min(q, L - 1) * L + k0 + key] * 1.4426950408889634f;
                 const float p = (FULL || key < kn) ? fast_exp2(sc) : 0.f;
                 float dpr = dp[r];
-                if (DROP) dpr *= kp[r];
-                dsf[r >> 3][r & 7] = (bf16)(p * (dpr - dl));
+                if (DROP) dpr = fmaf(kp[r] ? dpr : 0.f, dinv, -dl);
+                else dpr -= dl;
+                dsf[r >> 3][r & 7] = (bf16)(p * dpr);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -405,15 +427,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dp, 0, 0, 0);
             }
             bf16x8 pf[2], dsf[2];
+            bool kp[16];
+            if (DROP)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2)                  // registers r, r + 1: queries 2i, 2i + 1 of one block
+                    attn_keep2<false>(dseed, b * H + h, key, q0 + qt + (r & 3) + 8 * (r >> 2) + 4 * lh, L, dthresh, kp[r], kp[r + 1]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = qt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float sc = sacc[r] * scale_log2 - Ls[qi];
+                float sc = fmaf(sacc[r], scale_log2, -Ls[qi]);
                 if (MASK && kok && qi < qn) sc += amask[(size_t)(q0 + qi) * L + key] * 1.4426950408889634f;
                 const float p = (FULL || kok) ? fast_exp2(sc) : 0.f;
-                const float keep = DROP ? attn_keep(dseed, b * H + h, q0 + qi, key, L, dthresh, dinv) : 1.f;
-                pf[r >> 3][r & 7] = (bf16)(p * keep);
-                dsf[r >> 3][r & 7] = (bf16)(p * (dp[r] * keep - Dl[qi]));
+                // the keep scale of P's dropout multiplies dV at the end; dS = P o (dP o mask * scale - delta)
+                pf[r >> 3][r & 7] = (bf16)((!DROP || kp[r]) ? p : 0.f);
+                const float u = DROP ? fmaf(kp[r] ? dp[r] : 0.f, dinv, -Dl[qi]) : dp[r] - Dl[qi];
+                dsf[r >> 3][r & 7] = (bf16)(p * u);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -430,7 +458,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             bf16x4 a = {(bf16)(dk[4 * g] * scale), (bf16)(dk[4 * g + 1] * scale), (bf16)(dk[4 * g + 2] * scale), (bf16)(dk[4 * g + 3] * scale)};
-            bf16x4 c = {(bf16)dv[4 * g], (bf16)dv[4 * g + 1], (bf16)dv[4 * g + 2], (bf16)dv[4 * g + 3]};
+            const float dvs = DROP ? dinv : 1.f;
+            bf16x4 c = {(bf16)(dv[4 * g] * dvs), (bf16)(dv[4 * g + 1] * dvs), (bf16)(dv[4 * g + 2] * dvs), (bf16)(dv[4 * g + 3] * dvs)};
             *reinterpret_cast<bf16x4*>(krow + 8 * g + 4 * lh) = a;
             *reinterpret_cast<bf16x4*>(vrow + 8 * g + 4 * lh) = c;
         }
@@ -441,8 +470,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 
 extern "C" {
 
-// 16-bit drop threshold of a half hash word (0 = dropout off: p < 2^-17)
-static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u; }
+// 8-bit drop threshold of one byte of the block hash (0 = dropout off: p < 1/512), and the keep scale that makes the
+// mask unbiased for the quantised probability t / 256
+static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((double)p * 256.0 + 0.5) : 0u; }
+static inline float attn_keep_scale(uint32_t t) { return t ? 256.f / (256.f - (float)t) : 1.f; }
 
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, float scale,
                 float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
@@ -456,8 +487,7 @@ int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int
                     : (full ? attn_fwd_kernel<false, true> : attn_fwd_kernel<false, false>);
     if (attn_mask) kern = dth ? attn_fwd_kernel<true, false, true> : attn_fwd_kernel<false, false, true>;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
-                       scale * 1.4426950408889634f, dth, seed, dth ? 1.f / (1.f - drop_p) : 1.f,
-                       seed_epoch, attn_mask);
+                       scale * 1.4426950408889634f, dth, seed, attn_keep_scale(dth), seed_epoch, attn_mask);
     return mm_check_launch("attn_fwd");
 }
 
@@ -465,7 +495,7 @@ int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
                 int B, int L, int H, int head_dim, float scale, float drop_p, uint32_t seed,
                 const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
     const uint32_t dth = attn_thresh(drop_p);
-    const float dinv = dth ? 1.f / (1.f - drop_p) : 1.f;
+    const float dinv = attn_keep_scale(dth);
     MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_bwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);

@@ -85,29 +85,11 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: tile addressing stays in SGPRs
     const int lc = lane & 15, lg = lane >> 4;                       // MFMA lane = (row / column 0-15, group 0-3)
-    // ---- weights: global -> LDS by LDS-DMA.  LDS image [tap][rho][slot] x 16 B; a DMA writes wave-uniform base +
-    // 16 * lane, so wave w, instruction k covers tap k, rows rho = 16 w + (lane >> 2), slot = lane & 3.  LDS row rho
-    // holds output channel n = 4 (rho & 15) + (rho >> 4) (column tile j = rho >> 4, lane column c = rho & 15 <->
-    // channel 4 c + j); the channel segment in slot s is s ^ 2 ((rho >> 2) & 1).  Both permutations sit in the
-    // SOURCE address, which is affine in the tap (+64 bytes).
+    // ---- start-up order (profiles/r03_wres_*): what the first MFMA waits for longest is the first tile's halo (a cold
+    // HBM read, ~2 000 cycles), so its loads are issued before anything else that touches memory; then the weight DMA;
+    // the bias (four global loads) is parked last - everything is waited for together at the first boundary.
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
-    const bf16* wlane;
-    {
-        const int rho = wave * 16 + (lane >> 2), slot = lane & 3;
-        const int n = 4 * (rho & 15) + (rho >> 4);
-        wlane = a.w + (size_t)n * 27 * CIN + ((slot ^ (2 * ((rho >> 2) & 1))) << 3);
-    }
-    // three batches of nine, interleaved with the set-up arithmetic below: a DMA is bandwidth-bound (~64 B/clk per
-    // CU), the wave that issues 27 in a row just stalls on the full queue for ~1 700 cycles
-    auto dma_batch = [&](int p) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 9 * p; k < 9 * p + 9; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(wlane + k * CIN), (lptr_t*)(smem + k * BN * ROWB + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    dma_batch(0);
-    WR_TL(1)
     const int tw = (a.W + 7) / 8, th = (a.H + 7) / 8, td = (a.D + TD - 1) / TD;
     const int ntiles = a.B * td * th * tw;
 
@@ -139,9 +121,6 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     // to the plane's voxel (h0, w0), a one-hot (hh, hw) selector tested against the column's in-volume mask, and the
     // swizzled byte offset inside a ring slot (chunks past 400 park in an unused pitch column).
     int ldsp[2];
-    float sh[4];                                                     // a lane's four channels: 4 lc + j
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sh[j] = a.shift ? a.shift[4 * lc + j] : 0.f;
     {
         int goffp[2];
         unsigned selp[2];
@@ -155,11 +134,9 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
             selp[j] = real ? (1u << hh) | (1u << (10 + hw)) : 0x80000000u;
             ldsp[j] = real ? (hh * WP + hw) * ROWB + ((sg ^ (2 * (hh & 1))) << 4) : (HB + (tid & 1)) * ROWB + (sg << 4);
         }
-        asm volatile(WRES_INIT : : [g0] "v"(goffp[0]), [g1] "v"(goffp[1]), [s0] "v"(selp[0]), [s1] "v"(selp[1]),
-                     [sh0] "v"(sh[0]), [sh1] "v"(sh[1]), [sh2] "v"(sh[2]), [sh3] "v"(sh[3]) : WRES_CLOBBERS);
+        asm volatile(WRES_INIT : : [g0] "v"(goffp[0]), [g1] "v"(goffp[1]), [s0] "v"(selp[0]), [s1] "v"(selp[1]) : WRES_CLOBBERS);
     }
     WR_TL(2)
-    dma_batch(1);
     auto range_mask = [](int lo_, int hi_, int n) __attribute__((always_inline)) {      // bits [max(lo,0), min(hi,n))
         lo_ = lo_ < 0 ? 0 : lo_;
         hi_ = hi_ > n ? n : hi_;
@@ -184,13 +161,38 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
         return p;
     };
     Tile curT = coords(has_work ? lo : 0);
-    {   // the first tile's six planes: everything else of the set-up overlaps their latency and the weight DMA
+    {   // the first tile's six planes: everything else of the set-up overlaps their latency
         const Pf pf = pf_args(curT, 4 * curT.d, 6, has_work);
         asm volatile(WRES_PREFETCH : : [off0] "s"(pf.off0), [planeb] "s"(planeb), [pvalid] "s"(pf.pvalid), [mhw] "s"(pf.mhw),
                      [rsrc] "s"(xrsrc) : "memory", WRES_CLOBBERS);
     }
     WR_TL(0)
-    dma_batch(2);
+    // ---- weights: global -> LDS by LDS-DMA.  LDS image [tap][rho][slot] x 16 B; a DMA writes wave-uniform base +
+    // 16 * lane, so wave w, instruction k covers tap k, rows rho = 16 w + (lane >> 2), slot = lane & 3.  LDS row rho
+    // holds output channel n = 4 (rho & 15) + (rho >> 4) (column tile j = rho >> 4, lane column c = rho & 15 <->
+    // channel 4 c + j); the channel segment in slot s is s ^ 2 ((rho >> 2) & 1).  Both permutations sit in the
+    // SOURCE address, which is affine in the tap (+64 bytes).
+    {
+        const int rho = wave * 16 + (lane >> 2), slot = lane & 3;
+        const int n = 4 * (rho & 15) + (rho >> 4);
+        const bf16* wlane = a.w + (size_t)n * 27 * CIN + ((slot ^ (2 * ((rho >> 2) & 1))) << 3);
+        auto dma_taps = [&](int k0, int k1) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = k0; k < k1; ++k)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(wlane + k * CIN), (lptr_t*)(smem + k * BN * ROWB + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // taps 0-8 (kd = 0), the bias, then taps 9-26: the first tile starts once the halo and the first batch are in LDS
+        // (WRES_BOUNDARY_FIRST leaves this wave's last 18 pieces in flight; they land during the first nine taps)
+        dma_taps(0, 9);
+        if (a.shift && wave == 0) {                                  // 64 floats -> the (still unused) statistics area
+            __builtin_amdgcn_global_load_lds((gptr_t*)(a.shift + lane), (lptr_t*)(smem + S_OFF), 4, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dma_taps(9, 27);
+    }
+    WR_TL(1)
+    float sh[4] = {0.f, 0.f, 0.f, 0.f};                              // a lane's four channels 4 lc + j: read from LDS after the first boundary
 
     // ---- per-lane fragment bases (absolute LDS byte addresses).  Lane (lc, lg) of MFMA tile i reads the halo row
     // of voxel (h, w) = (4 (i >> 1) + (lc >> 2), 4 (i & 1) + (lc & 3)) shifted by (kh, kw), channel segment lg, in the
@@ -277,7 +279,19 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
                 asm volatile(WRES_BOUNDARY_ALL : : [sb0] "s"(sb[0]), [sb1] "s"(sb[1]), [sb2] "s"(sb[2]), [sb3] "s"(sb[3]), [sb4] "s"(sb[4]),
                              [sb5] "s"(sb[5]), [ldsp0] "v"(ldsp[0]), [ldsp1] "v"(ldsp[1]), [abn] "v"(abn), [bb0] "v"(bb0) : "memory", WRES_CLOBBERS);
         };
-        full_boundary(curT, false);
+        {   // first tile: wait for the halo, taps 0-8 of the weights and the bias only
+            int sb[6];
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) sb[pp] = __builtin_amdgcn_readfirstlane(hbase + slot_of(4 * curT.d + pp));
+            const int abn = lane_a0 + slot_of(4 * curT.d + wave);
+            asm volatile(WRES_BOUNDARY_FIRST : : [sb0] "s"(sb[0]), [sb1] "s"(sb[1]), [sb2] "s"(sb[2]), [sb3] "s"(sb[3]), [sb4] "s"(sb[4]),
+                         [sb5] "s"(sb[5]), [ldsp0] "v"(ldsp[0]), [ldsp1] "v"(ldsp[1]), [abn] "v"(abn), [bb0] "v"(bb0) : "memory", WRES_CLOBBERS);
+        }
+        if (a.shift) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(smem + S_OFF + 16 * lc);
+            sh[0] = b4[0]; sh[1] = b4[1]; sh[2] = b4[2]; sh[3] = b4[3];
+        }
+        asm volatile(WRES_INIT_BIAS : : [sh0] "v"(sh[0]), [sh1] "v"(sh[1]), [sh2] "v"(sh[2]), [sh3] "v"(sh[3]) : WRES_CLOBBERS);
         WR_TL(3)
         int cur = 0, tile = lo;
         while (tile < hi) {
@@ -319,6 +333,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
                                        __builtin_amdgcn_readfirstlane(so[2]), __builtin_amdgcn_readfirstlane(so[3])};
                     if (cur == 0) {
                         if (pending) asm volatile(WRES_K_X_EPI_MARCH : : WR_AB, WR_PF, WR_MARCH, WR_EPI : "memory", WRES_CLOBBERS);
+                        else if (tile == lo) asm volatile(WRES_K_X_MARCH_FIRST : : WR_AB, WR_PF, WR_MARCH : "memory", WRES_CLOBBERS);
                         else asm volatile(WRES_K_X_MARCH : : WR_AB, WR_PF, WR_MARCH : "memory", WRES_CLOBBERS);
                     } else {
                         if (pending) asm volatile(WRES_K_Y_EPI_MARCH : : WR_AB, WR_PF, WR_MARCH, WR_EPI : "memory", WRES_CLOBBERS);
@@ -333,6 +348,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
                     const bool epi = pending;
                     if (cur == 0) {
                         if (pending) asm volatile(WRES_K_X_EPI_COL : : WR_AB, WR_PF, WR_EPI : "memory", WRES_CLOBBERS);
+                        else if (tile == lo) asm volatile(WRES_K_X_COL_FIRST : : WR_AB, WR_PF : "memory", WRES_CLOBBERS);
                         else asm volatile(WRES_K_X_COL : : WR_AB, WR_PF : "memory", WRES_CLOBBERS);
                     } else {
                         if (pending) asm volatile(WRES_K_Y_EPI_COL : : WR_AB, WR_PF, WR_EPI : "memory", WRES_CLOBBERS);

@@ -71,6 +71,41 @@ class fMRIFusionNet(nn.Module):
         return {"activation": w[0].item(), "connectivity": w[1].item()}
 
 
+class _fMRISingleBranch(nn.Module):
+    """one tabular encoder + the Linear-ReLU-Dropout-Linear head (``run_fmri_v11.py:311-370``); state_dict keys
+    ``encoder.encoder.{0,1,4,5}.*``, ``head.{0,3}.*`` as in the reference."""
+    _encoder_cls = ActivationEncoder
+
+    def __init__(self, in_dim: int, hidden_dim: int = 64, num_classes: int = 2, dropout: float = 0.4,
+                 task: str = "classification"):
+        super().__init__()
+        self.task = task
+        self.encoder = self._encoder_cls(in_dim, hidden_dim, dropout)
+        self.head = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2), nn.ReLU(), nn.Dropout(dropout),
+                                  nn.Linear(hidden_dim // 2, num_classes if task == "classification" else 1))
+        self.drop_p = dropout
+
+    def _run(self, x):
+        output = ops.fmri_single_forward(self, x)
+        return output.squeeze(-1) if self.task == "regression" else output
+
+
+class fMRIActivationOnly(_fMRISingleBranch):
+    """activation features only; ``forward(activation, connectivity=None)`` ignores the second argument
+    (``run_fmri_v11.py:311-337``), so the three model kinds share ``train_epoch`` / ``evaluate``."""
+
+    def forward(self, activation, connectivity=None):
+        return self._run(activation)
+
+
+class fMRIConnectivityOnly(_fMRISingleBranch):
+    """connectivity features only (``run_fmri_v11.py:340-366``)."""
+    _encoder_cls = ConnectivityEncoder
+
+    def forward(self, activation=None, connectivity=None):
+        return self._run(connectivity)
+
+
 class fMRIVolumeEncoder3D(nn.Module):
     """(B, 1, D, H, W) fp32 volume -> (B, out_dim) feature.
 
@@ -286,3 +321,140 @@ def load_fmri_labels(label_path, subject_list):
             label = 1 if label.lower() in ("good", "positive", "yes", "1") else 0
         labels[int(subj)] = int(label)
     return labels
+
+
+# ---------------------------------------------------------------------------
+# the fMRI driver (run_fmri_v11.py:43-77, 715-934): configuration bag and the cross-validated experiment
+# ---------------------------------------------------------------------------
+SEED = 42            # run_fmri_v11.py:28
+
+
+class fMRIConfig:
+    """attribute bag of ``run_fmri_v11.py:43-77``: same names and defaults.  ``base_path`` defaults to the
+    environment variable FMRI_DATA_PATH or the working directory (the reference hard-codes a Windows path); the
+    three output directories are created on construction, as there."""
+
+    def __init__(self, base_path=None):
+        import os
+        from pathlib import Path
+        self.base_path = Path(base_path if base_path is not None else os.environ.get("FMRI_DATA_PATH", "."))
+        self.data_dir = self.base_path
+        self.label_path = self.base_path / "DATA" / "labels"
+        self.subject_list = list(range(1, 33))
+        self.activation_types = ["sensory", "AN", "LN", "cognitive", "DMN"]
+        self.connectivity_types = ["DMN"]
+        self.agg_method = "both"
+        self.hidden_dim = 64
+        self.fusion_dim = 128
+        self.dropout = 0.4
+        self.num_classes = 2
+        self.batch_size = 8
+        self.num_epochs = 100
+        self.learning_rate = 1e-4
+        self.weight_decay = 1e-4
+        self.patience = 15
+        self.n_splits = 5
+        self.val_ratio = 0.15
+        self.grad_clip = 1.0
+        self.output_dir = Path("./results_fmri")
+        self.checkpoint_dir = Path("./checkpoints_fmri")
+        self.log_dir = Path("./logs_fmri")
+        for d in (self.output_dir, self.checkpoint_dir, self.log_dir):
+            d.mkdir(parents=True, exist_ok=True)
+
+    def __repr__(self):
+        return (f"fMRIConfig(subjects={len(self.subject_list)}, activation={self.activation_types}, "
+                f"connectivity={self.connectivity_types}, agg={self.agg_method}, val_ratio={self.val_ratio})")
+
+
+def run_experiment(dataset, config, task="classification", device=None, optimizer_factory=None, verbose=True):
+    """The protocol of ``run_fmri_v11.py:715-934``: (stratified) K-fold over the subjects; inside every fold the
+    training part is split again into train / validation (``val_ratio``, seeded per fold); the three models
+    (fusion, activation only, connectivity only) are trained with AdamW + ReduceLROnPlateau(0.5, 5) on the
+    VALIDATION metric (1 - F1, or -R2), early-stopped on it (``patience``), the best state is restored and scored
+    once on the held-out test part.  Returns ``(results, fusion_weights_all)`` with the reference's structure:
+    ``results[name]`` = list of per-fold metric dicts.  The model calls run on the HIP kernels; the optimizer is
+    ``optim.FusedAdamW`` (clip + AdamW in one launch) unless ``optimizer_factory(params, lr, weight_decay)`` says
+    otherwise."""
+    import copy
+    import numpy as np
+    from sklearn.model_selection import KFold, StratifiedKFold, train_test_split
+    from sklearn.utils.class_weight import compute_class_weight
+    from torch.utils.data import DataLoader, Subset
+    from .optim import FusedAdamW
+    from .bridge_utils import WeightedCrossEntropy
+    from .crossmodal_eeg_scr import _PlateauLR
+    say = print if verbose else (lambda *a, **k: None)
+    device = device or torch.device("cuda")
+    if task == "classification":
+        labels = np.array([s["class_label"] for s in dataset.samples])
+        num_classes = len(np.unique(labels))
+    else:
+        labels = np.array([s["reg_label"] for s in dataset.samples])
+        num_classes = 1
+    sample = dataset[0]
+    activation_dim, connectivity_dim = sample[0].shape[0], sample[1].shape[0]
+    say(f"EXPERIMENT: {task.upper()}  device {device}  validation ratio {config.val_ratio}")
+    say(f"  activation dim {activation_dim}, connectivity dim {connectivity_dim}, samples {len(dataset)}")
+    if task == "classification":
+        splits = list(StratifiedKFold(n_splits=config.n_splits, shuffle=True, random_state=SEED).split(np.zeros(len(dataset)), labels))
+    else:
+        splits = list(KFold(n_splits=config.n_splits, shuffle=True, random_state=SEED).split(np.zeros(len(dataset))))
+    results = {"fusion": [], "activation_only": [], "connectivity_only": []}
+    fusion_weights_all = []
+    for fold_idx, (train_val_idx, test_idx) in enumerate(splits, 1):
+        strat = labels[train_val_idx] if task == "classification" else None
+        train_idx, val_idx = train_test_split(np.arange(len(train_val_idx)), test_size=config.val_ratio, stratify=strat,
+                                              random_state=SEED + fold_idx)
+        actual_train_idx, actual_val_idx = train_val_idx[train_idx], train_val_idx[val_idx]
+        say(f"FOLD {fold_idx}/{config.n_splits}: train {len(actual_train_idx)}, val {len(actual_val_idx)}, test {len(test_idx)}")
+        mk = lambda idx, shuffle: DataLoader(Subset(dataset, idx), batch_size=config.batch_size, shuffle=shuffle,   # noqa: E731
+                                             collate_fn=collate_fmri)
+        train_loader, val_loader, test_loader = mk(actual_train_idx, True), mk(actual_val_idx, False), mk(test_idx, False)
+        if task == "classification":
+            train_labels = labels[actual_train_idx]
+            cw = compute_class_weight("balanced", classes=np.unique(train_labels), y=train_labels)
+            criterion = WeightedCrossEntropy(torch.tensor(cw, dtype=torch.float32)).to(device)
+        else:
+            criterion = nn.MSELoss()
+        for model_name in ("fusion", "activation_only", "connectivity_only"):
+            if model_name == "fusion":
+                model = fMRIFusionNet(activation_dim=activation_dim, connectivity_dim=connectivity_dim, hidden_dim=config.hidden_dim,
+                                      num_classes=num_classes, dropout=config.dropout, task=task)
+            elif model_name == "activation_only":
+                model = fMRIActivationOnly(in_dim=activation_dim, hidden_dim=config.hidden_dim, num_classes=num_classes,
+                                           dropout=config.dropout, task=task)
+            else:
+                model = fMRIConnectivityOnly(in_dim=connectivity_dim, hidden_dim=config.hidden_dim, num_classes=num_classes,
+                                             dropout=config.dropout, task=task)
+            model = model.to(device)
+            if optimizer_factory is not None:
+                optimizer = optimizer_factory(model.parameters(), config.learning_rate, config.weight_decay)
+            else:
+                optimizer = FusedAdamW(model.parameters(), lr=config.learning_rate, weight_decay=config.weight_decay)
+            # ReduceLROnPlateau(mode='min', factor=0.5, patience=5) on either optimizer kind (torch's class insists on a
+            # torch.optim.Optimizer; _PlateauLR is the same rule on ``param_groups``)
+            scheduler = _PlateauLR(optimizer, factor=0.5, patience=5)
+            best_val_metric, best_state, patience_counter = -np.inf, None, 0
+            for epoch in range(1, config.num_epochs + 1):
+                train_loss = train_epoch(model, train_loader, optimizer, criterion, device, task, config.grad_clip)
+                val_metrics, _, _ = evaluate(model, val_loader, device, task, num_classes)
+                current = val_metrics["F1"] if task == "classification" else val_metrics["R2"]
+                scheduler.step(1 - current if task == "classification" else -current)
+                if epoch % 10 == 0:
+                    say(f"  {model_name} epoch {epoch:3d}: loss {train_loss:.4f}, val {current:.4f}")
+                if current > best_val_metric:
+                    best_val_metric, best_state, patience_counter = current, copy.deepcopy(model.state_dict()), 0
+                else:
+                    patience_counter += 1
+                if patience_counter >= config.patience:
+                    say(f"  {model_name}: early stopping at epoch {epoch}")
+                    break
+            if best_state:
+                model.load_state_dict(best_state)
+            test_metrics, _, _ = evaluate(model, test_loader, device, task, num_classes)
+            results[model_name].append(test_metrics)
+            if model_name == "fusion":
+                fusion_weights_all.append(model.get_fusion_weights())
+            say(f"  {model_name} test: " + ", ".join(f"{k}={v:.4f}" for k, v in test_metrics.items()))
+    return results, fusion_weights_all

@@ -166,12 +166,14 @@ class _KernelTimer:
         a.record()
         return b
 
-    def mean_ms(self, name):
+    def all_ms(self, name):
         lst = self._ev.get(name) or []
-        if not lst:
-            return None
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in lst) / len(lst)
+        return [a.elapsed_time(b) for a, b in lst]
+
+    def mean_ms(self, name):
+        v = self.all_ms(name)
+        return sum(v) / len(v) if v else None
 
 
 kernel_timer = _KernelTimer()
@@ -967,6 +969,21 @@ def fmri_mlp_forward(seq, x, drop_p, training):
     h, _ = small_linear(_f32c(x), seq[0], act="relu", bn=seq[1])
     h, _ = small_linear(h, seq[4], act="relu", bn=seq[5])
     return h
+
+
+def fmri_single_forward(m, x):
+    """fMRIActivationOnly / fMRIConnectivityOnly (run_fmri_v11.py:311-370): encoder MLP -> Linear-ReLU-Dropout-Linear."""
+    _need_gpu(x)
+    if m.training:
+        from . import small_autograd as sa
+        p = m.drop_p
+        feat = fmri_mlp_forward(m.encoder.encoder, x, p, True)
+        return sa.linear(sa.linear(feat, m.head[0], "relu", p), m.head[3])
+    with torch.no_grad():
+        feat = fmri_mlp_forward(m.encoder.encoder, x, 0.0, False)
+        h, _ = small_linear(feat, m.head[0], act="relu")
+        out, _ = small_linear(h, m.head[3])
+    return out
 
 
 def fmri_fusion_forward(m, activation, connectivity):

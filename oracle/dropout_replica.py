@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY.  Host replica of the HIP path's counter-hash dropout masks
-(csrc/common.h: mm_hash / dropout_scale, csrc/attention.hip: attn_keep) and a restatement of the
+(csrc/common.h: mm_hash / dropout_scale, csrc/attention.hip: attn_block_hash / attn_keep2) and a restatement of the
 reference's TRAIN-mode EnhancedERPEncoder forward (enhanced_models_v4.py:128-144, 44-55, 88-105,
 161-193) with an explicit keep-mask at every nn.Dropout site, so that a whole-encoder forward/backward
 with dropout > 0 can be checked against the CPU oracle.  The reference draws its masks from torch's RNG
@@ -32,20 +32,22 @@ def keep_scale(seed: int, n: int, p: float) -> torch.Tensor:
 
 
 def attn_keep_scale(seed: int, bh: int, L: int, p: float) -> torch.Tensor:
-    """[bh, L, L] float32 attention-probability mask (attention.hip: attn_pair_hash / attn_keep): one hash per pair of
-    adjacent keys of a query row, pair index (bh * L + q) * ceil(L / 2) + key // 2; its low / high 16 bits decide the
-    even / odd key, keep iff half >= round(p * 2^16)."""
-    t16 = int(p * 65536.0 + 0.5)
-    if t16 == 0:
+    """[bh, L, L] float32 attention-probability mask (attention.hip: attn_block_hash / attn_keep2): one hash per 2 x 2
+    block (queries 2i, 2i + 1) x (keys 2j, 2j + 1), block index (bh * ceil(L / 2) + q // 2) * ceil(L / 2) + key // 2;
+    byte 2 (q & 1) + (key & 1) of the word decides the score, keep iff byte >= t = round(p * 256); kept scores are scaled
+    by 256 / (256 - t) (unbiased for the quantised probability)."""
+    t8 = int(p * 256.0 + 0.5)
+    if t8 == 0:
         return torch.ones(bh, L, L)
     Lh = (L + 1) // 2
-    idx = torch.arange(bh * L * Lh, dtype=torch.int64)
+    idx = torch.arange(bh * Lh * Lh, dtype=torch.int64)
     x = (idx * 0x9E3779B1 + int(seed)) & 0xFFFFFFFF
-    x ^= x >> 15
-    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
     x ^= x >> 13
-    keep = torch.stack([(x & 0xFFFF) >= t16, (x >> 16) >= t16], dim=-1).view(bh, L, 2 * Lh)[:, :, :L]
-    return keep.float() / (1.0 - p)
+    x = ((x & 0xFFFFFF) * 0xB5297B) & 0xFFFFFFFF
+    x ^= x >> 15
+    by = torch.stack([(x >> (8 * k)) & 0xFF for k in range(4)], dim=-1)                 # [blocks, 2 (q & 1) + (key & 1)]
+    keep = (by >= t8).view(bh, Lh, Lh, 2, 2).permute(0, 1, 3, 2, 4).reshape(bh, 2 * Lh, 2 * Lh)[:, :L, :L]
+    return keep.float() * (256.0 / (256.0 - t8))
 
 
 def erp_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int], p: float, p_attn: float,

@@ -275,6 +275,16 @@ def fmri_fusion_net(sd: SD, act, conn, p: str = "", task: str = "classification"
     return out, fused
 
 
+def fmri_single_branch(sd: SD, x, p: str = "", task: str = "classification", train: bool = False):
+    """fMRIActivationOnly / fMRIConnectivityOnly (fMRI_CODE/run_fmri_v11.py:311-370): the tabular encoder MLP
+    (:272-305, the same arithmetic as fmri_utils.py:23-56 which the a9 golden pins) -> Linear -> ReLU -> Dropout ->
+    Linear.  run_fmri_v11.py itself is not importable here (seaborn), so these two classes have no golden of their
+    own: they are pinned through their parts."""
+    feat = _fmri_mlp(sd, x, p + "encoder.", train)
+    out = _lin(sd, p + "head.3.", torch.relu(_lin(sd, p + "head.0.", feat)))
+    return out.squeeze(-1) if task == "regression" else out
+
+
 # --------------------------------------------------------------------------
 # a11 EEGfMRIBridgeFusionNet (bridge_utils.py:68-103)
 # --------------------------------------------------------------------------

@@ -808,11 +808,11 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     out0 = torch.empty_like(out)
     hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
     # recover the mask from V = identity-like probe: compare row sums of kept probabilities
-    # host replica of the attention kernels' index hash (attention.hip: attn_keep)
+    # host replica of the attention kernels' block hash (attention.hip: attn_block_hash / attn_keep2)
     from oracle.dropout_replica import attn_keep_scale
     m = attn_keep_scale(seed, B * H, L, p).view(B, H, L, L).double()
     q, k, v = (t.view(B, L, H, 32).transpose(1, 2).double() for t in qkv.split(E, dim=2))
-    q.requires_grad_(True)
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(32)
     o_ref = ((torch.softmax(s, -1) * m) @ v).transpose(1, 2).reshape(B, L, E)
     torch.testing.assert_close(out.float().cpu(), o_ref.detach().float(), rtol=3e-2, atol=3e-2)
@@ -824,6 +824,11 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None)
     dq_got = dqkv.float().cpu()[:, :, :E].view(B, L, H, 32).transpose(1, 2)
     assert ((dq_got - q.grad.float()).norm() / q.grad.float().norm()).item() < 3e-2
+    # the dkv kernel's registers run along the queries: it reads the other two bytes of each 2 x 2 block hash
+    dk_got = dqkv.float().cpu()[:, :, E:2 * E].view(B, L, H, 32).transpose(1, 2)
+    dv_got = dqkv.float().cpu()[:, :, 2 * E:].view(B, L, H, 32).transpose(1, 2)
+    assert ((dk_got - k.grad.float()).norm() / k.grad.float().norm()).item() < 3e-2
+    assert ((dv_got - v.grad.float()).norm() / v.grad.float().norm()).item() < 3e-2
 
 
 def test_batched_launches_equal_their_single_forms():

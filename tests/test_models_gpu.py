@@ -199,7 +199,7 @@ def test_volume_encoder_frozen_bn_backward_vs_oracle():
     assert w[1] <= 6e-2, w
     assert mg.conv_layers[0].bias.grad is not None and mg.conv_layers[0].bias.grad.abs().max().item() > 0   # not zero with a frozen BN
     # (2) the volume wants a gradient too: layer 1 as an implicit GEMM, its pre-BatchNorm tensor kept in bf16
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
     xo = x.clone().requires_grad_(True)
     with bf16_operands(l1_as_gemm=True):
         out = RF.volume_encoder3d(sd, xo, train=False)

@@ -94,6 +94,61 @@ def test_a10_fmri_train_epoch_and_evaluate():
     assert set(m) == {"MSE", "RMSE", "MAE", "R2"} and p.shape == t.shape == (64,)
 
 
+def test_a9_fmri_single_branch_nets_vs_oracle():
+    """fMRIActivationOnly / fMRIConnectivityOnly (run_fmri_v11.py:311-370): reference state_dict layout, eval output and
+    train-mode gradients (dropout 0) against the oracle's restatement; the unused second argument is ignored."""
+    from oracle import ref_functional as RF
+    for cls, seed in ((Fm.fMRIActivationOnly, 91), (Fm.fMRIConnectivityOnly, 92)):
+        m = build(cls, seed, 50, 64, 2, 0.0)
+        assert sorted(k for k in m.state_dict() if "num_batches" not in k) == sorted(
+            [f"encoder.encoder.{i}.{n}" for i in (0, 4) for n in ("weight", "bias")] +
+            [f"encoder.encoder.{i}.{n}" for i in (1, 5) for n in ("weight", "bias", "running_mean", "running_var")] +
+            [f"head.{i}.{n}" for i in (0, 3) for n in ("weight", "bias")])
+        x = seeded_randn(seed + 100, 16, 50)
+        other = seeded_randn(seed + 200, 16, 7)
+        args = (x.cuda(), other.cuda()) if cls is Fm.fMRIActivationOnly else (other.cuda(), x.cuda())
+        sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+        want_eval = RF.fmri_single_branch(sd, x, train=False).detach()
+        out = RF.fmri_single_branch(sd, x, train=True)
+        gy = seeded_randn(seed + 300, 16, 2)
+        out.backward(gy)
+        mg = m.cuda()
+        with torch.no_grad():
+            got = mg.eval()(*args)
+        torch.testing.assert_close(got.cpu(), want_eval, rtol=1e-4, atol=1e-5)
+        y = mg.train()(*args)
+        y.backward(gy.cuda())
+        torch.testing.assert_close(y.detach().cpu(), out.detach(), rtol=1e-4, atol=1e-5)
+        for n, prm in mg.named_parameters():
+            torch.testing.assert_close(prm.grad.cpu(), sd[n].grad, rtol=2e-3, atol=1e-5, msg=lambda s, n=n: f"{n}: {s}")
+    reg = build(Fm.fMRIActivationOnly, 93, 50, 64, 2, 0.0, "regression").cuda().eval()
+    with torch.no_grad():
+        assert reg(seeded_randn(5, 4, 50).cuda()).shape == (4,)
+
+
+def test_a10_fmri_run_experiment_protocol(tmp_path, monkeypatch):
+    """run_fmri_v11.py:715-934 on 60 separable synthetic subjects: stratified 3-fold, inner validation split, the three
+    models per fold, plateau LR + early stopping on the validation F1, best state restored, held-out test metrics with the
+    reference's result structure; fMRIConfig keeps the reference's fields and defaults."""
+    monkeypatch.chdir(tmp_path)
+    cfg = Fm.fMRIConfig(tmp_path)
+    assert (cfg.hidden_dim, cfg.dropout, cfg.batch_size, cfg.num_epochs, cfg.learning_rate, cfg.weight_decay, cfg.patience,
+            cfg.n_splits, cfg.val_ratio, cfg.grad_clip, cfg.agg_method) == (64, 0.4, 8, 100, 1e-4, 1e-4, 15, 5, 0.15, 1.0, "both")
+    assert cfg.subject_list == list(range(1, 33)) and cfg.connectivity_types == ["DMN"] and (tmp_path / "results_fmri").is_dir()
+    assert "val_ratio=0.15" in repr(cfg)
+    act, conn, lab = _separable_fmri(60, 24, 30, 9)
+    ds = Fm.fMRIDataset(act, conn, lab)
+    cfg.n_splits, cfg.num_epochs, cfg.learning_rate, cfg.patience, cfg.dropout = 3, 12, 3e-3, 6, 0.1
+    torch.manual_seed(0)
+    results, fw = Fm.run_experiment(ds, cfg, "classification", verbose=False)
+    assert set(results) == {"fusion", "activation_only", "connectivity_only"} and len(fw) == 3
+    for name, folds in results.items():
+        assert len(folds) == 3 and all(set(f) >= {"Accuracy", "F1", "Precision", "Recall", "AUC"} for f in folds)
+    assert sum(f["Accuracy"] for f in results["fusion"]) / 3 >= 0.8
+    assert sum(f["Accuracy"] for f in results["activation_only"]) / 3 >= 0.8
+    assert all(abs(w["activation"] + w["connectivity"] - 1.0) < 1e-5 for w in fw)
+
+
 def test_f1_bridge_loocv_protocol():
     """_test_bridge.py:826-970 on 12 synthetic subjects whose class shifts both feature vectors: every
     fold trains a fresh bridge on the HIP path, the held-out predictions beat chance clearly, and every

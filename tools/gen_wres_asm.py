@@ -40,6 +40,11 @@ import sys
 # ablation builds (tools/abl_build.sh): 1 no epilogue instructions, 2 no ds_reads inside the K loop, 4 no MFMAs,
 # 8 no global stores, 64 no halo prefetch, 128 no in-loop barriers, 256 no in-loop vmcnt waits.  0 in the product.
 ABL = int(os.environ.get("WRES_ABL", "0"))
+# schedule / epilogue experiments (A/B builds, profiles/r03_wres_ab.txt; 0 in the product): 1 packed fp32 math
+# (v_pk_*) for the bias add and the BatchNorm sums inside the K loop (measured: +12 % K-loop cycles - a v_pk_* in an
+# MFMA's shadow costs more than the two instructions it replaces), 2 a side instruction ALSO in the MFMA gaps that
+# carry a ds_read (round 2's schedule; one instruction per gap is 2 % fewer K-loop cycles)
+OPT = int(os.environ.get("WRES_OPT", "0"))
 # cache policy of the output stores: write-through ("sc0 sc1") - the 16.8 MB leave the XCD's L2 while the kernel
 # still computes instead of as one write-back burst at the kernel boundary (measured at C2, graph-replayed:
 # plain 17.9 us, sc1 / nt 16.6, sc0 sc1 15.8); the consumer is on another XCD's L2 anyway.
@@ -147,18 +152,26 @@ class Stream:
         self.vm_done = idx + 1
 
 
-def epilogue_group(prev, q):
+def epilogue_group(prev, q, bias=True):
     """store group q = 4 i + r of the previous tile: registers r of the four column tiles of M-tile i ->
-    4 channels x 4 voxel rows per lane quad: 19 instructions"""
+    4 channels x 4 voxel rows per lane quad: 19 instructions (15 without a bias)"""
     i, r = q >> 2, q & 3
     out = [f"v_accvgpr_read_b32 {TT[j]}, a{ACC[prev] + 4 * (4 * i + j) + r}" for j in range(4)]
-    out += [f"v_add_f32 {TT[j]}, {TT[j]}, {SH[j]}" for j in range(4)]
+    if bias:
+        if OPT & 1:
+            out += ["v_pk_add_f32 v[236:237], v[236:237], v[232:233]", "v_pk_add_f32 v[238:239], v[238:239], v[234:235]"]
+        else:
+            out += [f"v_add_f32 {TT[j]}, {TT[j]}, {SH[j]}" for j in range(4)]
     out += [f"v_cvt_pk_bf16_f32 v240, {TT[0]}, {TT[1]}", f"v_cvt_pk_bf16_f32 v241, {TT[2]}, {TT[3]}"]
     if not (ABL & 8):
         voff = VOFA if (i >> 1) == 0 else VOFB
         out.append(f"global_store_dwordx2 {voff}, {PK}, %[pbase] offset:{(4 * (i & 1) + r) * BN * 2} {STORE_BITS}".rstrip())
-    for j in range(4):
-        out += [f"v_add_f32 {S1[j]}, {S1[j]}, {TT[j]}", f"v_fmac_f32 {S2[j]}, {TT[j]}, {TT[j]}"]
+    if OPT & 1:
+        out += ["v_pk_add_f32 v[224:225], v[224:225], v[236:237]", "v_pk_add_f32 v[226:227], v[226:227], v[238:239]",
+                "v_pk_fma_f32 v[228:229], v[236:237], v[236:237], v[228:229]", "v_pk_fma_f32 v[230:231], v[238:239], v[238:239], v[230:231]"]
+    else:
+        for j in range(4):
+            out += [f"v_add_f32 {S1[j]}, {S1[j]}, {TT[j]}", f"v_fmac_f32 {S2[j]}, {TT[j]}, {TT[j]}"]
     return out
 
 
@@ -199,7 +212,7 @@ def is_plane_load(pp):
     return lambda s: s.startswith("buffer_load") and any(t in s for t in tags)
 
 
-def kloop(cur, prev=None, march=True):
+def kloop(cur, prev=None, march=True, bias=True, first=False):
     """27 taps of one tile into set `cur`.  march: the next tile is the next one down the column - its four new
     planes are prefetched in taps 0-3, written into the ring after each kd phase, and the statement ends with the
     fragment reads of ITS tap 0.  Otherwise: six planes of the next column (or nothing: all-invalid masks) are
@@ -223,7 +236,7 @@ def kloop(cur, prev=None, march=True):
         if prev is not None and not (ABL & 1) and e0 <= t <= e1:
             want = ((t - e0 + 1) * 16 + (e1 - e0)) // (e1 - e0 + 1)       # groups due by the end of tap t
             while ngroups < min(want, 16):
-                side += epilogue_group(prev, ngroups)
+                side += epilogue_group(prev, ngroups, bias)
                 ngroups += 1
         nxt = list(READ_ORDER) if t + 1 < TAPS else []
         for g, (i, j) in enumerate(MFMA_ORDER):
@@ -235,7 +248,15 @@ def kloop(cur, prev=None, march=True):
             # the reads of tap t + 1 go to the OTHER fragment set, whose last readers (tap t - 1's MFMAs) have issued
             if nxt and g < 8:
                 st.read(t + 1, nxt.pop(0))
-                budget -= 1
+                budget -= 1 if (OPT & 2) else 2
+            if first and t == 7 and g == 8:
+                # the first tile of a workgroup started with only taps 0-8 of the weights in LDS (WRES_BOUNDARY_FIRST): the
+                # other 18 DMA pieces of this wave are older than every load this statement has issued, so waiting for
+                # all but those leaves them landed; the barrier publishes every wave's rows before tap 9's B reads (gaps
+                # 0-7 of tap 8) are issued
+                st.lines.append(f"s_waitcnt vmcnt({len(st.vm)})")
+                st.emit("s_barrier")
+                budget = 0
             if march and t in (8, 17, 26) and g == 8:
                 # end of a kd phase.  Every fragment of this tap has landed (so no wave still reads the dying plane
                 # once all have passed the barrier); the new plane's loads have landed; then overwrite.
@@ -307,13 +328,13 @@ def prefetch_only():
     return lines
 
 
-def boundary(younger):
+def boundary(younger, nplanes=6):
     """column change / first tile: six prefetched planes -> LDS slots sb0..sb5, between the two barriers that
     separate the previous tile's LDS reads from the overwrite; then the fragment reads of the new tile's tap 0.
     `younger`: vector-memory operations issued after the plane loads that may still be in flight (the 16 stores of
     an epilogue: vmcnt counts in issue order); 0 = wait for everything (first tile: the weight DMA too)"""
     lines = [f"s_waitcnt vmcnt({younger})", "s_barrier"]
-    for pp in range(6):
+    for pp in range(nplanes):
         lines += plane_write(pp, f"sb{pp}")
     lines += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
     for w in READ_ORDER:                              # tap 0 of the tile that starts now
@@ -322,8 +343,14 @@ def boundary(younger):
 
 
 def init_consts():
+    """first thing a wave does: the halo-chunk constants the prefetch statements read, and zeroed BatchNorm sums"""
     return [f"v_accvgpr_write_b32 a{GOFFP + j}, %[g{j}]" for j in range(2)] + [f"v_accvgpr_write_b32 a{SELP + j}, %[s{j}]" for j in range(2)] + \
-           [f"v_accvgpr_write_b32 a{BIAS + j}, %[sh{j}]" for j in range(4)] + [f"v_accvgpr_write_b32 a{STATS + k}, 0" for k in range(8)]
+           [f"v_accvgpr_write_b32 a{STATS + k}, 0" for k in range(8)]
+
+
+def init_bias():
+    """the lane's four bias values (global loads: parked after the halo prefetch and the weight DMA have been issued)"""
+    return [f"v_accvgpr_write_b32 a{BIAS + j}, %[sh{j}]" for j in range(4)]
 
 
 def stats_out():
@@ -360,8 +387,14 @@ def main():
             define(f"WRES_EXTRACT_{cur}_{i}", extract(cur, i))
     define("WRES_PREFETCH", prefetch_only())
     define("WRES_BOUNDARY_ALL", boundary(0))
+    # first tile of a workgroup: the halo loads, the DMA of taps 0-8 and the bias piece are older than the DMA of taps
+    # 9-26 (18 pieces per wave), which lands during the first nine taps (WRES_K_X_*_FIRST waits for it)
+    define("WRES_BOUNDARY_FIRST", boundary(18))
+    for march in (True, False):
+        define("WRES_K_X_" + ("MARCH" if march else "COL") + "_FIRST", kloop("X", march=march, first=True))
     define("WRES_BOUNDARY_EPI", boundary(16))
     define("WRES_INIT", init_consts())
+    define("WRES_INIT_BIAS", init_bias())
     define("WRES_STATS_OUT", stats_out())
     with open(out, "w") as f:
         f.write("\n".join(parts) + "\n")
