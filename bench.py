@@ -54,6 +54,21 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def cgroup_cpu_limit():
+    """CPUs the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
     """oracle/ training step on the host (checker code, reported baseline only): every core of the affinity mask,
     2 warm-up + 5 timed steps, CPU model stated."""
@@ -62,7 +77,11 @@ def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
     import multimodal_eeg_fmri_amd.enhanced_models_v4 as E
     import multimodal_eeg_fmri_amd.fmri_utils as Fm
     import multimodal_eeg_fmri_amd.bridge_utils as Bu
-    cores = len(os.sched_getaffinity(0))
+    affinity = len(os.sched_getaffinity(0))
+    quota = cgroup_cpu_limit()
+    # every core this process may use: the affinity mask, capped by the container's CPU quota when there is one (a GPU box
+    # hands each 1-GPU job a share of the host: more threads than that share only add contention)
+    cores = max(1, min(affinity, int(quota + 0.5))) if quota else affinity
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     mods = {"e.": E.EnhancedERPEncoder(EEG_CH, 128, 2, 4, 0.0), "f.": Fm.fMRIVolumeEncoder3D(1, 64, dropout=0.0),
@@ -86,8 +105,11 @@ def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
         loss.backward()
         torch.nn.utils.clip_grad_norm_([p for p in leaves if p.grad is not None], 1.0)
         opt.step()
+    t0 = time.perf_counter()
     for _ in range(warmup):
         step()
+    warm = (time.perf_counter() - t0) / warmup
+    steps = max(2, min(steps, int(25.0 / max(warm, 1e-3))))      # bounded sample: ~10-30 s of CPU work in all
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -99,6 +121,7 @@ def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
     torch.set_num_threads(cores)
     c1 = cpu_baseline_c1_lite()
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "affinity_cores": affinity, "cgroup_cpu_limit": quota,
             "sample": f"{steps} timed + {warmup} warm-up full training steps of {pairs} pairs "
                       f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step, torch threads = {cores} (all affinity cores)",
             "one_thread": {"value": pairs / dt1, "unit": "pairs/s", "sample": f"1 step, {dt1:.1f} s"},
@@ -276,6 +299,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loss_timed = out["loss"].item()           # read before any other step overwrites the trainer's result buffer
+    tr_capture_mode = tr.capture_mode
     t = torch.tensor([dt], device="cuda")
     if world > 1:
         import torch.distributed as dist
@@ -377,7 +401,9 @@ def main():
                                "(3-D conv encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW",
                    "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": global_batch, "parallelism": f"dp{world}",
                    "dropout": args.dropout, "mfma_operands": "bf16", "accumulate": "fp32",
-                   "execution": "hipGraph replay" if world == 1 else "3 hipGraph segments + 2 RCCL collectives (all-gather of embeddings, all-reduce of gradients)"},
+                   "execution": "hipGraph replay" if world == 1 else
+                   f"{tr_capture_mode} (all-gather of embeddings; all-reduce of the fMRI third of the gradient bucket beside the "
+                   "EEG backward, of the remainder after it)"},
         "top1_retrieval_acc": {"eeg_to_fmri": ev["top1_e2f"].item(), "fmri_to_eeg": ev["top1_f2e"].item(),
                                "chance": 1.0 / global_batch, "note": "on the training batch after the timed steps",
                                "held_out_after_fit": fit},

@@ -378,10 +378,19 @@ int mm_smoothed_ce(const float* logits, const void* target_i64, float* loss_out,
 int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, int T, int nfft, int hop,
                   int ch_off, int ch_total, hipStream_t stream);
 /* normalize_modality (run_training_lite.py:48-51; applied per sample to the power features at :162):
- * out[b] = bf16((x[b] - mean(x[b])) / (std_unbiased(x[b]) + eps)) over all rows x ch_valid elements of
+ * out[b] = bf16((x[b] - mean(x[b])) / (std(x[b]) + eps)), population std (numpy ddof = 0), over all rows x ch_valid elements of
  * sample b; x / out [B][rows][ch_total] channels-last, channels >= ch_valid are written as zeros. */
 int mm_sample_zscore_bf16(const float* x, void* out_bf16, int B, int rows, int ch_valid, int ch_total, float eps,
                           hipStream_t stream);
+/* Backward of the STFT power front-end and of its z-score (gradient w.r.t. the RAW EEG: saliency / integrated
+ * gradients on the config-#5 model, the protocol of bridge_utils.py:158-229 / eeg_xai_analysis.py on an end-to-end
+ * path).  mm_sample_zscore_bwd: x = the fp32 spectra the forward z-scored, g_bf16 = gradient w.r.t. the z-scored
+ * bf16 tensor (same [B][rows][ch_total] layout) -> dx fp32 (padding channels 0).  mm_stft_power_bwd: g_power fp32
+ * [B][frames][ch_total] -> dx fp32 [B][C][T] is ADDED to (one launch per scale; zero it first).  Gathers, no atomics. */
+int mm_sample_zscore_bwd(const float* x, const void* g_bf16, float* dx, int B, int rows, int ch_valid, int ch_total,
+                         float eps, hipStream_t stream);
+int mm_stft_power_bwd(const float* x, const float* g_power, float* dx, int B, int C, int T, int nfft, int hop,
+                      int ch_off, int ch_total, hipStream_t stream);
 int mm_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 /* Encoder tail (enhanced_models_v4.py:161-167, 186-191: mean over time -> output_proj = Linear -> GELU ->
  * Dropout).  mm_linear_fwd_meanpool is the last transformer block's linear2 (+ dropout + residual, fp32 rows

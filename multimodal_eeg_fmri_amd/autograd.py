@@ -466,10 +466,10 @@ class PowerEncoderFn(_ModuleFn):
     @staticmethod
     def forward(ctx, m, x, packed, *params):
         xb = x if packed else ops.pack_nct(x.float())
-        need_dx = (not packed) and x.requires_grad
+        need_dx = bool(x.requires_grad)                  # packed: the gradient goes back as the packed bf16 image (StftFrontEndFn)
         out, saved = ops._power_forward_impl(m, xb, m.training, need_dx, save=True)
         ctx.saved, ctx.params = saved, params
-        ctx.need_dx, ctx.x_shape = need_dx, tuple(x.shape)
+        ctx.need_dx, ctx.x_shape, ctx.packed = need_dx, tuple(x.shape), bool(packed)
         return out
 
     @staticmethod
@@ -479,11 +479,48 @@ class PowerEncoderFn(_ModuleFn):
             g, finish = power_encoder_bwd(bag, ctx.saved, dout.contiguous(), ctx.need_dx)
         finish()
         dx = None
-        if ctx.need_dx:
+        if ctx.need_dx and ctx.packed:
+            dx = g
+        elif ctx.need_dx:
             Bx, C, T = ctx.x_shape
             dx = _empty((Bx, C, T), _F32, dout)
             _hip.call("mm_unpack_ntc_f32", g, dx, Bx, C, T, g.shape[2])
         return (None, dx, None) + tuple(bag.result(p) for p in ctx.params)
+
+
+class StftFrontEndFn(torch.autograd.Function):
+    """multi-scale STFT power front-end [+ per-sample z-score] as a differentiable step: raw EEG (B, C, T) fp32 ->
+    channels-last bf16 spectra (B, frames, Cp).  Backward: the gradient w.r.t. the packed spectra -> z-score backward
+    (fp32) -> per scale, the gradient of |DFT(window * frame)|^2 gathered back onto the samples (mm_stft_power_bwd) ->
+    d / d raw EEG (saliency / integrated gradients on the config-#5 model)."""
+
+    @staticmethod
+    def forward(ctx, x, n_ffts, hop, normalize):
+        xc = x.float().contiguous()
+        out, spec = ops.stft_front_end(xc, n_ffts, hop, normalize, keep_spec=True)
+        ctx.save_for_backward(xc, spec if spec is not None else out)
+        ctx.cfg = (tuple(n_ffts), int(hop), bool(normalize))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, spec = ctx.saved_tensors
+        n_ffts, hop, normalize = ctx.cfg
+        B, C, T = xc.shape
+        frames, cp = g.shape[1], g.shape[2]
+        widths = [C * (n // 2 + 1) for n in n_ffts]
+        g = g.contiguous()
+        if normalize:
+            gp = _empty((B, frames, cp), _F32, g)
+            _hip.call("mm_sample_zscore_bwd", spec, g, gp, B, frames, sum(widths), cp, 1e-8)
+        else:
+            gp = g.float()
+        dx = torch.zeros_like(xc)
+        off = 0
+        for n, wdt in zip(n_ffts, widths):
+            _hip.call("mm_stft_power_bwd", xc, gp, dx, B, C, T, int(n), hop, off, cp)
+            off += wdt
+        return dx, None, None, None
 
 
 class AddPositionalFn(torch.autograd.Function):

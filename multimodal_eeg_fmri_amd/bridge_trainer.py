@@ -4,10 +4,17 @@ One process per GPU (``torch.distributed`` backend ``nccl`` == RCCL over xGMI).
 Per step and per rank: EEG temporal encoder + fMRI voxel encoder forward on the
 local (EEG-epoch, fMRI-volume) pairs, projection heads, one all-gather of the
 packed L2-normalised embeddings (global contrastive negatives), fused
-similarity/InfoNCE forward+backward, one reduce-scatter of the embedding
-gradients, encoder backward, ONE all-reduce of the flat fp32 gradient bucket,
-fused clip+AdamW on the flat parameter bucket.  BatchNorm statistics stay
-per-rank (the reference has no SyncBN).
+similarity/InfoNCE forward+backward on this rank's rows of the gathered batch
+(every rank evaluates all rows, so no reduce-scatter of column gradients is
+issued), encoder backward, the all-reduce of the flat fp32 gradient bucket in
+two parts - the fMRI encoder's third as soon as its (shorter) backward has
+finished, on that branch's stream, hidden beside the rest of the EEG backward;
+the remainder after the chain - and the fused clip+AdamW on the flat parameter
+bucket.  At world size > 1 the whole step, collectives included, is ONE
+hipGraph when the backend's collectives can be captured (RCCL), else three
+graph segments around two eager collectives (``capture_mode`` says which).
+BatchNorm statistics stay per-rank (the reference has no SyncBN; SURVEY.md
+section 8e).
 
 The reference has no such trainer (its loops are run_training_lite.py:474-489
 and _test_bridge.py:775-788: zero_grad / forward / backward / clip 1.0 / AdamW);
@@ -49,7 +56,7 @@ class BridgeTrainer(nn.Module):
         import os
         # MM_ONE_STREAM=1 (diagnostic): run the fMRI branch on the main stream after the EEG branch
         self._one_stream = bool(os.environ.get("MM_ONE_STREAM"))
-        self._side_stream = torch.cuda.Stream()
+        self._side_stream = None                      # created on first use (the host logic also constructs on CPU)
         self.lr, self.weight_decay, self.grad_clip = lr, weight_decay, grad_clip
         self.betas, self.eps = betas, eps
         br = self.head.bridge
@@ -58,9 +65,13 @@ class BridgeTrainer(nn.Module):
         for name, p in br.named_parameters():
             if not (name.startswith("eeg_proj") or name.startswith("fmri_proj")):
                 p.requires_grad_(False)
-        train_params = (list(self.eeg_encoder.parameters()) + list(self.fmri_encoder.parameters())
-                        + [p for p in br.parameters() if p.requires_grad] + [self.head.logit_scale])
+        # bucket order: EEG encoder | projection heads | logit scale | fMRI encoder.  The fMRI encoder's slice is the
+        # tail, so "the part whose gradients are final first" is one contiguous range [fmri_lo, n)
+        head_params = [p for p in br.parameters() if p.requires_grad] + [self.head.logit_scale]
+        train_params = list(self.eeg_encoder.parameters()) + head_params + list(self.fmri_encoder.parameters())
         self.bucket = FlatBucket(train_params)
+        self.fmri_lo = self.bucket.n - sum(p.numel() for p in self.fmri_encoder.parameters() if p.requires_grad)
+        self.capture_mode = None                      # "one graph" | "one graph + captured RCCL collectives" | "3 segments + 2 eager collectives"
         self.bucket.state[2] = lr
         # {loss, top-1 e->f, top-1 f->e, d loss / d logit_scale} of the last step: owned by this trainer
         # (plain stores of the loss kernel), so the tensors a step returns are overwritten only by THIS
@@ -70,7 +81,11 @@ class BridgeTrainer(nn.Module):
 
     @property
     def _side(self):
-        return torch.cuda.current_stream() if self._one_stream else self._side_stream
+        if self._one_stream:
+            return torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
 
     @property
     def world(self):
@@ -123,7 +138,7 @@ class BridgeTrainer(nn.Module):
     # ---- the segments of the autograd-free tape ------------------------------
     STAMP_NAMES = ("step start", "weights prepared", "EEG fwd done", "fMRI fwd start", "fMRI fwd done",
                    "heads fwd done", "loss done", "heads bwd done", "EEG bwd done", "fMRI bwd start",
-                   "fMRI bwd done", "grad reductions done", "AdamW done")
+                   "fMRI bwd done", "grad reductions done", "AdamW done", "side stream done")
 
     def _stamp(self, i):
         if self.stamps is not None:
@@ -169,7 +184,9 @@ class BridgeTrainer(nn.Module):
         _hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, ws, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
         self._stamp(6)
 
-    def _seg_backward(self, saved, dz, scal):
+    def _seg_backward(self, saved, dz, scal, reduce_fmri: bool = False):
+        """``reduce_fmri``: all-reduce the fMRI encoder's slice of the gradient bucket on the side stream as soon as that
+        branch's backward and its reductions are done (~160 us before the EEG chain ends at C2)"""
         sv_e, sv_f, sv_h = saved
         bag = GradBag()
         with deferred(bag, dz.device):           # ONE batched reduction after both branches joined
@@ -204,16 +221,19 @@ class BridgeTrainer(nn.Module):
                 with deferred(bag_f, dz.device):     # hidden beside the rest of the EEG backward
                     volume_encoder_bwd(bag_f, sv_f, dff)
                 self._stamp(10)
+                if reduce_fmri:
+                    dp.allreduce_sum_(self.bucket.g[self.fmri_lo:], self.group)
                 for hb, ev in handed:
                     self._side.wait_event(ev)
                     hb.flush(dz.device)
+                self._stamp(13)
             main.wait_stream(self._side)
         self._stamp(11)
         self._bags = getattr(self, "_bags", [])[-12:] + [bag, bag_f] + [hb for hb, _ in handed]   # keep descriptor tables alive
 
-    def _seg_optimizer(self):
+    def _seg_optimizer(self, fmri_reduced: bool = False):
         b = self.bucket
-        dp.allreduce_sum_(b.g, self.group)
+        dp.allreduce_sum_(b.g[:self.fmri_lo] if fmri_reduced else b.g, self.group)
         self._seg_adamw()
 
     def _seg_adamw(self):
@@ -242,8 +262,9 @@ class BridgeTrainer(nn.Module):
         z_all = dp.gather_embeddings(z, self.group)
         scal, dz = self._scal, ops._empty(tuple(z.shape), torch.float32, z)
         self._seg_loss(z_all, scal, dz)
-        self._seg_backward(saved, dz, scal)
-        self._seg_optimizer()
+        early = self.world > 1
+        self._seg_backward(saved, dz, scal, reduce_fmri=early)
+        self._seg_optimizer(fmri_reduced=early)
         return {"loss": scal[0], "top1_e2f": scal[1], "top1_f2e": scal[2]}
 
     # ---- hipGraph capture ------------------------------------------------------
@@ -284,7 +305,9 @@ class BridgeTrainer(nn.Module):
         B = eeg.shape[0]
         N2 = 2 * self.head.bridge.bridge_dim
         c["scal"] = self._scal
-        if world == 1 and not (self.force_segments and self.group is not None):
+        import os
+        dist_step = not (world == 1 and not (self.force_segments and self.group is not None))
+        if not dist_step:
             def whole():
                 z, saved = self._seg_forward(c["eeg"], c["fmri"], xb=c["xb"])
                 c["dz"] = ops._empty(tuple(z.shape), torch.float32, z)
@@ -292,7 +315,11 @@ class BridgeTrainer(nn.Module):
                 self._seg_backward(saved, c["dz"], c["scal"])
                 self._seg_adamw()
             record(whole)
+            self.capture_mode = "one graph"
+        elif dp.CAPTURABLE and os.environ.get("MM_DP_CAPTURE", "1") != "0" and self._capture_with_collectives(c, record, B, N2, world, dev):
+            self.capture_mode = "one graph + captured RCCL collectives"
         else:
+            self.capture_mode = "3 segments + 2 eager collectives"
             def seg1():
                 c["z"], c["saved"] = self._seg_forward(c["eeg"], c["fmri"], xb=c["xb"])
                 c["dz"] = ops._empty((B, N2), torch.float32, c["z"])
@@ -306,6 +333,34 @@ class BridgeTrainer(nn.Module):
             record(self._seg_adamw)
         c["graphs"] = graphs
         self._cap = c
+
+    def _capture_with_collectives(self, c, record, B, N2, world, dev) -> bool:
+        """the N > 1 step as ONE hipGraph: all-gather of the embeddings, the fMRI slice's all-reduce on the side branch
+        and the remainder's all-reduce on the chain are graph nodes (no replay gaps, no host in the step).  Returns
+        False - nothing recorded - when the backend refuses the capture; the caller then records the three segments."""
+        c["z_all"] = torch.empty(world * B, N2, device=dev)
+        # the communicator must exist before the capture starts (its lazy initialisation is not capturable)
+        dp.all_gather_into(c["z_all"], torch.zeros(B, N2, device=dev), self.group)
+        dp.allreduce_sum_(torch.zeros(8, device=dev), self.group)
+        torch.cuda.synchronize()
+
+        def whole_dp():
+            z, saved = self._seg_forward(c["eeg"], c["fmri"], xb=c["xb"])
+            c["dz"] = ops._empty((B, N2), torch.float32, z)
+            dp.all_gather_into(c["z_all"], z, self.group)
+            self._seg_loss(c["z_all"], c["scal"], c["dz"])
+            self._seg_backward(saved, c["dz"], c["scal"], reduce_fmri=True)
+            self._seg_optimizer(fmri_reduced=True)
+        try:
+            record(whole_dp)
+            return True
+        except Exception as e:  # noqa: BLE001 - any refusal (RCCL, the caching allocator, a host sync) -> segments
+            import warnings
+            warnings.warn(f"collectives not captured into the step's hipGraph ({type(e).__name__}: {e}); using three segments")
+            torch.cuda.synchronize()
+            ops.arena.end()
+            ops.weights_changed()
+            return False
 
     def _step_graph(self, eeg, fmri):
         if self._cap is None or self._cap["eeg"].shape != eeg.shape or self._cap["fmri"].shape != fmri.shape:

@@ -116,33 +116,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    // K / V chunks: global -> registers -> LDS, with the NEXT chunk's loads issued before the current chunk's tiles are
+    // computed (a chunk is ~2 us of work, a load round trip from L2 / MALL ~1.5 us: exposed four times per workgroup it
+    // was a third of the kernel, profiles/r03_attention_ab.txt)
+    constexpr int NI = KCH * 4 / 256;
+    uint4 kreg[NI], vreg[NI];
+    auto load_chunk = [&](int k0) __attribute__((always_inline)) {
+        const int kn = min(KCH, L - k0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+            kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = make_uint4(0, 0, 0, 0);
+            if (key < kn) {
+                const bf16* row = base + (size_t)(k0 + key) * E3;
+                kreg[i] = *reinterpret_cast<const uint4*>(row + E + sg * 8);
+                vreg[i] = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
+            }
+        }
+    };
+    load_chunk(0);
+    // the query fragments are complete from here on, and the compiler must know it: their first use would otherwise carry
+    // an s_waitcnt vmcnt(0) INSIDE the tile loop (the waits in front of the LDS writes sit in divergent blocks), which
+    // would also wait for the prefetched chunk
+    asm volatile("" : : "v"(qf[0]), "v"(qf[1]));
     for (int k0 = 0; k0 < L; k0 += KCH) {
         const int kn = min(KCH, L - k0);
         const int kn32 = (kn + 31) & ~31;
         __syncthreads();
-        // stage K rows and V^T (zero-padded to a multiple of 32 keys)
-        {   // all loads of the chunk are in flight before the first LDS write
-            constexpr int NI = KCH * 4 / 256;
-            uint4 kreg[NI], vreg[NI];
+        // K rows and V rows (zero-padded to a multiple of 32 keys) of this chunk
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
-                kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = make_uint4(0, 0, 0, 0);
-                if (key < kn) {
-                    const bf16* row = base + (size_t)(k0 + key) * E3;
-                    kreg[i] = *reinterpret_cast<const uint4*>(row + E + sg * 8);
-                    vreg[i] = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
-                if (key >= kn32) continue;
-                *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
-                *reinterpret_cast<uint4*>(Vs + vperm(key) * VR + sg * 8) = vreg[i];
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+            if (key >= kn32) continue;
+            *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs + vperm(key) * VR + sg * 8) = vreg[i];
         }
         __syncthreads();
+        if (k0 + KCH < L) load_chunk(k0 + KCH);
         for (int kt = 0; kt < kn32; kt += 32) {
             f32x16 sacc;
 #pragma unroll
@@ -272,33 +282,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 
+    constexpr int NI = KCH * 4 / 256;                    // next chunk prefetched into registers, as in the forward
+    uint4 kreg[NI], vreg[NI];
+    auto load_chunk = [&](int k0) __attribute__((always_inline)) {
+        const int kn = min(KCH, L - k0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+            kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = make_uint4(0, 0, 0, 0);
+            if (key < kn) {
+                const bf16* row = base + (size_t)(k0 + key) * E3;
+                kreg[i] = *reinterpret_cast<const uint4*>(row + E + sg * 8);
+                vreg[i] = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
+            }
+        }
+    };
+    load_chunk(0);
+    asm volatile("" : : "v"(qf[0]), "v"(qf[1]), "v"(dof[0]), "v"(dof[1]), "v"(dl), "v"(lse2));      // (as in the forward)
     for (int k0 = 0; k0 < L; k0 += KCH) {
         const int kn = min(KCH, L - k0);
         const int kn32 = (kn + 31) & ~31;
         __syncthreads();
-        {
-            constexpr int NI = KCH * 4 / 256;
-            uint4 kreg[NI], vreg[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
-                kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = make_uint4(0, 0, 0, 0);
-                if (key < kn) {
-                    const bf16* row = base + (size_t)(k0 + key) * E3;
-                    kreg[i] = *reinterpret_cast<const uint4*>(row + E + sg * 8);
-                    vreg[i] = *reinterpret_cast<const uint4*>(row + 2 * E + sg * 8);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int s = tid + i * 256, key = s >> 2, sg = s & 3;
-                if (key >= kn32) continue;
-                *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
-                *reinterpret_cast<uint4*>(Vs + key * KS + sg * 8) = vreg[i];
-                *reinterpret_cast<uint4*>(Kr + vperm(key) * VR + sg * 8) = kreg[i];
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int s = tid + i * 256, key = s >> 2, sg = s & 3;
+            if (key >= kn32) continue;
+            *reinterpret_cast<uint4*>(Ks + key * KS + sg * 8) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs + key * KS + sg * 8) = vreg[i];
+            *reinterpret_cast<uint4*>(Kr + vperm(key) * VR + sg * 8) = kreg[i];
         }
         __syncthreads();
+        if (k0 + KCH < L) load_chunk(k0 + KCH);
         for (int kt = 0; kt < kn32; kt += 32) {
             f32x16 sacc, dp;
 #pragma unroll
@@ -382,38 +396,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
 
+    constexpr int NI = QCH * 4 / 256;                    // next chunk (Q, dO rows, lse, delta) prefetched into registers
+    static_assert(QCH <= 256, "one lse / delta value per thread");
+    uint4 qreg[NI], dreg[NI];
+    float lreg = INFINITY, dlreg = 0.f;
+    auto load_chunk = [&](int q0) __attribute__((always_inline)) {
+        const int qn = min(QCH, L - q0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s = tid + i * 256, qi = s >> 2, sg = s & 3;
+            qreg[i] = make_uint4(0, 0, 0, 0); dreg[i] = make_uint4(0, 0, 0, 0);
+            if (qi < qn) {
+                qreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)(q0 + qi) * E3 + sg * 8);
+                dreg[i] = *reinterpret_cast<const uint4*>(dout + ((size_t)b * L + q0 + qi) * E + h * DH + sg * 8);
+            }
+        }
+        const bool ok = tid < qn;
+        lreg = ok ? lse[((size_t)b * H + h) * L + q0 + tid] : INFINITY;      // (scaled to log2 units when it is parked: no arithmetic - no wait - here)
+        dlreg = ok ? delta[((size_t)b * H + h) * L + q0 + tid] : 0.f;
+    };
+    load_chunk(0);
+    asm volatile("" : : "v"(kf[0]), "v"(kf[1]), "v"(vf[0]), "v"(vf[1]));                              // (as in the forward)
     for (int q0 = 0; q0 < L; q0 += QCH) {
         const int qn = min(QCH, L - q0);
         const int qn32 = (qn + 31) & ~31;
         __syncthreads();
-        {
-            constexpr int NI = QCH * 4 / 256;
-            uint4 qreg[NI], dreg[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int s = tid + i * 256, qi = s >> 2, sg = s & 3;
-                qreg[i] = make_uint4(0, 0, 0, 0); dreg[i] = make_uint4(0, 0, 0, 0);
-                if (qi < qn) {
-                    qreg[i] = *reinterpret_cast<const uint4*>(base + (size_t)(q0 + qi) * E3 + sg * 8);
-                    dreg[i] = *reinterpret_cast<const uint4*>(dout + ((size_t)b * L + q0 + qi) * E + h * DH + sg * 8);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int s = tid + i * 256, qi = s >> 2, sg = s & 3;
-                if (qi >= qn32) continue;
-                *reinterpret_cast<uint4*>(Qs + qi * KS + sg * 8) = qreg[i];
-                *reinterpret_cast<uint4*>(Ds + qi * KS + sg * 8) = dreg[i];
-                *reinterpret_cast<uint4*>(Qr + vperm(qi) * VR + sg * 8) = qreg[i];
-                *reinterpret_cast<uint4*>(Dr + vperm(qi) * VR + sg * 8) = dreg[i];
-            }
+        for (int i = 0; i < NI; ++i) {
+            const int s = tid + i * 256, qi = s >> 2, sg = s & 3;
+            if (qi >= qn32) continue;
+            *reinterpret_cast<uint4*>(Qs + qi * KS + sg * 8) = qreg[i];
+            *reinterpret_cast<uint4*>(Ds + qi * KS + sg * 8) = dreg[i];
+            *reinterpret_cast<uint4*>(Qr + vperm(qi) * VR + sg * 8) = qreg[i];
+            *reinterpret_cast<uint4*>(Dr + vperm(qi) * VR + sg * 8) = dreg[i];
         }
-        for (int i = tid; i < qn32; i += 256) {
-            const bool ok = i < qn;
-            Ls[i] = ok ? lse[((size_t)b * H + h) * L + q0 + i] * 1.4426950408889634f : INFINITY;
-            Dl[i] = ok ? delta[((size_t)b * H + h) * L + q0 + i] : 0.f;
-        }
+        if (tid < qn32) { Ls[tid] = lreg * 1.4426950408889634f; Dl[tid] = dlreg; }
         __syncthreads();
+        if (q0 + QCH < L) load_chunk(q0 + QCH);
         for (int qt = 0; qt < qn32; qt += 32) {
             // S[q][key] and dP[q][key]: rows = q (registers), column = this lane's key
             f32x16 sacc, dp;

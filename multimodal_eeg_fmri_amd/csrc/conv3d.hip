@@ -480,6 +480,12 @@ int mm_conv3d_fwd(const void* x, const void* w, int B, int D, int H, int W, int 
     const long tiles2 = (long)B * ceil_div(D, 2) * ceil_div(H, 8) * ceil_div(W, 8);
     if (conv3d_wres_applies(a)) return launch3d_wres(a, st);          // Cin 32 -> Cout 64, bf16 out: conv3d_wres.hip
     if (conv3d_stream_applies(a)) return launch3d_stream(a, st);      // 64 -> 128, 128 -> 64, 64 -> 32: conv3d_stream.hip
+    // mm_prep_conv_weight stores the weight image of these shapes in the streaming kernel's lane order (common.h:
+    // conv_image_index keys on the shape alone); the generic kernel below reads the plain [n][tap][c] image and would
+    // silently compute with scrambled weights
+    if (conv3d_stream_shape(Cout, Cin))
+        return mm_fail(MM_ERR_UNSUPPORTED, "conv3d_fwd: Cin=%d Cout=%d volumes of %d x %d x %d voxels exceed the streaming kernel's "
+                                           "32-bit per-sample offsets (its weight image is in that kernel's lane order)", Cin, Cout, D, H, W);
     if (Cout <= 32) return launch3d<2, 32, 4, 1>(a, st);
     if (Cout <= 64) {
         if (tiles2 >= 256 && D % 2 == 0) return launch3d<2, 64, 4, 1>(a, st);

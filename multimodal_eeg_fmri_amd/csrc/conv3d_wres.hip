@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     // holds output channel n = 4 (rho & 15) + (rho >> 4) (column tile j = rho >> 4, lane column c = rho & 15 <->
     // channel 4 c + j); the channel segment in slot s is s ^ 2 ((rho >> 2) & 1).  Both permutations sit in the
     // SOURCE address, which is affine in the tap (+64 bytes).
+    const bf16* wsrc9;                                                // this lane's source of tap 9
     {
         const int rho = wave * 16 + (lane >> 2), slot = lane & 3;
         const int n = 4 * (rho & 15) + (rho >> 4);
@@ -182,14 +183,14 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
                 __builtin_amdgcn_global_load_lds((gptr_t*)(wlane + k * CIN), (lptr_t*)(smem + k * BN * ROWB + wave * 1024), 16, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
-        // taps 0-8 (kd = 0), the bias, then taps 9-26: the first tile starts once the halo and the first batch are in LDS
-        // (WRES_BOUNDARY_FIRST leaves this wave's last 18 pieces in flight; they land during the first nine taps)
+        // taps 0-8 (kd = 0) and the bias: the first tile starts once the halo and this first batch are in LDS; taps 9-26
+        // are issued in the MFMA gaps of its first taps (WRES_K_X_*_FIRST) and land before tap 9 needs them
         dma_taps(0, 9);
         if (a.shift && wave == 0) {                                  // 64 floats -> the (still unused) statistics area
             __builtin_amdgcn_global_load_lds((gptr_t*)(a.shift + lane), (lptr_t*)(smem + S_OFF), 4, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        dma_taps(9, 27);
+        wsrc9 = wlane + 9 * CIN;
     }
     WR_TL(1)
     float sh[4] = {0.f, 0.f, 0.f, 0.f};                              // a lane's four channels 4 lc + j: read from LDS after the first boundary
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
     const int lane_a1 = arow + ((lg ^ (2 * (((lc >> 2) + 1) & 1))) << 4);    // kh odd
     const int bb0 = lds0 + lc * ROWB + ((lg ^ (2 * ((lc >> 2) & 1))) << 4);
     const int bb1 = bb0 + 13 * BN * ROWB;                                     // taps 13..26: ds offsets are 16-bit
+    const int wlds9 = __builtin_amdgcn_readfirstlane(lds0 + 9 * BN * ROWB + wave * 1024);      // this wave's LDS piece of tap 9
     const unsigned pitch_b = (unsigned)a.W * BN * 2;                 // one h step of the output, in bytes
     const unsigned pitch4 = __builtin_amdgcn_readfirstlane(4 * pitch_b);
     // accumulator register r of lane (lc, lg) in MFMA tile (i, j) is voxel (h, w) = (4 (i >> 1) + lg, 4 (i & 1) + r)
@@ -224,6 +226,8 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
 #define WR_MARCH [abn] "v"(abn), [sb0] "s"(sb[0]), [sb1] "s"(sb[1]), [sb2] "s"(sb[2]), [sb3] "s"(sb[3]), [ldsp0] "v"(ldsp[0]),   \
                  [ldsp1] "v"(ldsp[1])
 #define WR_EPI [pbase] "s"(pbase), [pitch4] "s"(pitch4), [voff0] "v"(voff0)
+#define WR_W9 [wlo] "v"((unsigned)(reinterpret_cast<unsigned long long>(wsrc9))), [whi] "v"((unsigned)(reinterpret_cast<unsigned long long>(wsrc9) >> 32)), \
+              [wlds] "s"(wlds9)
     // a ragged tile (volume edge) leaves the accumulator file through sixteen "=v" operands per MFMA-tile row and is
     // stored by ordinary code with per-voxel predicates, right after its K loop (exposed; edge tiles only)
 #define WR_X16(v) "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]), "=v"(v[8]), \
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
                                        __builtin_amdgcn_readfirstlane(so[2]), __builtin_amdgcn_readfirstlane(so[3])};
                     if (cur == 0) {
                         if (pending) asm volatile(WRES_K_X_EPI_MARCH : : WR_AB, WR_PF, WR_MARCH, WR_EPI : "memory", WRES_CLOBBERS);
-                        else if (tile == lo) asm volatile(WRES_K_X_MARCH_FIRST : : WR_AB, WR_PF, WR_MARCH : "memory", WRES_CLOBBERS);
+                        else if (tile == lo) asm volatile(WRES_K_X_MARCH_FIRST : : WR_AB, WR_PF, WR_MARCH, WR_W9 : "memory", WRES_CLOBBERS);
                         else asm volatile(WRES_K_X_MARCH : : WR_AB, WR_PF, WR_MARCH : "memory", WRES_CLOBBERS);
                     } else {
                         if (pending) asm volatile(WRES_K_Y_EPI_MARCH : : WR_AB, WR_PF, WR_MARCH, WR_EPI : "memory", WRES_CLOBBERS);
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
                     const bool epi = pending;
                     if (cur == 0) {
                         if (pending) asm volatile(WRES_K_X_EPI_COL : : WR_AB, WR_PF, WR_EPI : "memory", WRES_CLOBBERS);
-                        else if (tile == lo) asm volatile(WRES_K_X_COL_FIRST : : WR_AB, WR_PF : "memory", WRES_CLOBBERS);
+                        else if (tile == lo) asm volatile(WRES_K_X_COL_FIRST : : WR_AB, WR_PF, WR_W9 : "memory", WRES_CLOBBERS);
                         else asm volatile(WRES_K_X_COL : : WR_AB, WR_PF : "memory", WRES_CLOBBERS);
                     } else {
                         if (pending) asm volatile(WRES_K_Y_EPI_COL : : WR_AB, WR_PF, WR_EPI : "memory", WRES_CLOBBERS);
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(256) void conv3d_wres_kernel(Conv3dArgs a) {
 #undef WR_PF
 #undef WR_MARCH
 #undef WR_EPI
+#undef WR_W9
 #undef WR_X16
 }
 

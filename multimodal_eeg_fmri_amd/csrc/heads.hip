@@ -1068,7 +1068,7 @@ __global__ void stft_power_kernel(const float* __restrict__ x, bf16* __restrict_
 
 // ---------------------------------------------------------------------------
 // normalize_modality (run_training_lite.py:48-51, applied to every sample's power features at :162):
-// x[b] <- (x[b] - mean(x[b])) / (std_unbiased(x[b]) + eps) over ALL elements of sample b, fp32 in ->
+// x[b] <- (x[b] - mean(x[b])) / (std(x[b]) + eps), population std (the reference z-scores numpy arrays: ddof = 0), over ALL elements of sample b, fp32 in ->
 // bf16 channels-last out (the Power encoder's first-conv operand).  x [B][rows][ch_total]; only channels
 // < ch_valid count (the padding channels stay zero).  One workgroup per sample, two sweeps; fixed-order
 // sums (bit-reproducible); the mean is subtracted before squaring (two-pass variance).
@@ -1099,8 +1099,147 @@ __global__ __launch_bounds__(1024) void sample_zscore_kernel(const float* __rest
         const float d = ((int)(i % ch_total) < ch_valid) ? xs[i] - mean : 0.f;
         q += d * d;
     }
-    const float inv = 1.f / (sqrtf(block_sum(q) / fmaxf(cnt - 1.f, 1.f)) + eps);
+    const float inv = 1.f / (sqrtf(block_sum(q) / cnt) + eps);       // population std: the reference z-scores numpy arrays (ddof = 0)
     for (size_t i = tid; i < n; i += 1024) os[i] = (bf16)(((int)(i % ch_total) < ch_valid) ? (xs[i] - mean) * inv : 0.f);
+}
+
+// backward of sample_zscore_kernel: y = (x - mean) / d, d = std + eps (population std over the cnt valid elements):
+//   dx_i = (g_i - mean(g)) / d - y_i * mean(g * y) / std        (padding channels: 0)
+// g = bf16 gradient w.r.t. the z-scored (bf16) tensor, same layout; dx fp32.  Fixed-order block sums.
+__global__ __launch_bounds__(1024) void sample_zscore_bwd_kernel(const float* __restrict__ x, const bf16* __restrict__ g,
+                                                                 float* __restrict__ dx, int rows, int ch_valid, int ch_total,
+                                                                 float eps) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t n = (size_t)rows * ch_total;
+    const float* xs = x + (size_t)b * n;
+    const bf16* gs = g + (size_t)b * n;
+    float* os = dx + (size_t)b * n;
+    const float cnt = (float)rows * (float)ch_valid;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        return t;
+    };
+    auto valid = [&](size_t i) { return (int)(i % ch_total) < ch_valid; };
+    float s = 0.f;
+    for (size_t i = tid; i < n; i += 1024) s += valid(i) ? xs[i] : 0.f;
+    const float mean = block_sum(s) / cnt;
+    float q = 0.f;
+    for (size_t i = tid; i < n; i += 1024) {
+        const float d = valid(i) ? xs[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float sd = sqrtf(block_sum(q) / cnt);
+    const float inv = 1.f / (sd + eps);
+    float sg = 0.f, sgy = 0.f;
+    for (size_t i = tid; i < n; i += 1024)
+        if (valid(i)) {
+            const float gi = (float)gs[i];
+            sg += gi;
+            sgy += gi * (xs[i] - mean) * inv;
+        }
+    const float mg = block_sum(sg) / cnt;
+    const float mgy = block_sum(sgy) / cnt;
+    const float c2 = mgy / fmaxf(sd, 1e-30f);
+    for (size_t i = tid; i < n; i += 1024)
+        os[i] = valid(i) ? ((float)gs[i] - mg) * inv - (xs[i] - mean) * inv * c2 : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// backward of stft_power_kernel: dx[b, c, t] += sum over the (frame, n) that read sample t (directly or through the
+// reflect padding) of win[n] * dv[frame][n],   dv[n] = 2 sum_f gP[f] (re_f cos(2 pi f n / N) - im_f sin(2 pi f n / N)).
+// One workgroup per (b, c): frames in blocks of 8 - windowed frames and their DFT recomputed in LDS, the gradient of
+// the windowed frame formed by the inverse sum, then every thread GATHERS the contributions to the samples it owns
+// in a fixed order (frame ascending; direct, left-reflected, right-reflected position): no atomics, bit-reproducible.
+// gP fp32 [B][frames][ch_total] (channels ch_off + c * F + f); dx fp32 [B][C][T] is ADDED to (one launch per scale).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stft_power_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gP,
+                                                             float* __restrict__ dx, int C, int T, int nfft, int hop,
+                                                             int frames, int ch_off, int ch_total) {
+    extern __shared__ float sm[];
+    const int F = nfft / 2 + 1;
+    float* tw_c = sm;                  // [nfft]
+    float* tw_s = tw_c + nfft;         // [nfft]
+    float* win = tw_s + nfft;          // [nfft]
+    float* fr = win + nfft;            // [8][nfft] windowed frames, then their gradient
+    float* cr = fr + 8 * nfft;         // [8][F]  2 gP re
+    float* ci = cr + 8 * F;            // [8][F]  2 gP im
+    float* acc = ci + 8 * F;           // [T]
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    for (int n = tid; n < nfft; n += 256) {
+        float s, co;
+        __sincosf(6.283185307179586f * (float)n / (float)nfft, &s, &co);
+        tw_c[n] = co; tw_s[n] = s;
+        win[n] = 0.5f - 0.5f * __cosf(6.283185307179586f * (float)n / (float)nfft);
+    }
+    for (int t = tid; t < T; t += 256) acc[t] = 0.f;
+    const float* xr = x + ((size_t)b * C + c) * T;
+    __syncthreads();
+    for (int f0 = 0; f0 < frames; f0 += 8) {
+        for (int i = tid; i < 8 * nfft; i += 256) {
+            const int fi = i / nfft, n = i % nfft, frame = f0 + fi;
+            float v = 0.f;
+            if (frame < frames) {
+                int t = frame * hop + n - nfft / 2;
+                if (t < 0) t = -t;
+                if (t >= T) t = 2 * (T - 1) - t;
+                v = xr[t] * win[n];
+            }
+            fr[i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * F; i += 256) {
+            const int fi = i / F, f = i % F, frame = f0 + fi;
+            float re = 0.f, im = 0.f;
+            if (frame < frames) {
+                const float* fv = fr + fi * nfft;
+                for (int n = 0; n < nfft; ++n) {
+                    const int k = (f * n) & (nfft - 1);
+                    re += fv[n] * tw_c[k];
+                    im -= fv[n] * tw_s[k];
+                }
+                const float g2 = 2.f * gP[((size_t)b * frames + frame) * ch_total + ch_off + (size_t)c * F + f];
+                re *= g2; im *= g2;
+            }
+            cr[i] = re; ci[i] = im;
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * nfft; i += 256) {             // gradient of the windowed frame, times the window
+            const int fi = i / nfft, n = i % nfft;
+            float dv = 0.f;
+            const float *pr = cr + fi * F, *pi = ci + fi * F;
+            for (int f = 0; f < F; ++f) {
+                const int k = (f * n) & (nfft - 1);
+                dv += pr[f] * tw_c[k] - pi[f] * tw_s[k];
+            }
+            fr[i] = dv * win[n];
+        }
+        __syncthreads();
+        for (int t0 = tid; t0 < T; t0 += 256) {
+            float a = acc[t0];
+            for (int fi = 0; fi < 8; ++fi) {
+                const int frame = f0 + fi;
+                if (frame >= frames) break;
+                const int base = nfft / 2 - frame * hop;
+                int n = t0 + base;                                              // read directly
+                if (n >= 0 && n < nfft) a += fr[fi * nfft + n];
+                n = -t0 + base;                                                 // read as the left reflection of t = -t0
+                if (t0 > 0 && n >= 0 && n < nfft) a += fr[fi * nfft + n];
+                n = 2 * (T - 1) - t0 + base;                                    // right reflection
+                if (t0 < T - 1 && n >= 0 && n < nfft) a += fr[fi * nfft + n];
+            }
+            acc[t0] = a;
+        }
+        __syncthreads();
+    }
+    float* dr = dx + ((size_t)b * C + c) * T;
+    for (int t = tid; t < T; t += 256) dr[t] += acc[t];
 }
 
 __global__ void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
@@ -1466,6 +1605,28 @@ int mm_sample_zscore_bf16(const float* x, void* out_bf16, int B, int rows, int c
     MM_REQUIRE(x && out_bf16 && B > 0 && rows > 0 && ch_valid > 0 && ch_valid <= ch_total, "sample_zscore: null/invalid");
     hipLaunchKernelGGL(sample_zscore_kernel, dim3(B), dim3(1024), 0, st, x, (bf16*)out_bf16, rows, ch_valid, ch_total, eps);
     return mm_check_launch("sample_zscore");
+}
+
+int mm_stft_power_bwd(const float* x, const float* g_power, float* dx, int B, int C, int T, int nfft, int hop, int ch_off,
+                      int ch_total, hipStream_t st) {
+    MM_REQUIRE(x && g_power && dx && B > 0 && C > 0 && T > 0, "stft_power_bwd: null/invalid");
+    MM_REQUIRE(nfft >= 8 && nfft <= 1024 && (nfft & (nfft - 1)) == 0 && hop > 0 && T > nfft / 2, "stft_power_bwd: nfft=%d hop=%d", nfft, hop);
+    const int frames = T / hop + 1;
+    const int F = nfft / 2 + 1;
+    MM_REQUIRE(ch_off >= 0 && ch_off + C * F <= ch_total, "stft_power_bwd: channel window");
+    const size_t lds = (size_t)(3 * nfft + 8 * nfft + 16 * F + T) * sizeof(float);
+    if (lds > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "stft_power_bwd: T=%d nfft=%d needs %zu bytes of LDS", T, nfft, lds);
+    auto kern = stft_power_bwd_kernel;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(C, B), dim3(256), lds, st, x, g_power, dx, C, T, nfft, hop, frames, ch_off, ch_total);
+    return mm_check_launch("stft_power_bwd");
+}
+
+int mm_sample_zscore_bwd(const float* x, const void* g_bf16, float* dx, int B, int rows, int ch_valid, int ch_total, float eps,
+                         hipStream_t st) {
+    MM_REQUIRE(x && g_bf16 && dx && B > 0 && rows > 0 && ch_valid > 0 && ch_valid <= ch_total, "sample_zscore_bwd: null/invalid");
+    hipLaunchKernelGGL(sample_zscore_bwd_kernel, dim3(B), dim3(1024), 0, st, x, (const bf16*)g_bf16, dx, rows, ch_valid, ch_total, eps);
+    return mm_check_launch("sample_zscore_bwd");
 }
 
 int mm_attn_1xk(const float* p0, const float* p1, const float* p2, const float* p3, int K, const float* dctx,

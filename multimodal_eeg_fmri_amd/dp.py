@@ -19,6 +19,11 @@ import torch
 import torch.distributed as dist
 
 
+# the collectives below can be recorded into a hipGraph (RCCL: yes).  tools/gloo_staging.py (one-GPU rehearsals: gloo
+# carrying device tensors through host memory) sets this to False, and the trainer then keeps its three-segment form.
+CAPTURABLE = True
+
+
 def world_size(group) -> int:
     return dist.get_world_size(group) if group is not None else 1
 

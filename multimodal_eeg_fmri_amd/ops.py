@@ -1092,7 +1092,7 @@ def _power_merged(m, device):
     return torch.cat(ws, dim=0).contiguous(), torch.cat(o4, dim=1).contiguous()
 
 
-def stft_front_end(x: torch.Tensor, n_ffts, hop: int, normalize: bool = False) -> torch.Tensor:
+def stft_front_end(x: torch.Tensor, n_ffts, hop: int, normalize: bool = False, keep_spec: bool = False):
     """(B, C, T) fp32 -> channels-last bf16 (B, frames, Cp) multi-scale STFT power,
     channel order [scale][c][f] as torch.cat([stft_power(x, n) ...], dim=1).
     ``normalize``: z-score every sample's spectra (the reference's normalize_modality on its power
@@ -1115,20 +1115,21 @@ def stft_front_end(x: torch.Tensor, n_ffts, hop: int, normalize: bool = False) -
         off += wdt
     if normalize:
         _hip.call("mm_sample_zscore_bf16", spec, out, B, frames, total, cp, 1e-8)
-    return out
+    return (out, spec) if keep_spec else out
 
 
 def stft_power_encoder_forward(m, x):
-    """MultiScaleSTFTPowerEncoder: STFT power front-end -> EnhancedPowerEncoder.
-    The front-end has no parameters; gradients stop at the spectra (no d/d raw-EEG)."""
+    """MultiScaleSTFTPowerEncoder: STFT power front-end -> EnhancedPowerEncoder.  The front-end has no parameters; when
+    the raw EEG asks for a gradient it is differentiated too (autograd.StftFrontEndFn)."""
     _need_gpu(x)
     enc = m.encoder
-    if enc.training or _wants_grad(enc, x.detach()):
-        if x.requires_grad:
-            raise NotImplementedError("MultiScaleSTFTPowerEncoder: no gradient w.r.t. the raw EEG input is built")
-        from .autograd import PowerEncoderFn
-        with torch.no_grad():
-            spec = stft_front_end(x, m.n_ffts, m.hop, m.normalize)
+    if enc.training or _wants_grad(enc, x):
+        from .autograd import PowerEncoderFn, StftFrontEndFn
+        if x.requires_grad and torch.is_grad_enabled():           # d / d raw EEG: the front-end joins the tape
+            spec = StftFrontEndFn.apply(x, m.n_ffts, m.hop, m.normalize)
+        else:
+            with torch.no_grad():
+                spec = stft_front_end(x, m.n_ffts, m.hop, m.normalize)
         return PowerEncoderFn.run(enc, spec, packed=True)
     with torch.no_grad():
         return _power_forward_ntc(enc, stft_front_end(x, m.n_ffts, m.hop, m.normalize))

@@ -51,13 +51,13 @@ def attn_keep_scale(seed: int, bh: int, L: int, p: float) -> torch.Tensor:
 
 
 def erp_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int], p: float, p_attn: float,
-                                 p_pe: float, nhead: int = 4):
+                                 p_pe: float, nhead: int = 4, pre: str = ""):
     """``seeds``: the dropout seeds in the order the product path draws them (ops._next_seed):
     conv1, conv2, conv3, positional, then per block (attention probs, dropout1, FFN activation,
     dropout2), then the output head."""
     F = RF.F                                             # honours oracle.bf16_emulation.bf16_operands()
     it = iter(seeds)
-    c = "conv_layers."
+    c = pre + "conv_layers."
 
     def drop_bct(h, prob):                               # (B, C, T) tensor, mask indexed as (B, T, C)
         B, C, T = h.shape
@@ -70,11 +70,11 @@ def erp_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int
     h = drop_bct(TF.max_pool1d(h, 2), p)
     h = RF.gelu(RF._bn(sd, c + "10.", F.conv1d(h, sd[c + "9.weight"], sd[c + "9.bias"], padding=1), True))
     h = drop_bct(h, p)
-    t = RF.positional_encoding(sd, "pos_encoder.", h.transpose(1, 2))
+    t = RF.positional_encoding(sd, pre + "pos_encoder.", h.transpose(1, 2))
     B, L, D = t.shape
     t = t * keep_scale(next(it), B * L * D, p_pe).view(B, L, D)
-    for i in range(RF._num_layers(sd, "")):
-        q = f"transformer_layers.{i}."
+    for i in range(RF._num_layers(sd, pre)):
+        q = pre + f"transformer_layers.{i}."
         sa, s1, s2, s3 = next(it), next(it), next(it), next(it)
         hn = RF._ln(sd, q + "norm1.", t)
         W, b = sd[q + "self_attn.in_proj_weight"], sd[q + "self_attn.in_proj_bias"]
@@ -91,5 +91,49 @@ def erp_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int
         f = f * keep_scale(s2, f.numel(), p).view(f.shape)
         f = F.linear(f, sd[q + "linear2.weight"], sd[q + "linear2.bias"])
         t = t + f * keep_scale(s3, B * L * D, p).view(B, L, D)
-    out = RF.gelu(F.linear(t.mean(dim=1), sd["output_proj.2.weight"], sd["output_proj.2.bias"]))
+    out = RF.gelu(F.linear(t.mean(dim=1), sd[pre + "output_proj.2.weight"], sd[pre + "output_proj.2.bias"]))
     return out * keep_scale(next(it), out.numel(), p).view(out.shape)
+
+
+def volume_encoder_train_with_masks(sd: Dict[str, torch.Tensor], x, seeds: List[int], p: float, pre: str = ""):
+    """TRAIN-mode fMRIVolumeEncoder3D (the a-X1 extension: Conv3d-BN-GELU-MaxPool-Dropout x2, Conv3d-BN-GELU-Dropout,
+    global average, Linear-GELU-Dropout) with an explicit keep-mask at its four nn.Dropout sites.  ``seeds``: layer 1,
+    layer 2, layer 3, output head - the order ops._vol_forward_impl draws them.  Mask index = flat index of the dropped
+    tensor in the kernels' channels-last layout (B, D, H, W, C) - for the pooled layers the POOLED tensor."""
+    F = RF.F
+    it = iter(seeds)
+    c = pre + "conv_layers."
+
+    def drop_cl(h):
+        B, C, D, H, W = h.shape
+        m = keep_scale(next(it), h.numel(), p).view(B, D, H, W, C).permute(0, 4, 1, 2, 3)
+        return h * m
+
+    h = RF.gelu(RF._bn(sd, c + "1.", F.conv3d(x, sd[c + "0.weight"], sd[c + "0.bias"], padding=1), True))
+    h = drop_cl(TF.max_pool3d(h, 2))
+    h = RF.gelu(RF._bn(sd, c + "6.", F.conv3d(h, sd[c + "5.weight"], sd[c + "5.bias"], padding=1), True))
+    h = drop_cl(TF.max_pool3d(h, 2))
+    h = RF.gelu(RF._bn(sd, c + "11.", F.conv3d(h, sd[c + "10.weight"], sd[c + "10.bias"], padding=1), True))
+    h = drop_cl(h)
+    out = RF.gelu(F.linear(h.mean(dim=(2, 3, 4)), sd[pre + "output_proj.2.weight"], sd[pre + "output_proj.2.bias"]))
+    return out * keep_scale(next(it), out.numel(), p).view(out.shape)
+
+
+def contrastive_head_with_masks(sd: Dict[str, torch.Tensor], eeg_feat, fmri_feat, seeds: List[int], p: float, pre: str = ""):
+    """both projection heads in TRAIN mode (bridge_utils.py:34-45: Linear -> LayerNorm -> GELU -> Dropout) followed by
+    F.normalize; ``seeds`` = (EEG head, fMRI head), mask index b * N + n."""
+    def head(q, x, seed):
+        a = RF.gelu(RF._ln(sd, q + "1.", RF._lin(sd, q + "0.", x)))
+        return RF.l2_normalize(a * keep_scale(seed, a.numel(), p).view(a.shape))
+    return head(pre + "eeg_proj.", eeg_feat, seeds[0]), head(pre + "fmri_proj.", fmri_feat, seeds[1])
+
+
+def bridge_step_with_masks(sd: Dict[str, torch.Tensor], eeg, fmri, seeds: List[int], p: float):
+    """the whole contrastive training step's forward (what bench.py times, at dropout p) with every keep-mask explicit:
+    names prefixed e. / f. / h. as in tests/test_trainer_gpu.py::_oracle_step; 13 + 4 + 2 seeds in draw order."""
+    assert len(seeds) == 19, len(seeds)
+    fe = erp_encoder_train_with_masks(sd, eeg, seeds[:13], p, p, p, pre="e.")
+    ff = volume_encoder_train_with_masks(sd, fmri, seeds[13:17], p, pre="f.")
+    ze, zf = contrastive_head_with_masks(sd, fe, ff, seeds[17:19], p, pre="h.bridge.")
+    loss = RF.clip_loss(ze, zf, ze, zf, sd["h.logit_scale"].exp())[0]
+    return loss, ze, zf

@@ -402,11 +402,12 @@ def clip_loss(ze, zf_all, ze_all, zf, logit_scale, row0: int = 0):
 
 
 def normalize_modality(feat, eps: float = 1e-8):
-    """run_training_lite.py:48-51: z-score over ALL elements of one sample's feature array
-    (torch .std() = unbiased), here batched: feat (B, ...)."""
+    """run_training_lite.py:48-51: z-score over ALL elements of one sample's feature array, here batched: feat (B, ...).
+    The reference applies it to NUMPY arrays (:108, 162, 216: ``mat[key].astype(np.float32)``), whose ``.std()`` is the
+    population standard deviation (ddof = 0) - not torch's unbiased default."""
     flat = feat.flatten(1)
     mean = flat.mean(dim=1).view(-1, *([1] * (feat.dim() - 1)))
-    std = flat.std(dim=1).view(-1, *([1] * (feat.dim() - 1))) + eps
+    std = flat.std(dim=1, unbiased=False).view(-1, *([1] * (feat.dim() - 1))) + eps
     return (feat - mean) / std
 
 

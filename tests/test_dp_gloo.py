@@ -90,3 +90,22 @@ def test_dp_contrastive_step_equals_global_batch():
     loss.backward()
     assert abs(got_loss.item() - loss.item()) < 1e-6
     torch.testing.assert_close(got_grad, w.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_trainer_bucket_puts_the_fmri_slice_last():
+    """bridge_trainer: the gradient bucket goes out in two parts - [fmri_lo, n) as soon as the fMRI branch's backward is
+    done, [0, fmri_lo) after the EEG chain.  The fMRI encoder's parameters must be exactly the bucket's tail, and the two
+    ranges must tile the bucket (host logic; no kernels run)."""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer
+    tr = BridgeTrainer(eeg_channels=8, device="cpu", mode="manual")
+    b = tr.bucket
+    n_f = sum(p.numel() for p in tr.fmri_encoder.parameters())
+    assert tr.fmri_lo == b.n - n_f and 0 < tr.fmri_lo < b.n
+    base = b.g.data_ptr()
+    for p in tr.fmri_encoder.parameters():
+        off = (p._mm_grad.data_ptr() - base) // 4
+        assert tr.fmri_lo <= off and off + p.numel() <= b.n
+    for p in list(tr.eeg_encoder.parameters()) + [tr.head.logit_scale]:
+        off = (p._mm_grad.data_ptr() - base) // 4
+        assert off + p.numel() <= tr.fmri_lo
+    assert b.g[:tr.fmri_lo].numel() + b.g[tr.fmri_lo:].numel() == b.n

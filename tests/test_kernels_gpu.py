@@ -913,3 +913,43 @@ def test_stage_inputs_equals_pack_plus_copies(B, C, T):
     assert torch.equal(xb2.view(torch.int16), want.view(torch.int16))
     with pytest.raises(hip.HipLibraryError):
         hip.call("mm_stage_inputs", eeg, xb2, None, B, C, T, cp, f2, fmri, fmri.numel() - 2)
+
+
+@pytest.mark.parametrize("B,C,T,nfft,hop", [(2, 3, 256, 64, 32), (1, 2, 1024, 128, 32), (2, 2, 200, 32, 16)])
+def test_stft_power_backward_vs_torch_autograd(B, C, T, nfft, hop):
+    """mm_stft_power_bwd (gather form, no atomics: every sample sums the frames - and the reflect-padding images - that read
+    it, in a fixed order) against autograd through torch.stft(center=True, reflect, periodic Hann) ** 2, and
+    mm_sample_zscore_bwd against autograd through the population-std z-score; fp32: 1e-3 of the tensor's scale; two runs
+    bit-identical."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(T + nfft)
+    x = torch.randn(B, C, T, generator=g)
+    F_ = nfft // 2 + 1
+    frames = T // hop + 1
+    cp = (C * F_ + 15) // 16 * 16 + 16                       # a channel window inside a wider (padded) tensor
+    off = 5
+    gP = torch.randn(B, frames, cp, generator=g)
+    xr = x.clone().requires_grad_(True)
+    z = torch.stft(xr.reshape(B * C, T), nfft, hop_length=hop, window=torch.hann_window(nfft, periodic=True), center=True,
+                   pad_mode="reflect", return_complex=True)
+    pw = (z.real ** 2 + z.imag ** 2).reshape(B, C * F_, frames).transpose(1, 2)          # (B, frames, C * F)
+    (pw * gP[:, :, off:off + C * F_]).sum().backward()
+    dx = torch.zeros(B, C, T, device="cuda")
+    hip.call("mm_stft_power_bwd", x.cuda(), gP.cuda(), dx, B, C, T, nfft, hop, off, cp)
+    scale = xr.grad.abs().max().item()
+    assert (dx.cpu() - xr.grad).abs().max().item() <= 1e-3 * scale
+    dx2 = torch.zeros_like(dx)
+    hip.call("mm_stft_power_bwd", x.cuda(), gP.cuda(), dx2, B, C, T, nfft, hop, off, cp)
+    assert torch.equal(dx, dx2)
+    # z-score backward: rows x ch_valid valid elements inside ch_total
+    rows, chv, cht = 9, 20, 32
+    s = torch.randn(B, rows, cht, generator=g) * 3 + 1
+    gz = _bf(torch.randn(B, rows, cht, generator=g))
+    sr = s.clone().requires_grad_(True)
+    v = sr[:, :, :chv]
+    flat = v.reshape(B, -1)
+    y = (v - flat.mean(1).view(B, 1, 1)) / (flat.std(1, unbiased=False).view(B, 1, 1) + 1e-8)
+    (y * gz[:, :, :chv]).sum().backward()
+    ds = torch.full((B, rows, cht), float("nan"), device="cuda")
+    hip.call("mm_sample_zscore_bwd", s.cuda(), gz.cuda().to(torch.bfloat16), ds, B, rows, chv, cht, 1e-8)
+    torch.testing.assert_close(ds.cpu(), sr.grad, rtol=1e-3, atol=1e-4)

@@ -105,6 +105,112 @@ def test_c2_shaped_train_step_vs_oracle():
     assert worst32f[1] <= 2e-1, ("voxel encoder vs fp32 oracle", worst32f)
 
 
+def test_projection_heads_with_dropout_match_masked_oracle():
+    """both projection heads' nn.Dropout (bridge_utils.py:34-45) at p = 0.3 in ONE launch each way
+    (mm_proj_heads_fwd / _bwd): embeddings, loss and every gradient against the CPU oracle evaluated with the same
+    counter-hash masks; fp32 kernels -> 1e-4 / 2e-3."""
+    from multimodal_eeg_fmri_amd import ops
+    from oracle.dropout_replica import contrastive_head_with_masks
+    p = 0.3
+    m = build(B.EEGfMRIContrastiveBridge, 43, dropout=p).train()
+    eeg, fmri = seeded_randn(143, 16, 128), seeded_randn(144, 16, 64)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    seeds = []
+    real = ops._next_seed
+
+    def logged():
+        v = real()
+        seeds.append(v)
+        return v
+    ops.set_seed_epoch(None)
+    ops.set_dropout_seed(99)
+    ops._next_seed = logged
+    try:
+        mg = m.cuda()
+        eg, fg = eeg.cuda().requires_grad_(True), fmri.cuda().requires_grad_(True)
+        l2, _, _ = mg(eg, fg)
+        l2.backward()
+    finally:
+        ops._next_seed = real
+    assert len(seeds) == 2, seeds
+    eo, fo = eeg.clone().requires_grad_(True), fmri.clone().requires_grad_(True)
+    ze, zf = contrastive_head_with_masks(sd, eo, fo, seeds, p, "bridge.")
+    loss = RF.clip_loss(ze, zf, ze, zf, sd["logit_scale"].exp())[0]
+    loss.backward()
+    assert 0.2 < (ze == 0).float().mean().item() < 0.4
+    assert abs(l2.item() - loss.item()) < 1e-4
+    torch.testing.assert_close(eg.grad.cpu(), eo.grad, rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(fg.grad.cpu(), fo.grad, rtol=2e-3, atol=1e-5)
+    for n, q in mg.named_parameters():
+        if q.grad is not None:
+            torch.testing.assert_close(q.grad.cpu(), sd[n].grad, rtol=2e-3, atol=1e-5, msg=n)
+
+
+def test_c2_shaped_train_step_with_dropout_vs_masked_oracle():
+    """the configuration bench.py times - BASELINE config #2 shapes, dropout 0.3 at all 19 sites (B = 4 so that the CPU
+    oracle finishes in seconds) - run as the eager tape, against the CPU oracle evaluated with the SAME keep-masks
+    (oracle/dropout_replica.py: bridge_step_with_masks): loss 2e-3, both embeddings cos >= 1 - 1e-4, every parameter
+    gradient of the flat bucket <= 7e-2 rel-L2 vs the oracle with bf16-rounded GEMM operands."""
+    import torch.nn.functional as F
+    from multimodal_eeg_fmri_amd import ops
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    from oracle.bf16_emulation import bf16_operands
+    from oracle.dropout_replica import bridge_step_with_masks
+    p = 0.3
+    torch.manual_seed(0)
+    tr = BridgeTrainer(eeg_channels=64, dropout=p, mode="manual").train()
+    eeg, fmri = synthetic_pairs(4, 64, 1024, (32, 32, 32), seed=4322)
+    sd = {}
+    for pre, m in (("e.", tr.eeg_encoder), ("f.", tr.fmri_encoder), ("h.", tr.head)):
+        for k, v in m.state_dict().items():
+            sd[pre + k] = v.detach().cpu().clone().requires_grad_(v.is_floating_point())
+    seeds = []
+    real = ops._next_seed
+
+    def logged():
+        v = real()
+        seeds.append(v)
+        return v
+    ops.set_seed_epoch(None)
+    ops.set_dropout_seed(31337)
+    ops._next_seed = logged
+    try:
+        with torch.no_grad():
+            z, saved = tr._seg_forward(eeg, fmri)
+            dz = torch.empty_like(z)
+            tr._seg_loss(z, tr._scal, dz)
+            tr._seg_backward(saved, dz, tr._scal)
+            ops.arena.end()
+    finally:
+        ops._next_seed = real
+    torch.cuda.synchronize()
+    assert len(seeds) == 19, seeds
+    with bf16_operands():
+        loss, ze16, zf16 = bridge_step_with_masks(sd, eeg.cpu(), fmri.cpu(), seeds, p)
+        loss.backward()
+    N = tr.head.bridge.bridge_dim
+    ze, zf = z[:, :N].cpu(), z[:, N:].cpu()
+    assert torch.equal(ze == 0, ze16 == 0) and torch.equal(zf == 0, zf16 == 0)          # the heads' masks are the replica's
+    cos_e = F.cosine_similarity(ze.double(), ze16.detach().double(), dim=1).min().item()
+    cos_f = F.cosine_similarity(zf.double(), zf16.detach().double(), dim=1).min().item()
+    assert cos_e >= 1 - 1e-4 and cos_f >= 1 - 1e-4, (cos_e, cos_f)
+    assert abs(tr._scal[0].item() - loss.item()) <= 2e-3 * max(1.0, abs(loss.item())), (tr._scal[0].item(), loss.item())
+    named = {}
+    for pre, m in (("e.", tr.eeg_encoder), ("f.", tr.fmri_encoder), ("h.", tr.head)):
+        named.update({pre + k: v for k, v in m.named_parameters()})
+    worst, checked = ("", 0.0), 0
+    for n, q in named.items():
+        sink = getattr(q, "_mm_grad", None)
+        want = sd[n].grad if n in sd else None
+        if sink is None or want is None or want.norm() < 1e-5:
+            continue
+        got = sink.detach().cpu().view(want.shape).double()
+        worst = max(worst, (n, ((got - want.double()).norm() / want.double().norm()).item()), key=lambda t: t[1])
+        checked += 1
+    assert checked >= 50, checked
+    assert worst[1] <= 7e-2, ("vs the masked bf16-operand oracle", worst)
+
+
 def test_step_results_are_owned_by_the_trainer():
     """the returned loss / top-1 tensors must not alias scratch another trainer rewrites"""
     from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs

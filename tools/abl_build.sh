@@ -16,7 +16,7 @@ for n in "$@"; do
       -c "$here/conv3d_wres.hip" -o "$here/build/conv3d_wres_abl$tag.o" 2>/dev/null
   objs=()
   for o in "$here"/build/*.o; do
-    case "$o" in *conv3d_wres.o|*conv3d_wres_abl*|*_sabl*) ;; *) objs+=("$o");; esac
+    case "$o" in *conv3d_wres.o|*conv3d_wres_abl*|*_sabl*|*/alt_*) ;; *) objs+=("$o");; esac
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$here/build/abl_$tag.so" "${objs[@]}" "$here/build/conv3d_wres_abl$tag.o"
   echo "built abl_$tag.so"

@@ -75,21 +75,27 @@ def run_rccl_world1():
         from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
         eeg, fmri = synthetic_pairs(8, 16, 256, (16, 16, 16), seed=1234)
         res = {}
-        for tag, group, force in (("one graph", None, False), ("segments + RCCL", dist.group.WORLD, True)):
+        for tag, group, force, cap in (("one graph", None, False, "1"), ("captured RCCL", dist.group.WORLD, True, "1"),
+                                       ("segments + RCCL", dist.group.WORLD, True, "0")):
+            os.environ["MM_DP_CAPTURE"] = cap
             torch.manual_seed(0)
             tr = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-3, group=group).train()
             tr.force_segments = force
             ls = [tr.train_step(eeg, fmri)["loss"].item() for _ in range(6)]
             torch.cuda.synchronize()
-            res[tag] = (ls, tr.bucket.p.detach().cpu().clone(), len(tr._cap["graphs"]))
+            res[tag] = (ls, tr.bucket.p.detach().cpu().clone(), len(tr._cap["graphs"]), tr.capture_mode)
             if force:                                   # what bench.py does after its timed region at N > 1
                 tr.mode = "manual"
                 tr.train_step(eeg, fmri)
                 ev = tr.evaluate(eeg, fmri)
                 assert ev["loss"].item() == ev["loss"].item()
-        a, b = res["one graph"], res["segments + RCCL"]
+        a, b, cg = res["one graph"], res["segments + RCCL"], res["captured RCCL"]
         rel = ((a[1] - b[1]).norm() / a[1].norm()).item()
-        return {"graphs": (a[2], b[2]), "losses": (a[0], b[0]), "param_rel": rel}
+        return {"graphs": (a[2], b[2]), "losses": (a[0], b[0]), "param_rel": rel,
+                # the N > 1 step with its collectives recorded into the graph (falls back to segments if RCCL refuses):
+                "captured": {"mode": cg[3], "graphs": cg[2], "losses": cg[0],
+                             "param_rel_vs_one_graph": ((a[1] - cg[1]).norm() / a[1].norm()).item(),
+                             "bit_identical_to_segments": bool(torch.equal(b[1], cg[1]))}}
     finally:
         dist.destroy_process_group()
 
@@ -106,7 +112,9 @@ def time_rccl_world1(steps=200):
         from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
         eeg, fmri = synthetic_pairs(32, 64, 1024, (32, 32, 32), seed=1234)
         out = {}
-        for tag, group, force in (("one graph", None, False), ("segments + RCCL", dist.group.WORLD, True)):
+        for tag, group, force, cap in (("one graph", None, False, "1"), ("one graph + captured RCCL collectives", dist.group.WORLD, True, "1"),
+                                       ("segments + RCCL", dist.group.WORLD, True, "0")):
+            os.environ["MM_DP_CAPTURE"] = cap
             torch.manual_seed(0)
             tr = BridgeTrainer(eeg_channels=64, dropout=0.3, group=group).train()
             tr.force_segments = force
@@ -119,7 +127,7 @@ def time_rccl_world1(steps=200):
             for _ in range(steps):
                 tr.train_step(e, f)
             torch.cuda.synchronize()
-            out[tag] = (time.perf_counter() - t0) / steps * 1e3
+            out[f"{tag} [{tr.capture_mode}]"] = (time.perf_counter() - t0) / steps * 1e3
         return out
     finally:
         dist.destroy_process_group()
@@ -133,6 +141,7 @@ if __name__ == "__main__":
         r = run_rccl_world1()
         print(r)
         assert r["graphs"] == (1, 3), r
+        assert r["captured"]["param_rel_vs_one_graph"] < 1e-2, r
         assert r["param_rel"] < 1e-2, r
         for i, (x, y) in enumerate(zip(*r["losses"])):      # (tolerances from before the step became bit-reproducible; kept loose: RCCL owns the reduction order)
             assert abs(x - y) <= (5e-3 if i < 3 else 3e-2) * abs(y), r

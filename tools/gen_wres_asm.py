@@ -112,7 +112,7 @@ class Stream:
     def emit(self, s):
         self.lines.append(s)
         op = s.split()[0]
-        if op.startswith("buffer_load") or op.startswith("global_store"):
+        if op.startswith("buffer_load") or op.startswith("global_store") or op.startswith("global_load_lds"):
             self.vm.append(s)
         elif op.startswith("ds_write"):
             self.ds.append("W")
@@ -229,6 +229,21 @@ def kloop(cur, prev=None, march=True, bias=True, first=False):
     ngroups = 0
     nplanes = 4 if march else 6
     e0, e1 = nplanes, 25                             # the previous tile's 16 store groups: taps e0 .. e1
+    if first:
+        # the first tile of a workgroup: taps 9-26 of the weights (18 LDS-DMA pieces of this wave: tap k -> its 1 KB of
+        # LDS at %[wlds] + 4096 (k - 9), source {%[whi], %[wlo]} + 64 (k - 9)) are issued HERE, in the MFMA gaps of taps 0-2,
+        # instead of before the first boundary: a wave that issues 27 pieces in a row sits ~2 000-3 000 cycles on the
+        # full queue (profiles/r03_wres_*) with the matrix pipe idle
+        # (m0 - the DMA's LDS base - is a register the compiler manages: saved in s93, restored after the last piece)
+        side += ["s_mov_b32 s93, m0"]
+        for k in range(9, TAPS):
+            # (an SALU write of m0 needs one wait state before the DMA that reads it)
+            # (no immediate offset on the DMA: it would be added to the LDS address as well; the per-piece source address is
+            # formed in v[244:245] - PF0 / PF1, free until the halo prefetch instructions that follow in the queue)
+            side += [f"s_add_i32 m0, %[wlds], {4096 * (k - 9)}",
+                     f"v_add_co_u32 v244, vcc, {64 * (k - 9)}, %[wlo]", "v_addc_co_u32 v245, vcc, 0, %[whi], vcc",
+                     "global_load_lds_dwordx4 v[244:245], off"]
+        side += ["s_mov_b32 m0, s93"]
     for t in range(TAPS):
         s = t & 1
         if not (ABL & 64) and t < nplanes:
@@ -250,11 +265,11 @@ def kloop(cur, prev=None, march=True, bias=True, first=False):
                 st.read(t + 1, nxt.pop(0))
                 budget -= 1 if (OPT & 2) else 2
             if first and t == 7 and g == 8:
-                # the first tile of a workgroup started with only taps 0-8 of the weights in LDS (WRES_BOUNDARY_FIRST): the
-                # other 18 DMA pieces of this wave are older than every load this statement has issued, so waiting for
-                # all but those leaves them landed; the barrier publishes every wave's rows before tap 9's B reads (gaps
-                # 0-7 of tap 8) are issued
-                st.lines.append(f"s_waitcnt vmcnt({len(st.vm)})")
+                # the first tile of a workgroup started with only taps 0-8 of the weights in LDS: wait for this wave's 18
+                # pieces issued above (the next tile's halo loads issued after them may stay in flight); the barrier
+                # publishes every wave's rows before tap 9's B reads (gaps 0-7 of tap 8) are issued
+                assert not any("m0" in x for x in side), "weight DMA not issued by tap 7"
+                st.need_vm(lambda x: x.startswith("global_load_lds"))
                 st.emit("s_barrier")
                 budget = 0
             if march and t in (8, 17, 26) and g == 8:
@@ -387,9 +402,9 @@ def main():
             define(f"WRES_EXTRACT_{cur}_{i}", extract(cur, i))
     define("WRES_PREFETCH", prefetch_only())
     define("WRES_BOUNDARY_ALL", boundary(0))
-    # first tile of a workgroup: the halo loads, the DMA of taps 0-8 and the bias piece are older than the DMA of taps
-    # 9-26 (18 pieces per wave), which lands during the first nine taps (WRES_K_X_*_FIRST waits for it)
-    define("WRES_BOUNDARY_FIRST", boundary(18))
+    # first tile of a workgroup: only the halo loads, the DMA of taps 0-8 and the bias piece have been issued; taps 9-26
+    # are issued and waited for inside WRES_K_X_*_FIRST
+    define("WRES_BOUNDARY_FIRST", boundary(0))
     for march in (True, False):
         define("WRES_K_X_" + ("MARCH" if march else "COL") + "_FIRST", kloop("X", march=march, first=True))
     define("WRES_BOUNDARY_EPI", boundary(16))

@@ -31,3 +31,4 @@ def install():
 
     dp.all_gather_into = all_gather_into
     dp.allreduce_sum_ = allreduce_sum_
+    dp.CAPTURABLE = False                 # host round trips cannot be recorded into a hipGraph
