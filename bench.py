@@ -123,7 +123,8 @@ def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
     return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "affinity_cores": affinity, "cgroup_cpu_limit": quota,
             "sample": f"{steps} timed + {warmup} warm-up full training steps of {pairs} pairs "
-                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step, torch threads = {cores} (all affinity cores)",
+                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step, torch threads = {cores} = min(affinity mask "
+                      f"{affinity}, container CPU quota {quota if quota else 'none'})",
             "one_thread": {"value": pairs / dt1, "unit": "pairs/s", "sample": f"1 step, {dt1:.1f} s"},
             "c1_lite": c1}
 

@@ -21,10 +21,17 @@ namespace {
 
 constexpr int DH = 32;
 constexpr int KCH = 128;                 // keys staged per chunk
+#ifndef ATTN_PIPE_BWD
+#define ATTN_PIPE_BWD 0                  // 1: the backward kernels prefetch the next tile's fragments too (A/B: stand-alone neutral, the STEP 1 % slower)
+#endif
 constexpr int KS = DH + 8;               // K row stride (elements): 80 B
 
-constexpr int VR = DH + 16;              // row stride (elements) of a row-major tile read through ds_read_b64_tr_b16: 96 B,
-                                         // the four rows a lane group touches fall on distinct banks
+constexpr int VR = DH;                   // row stride (elements) of a row-major tile read through ds_read_b64_tr_b16: 64 B, NO
+                                         // padding.  The instruction is served in two groups of 32 lanes; a group reads four
+                                         // rows x two 32-byte column halves, i.e. eight 8-bank windows at (16 row + 8 half)
+                                         // mod 64 - all distinct.  (The 96-byte stride of round 2 put row 3 / half 0 on the
+                                         // banks of row 0 / half 1: SQ_LDS_BANK_CONFLICT = 0.36 of the LDS cycles,
+                                         // profiles/r03_pmc_attn.summary.txt)
 
 // MFMA A operand of a TRANSPOSED product from a row-major LDS tile [k][32] (row stride VR): row index = lane & 31 =
 // tile column, k-slots 8 (lane >> 5) + {0..7} = tile rows row0 + 8 (lane >> 5) + {0..7} (hardware transpose, as in
@@ -77,6 +84,17 @@ __device__ __forceinline__ void attn_keep2(uint32_t seed, int bh, int mine, int 
         k0 = (x & 0xFFu) >= thresh8;
         k1 = ((x >> 16) & 0xFFu) >= thresh8;
     }
+}
+
+// exchange between the two halves of a wave (lanes l and l ^ 32) without an LDS round trip: v_permlane32_swap (gfx950)
+// leaves the lower half of its first operand / the upper half of its second in both halves
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // v_exp_f32 as is: arguments are <= 0 here and a result below 2^-126 may flush to zero (softmax
@@ -153,15 +171,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         }
         __syncthreads();
         if (k0 + KCH < L) load_chunk(k0 + KCH);
+        // software pipeline over the 32-key tiles (PMC, profiles/r03_pmc_attn.summary.txt: 43-53 % of the wave cycles were
+        // spent parked on s_waitcnt - fragment reads issued right in front of their MFMA, at two waves per SIMD): the K
+        // fragments of tile t + 1 and the V fragments of tile t are requested before tile t's softmax
+        bf16x8 kfr[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) kfr[s] = *reinterpret_cast<const bf16x8*>(Ks + lr * KS + 16 * s + 8 * lh);
         for (int kt = 0; kt < kn32; kt += 32) {
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt + lr) * KS + 16 * s + 8 * lh);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
-            }
+            for (int s = 0; s < 2; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sacc, 0, 0, 0);
+            bf16x8 vfr[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) vfr[s] = tr_frag32(Vs, kt + 16 * s, lane);
+            if (kt + 32 < kn32)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) kfr[s] = *reinterpret_cast<const bf16x8*>(Ks + (kt + 32 + lr) * KS + 16 * s + 8 * lh);
             // scores: raw MFMA output (the softmax scale rides in the exp's FMA: exp2(s * scale - m * scale)); with an additive
             // mask they are formed in scaled log2 units instead (sc2 = 1).  Padded keys -> -inf.
             const float sc2 = MASK ? 1.f : scale_log2;
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
                 sacc[r] = (FULL || key < kn) ? sc : -INFINITY;
                 mx = fmaxf(mx, sacc[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xhalf_max(mx);
             // lazy running maximum: the accumulators are rescaled only when some row's maximum grew by more than 2^8 (in the
             // exp's units) - p <= 256 is as exact in bf16 / fp32 as p <= 1 - so after the first tile of a row the 16
             // accumulator reads, multiplies and writes per tile are skipped (wave-uniform branch)
@@ -209,13 +236,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
             l_run += ps;
             const bf16x8* pf = pu.v;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 vf = tr_frag32(Vs, kt + 16 * s, lane);
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o, 0, 0, 0);
-            }
+            for (int s = 0; s < 2; ++s) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], pf[s], o, 0, 0, 0);
         }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = (DROP ? dinv : 1.f) / l_tot;
     if (q < L) {
         bf16* orow = out + ((size_t)b * L + q) * E + h * DH;
@@ -274,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
             for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)of[j];
         }
     }
-    dl += __shfl_xor(dl, 32, 64);
+    dl = xhalf_sum(dl);
     const float lse2 = qok ? lse[((size_t)b * H + h) * L + q] * 1.4426950408889634f : 0.f;
     if (qok && lh == 0) delta[((size_t)b * H + h) * L + q] = dl;
 
@@ -313,17 +337,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         }
         __syncthreads();
         if (k0 + KCH < L) load_chunk(k0 + KCH);
+        // software pipeline as in the forward: K / V fragments of tile t + 1 and the transposed K fragments of tile t are
+        // requested before tile t's element-wise work
+        bf16x8 kfr[2], vfr[2];
+        if (ATTN_PIPE_BWD)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kfr[s] = *reinterpret_cast<const bf16x8*>(Ks + lr * KS + 16 * s + 8 * lh);
+                vfr[s] = *reinterpret_cast<const bf16x8*>(Vs + lr * KS + 16 * s + 8 * lh);
+            }
         for (int kt = 0; kt < kn32; kt += 32) {
             f32x16 sacc, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
+            if (!ATTN_PIPE_BWD)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    kfr[s] = *reinterpret_cast<const bf16x8*>(Ks + (kt + lr) * KS + 16 * s + 8 * lh);
+                    vfr[s] = *reinterpret_cast<const bf16x8*>(Vs + (kt + lr) * KS + 16 * s + 8 * lh);
+                }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt + lr) * KS + 16 * s + 8 * lh);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt + lr) * KS + 16 * s + 8 * lh);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[s], qf[s], sacc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[s], dof[s], dp, 0, 0, 0);
             }
+            bf16x8 ktfr[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) ktfr[s] = tr_frag32(Kr, kt + 16 * s, lane);
+            if (ATTN_PIPE_BWD && kt + 32 < kn32)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    kfr[s] = *reinterpret_cast<const bf16x8*>(Ks + (kt + 32 + lr) * KS + 16 * s + 8 * lh);
+                    vfr[s] = *reinterpret_cast<const bf16x8*>(Vs + (kt + 32 + lr) * KS + 16 * s + 8 * lh);
+                }
             bf16x8 dsf[2];
             bool kp[16];
             if (DROP)
@@ -342,10 +388,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                 dsf[r >> 3][r & 7] = (bf16)(p * dpr);
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 ktf = tr_frag32(Kr, kt + 16 * s, lane);
-                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[s], dq, 0, 0, 0);
-            }
+            for (int s = 0; s < 2; ++s) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktfr[s], dsf[s], dq, 0, 0, 0);
         }
     }
     if (qok) {
@@ -359,6 +402,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 }
 
 constexpr int QCH = 128;                 // queries staged per chunk in the dK/dV pass
+
 
 template <bool DROP, bool FULL, bool MASK = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
@@ -433,18 +477,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
         if (tid < qn32) { Ls[tid] = lreg * 1.4426950408889634f; Dl[tid] = dlreg; }
         __syncthreads();
         if (q0 + QCH < L) load_chunk(q0 + QCH);
+        // software pipeline as in the forward: the Q / dO fragments of tile t + 1 and the transposed fragments of tile t
+        // are requested before tile t's element-wise work
+        bf16x8 qar[2], dar[2];
+        if (ATTN_PIPE_BWD)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qar[s] = *reinterpret_cast<const bf16x8*>(Qs + lr * KS + 16 * s + 8 * lh);
+                dar[s] = *reinterpret_cast<const bf16x8*>(Ds + lr * KS + 16 * s + 8 * lh);
+            }
         for (int qt = 0; qt < qn32; qt += 32) {
             // S[q][key] and dP[q][key]: rows = q (registers), column = this lane's key
             f32x16 sacc, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
+            if (!ATTN_PIPE_BWD)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    qar[s] = *reinterpret_cast<const bf16x8*>(Qs + (qt + lr) * KS + 16 * s + 8 * lh);
+                    dar[s] = *reinterpret_cast<const bf16x8*>(Ds + (qt + lr) * KS + 16 * s + 8 * lh);
+                }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt + lr) * KS + 16 * s + 8 * lh);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sacc, 0, 0, 0);
-                const bf16x8 da = *reinterpret_cast<const bf16x8*>(Ds + (qt + lr) * KS + 16 * s + 8 * lh);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dp, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qar[s], kf[s], sacc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dar[s], vf[s], dp, 0, 0, 0);
             }
+            bf16x8 dtar[2], qtar[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dtar[s] = tr_frag32(Dr, qt + 16 * s, lane);
+                qtar[s] = tr_frag32(Qr, qt + 16 * s, lane);
+            }
+            if (ATTN_PIPE_BWD && qt + 32 < qn32)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    qar[s] = *reinterpret_cast<const bf16x8*>(Qs + (qt + 32 + lr) * KS + 16 * s + 8 * lh);
+                    dar[s] = *reinterpret_cast<const bf16x8*>(Ds + (qt + 32 + lr) * KS + 16 * s + 8 * lh);
+                }
             bf16x8 pf[2], dsf[2];
             bool kp[16];
             if (DROP)
@@ -464,10 +533,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 dta = tr_frag32(Dr, qt + 16 * s, lane);
-                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dta, pf[s], dv, 0, 0, 0);
-                const bf16x8 qta = tr_frag32(Qr, qt + 16 * s, lane);
-                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsf[s], dk, 0, 0, 0);
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dtar[s], pf[s], dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtar[s], dsf[s], dk, 0, 0, 0);
             }
         }
     }
