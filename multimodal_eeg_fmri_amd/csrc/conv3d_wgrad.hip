@@ -3,8 +3,10 @@
 //   dW[n, tap, c] = sum_{b, v} dY[b, v, n] * X[b, v + off(tap), c]       (GEMM M = Cout, N = 27 Cin, K = voxels)
 //
 // Both operands are K-strided in memory (channels-last), so a face of dY [64 voxels][32 n] and the X halo plane
-// [10 x 10 voxels][32 c] are staged row-major and read with ds_read_b64_tr_b16 (hardware transpose); the row stride
-// of 96 B puts the four rows a lane group touches on distinct banks.  A workgroup owns ONE 32 (n) x 32 (c) block of
+// [10 x 10 voxels][32 c] are staged row-major and read with ds_read_b64_tr_b16 (hardware transpose).  Rows are 64 B,
+// UNPADDED: the instruction is served in two groups of 32 lanes, a group touches four consecutive rows x two 32-byte
+// halves = eight 8-bank windows at (16 row + 8 half) mod 64, all distinct (round 2's 96-byte rows put row 3 / half 0
+// on the banks of row 0 / half 1: 0.45-0.47 of the LDS cycles were conflicts, and a third of the DMA pieces padding).  A workgroup owns ONE 32 (n) x 32 (c) block of
 // one kd plane (9 taps: 9 x 16 accumulator registers per wave) - grid.y = 32-channel block of Cout, grid.z = kd x
 // 32-channel block of Cin - over a chunk (grid.x) of 1 x 8 x 8 output faces, and its four waves split K: a stage
 // holds two faces, wave w takes k-step w (voxels 16 w .. 16 w + 15) of both.  The waves are summed through LDS at
@@ -21,8 +23,7 @@
 //  * the faces arrive by LDS-DMA (buffer_load_dwordx4 ... lds: no registers, no ds_write, out-of-volume voxels
 //    zero-filled by the buffer's range check) into a ring of W3_ST stages, W3_ST - 1 stages ahead of the MFMAs, with
 //    counted vmcnt and ONE barrier per stage; a DMA writes 1 KB contiguous per wave, so a lane's chunk is chosen on
-//    the source side: chunk ci = 64 e + lane of a face image is row ci / 6, 16-byte column ci % 6 of the padded rows
-//    (columns 4, 5 are padding: those lanes fetch out of range);
+//    the source side: chunk ci = 64 e + lane of a face image is row ci / 4, 16-byte column ci % 4;
 //  * inside a stage the 18 (face, tap) units of a wave are software-pipelined by hand: the B fragment of unit q +
 //    W3_LA is requested before the MFMA of unit q, under counted lgkmcnt (left to the compiler the reads sat right
 //    in front of their MFMAs).  The reads are inline asm: the compiler cannot tell the ring stages apart and would
@@ -35,14 +36,17 @@
 namespace {
 
 constexpr int HB = 10;             // halo edge of an 8-wide face
-constexpr int W3_ROWB = 96;        // LDS row stride: 64 B of data (32 channels) + 32 B of padding
-constexpr int W3_ST = 3;           // stages of the LDS ring (96 KB: a 45-52 KB workgroup of the EEG chain still fits on the CU)
+constexpr int W3_ROWB = 64;        // LDS row stride: 64 B of data (32 channels), no padding
+constexpr int W3_ST = 4;           // stages of the LDS ring (96 KB: a 45-52 KB workgroup of the EEG chain still fits on the CU)
 constexpr int W3_LA = 5;           // B fragments of look-ahead (2 LDS reads each + an A pair: 12 of lgkmcnt's 15); the ring of W3_LA + 1
                                    // fragments divides the 18 units of a stage, so the pipeline runs on across stages
-constexpr int W3_YB = 64 * W3_ROWB;                 // 6 144 B: dY face image = 6 DMA instructions
-constexpr int W3_FACE = 16 * 1024;                  // dY image + X plane image (100 rows x 96 B = 9 600 B inside 10 instructions)
-constexpr int W3_STAGE = 2 * W3_FACE;               // two faces = 32 DMA instructions, 8 per wave
+constexpr int W3_YB = 64 * W3_ROWB;                 // 4 096 B: dY face image = 4 DMA instructions
+constexpr int W3_NP = 6;                            // DMA instructions per wave and stage: a face = 4 (dY) + 7 (X plane: 100 rows x 64 B =
+                                                    // 6 400 B) pieces of 1 KB + one dummy piece, split over two waves
+constexpr int W3_FACE = 2 * W3_NP * 1024;           // 12 KB: the 11 pieces + the dummy's KB
+constexpr int W3_STAGE = 2 * W3_FACE;               // two faces
 constexpr int W3_LDS = W3_ST * W3_STAGE;
+static_assert(W3_LDS >= 4 * 5 * 32 * 36 * 4, "the K-partial images of the epilogue reuse the ring");
 constexpr int W3_NQ = 18;                           // (face, tap) units per stage and wave
 
 struct Wgrad3dArgs {
@@ -103,34 +107,36 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
     const int li = lane & 15, g = lane >> 4;
     const int lds0 = (int)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    // ---- DMA plan.  Waves 0, 1 fill face 0 of a stage, waves 2, 3 face 1; instruction e' = 8 (wave & 1) + e of a face
-    // moves chunks ci = 64 e' + lane: e' < 6 is the dY image (row = voxel (row >> 3, row & 7) of the face), the rest the
-    // X plane image (row = halo voxel (row / 10, row % 10)).  Per lane and instruction: byte offset relative to the
-    // face's first voxel and a one-hot (row, column) selector of the voxel's face coordinates, tested per stage against
-    // the wave-uniform mask of coordinates that lie inside the volume (bit 31 = padding chunk / channel past the tensor).
+    // ---- DMA plan.  Waves 0, 1 fill face 0 of a stage, waves 2, 3 face 1; instruction e' = 6 (wave & 1) + e of a face
+    // moves chunks ci = 64 e' + lane: e' < 4 is the dY image (row = voxel (row >> 3, row & 7) of the face), 4 <= e' < 11
+    // the X plane image (row = halo voxel (row / 10, row % 10)), e' = 11 a dummy that keeps the two waves' instruction
+    // counts equal (counted vmcnt).  Per lane and instruction: byte offset relative to the face's first voxel and a
+    // one-hot (row, column) selector of the voxel's face coordinates, tested per stage against the wave-uniform mask
+    // of coordinates that lie inside the volume (bit 31 = row past the image / channel past the tensor / dummy).
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(a.dy), 0, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cout * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(a.x), 0, (unsigned)((size_t)a.B * a.D * a.H * a.W * a.Cin * 2), 0x00020000);
     const int face = wave >> 1;
-    int rel[8];
-    unsigned sel[8];
+    int rel[W3_NP];
+    unsigned sel[W3_NP];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ep = 8 * (wave & 1) + e;
-        const bool isy = ep < 6;                                 // wave-uniform
-        const int ci = 64 * (isy ? ep : ep - 6) + lane;
-        const int row = ci / 6, ch = ci - 6 * row;
+    for (int e = 0; e < W3_NP; ++e) {
+        const int ep = W3_NP * (wave & 1) + e;
+        const bool isy = ep < 4;                                 // wave-uniform
+        const int ci = 64 * (isy ? ep : ep - 4) + lane;
+        const int row = ci >> 2, ch = ci & 3;
         int vh, vw;
         bool ok;
         if (isy) {
             vh = row >> 3; vw = row & 7;
             rel[e] = ((vh * a.W + vw) * a.Cout + 8 * ch) * 2;
-            ok = ch < 4 && n0 + 8 * ch < a.Cout;
+            ok = n0 + 8 * ch < a.Cout;
         } else {
             vh = row / HB; vw = row - HB * vh;
             rel[e] = ((vh * a.W + vw) * a.Cin + 8 * ch) * 2;
-            ok = ch < 4 && row < HB * HB && c0 + 8 * ch < a.Cin;
+            ok = ep < 11 && row < HB * HB && c0 + 8 * ch < a.Cin;
+            if (!ok) { vh = 0; vw = 0; rel[e] = 0; }
         }
         sel[e] = ok ? (1u << vh) | (1u << (16 + vw)) : 0x80000000u;
     }
@@ -148,18 +154,18 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
         cd = q % a.D; cb = q / a.D;
     }
     int cstage = 0;
-    // One stage's fill is eight instructions per wave.  In the loop they are spread over the MFMA gaps of the stage being
+    // One stage's fill is W3_NP = 6 instructions per wave.  In the loop they are spread over the MFMA gaps of the stage being
     // computed (issued in one piece in front of it they cost ~600 cycles of scalar / vector issue per stage that nothing hid).
     struct Fill { int ybase, xbase; unsigned ymask, xmask; char* dst; } fill;
     auto fill_begin = [&]() __attribute__((always_inline)) {
-        // always eight loads per wave (counted vmcnt): a face past the chunk's end fetches out of range = zeros
+        // always W3_NP loads per wave (counted vmcnt): a face past the chunk's end fetches out of range = zeros
         const bool live = ctile < tend;
         const int dd = cd + kd - 1;
         fill.ybase = ((((cb * a.D + cd) * a.H + ch0) * a.W + cw0) * a.Cout + n0) * 2;
         fill.xbase = ((((cb * a.D + dd) * a.H + ch0 - 1) * a.W + cw0 - 1) * a.Cin + c0) * 2;
         fill.ymask = live ? range_bits(0, a.H - ch0, 8) | (range_bits(0, a.W - cw0, 8) << 16) : 0u;
         fill.xmask = (live && dd >= 0 && dd < a.D) ? range_bits(1 - ch0, a.H + 1 - ch0, HB) | (range_bits(1 - cw0, a.W + 1 - cw0, HB) << 16) : 0u;
-        fill.dst = smem + (cstage % W3_ST) * W3_STAGE + wave * 8 * 1024;
+        fill.dst = smem + (cstage % W3_ST) * W3_STAGE + face * W3_FACE + (wave & 1) * W3_NP * 1024;
         ++cstage;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {                          // the cursor moves two faces on
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
         }
     };
     auto fill_one = [&](int e) __attribute__((always_inline)) {
-        const bool isy = 8 * (wave & 1) + e < 6;
+        const bool isy = W3_NP * (wave & 1) + e < 4;
         const unsigned allowed = __builtin_amdgcn_readfirstlane(isy ? fill.ymask : fill.xmask);
         const int base = __builtin_amdgcn_readfirstlane(isy ? fill.ybase : fill.xbase);
         const int off = (sel[e] & ~allowed) == 0u ? base + rel[e] : -1;
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
     auto issue = [&]() __attribute__((always_inline)) {
         fill_begin();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fill_one(e);
+        for (int e = 0; e < W3_NP; ++e) fill_one(e);
     };
 
     f32x16 acc[9];
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
     // (kbase = 8 (g >> 1) + (li >> 2)); dY row = k, X row = halo voxel (k >> 3, k & 7) + tap offset.
     const int kA = 16 * wave + 8 * (g >> 1) + (li >> 2), kB = kA + 4;
     const int colb = ((g & 1) * 16 + 4 * (li & 3)) * 2;
-    const int ya = kA * W3_ROWB + colb;                                                 // + 4 rows = + 384 B for the second half
+    const int ya = kA * W3_ROWB + colb;                                                 // + 4 rows for the second half
     const int xa = W3_YB + ((kA >> 3) * HB + (kA & 7)) * W3_ROWB + colb;
     const int xb = W3_YB + ((kB >> 3) * HB + (kB & 7)) * W3_ROWB + colb;
 
@@ -205,11 +211,11 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
     // B fragment of unit q + W3_LA - of the NEXT stage for the last W3_LA units - and then runs its MFMA; the A pair of a
     // face is requested just before the face's first B fragment.  The stage's barrier sits in the middle (unit 9): it
     // certifies that stage st + 1 has landed (counted vmcnt: one later stage may still be in flight) before unit 13 first
-    // reads it, and that every wave has left stage st - 1, whose buffer the eight DMA instructions of stage st + 3 -
-    // spread over the gaps of units 10 .. 17 - then refill.  (With the barrier and the fill in front of each stage and the
+    // reads it, and that every wave has left stage st - 1, whose buffer the W3_NP DMA instructions of stage st + W3_ST - 1 -
+    // spread over the gaps of units 10 .. 15 - then refill.  (With the barrier and the fill in front of each stage and the
     // pipeline restarted behind it a stage took 1 640 cycles for 576 of MFMA work.)
     W3_TL(0)
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"((W3_ST - 2) * 8) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"((W3_ST - 2) * W3_NP) : "memory");
     __builtin_amdgcn_s_barrier();                          // stage 0 is in LDS
     Frag af[2], bfq[W3_LA + 1];
     int pya = lds0 + ya, pxa = lds0 + xa, pxb = lds0 + xb;  // current stage; *_n: the next one
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
         static_for<0, W3_NQ>([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             if constexpr (q == 9) {
-                asm volatile("s_waitcnt vmcnt(%0)" : : "n"((W3_ST - 3) * 8) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"((W3_ST - 3) * W3_NP) : "memory");
                 __builtin_amdgcn_s_barrier();
                 fill_begin();
             }
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
                 for (int j = 0; j < 8; ++j) bsum += (float)af[(q / 9) & 1].v[j];
             }
             acc[q % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(q / 9) & 1].v, bfq[q % (W3_LA + 1)].v, acc[q % 9], 0, 0, 0);
-            if constexpr (q >= 10) fill_one(q - 10);
+            if constexpr (q >= 10 && q < 10 + W3_NP) fill_one(q - 10);
             __builtin_amdgcn_sched_barrier(0);
         });
         pya = pya_n; pxa = pxa_n; pxb = pxb_n;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
 #endif
 }
 
-// faces per workgroup: one workgroup per CU (128 KB of LDS ring), every one at least 2 W3_ST faces deep so that the ring
+// faces per workgroup: one workgroup per CU (96 KB of LDS ring), every one at least 2 W3_ST faces deep so that the ring
 // fills; the more output blocks there are, the fewer chunks - and slots for the scatter to sum - it takes to get there.
 int wgrad3d_tiles_per_wg(int B, int D, int H, int W, int Cin, int Cout) {
     const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
