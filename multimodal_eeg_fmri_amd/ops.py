@@ -827,13 +827,6 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().float().contiguous()
 
 
-def _eval_only(what: str, training: bool):
-    if training and torch.is_grad_enabled():
-        raise NotImplementedError(
-            f"{what}: training on the HIP path is not built yet (eval/inference only this round; "
-            "see DESIGN.md 'next'); call .eval() and torch.no_grad()")
-
-
 def learned_fusion(m, feats: List[torch.Tensor], training: bool, autograd: bool = False):
     """LearnedFusionModule.forward -> (fused (B, H), weights (B, M)).  ``autograd``: differentiable
     composition even in eval mode (its gate dropout is then off)."""

@@ -7,6 +7,13 @@ set -uo pipefail
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out"
 mkdir -p "$out"
+# plain timings first: a --pmc pass leaves the clocks in the profiling state for the rest of the call
+cd "$root"
+MMEEG_HIP_LIB="$root/multimodal_eeg_fmri_amd/csrc/build/abl_s0_n.so" python3 tools/kbench.py stamp 2>&1 | grep -v amdgpu > "$out/r03_wres_cycle_stamps.txt"
+python3 tools/kbench.py c4b 2>&1 | grep conv3d > "$out/r03_wres_graph_replayed.txt"
+{ python3 tools/kbench.py stream 2>&1 | grep conv3d; python3 tools/kbench.py wgrad3 2>&1 | grep wgrad3d; } > "$out/r03_conv3d_family_standalone.txt"
+python3 tools/kbench.py attn 2>&1 | grep attention > "$out/r03_attention_standalone.txt"
+python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --fit-steps 0 --stamps 2>&1 | grep -v "^{" | grep -v amdgpu > "$out/r03_step_phase_stamps.txt"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/r03_prof" -- \
     python3 "$root/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --profile > "$out/r03_prof.log" 2>&1
@@ -32,10 +39,4 @@ done
 "$root/profiles/run_pmc_wres.sh" r03_c2 pmc3d > /dev/null 2>&1
 "$root/profiles/run_pmc_wres.sh" r03_c4 pmc4 > /dev/null 2>&1
 "$root/profiles/run_pmc_lds.sh" r03 > /dev/null 2>&1
-cd "$root"
-MMEEG_HIP_LIB="$root/multimodal_eeg_fmri_amd/csrc/build/abl_s0_n.so" python3 tools/kbench.py stamp 2>&1 | grep -v amdgpu > "$out/r03_wres_cycle_stamps.txt"
-python3 tools/kbench.py c4b 2>&1 | grep conv3d > "$out/r03_wres_graph_replayed.txt"
-{ python3 tools/kbench.py stream 2>&1 | grep conv3d; python3 tools/kbench.py wgrad3 2>&1 | grep wgrad3d; } > "$out/r03_conv3d_family_standalone.txt"
-python3 tools/kbench.py attn 2>&1 | grep attention > "$out/r03_attention_standalone.txt"
-python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --fit-steps 0 --stamps 2>&1 | grep -v "^{" | grep -v amdgpu > "$out/r03_step_phase_stamps.txt"
 echo done
