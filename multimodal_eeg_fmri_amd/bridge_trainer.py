@@ -296,9 +296,9 @@ class BridgeTrainer(nn.Module):
         pool = torch.cuda.graph_pool_handle()
         graphs = []
 
-        def record(fn):
+        def record(fn, mode="global"):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool), torch.no_grad():
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode), torch.no_grad():
                 fn()
             graphs.append(g)
 
@@ -352,7 +352,8 @@ class BridgeTrainer(nn.Module):
             self._seg_backward(saved, c["dz"], c["scal"], reduce_fmri=True)
             self._seg_optimizer(fmri_reduced=True)
         try:
-            record(whole_dp)
+            # thread-local capture mode: the process group's watchdog thread polls its events while this thread captures
+            record(whole_dp, mode="thread_local")
             return True
         except Exception as e:  # noqa: BLE001 - any refusal (RCCL, the caching allocator, a host sync) -> segments
             import warnings
