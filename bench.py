@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # dense, /opt/skills/guides/MI355X_MICROARCH.md
 PAIRS_PER_GPU = 32
+PRECONDITION_STEPS = 300                # untimed steps in front of the --warmup steps (clock conditioning, ~0.25 s)
 EEG_CH, EEG_T, VOL = 64, 1024, (32, 32, 32)
 
 
@@ -291,14 +292,25 @@ def main():
     NBATCH = 4
     dev_batches = [synthetic_pairs(PAIRS_PER_GPU, EEG_CH, EEG_T, VOL, seed=1234 + rank + 1000 * i) for i in range(NBATCH)]
     tr.train_step(eeg, fmri)                  # capture (not a warm-up step: lazy initialisation, graph capture)
+    # clock conditioning (untimed, disclosed as `preconditioning_steps`): the process has kept the GPU nearly idle for seconds
+    # (imports, capture), and the chip needs ~25 ms of this workload to settle - per-10-step event timings read 0.86, 0.84, 0.82
+    # and then 0.815 ms per step (tools/r3/jitter.py).  A short --warmup would put that ramp inside a short timed region.
+    precondition = 0 if args.profile else PRECONDITION_STEPS        # (profiler runs count kernels per step: keep their traces short)
+    for i in range(precondition):
+        tr.train_step(*dev_batches[i % NBATCH])
     for i in range(args.warmup):
         tr.train_step(*dev_batches[i % NBATCH])
+    import gc
+    gc.collect()
+    gc.freeze()                               # a generation-2 collection in the timed loop is a 20-30 ms host stall (seen 1 run in 8)
+    gc.disable()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = tr.train_step(*dev_batches[i % NBATCH])
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     loss_timed = out["loss"].item()           # read before any other step overwrites the trainer's result buffer
     tr_capture_mode = tr.capture_mode
     t = torch.tensor([dt], device="cuda")
@@ -336,11 +348,14 @@ def main():
                 tr.train_step(*stage[i % 2])
                 consumed[i % 2].record()
         h2d_loop(max(6, min(args.warmup, 20)))        # its own warm-up: copy stream, pinned copies, event pool (first use
-        sync()                                          # of each costs milliseconds - more than a 20-step timed region)
+        gc.collect()                                    # of each costs milliseconds - more than a 20-step timed region)
+        gc.disable()
+        sync()
         t0 = time.perf_counter()
         h2d_loop(args.steps)
         sync()
         dt_h2d = time.perf_counter() - t0
+        gc.enable()
         t = torch.tensor([dt_h2d], device="cuda")
         if world > 1:
             import torch.distributed as dist
@@ -395,7 +410,8 @@ def main():
     achieved = flops / (kt * 1e-3) / 1e12 if kt else None
     line = {
         "metric": "pairs_per_sec_per_node", "value": global_batch * args.steps / dt, "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preconditioning_steps": precondition,
+        "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
         "config": {"workload": "C2 bridge train step: 64ch x 1024 EEG (EnhancedERPEncoder) + 32^3 fMRI "

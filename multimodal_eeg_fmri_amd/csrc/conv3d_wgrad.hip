@@ -30,6 +30,7 @@
 //    order every LDS read behind ALL outstanding DMA.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 
@@ -331,7 +332,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(Wgrad3dArgs a) {
 int wgrad3d_tiles_per_wg(int B, int D, int H, int W, int Cin, int Cout) {
     const int tiles_total = B * D * ceil_div(H, 8) * ceil_div(W, 8);
     const int par = ceil_div(Cout, 32) * 3 * ceil_div(Cin, 32);
-    int chunks = 256 / par;
+    // workgroups (= CUs: 96 KB of LDS each) to spread over.  MM_W3_CUS (A/B runs): fewer than 256 leaves whole CUs to the kernels of
+    // the other stream, which cannot co-reside with a 96 KB workgroup
+    static const int cus = getenv("MM_W3_CUS") ? atoi(getenv("MM_W3_CUS")) : 256;
+    int chunks = cus / par;
     if (chunks > tiles_total / (2 * W3_ST)) chunks = tiles_total / (2 * W3_ST);
     if (chunks < 1) chunks = 1;
     int per = ceil_div(tiles_total, chunks);
