@@ -177,6 +177,18 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
                            const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
                            float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t stream);
 
+/* EnhancedERPEncoder.conv_layers backward (enhanced_models_v4.py:99-105, autograd of Conv1d -> BatchNorm1d -> GELU
+ * [-> MaxPool1d(2)] -> Dropout stacked twice): the data gradient of one conv block (dy (B, T, Cin) bf16, w_dgrad = that
+ * block's data-gradient weight image, dx_bf16 (B, T, Cout) bf16 = d(out) of the block BELOW) with the BatchNorm-backward
+ * reduce pass of the block below as its epilogue.  y_below (B, T * pool, Cout) fp32, out4_below, sums_below (zeroed
+ * [32][2][Cout] workspace) and the activation / pool / dropout arguments are those of
+ * mm_bn_act_bwd_reduce(y_below, out4_below, dx_bf16, NULL, sums_below, B, T * pool, Cout, ...), whose launch this replaces
+ * (drop2_p = 0).  Needs taps > 1 or Cout <= 64 (the 64 x 64 tile). */
+int mm_conv1d_dgrad_bn_reduce(const void* dy, const void* w_dgrad, int B, int T, int Cin, int Cout, int taps, int pad,
+                              void* dx_bf16, const float* y_below, const float* out4_below, float* sums_below, int act,
+                              int pool, int drop_first, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                              hipStream_t stream);
+
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,
  * lse [B][H][L] fp32.  drop_p = attention-probability dropout (train mode).  The

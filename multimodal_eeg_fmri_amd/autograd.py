@@ -9,6 +9,7 @@ autograd receives ``None``; otherwise a fresh tensor is returned to autograd.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -237,16 +238,31 @@ def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *,
     return (r["f32"] if dx_f32 else r["bf16"]).view(M, cinp)
 
 
-def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_dx=True):
-    """backward of ops.conv_bn_act (train mode). returns dx (B, T, Cinp) bf16."""
+_NO_BNRED = bool(os.environ.get("MM_NO_BNRED"))     # A/B knob: the BatchNorm-backward reduce as its own launch
+
+
+def _bn_bwd_args(s: dict, y):
+    B, T, N = y.shape
+    d2 = s.get("drop2", (0.0, 0))
+    return (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]),
+            float(d2[0]), int(d2[1]), ops.EP())
+
+
+def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_dx=True, sums=None, below=None):
+    """backward of ops.conv_bn_act (train mode). returns dx (B, T, Cinp) bf16.
+
+    ``sums``: this block's BatchNorm-backward sums when the producer of ``dout`` already formed them (skips the
+    reduce launch).  ``below`` = the saved dict of the conv block whose output fed this one: the data-gradient GEMM
+    then runs that block's reduce pass as its epilogue (mm_conv1d_dgrad_bn_reduce) and the call returns
+    ``(dx, sums_below)``; ``sums_below`` is None when the shapes do not allow the fusion (the caller passes it on
+    either way)."""
     conv, bn = s["conv"], s["bn"]
     y, out4, xb = s["y"], s["out4"], s["xb"]
     B, T, N = y.shape
-    sums = _zeros((REPL, 2, N), y)
-    d2 = s.get("drop2", (0.0, 0))
-    args = (B, T, N, ACT[s["act"]], s["pool"], 1 if s["drop_first"] else 0, float(s["drop_p"]), int(s["seed"]),
-            float(d2[0]), int(d2[1]), ops.EP())
-    _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
+    args = _bn_bwd_args(s, y)
+    if sums is None:
+        sums = _zeros((REPL, 2, N), y)
+        _hip.call("mm_bn_act_bwd_reduce", y, out4, dout_bf16, dout_f32, sums, *args)
     dy = _empty((B, T, N), _BF, y)
     # the apply pass sums the 32 replicas itself (no compaction launch between the two passes)
     _hip.call("mm_bn_act_bwd_apply", y, out4, dout_bf16, dout_f32, sums, dy, None, *args,
@@ -263,9 +279,20 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
         if db is not None:
             _reduce_into(db, dbr, N, N)
     if not need_dx:
-        return None
+        return None if below is None else (None, None)
     _, wd, cinp, coutp = ops.weights.get(conv.weight, True)
     assert coutp == N
+    if below is not None:
+        yb = below["y"]
+        d2 = below.get("drop2", (0.0, 0))
+        if not _NO_BNRED and (k > 1 or cinp <= 64) and yb.shape[2] == cinp and yb.shape[1] == T * below["pool"] and float(d2[0]) == 0.0:
+            dx = _empty((B, T, cinp), _BF, y)
+            sums_b = _zeros((REPL, 2, cinp), y)
+            _hip.call("mm_conv1d_dgrad_bn_reduce", dy, wd, B, T, N, cinp, k, k - 1 - pad, dx, yb, below["out4"], sums_b,
+                      ACT[below["act"]], below["pool"], 1 if below["drop_first"] else 0, float(below["drop_p"]),
+                      int(below["seed"]), ops.EP())
+            return dx, sums_b
+        return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"], None
     return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"]
 
 
@@ -388,11 +415,11 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     if after_blocks is not None:
         after_blocks()
     c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
-    g = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D))
-    g = conv_bn_act_bwd(bag, c2, dout_bf16=g)
+    g, sm = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D), below=c2)
+    g, sm = conv_bn_act_bwd(bag, c2, dout_bf16=g, sums=sm, below=c1)
     if after_conv2 is not None:
         after_conv2()
-    g = conv_bn_act_bwd(bag, c1, dout_bf16=g, need_dx=need_dx)
+    g = conv_bn_act_bwd(bag, c1, dout_bf16=g, need_dx=need_dx, sums=sm)
     if not need_dx:
         return None
     Bx, C, T = sv["x_shape"]

@@ -110,6 +110,42 @@ __device__ __forceinline__ uint32_t mm_eff_seed(uint32_t base, const uint32_t* e
     return epoch ? base ^ (epoch[0] * 0x85EBCA6Bu + 0xC2B2AE35u) : base;
 }
 
+// BatchNorm + activation [+ pool 2] [+ dropout] backward, element level (elementwise.hip's two passes and the reduce pass
+// fused behind a data-gradient GEMM, igemm1d.hip): dz for the (up to) two inputs of one pooled output element.
+// Args carries act, pool, drop_first, thresh, seed (already mm_eff_seed'ed), inv_keep.  ACT >= 0 / POOL > 0: compiled for that activation /
+// pool size (the per-element switch and the two-way pool logic of the generic form made these passes VALU-bound)
+template <int ACT, int POOL, class Args>
+__device__ __forceinline__ void bn_dz_pair(const Args& a, float y0, float y1, float sc, float sh, float g,
+                                           uint32_t i0, uint32_t i1, uint32_t io, float& dz0, float& dz1) {
+    const int act = ACT >= 0 ? ACT : a.act;
+    const int pool = POOL > 0 ? POOL : a.pool;
+    const float z0 = y0 * sc + sh;
+    if (pool == 1) {
+        float m = a.thresh ? dropout_scale(a.seed, i0, a.thresh, a.inv_keep) : 1.f;
+        dz0 = g * m * act_grad(z0, act);
+        dz1 = 0.f;
+        return;
+    }
+    const float z1 = y1 * sc + sh;
+    float a0 = apply_act(z0, act), a1 = apply_act(z1, act);
+    float m0 = 1.f, m1 = 1.f;
+    if (a.thresh) {
+        if (a.drop_first) {
+            m0 = dropout_scale(a.seed, i0, a.thresh, a.inv_keep);
+            m1 = dropout_scale(a.seed, i1, a.thresh, a.inv_keep);
+            a0 *= m0; a1 *= m1;
+        } else {
+            g *= dropout_scale(a.seed, io, a.thresh, a.inv_keep);
+        }
+    }
+    const bool first = a0 >= a1;                       // ties -> first (torch max_pool)
+    // ONE derivative, at the winner (two selects of act_grad(z0) / act_grad(z1) evaluate both)
+    const float d = g * (first ? m0 : m1) * act_grad(first ? z0 : z1, act);
+    dz0 = first ? d : 0.f;
+    dz1 = first ? 0.f : d;
+}
+
+
 // Per-channel reductions (BN statistics, dgamma/dbeta, dbias) are accumulated across workgroups with
 // 64-bit INTEGER atomics on fixed-point values: integer addition is associative, so the sum does not
 // depend on the order the workgroups arrive in and a training step is bit-reproducible (fp32 atomics

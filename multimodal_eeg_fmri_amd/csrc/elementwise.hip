@@ -132,39 +132,6 @@ struct BnBwdArgs {
     int sums_nrep;               // apply: sums is [sums_nrep][2][N]; the block reduces the replicas itself
 };
 
-// computes dz for the (up to) two inputs of one pooled output element.  ACT >= 0 / POOL > 0: compiled for that activation /
-// pool size (the per-element switch and the two-way pool logic of the generic form made these passes VALU-bound)
-template <int ACT, int POOL>
-__device__ __forceinline__ void bn_dz_pair(const BnBwdArgs& a, float y0, float y1, float sc, float sh, float g,
-                                           uint32_t i0, uint32_t i1, uint32_t io, float& dz0, float& dz1) {
-    const int act = ACT >= 0 ? ACT : a.act;
-    const int pool = POOL > 0 ? POOL : a.pool;
-    const float z0 = y0 * sc + sh;
-    if (pool == 1) {
-        float m = a.thresh ? dropout_scale(a.seed, i0, a.thresh, a.inv_keep) : 1.f;
-        dz0 = g * m * act_grad(z0, act);
-        dz1 = 0.f;
-        return;
-    }
-    const float z1 = y1 * sc + sh;
-    float a0 = apply_act(z0, act), a1 = apply_act(z1, act);
-    float m0 = 1.f, m1 = 1.f;
-    if (a.thresh) {
-        if (a.drop_first) {
-            m0 = dropout_scale(a.seed, i0, a.thresh, a.inv_keep);
-            m1 = dropout_scale(a.seed, i1, a.thresh, a.inv_keep);
-            a0 *= m0; a1 *= m1;
-        } else {
-            g *= dropout_scale(a.seed, io, a.thresh, a.inv_keep);
-        }
-    }
-    const bool first = a0 >= a1;                       // ties -> first (torch max_pool)
-    // ONE derivative, at the winner (two selects of act_grad(z0) / act_grad(z1) evaluate both)
-    const float d = g * (first ? m0 : m1) * act_grad(first ? z0 : z1, act);
-    dz0 = first ? d : 0.f;
-    dz1 = first ? 0.f : d;
-}
-
 template <bool APPLY, int ACT = -1, int POOL = 0>
 __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     a.seed = mm_eff_seed(a.seed, a.epoch);

@@ -22,6 +22,19 @@ namespace {
 
 constexpr int KPAD = 8;       // +16 B per LDS row
 
+// BatchNorm-backward reduce pass of the layer BELOW, fused behind the data-gradient GEMM that produces that layer's
+// d(out) (epilogue_bn_reduce): the tile's bf16 d(out) values are routed through dropout / pool / act' exactly as
+// elementwise.hip's bn_act_bwd_kernel<false> does and summed into the same accumulator workspace
+struct BnRed {
+    const float* y = nullptr;      // [B][T * pool][N] pre-BatchNorm activations of that layer (nullptr = off)
+    const float* out4 = nullptr;   // [4][N] scale, shift, mean, rstd
+    float* sums = nullptr;         // [MM_REPL][2][N] workspace (zeroed by the caller): sum dz | sum dz * xhat
+    int act = 0, pool = 1, drop_first = 0;
+    uint32_t thresh = 0, seed = 0;
+    float inv_keep = 1.f;
+    const uint32_t* epoch = nullptr;
+};
+
 struct EpiArgs {
     const float* scale;       // [N] multiply (nullptr = 1)
     const float* shift;       // [N] add (bias / folded BN shift) (nullptr = 0)
@@ -57,6 +70,7 @@ struct EpiArgs {
     const float* lnf_gamma;
     const float* lnf_beta;
     float lnf_eps;
+    BnRed bn;
 };
 
 struct ConvArgs {
@@ -72,12 +86,14 @@ struct ConvArgs {
 // the activation switch compiled out: the generic epilogue cost ~2.4 us per million outputs in branches and dead work
 // (FFN-1 forward, 8.4 M outputs: 25.7 us generic, 17.5 us specialised).
 enum : unsigned { EF_RES = 1, EF_PE = 2, EF_PRE = 4, EF_GRADZ = 8, EF_STATS = 16, EF_POOLOUT = 32, EF_LNF = 64, EF_POOL2 = 128,
-                  EF_DROP = 256, EF_SCALE = 512, EF_F32 = 1024, EF_BF16 = 2048, EF_SHIFT = 4096, EF_LNBWD = 8192, EF_ANY = 0xFFFFFFFFu };
+                  EF_DROP = 256, EF_SCALE = 512, EF_F32 = 1024, EF_BF16 = 2048, EF_SHIFT = 4096, EF_LNBWD = 8192,
+                  EF_BNRED = 16384, EF_BNPOOL2 = 32768 /* bits 24-27: the fused BatchNorm-backward's activation */, EF_ANY = 0xFFFFFFFFu };
 static unsigned epi_mask(const EpiArgs& e) {
     return (e.residual ? EF_RES : 0) | (e.pe ? EF_PE : 0) | (e.out_pre ? EF_PRE : 0) | (e.gradz ? EF_GRADZ : 0) | (e.stats ? EF_STATS : 0) |
            (e.pool_out ? EF_POOLOUT : 0) | (e.lnf_out ? EF_LNF : 0) | (e.pool == 2 ? EF_POOL2 : 0) | (e.drop_thresh ? EF_DROP : 0) |
            (e.scale ? EF_SCALE : 0) | (e.out_f32 ? EF_F32 : 0) | (e.out_bf16 ? EF_BF16 : 0) | (e.shift ? EF_SHIFT : 0) | (e.ln_x ? EF_LNBWD : 0) |
-           ((unsigned)e.act << 16) | ((unsigned)(e.gradz ? e.gradz_act : 0) << 20);
+           ((unsigned)e.act << 16) | ((unsigned)(e.gradz ? e.gradz_act : 0) << 20) |
+           (e.bn.y ? (EF_BNRED | (e.bn.pool == 2 ? EF_BNPOOL2 : 0) | ((unsigned)e.bn.act << 24)) : 0);
 }
 
 
@@ -220,6 +236,79 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
         }
     }
 #undef EF_ON
+}
+
+// dgrad GEMM -> bf16 d(out) of the layer below + that layer's BatchNorm-backward reduce pass (host: no scale / shift /
+// activation / pooling of this GEMM's own, Cout == the BatchNorm's channel count).  Thread layout as epilogue_rows: one
+// 4-column group per thread, BM / RPP rows; the rows' pre-BN values are fetched before the first row is touched.
+struct BnDz { int act, pool, drop_first; uint32_t thresh, seed; float inv_keep; };
+template <int BM, int BN, unsigned FEAT>
+__device__ __forceinline__ void epilogue_bn_reduce(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
+                                                   int n0, int N) {
+#pragma clang fp contract(off)
+    constexpr bool ANY = FEAT == EF_ANY;
+    constexpr int LDC = BN + 4, CG = BN / 4, RPP = 256 / CG, NR = BM / RPP;
+    const int cg = tid % CG, rr = tid / CG;
+    const int n = n0 + cg * 4;
+    const bool nok = n < N;
+    BnDz bn;
+    bn.act = ANY ? e.bn.act : (int)((FEAT >> 24) & 15u);
+    bn.pool = ANY ? e.bn.pool : ((FEAT & EF_BNPOOL2) ? 2 : 1);
+    bn.drop_first = e.bn.drop_first; bn.thresh = e.bn.thresh; bn.inv_keep = e.bn.inv_keep;
+    bn.seed = mm_eff_seed(e.bn.seed, e.bn.epoch);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 y0[NR], y1[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int t = t0 + rr + k * RPP;
+        const bool ok = nok && t < T;                    // rows / columns outside the tensor read element 0 (unused below)
+        const size_t in0 = ok ? ((size_t)b * T + t) * bn.pool * N + n : 0;
+        y0[k] = *reinterpret_cast<const float4*>(e.bn.y + in0);
+        y1[k] = *reinterpret_cast<const float4*>(e.bn.y + in0 + (bn.pool == 2 ? N : 0));
+    }
+    float4 c4[4] = {z4, z4, z4, z4};
+    if (nok)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c4[q] = *reinterpret_cast<const float4*>(e.bn.out4 + (size_t)q * N + n);
+    const float scs[4] = {c4[0].x, c4[0].y, c4[0].z, c4[0].w}, shs[4] = {c4[1].x, c4[1].y, c4[1].z, c4[1].w};
+    const float mus[4] = {c4[2].x, c4[2].y, c4[2].z, c4[2].w}, rss[4] = {c4[3].x, c4[3].y, c4[3].z, c4[3].w};
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int row = rr + k * RPP, t = t0 + row;
+        if (!nok || t >= T) continue;
+        const float4 a4 = *reinterpret_cast<const float4*>(Cs + row * LDC + cg * 4);
+        const size_t oi = ((size_t)b * T + t) * N + n;
+        const size_t in0 = ((size_t)b * T + t) * bn.pool * N + n;
+        const bf16x4 ov = {(bf16)a4.x, (bf16)a4.y, (bf16)a4.z, (bf16)a4.w};
+        *reinterpret_cast<bf16x4*>(e.out_bf16 + oi) = ov;
+        const float y0s[4] = {y0[k].x, y0[k].y, y0[k].z, y0[k].w}, y1s[4] = {y1[k].x, y1[k].y, y1[k].z, y1[k].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float d0, d1;                                   // the stand-alone pass reads the bf16 d(out): so does this one
+            bn_dz_pair<-1, 0>(bn, y0s[c], y1s[c], scs[c], shs[c], (float)ov[c], (uint32_t)(in0 + c), (uint32_t)(in0 + N + c),
+                              (uint32_t)(oi + c), d0, d1);
+            const float xh0 = (y0s[c] - mus[c]) * rss[c], xh1 = (y1s[c] - mus[c]) * rss[c];
+            s1[c] += d0 + d1;
+            s2[c] += d0 * xh0 + d1 * xh1;
+        }
+    }
+    __syncthreads();                                       // every thread is done reading Cs
+    float* part = const_cast<float*>(Cs);                  // [RPP][2][BN]
+    static_assert(RPP * 2 * BN <= BM * LDC, "partials fit the C tile");
+    *reinterpret_cast<float4*>(part + (rr * 2 + 0) * BN + cg * 4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(part + (rr * 2 + 1) * BN + cg * 4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    __syncthreads();
+    mm_acc_t* rep = acc_rep(e.bn.sums, blockIdx.x % MM_ACC_REPL, 2 * (size_t)N);
+    for (int i = tid; i < 2 * BN; i += 256) {
+        const int which = i / BN, col = i % BN;
+        if (n0 + col < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP; ++r) s += part[(r * 2 + which) * BN + col];
+            acc_add<MM_ACC_GRAD>(&rep[which * N + n0 + col], s);
+        }
+    }
 }
 
 // dgrad GEMM -> LayerNorm backward in one pass (N == BN == 128, T % BM == 0: checked on the host).
@@ -433,6 +522,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
             return;
         }
     }
+    if constexpr (BM == 64 && BN == 64) {
+        if ((FEAT == EF_ANY && a.e.bn.y) || (FEAT != EF_ANY && (FEAT & EF_BNRED))) {
+            epilogue_bn_reduce<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout);
+            return;
+        }
+    }
     epilogue_rows<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
 }
 
@@ -481,6 +576,8 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
         switch (m) {
             EPI_CASE(0x001410u)          // conv block forward: bias, BatchNorm sums, fp32 out
             EPI_CASE(0x000800u)          // conv data gradient, bf16 out
+            EPI_CASE(0x1004800u)         // ... + the BatchNorm-backward reduce of the layer below (GELU)
+            EPI_CASE(0x100c800u)         // ... the same below a MaxPool1d(2)
             default: break;
         }
     }
@@ -1005,6 +1102,26 @@ int mm_prep_many_zero(const void* desc_host, int ndesc, float* zero, int64_t nze
 
 int mm_prep_many(const void* desc_host, int ndesc, hipStream_t st) { return mm_prep_many_zero(desc_host, ndesc, nullptr, 0, st); }
 
+static int conv1d_dispatch(const ConvArgs& a, hipStream_t st) {
+    // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
+    // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS
+    const int taps = a.taps, Cin = a.Cin, Cout = a.Cout, B = a.B, T = a.T;
+    const int kct = (taps == 1 && Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : (Cin % 32 == 0 ? 32 : 16));
+    const bool narrow = Cout <= 64 || taps > 1;
+#define MM_FWD(BM_, BN_, WM_, WN_)                                               \
+    switch (kct) {                                                               \
+        case 16: return launch_fwd<BM_, BN_, WM_, WN_, 16>(a, st);               \
+        case 32: return launch_fwd<BM_, BN_, WM_, WN_, 32>(a, st);               \
+        case 64: return launch_fwd<BM_, BN_, WM_, WN_, 64>(a, st);               \
+        default: return launch_fwd<BM_, BN_, WM_, WN_, 128>(a, st);              \
+    }
+    if (narrow) { MM_FWD(64, 64, 2, 2) }
+    // few row tiles (M <= 16k): halve BM so that >= 2 workgroups share a CU and overlap
+    if ((long)B * ceil_div(T, 64) * ceil_div(Cout, 128) <= 512) { MM_FWD(32, 128, 1, 4) }
+    MM_FWD(64, 128, 2, 2)
+#undef MM_FWD
+}
+
 // Generic forward implicit GEMM.  See include/mmeeg_hip.h for the contract.
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual, const float* pe,
@@ -1032,22 +1149,41 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.ln_x = nullptr; a.e.ln_stat = nullptr; a.e.ln_gamma = nullptr; a.e.ln_dgb = nullptr;
     a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
     a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
-    // tile / chunk choice: full-K staging for linears (taps == 1), 64-wide chunks
-    // for the k>1 convs with BN = 64 so that two workgroups fit one CU's LDS
-    const int kct = (taps == 1 && Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : (Cin % 32 == 0 ? 32 : 16));
-    const bool narrow = Cout <= 64 || taps > 1;
-#define MM_FWD(BM_, BN_, WM_, WN_)                                               \
-    switch (kct) {                                                               \
-        case 16: return launch_fwd<BM_, BN_, WM_, WN_, 16>(a, st);               \
-        case 32: return launch_fwd<BM_, BN_, WM_, WN_, 32>(a, st);               \
-        case 64: return launch_fwd<BM_, BN_, WM_, WN_, 64>(a, st);               \
-        default: return launch_fwd<BM_, BN_, WM_, WN_, 128>(a, st);              \
-    }
-    if (narrow) { MM_FWD(64, 64, 2, 2) }
-    // few row tiles (M <= 16k): halve BM so that >= 2 workgroups share a CU and overlap
-    if ((long)B * ceil_div(T, 64) * ceil_div(Cout, 128) <= 512) { MM_FWD(32, 128, 1, 4) }
-    MM_FWD(64, 128, 2, 2)
-#undef MM_FWD
+    return conv1d_dispatch(a, st);
+}
+
+// Data-gradient convolution of a conv block (dy (B, T, Cin) bf16 x that block's dgrad weight image -> dx (B, T, Cout)
+// bf16) with the BatchNorm-backward REDUCE pass of the block below as its epilogue: dx is that block's d(out), and its
+// sums (sum dz | sum dz * xhat over the B * T * pool pre-BN rows y_below) land in sums_below exactly as
+// mm_bn_act_bwd_reduce(y_below, out4_below, dx, nullptr, sums_below, B, T * pool, Cout, ...) would leave them.
+int mm_conv1d_dgrad_bn_reduce(const void* dy, const void* w_dgrad, int B, int T, int Cin, int Cout, int taps, int pad,
+                              void* dx_bf16, const float* y_below, const float* out4_below, float* sums_below, int act,
+                              int pool, int drop_first, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                              hipStream_t st) {
+    MM_REQUIRE(dy && w_dgrad && dx_bf16 && y_below && out4_below && sums_below, "conv1d_dgrad_bn_reduce: null");
+    MM_REQUIRE(B > 0 && T > 0 && Cout > 0 && taps >= 1 && taps <= 9 && pad >= 0 && pad < taps, "conv1d_dgrad_bn_reduce: bad dims");
+    MM_REQUIRE(Cin > 0 && Cin % 16 == 0 && Cout % 4 == 0, "conv1d_dgrad_bn_reduce: Cin=%d (x16) Cout=%d (x4)", Cin, Cout);
+    MM_REQUIRE(taps > 1 || Cout <= 64, "conv1d_dgrad_bn_reduce: the fused reduce runs on the 64 x 64 tile (taps > 1 or Cout <= 64)");
+    MM_REQUIRE(pool == 1 || pool == 2, "conv1d_dgrad_bn_reduce: pool=%d", pool);
+    MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1d_dgrad_bn_reduce: drop_p");
+    MM_REQUIRE((size_t)B * T * pool * Cout < (1ull << 32), "conv1d_dgrad_bn_reduce: 32-bit dropout indices");
+    ConvArgs a;
+    a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad;
+    a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.taps = taps; a.pad = pad;
+    a.e.scale = nullptr; a.e.shift = nullptr; a.e.residual = nullptr; a.e.pe = nullptr; a.e.stats = nullptr;
+    a.e.out_f32 = nullptr; a.e.out_bf16 = (bf16*)dx_bf16; a.e.out_pre = nullptr;
+    a.e.act = 0; a.e.pool = 1;
+    a.e.drop_thresh = 0u; a.e.drop_seed = 0u; a.e.drop_epoch = nullptr; a.e.drop_inv_keep = 1.f;
+    a.e.gradz = nullptr; a.e.gradz_act = 0;
+    a.e.ln_x = nullptr; a.e.ln_stat = nullptr; a.e.ln_gamma = nullptr; a.e.ln_dgb = nullptr;
+    a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
+    a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
+    a.e.bn.y = y_below; a.e.bn.out4 = out4_below; a.e.bn.sums = sums_below;
+    a.e.bn.act = act; a.e.bn.pool = pool; a.e.bn.drop_first = drop_first;
+    a.e.bn.thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    a.e.bn.seed = seed; a.e.bn.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.e.bn.epoch = seed_epoch;
+    return conv1d_dispatch(a, st);
 }
 
 // y = dropout(x W^T + b) + residual, fp32 rows of width 128 (a transformer sub-layer's output), with up to two

@@ -516,6 +516,44 @@ def test_bn_act_pool_train_fwd_bwd(pool, N):
     torch.testing.assert_close(dy2.float(), dy.float(), rtol=1e-2, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,T,Cin,Cout,k,pool,p,generic", [
+    (32, 512, 128, 128, 3, 2, 0.3, False),       # EEG conv block 3's data gradient over block 2 (MaxPool1d(2) between), C2 size
+    (32, 1024, 128, 64, 5, 1, 0.3, False),       # block 2's over block 1
+    (3, 100, 64, 48, 7, 1, 0.0, False),          # ragged row tile, ragged column tile, no dropout
+    (2, 70, 32, 64, 3, 2, 0.2, True),            # generic (run-time) epilogue
+])
+def test_conv1d_dgrad_with_fused_bn_backward_reduce(B, T, Cin, Cout, k, pool, p, generic, monkeypatch):
+    """mm_conv1d_dgrad_bn_reduce = mm_conv1d_fwd (data gradient) + mm_bn_act_bwd_reduce of the block below:
+    the same bf16 d(out), the same sums (up to fp32 partial-sum grouping)."""
+    hip = _hip()
+    if generic:
+        monkeypatch.setenv("MM_EPI_GENERIC", "1")
+    g = torch.Generator().manual_seed(B * T + Cout)
+    w = torch.randn(Cin, Cout, k, generator=g) / math.sqrt(Cout * k)       # the upper block's weight: (its Cout = Cin here, its Cin = Cout here)
+    _, wd = _prep_w(hip, w, Cout, Cin)
+    dy = (torch.randn(B, T, Cin, generator=g) * 0.1).cuda().to(torch.bfloat16)
+    yb = (torch.randn(B, T * pool, Cout, generator=g) * 1.2 + 0.1).cuda()
+    out4 = torch.stack([0.5 + torch.rand(Cout, generator=g), torch.randn(Cout, generator=g) * 0.2,
+                        torch.randn(Cout, generator=g) * 0.1, 0.8 + 0.4 * torch.rand(Cout, generator=g)]).cuda().contiguous()
+    seed = 4242
+    dx_a = torch.full((B, T, Cout), float("nan"), device="cuda").to(torch.bfloat16)
+    hip.call("mm_conv1d_fwd", dy, wd, B, T, Cin, Cout, k, k - 1 - k // 2, None, None, 0, None, None, 1,
+             None, None, dx_a, None, 0.0, 0, None, None, 0)
+    sums_a = torch.zeros(32, 2, Cout, device="cuda")
+    hip.call("mm_bn_act_bwd_reduce", yb, out4, dx_a, None, sums_a, B, T * pool, Cout, 1, pool, 0, p, seed, 0.0, 0, None)
+    dx_b = torch.full((B, T, Cout), float("nan"), device="cuda").to(torch.bfloat16)
+    sums_b = torch.zeros(32, 2, Cout, device="cuda")
+    hip.call("mm_conv1d_dgrad_bn_reduce", dy, wd, B, T, Cin, Cout, k, k - 1 - k // 2, dx_b, yb, out4, sums_b,
+             1, pool, 0, p, seed, None)
+    assert torch.equal(dx_a, dx_b) and torch.isfinite(dx_b.float()).all()
+    sa, sb = _grad(sums_a).cpu(), _grad(sums_b).cpu()
+    assert sa.abs().max() > 1e-2
+    torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()))
+    # the wide-Linear tiles have no such epilogue: refused, not ignored
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_conv1d_dgrad_bn_reduce", dy, wd, B, T, Cin, 128, 1, 0, dx_b, yb, out4, sums_b, 1, pool, 0, p, seed, None)
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 
