@@ -75,15 +75,48 @@ __device__ __forceinline__ float act_grad(float z, int act) {
     }
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions without the LDS crossbar: __shfl_xor() is a ds_bpermute round trip (~100 cycles, and the
+// compiler waits for each one), six of them per wave_sum; rows of 16 lanes reduce with four DPP adds (VALU), row
+// pairs with v_permlane16_swap, the two halves of the wave with v_permlane32_swap (gfx950).  Every lane of the group
+// ends up with the group's total; the pairing is the xor butterfly's (1, 2, 4, 8, 16, 32).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;   // quad_perm [1,0,3,2] / [2,3,0,1]
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<DPP_XOR1>(v);
+    v += dpp_f32<DPP_XOR2>(v);
+    v += dpp_f32<DPP_HALF_MIRROR>(v);          // lane i <- lane 7 - i of its half row: the other quad (quads are uniform by now)
+    v += dpp_f32<DPP_MIRROR>(v);               // lane i <- lane 15 - i: the other half row
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f32<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
     return v;
+}
+// sum over each aligned group of 32 lanes (rows 0+1, rows 2+3)
+__device__ __forceinline__ float half32_sum(float v) {
+    v = row16_sum(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half32_max(float v) {
+    v = row16_max(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = half32_sum(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = half32_max(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 // counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.

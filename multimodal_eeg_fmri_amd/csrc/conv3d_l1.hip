@@ -284,21 +284,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
 
 // S[tap] = sum over output voxels v of x~[v + tap - 1] (zero padded, bf16-rounded as the conv sees it):
 // input voxel u = (d, h, w) feeds tap (kd, kh, kw) iff u - (k - 1) is inside the volume, i.e. the
-// indicator factorises per axis.  One thread owns one (b, d, h) row: three row sums (all w, all but
-// the last, all but the first) and nine conditional adds of them - 27 adds per ROW, not per voxel.
+// indicator factorises per axis.  Per (b, d, h) row: three row sums (all w, all but the last, all but
+// the first) and nine conditional adds of them - 27 adds per ROW, not per voxel.
+// W % 4 == 0: eight lanes share a row (one float4 each per 32 voxels: a wave reads 8 rows x 128 contiguous bytes
+// per instruction; a thread per row read 64 different cache lines per instruction and took 12 us for 4 MB), the
+// row sum is a 3-step shuffle and lane 0 of the group keeps the tap sums.  Otherwise: a thread per row.
 __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict__ x, float* __restrict__ out /* [REPL][32] */,
                                                         int B, int D, int H, int W) {
     const size_t nrows = (size_t)B * D * H;
     float s[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) s[t] = 0.f;
-    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
+    auto add_row = [&](size_t row, float all, float first, float last) __attribute__((always_inline)) {
         const unsigned rq = (unsigned)row / (unsigned)H;            // 32-bit divisions: rows = B D H < 2^31 (host-checked)
         const int h = (int)((unsigned)row - rq * (unsigned)H), d = (int)(rq % (unsigned)D);
-        const float* xr = x + row * W;
-        float all = 0.f;
-        for (int w = 0; w < W; ++w) all += (float)(bf16)xr[w];
-        const float rw[3] = {all - (float)(bf16)xr[W - 1], all, all - (float)(bf16)xr[0]};   // kw = 0, 1, 2
+        const float rw[3] = {all - last, all, all - first};         // kw = 0, 1, 2
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
             const bool okd = (kd == 0) ? d <= D - 2 : (kd == 2 ? d >= 1 : true);
@@ -310,17 +310,64 @@ __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict_
                     for (int kw = 0; kw < 3; ++kw) s[(kd * 3 + kh) * 3 + kw] += rw[kw];
             }
         }
-    }
-    __shared__ float red[4][32];                       // one row per wave, summed in wave order: no LDS atomics
+    };
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int sub = threadIdx.x & 7, W4 = W >> 2;
+        const size_t g0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3, gstep = ((size_t)gridDim.x * blockDim.x) >> 3;
+        const size_t nloop = (nrows + gstep - 1) / gstep;           // same trip count for the 8 lanes of a group AND the wave (shuffles)
+        for (size_t it = 0; it < nloop; ++it) {
+            const size_t row = g0 + it * gstep;
+            const bool ok = row < nrows;
+            const float4* xr = reinterpret_cast<const float4*>(x + (ok ? row : 0) * W);
+            float part = 0.f, first = 0.f, last = 0.f;
+            for (int w4 = sub; w4 < W4; w4 += 8) {
+                const float4 v = xr[w4];
+                const float a = (float)(bf16)v.x, b = (float)(bf16)v.y, c = (float)(bf16)v.z, e = (float)(bf16)v.w;
+                part += (a + b) + (c + e);
+                if (w4 == 0) first = a;
+                if (w4 == W4 - 1) last = e;
+            }
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        const float v = wave_sum(s[t]);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = v;
+            for (int o = 1; o < 8; o <<= 1) {
+                part += __shfl_xor(part, o, 64);
+                first += __shfl_xor(first, o, 64);                  // one owner each, zeros elsewhere
+                last += __shfl_xor(last, o, 64);
+            }
+            if (ok && sub == 0) add_row(row, part, first, last);
+        }
+    } else {
+        for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
+            const float* xr = x + row * W;
+            float all = 0.f;
+            for (int w = 0; w < W; ++w) all += (float)(bf16)xr[w];
+            add_row(row, all, (float)(bf16)xr[0], (float)(bf16)xr[W - 1]);
+        }
+    }
+    // block sum of the 27 x (32 or 256) partials through LDS in a fixed order (27 wave_sum()s were 162 dependent
+    // ds_bpermute round trips per wave: ~9 us, the whole kernel, whatever the grid)
+    const bool fast = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const int holders = fast ? 32 : 256;               // fast path: lane 0 of every 8-lane group holds the sums
+    __shared__ float red[256 * 28];
+    __shared__ float red2[8][28];
+    if (!fast || (threadIdx.x & 7) == 0) {
+        float* dst = red + (fast ? threadIdx.x >> 3 : threadIdx.x) * 28;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) dst[t] = s[t];
     }
     __syncthreads();
-    if (threadIdx.x < 27)
-        acc_add<MM_ACC_STAT>(acc_rep(out, blockIdx.x % MM_ACC_REPL, 32) + threadIdx.x,
-                             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (threadIdx.x < 27 * 8) {
+        const int tap = threadIdx.x % 27, part = threadIdx.x / 27, per = holders / 8;
+        float a = 0.f;
+        for (int i = 0; i < per; ++i) a += red[(part * per + i) * 28 + tap];
+        red2[part][tap] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        float a = 0.f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) a += red2[part][threadIdx.x];
+        acc_add<MM_ACC_STAT>(acc_rep(out, blockIdx.x % MM_ACC_REPL, 32) + threadIdx.x, a);
+    }
 }
 
 // dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1   (all inputs: fixed-point accumulators x MM_ACC_REPL)
@@ -397,9 +444,15 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     return mm_check_launch("conv3d_l1");
 }
 
+static int l1_tapsum_grid(int B, int D, int H, int W) {
+    const long rows = (long)B * D * H, threads = (W & 3) == 0 ? rows * 8 : rows;
+    const long g = (threads + 255) / 256;
+    return (int)(g < 1024 ? g : 1024);
+}
+
 int mm_conv3d_l1_tapsum(const float* x, float* tapsum, int B, int D, int H, int W, hipStream_t st) {
     MM_REQUIRE(x && tapsum && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_tapsum: null/invalid");
-    hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(l1_tapsum_kernel, dim3(l1_tapsum_grid(B, D, H, W)), dim3(256), 0, st,
                        x, tapsum, B, D, H, W);
     return mm_check_launch("conv3d_l1_tapsum");
 }
@@ -419,7 +472,7 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
     a.epoch = seed_epoch;
     const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
     if (!tapsum_ready)
-        hipLaunchKernelGGL(l1_tapsum_kernel, dim3(ceil_div(B * D * H, 256) < 256 ? ceil_div(B * D * H, 256) : 256), dim3(256), 0,
+        hipLaunchKernelGGL(l1_tapsum_kernel, dim3(l1_tapsum_grid(B, D, H, W)), dim3(256), 0,
                            st, x, tapsum, B, D, H, W);
     if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<4, true>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3d_l1_kernel<4, false>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);

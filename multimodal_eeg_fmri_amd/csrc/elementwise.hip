@@ -332,11 +332,7 @@ __global__ void layernorm_bwd_kernel(const bf16* __restrict__ dy_bf16, const flo
 // D == 128 fast path (the transformer width): one 32-lane half-wave per row, one
 // 16-byte vector per lane, two rows per wave in flight, 5-step shuffle reductions.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float half_sum(float v) { return half32_sum(v); }
 
 __global__ void layernorm128_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                         const float* __restrict__ b, bf16* __restrict__ out_bf16,

@@ -174,13 +174,11 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
         if constexpr (BN == 128) {
             if (EF_ON(EF_LNF, e.lnf_out)) {                       // host guarantees N == 128, pool == 1: 32 lanes hold this row
                 float sm = (o[0] + o[1]) + (o[2] + o[3]);
-#pragma unroll
-                for (int k = 16; k > 0; k >>= 1) sm += __shfl_xor(sm, k, 64);
+                sm = half32_sum(sm);
                 const float mean = sm * (1.f / 128.f);
                 const float d0 = o[0] - mean, d1 = o[1] - mean, d2 = o[2] - mean, d3 = o[3] - mean;
                 float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-#pragma unroll
-                for (int k = 16; k > 0; k >>= 1) sq += __shfl_xor(sq, k, 64);
+                sq = half32_sum(sq);
                 const float rstd = rsqrtf(sq * (1.f / 128.f) + e.lnf_eps);
                 const float4 g4 = *reinterpret_cast<const float4*>(e.lnf_gamma + n);
                 const float4 b4 = *reinterpret_cast<const float4*>(e.lnf_beta + n);
@@ -351,8 +349,7 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
             s1 += gh; s2 += gh * xh[c];
             ag[c] += dyv[c] * xh[c]; ab[c] += dyv[c];
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 = half32_sum(s1); s2 = half32_sum(s2);
         s1 *= (1.f / 128.f); s2 *= (1.f / 128.f);
         float o4[4];
 #pragma unroll

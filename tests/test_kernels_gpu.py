@@ -554,6 +554,21 @@ def test_conv1d_dgrad_with_fused_bn_backward_reduce(B, T, Cin, Cout, k, pool, p,
         hip.call("mm_conv1d_dgrad_bn_reduce", dy, wd, B, T, Cin, 128, 1, 0, dx_b, yb, out4, sums_b, 1, pool, 0, p, seed, None)
 
 
+@pytest.mark.parametrize("B,D,H,W", [(32, 32, 32, 32), (3, 5, 7, 12), (2, 6, 4, 48), (2, 4, 6, 10), (1, 1, 1, 4)])
+def test_conv3d_l1_tap_sums(B, D, H, W):
+    """mm_conv3d_l1_tapsum: S[tap] = sum over output voxels of the zero-padded, bf16-rounded input at that tap
+    (eight lanes per row when W % 4 == 0, a thread per row otherwise)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    x = torch.randn(B, D, H, W, generator=g) + 0.3
+    xp = F.pad(_bf(x).double(), (1, 1, 1, 1, 1, 1))
+    ref = torch.stack([xp[:, kd:kd + D, kh:kh + H, kw:kw + W].sum() for kd in range(3) for kh in range(3) for kw in range(3)])
+    ws = torch.zeros(32, 32, device="cuda")
+    hip.call("mm_conv3d_l1_tapsum", x.cuda(), ws, B, D, H, W)
+    got = _stat(ws)[:27].cpu().double()
+    torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()) + 1e-4)
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 
