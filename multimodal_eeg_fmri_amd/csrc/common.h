@@ -37,7 +37,7 @@ int mm_check_launch(const char* what);            // hipGetLastError -> code
 // erff; the exp(-x^2/2) is shared with the Gaussian pdf that GELU' needs.
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf_unnorm) {
     const float u = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * u);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * u);      // v_rcp_f32 (1 ulp); __frcp_rn() is the ~10-instruction IEEE division
     const float e = __expf(-u * u);                                   // = exp(-x^2 / 2)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erfa = 1.0f - poly * e;                               // erf(|x| / sqrt 2)

@@ -148,6 +148,22 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     float scs[4], shs[4], mus[4], rss[4], c0[4], c1[4];
     __shared__ float csum[APPLY ? 2048 : 1];           // sum dz | sum dz*xhat per channel (N <= 1024)
+    // One iteration of input loads stays in flight ahead of the arithmetic, and the first one is issued BEFORE the
+    // prologue below: a workgroup used to pay its global round trips one after the other (replica sums, BatchNorm
+    // constants, first rows) - with four workgroups per CU all starting together nothing hid them (10 us for 17 MB).
+    struct In { float4 y0, y1, gf; bf16x4 gb; };
+    const size_t rstep = (size_t)gridDim.x * rows_per_blk;
+    size_t row = (size_t)blockIdx.x * rows_per_blk + ri;
+    auto load = [&](size_t r, In& v) __attribute__((always_inline)) {
+        const size_t in0 = r * a.pool * a.N + n4, oidx = r * a.N + n4;
+        if (a.dout_f32) v.gf = *reinterpret_cast<const float4*>(a.dout_f32 + oidx);
+        else v.gb = *reinterpret_cast<const bf16x4*>(a.dout_bf16 + oidx);
+        v.y0 = *reinterpret_cast<const float4*>(a.y + in0);
+        if (a.pool == 2) v.y1 = *reinterpret_cast<const float4*>(a.y + in0 + a.N);
+    };
+    In cur, nxt;
+    bool have = active && row < nrows;
+    if (have) load(row, cur);
     if (APPLY && a.train) {
         // replica reduction in the prologue: a separate 5 us compaction launch sat between the two passes
         for (int i = threadIdx.x; i < 2 * a.N; i += 256) {
@@ -164,24 +180,19 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
         c0[q] = (APPLY && a.train) ? csum[n4 + q] : 0.f;
         c1[q] = (APPLY && a.train) ? csum[a.N + n4 + q] : 0.f;
     }
-    if (active)
-        for (size_t row = (size_t)blockIdx.x * rows_per_blk + ri; row < nrows; row += (size_t)gridDim.x * rows_per_blk) {
+        for (; have; row += rstep) {
+            const bool hn = row + rstep < nrows;
+            if (hn) load(row + rstep, nxt);
             const size_t in0 = row * a.pool * a.N + n4;             // (r * S + so * pool) = row * pool: no division
             const size_t oidx = row * a.N + n4;
             float g[4];
-            if (a.dout_f32) {
-                const float4 t = *reinterpret_cast<const float4*>(a.dout_f32 + oidx);
-                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
-            } else {
-                const bf16x4 t = *reinterpret_cast<const bf16x4*>(a.dout_bf16 + oidx);
-                g[0] = (float)t[0]; g[1] = (float)t[1]; g[2] = (float)t[2]; g[3] = (float)t[3];
-            }
+            if (a.dout_f32) { g[0] = cur.gf.x; g[1] = cur.gf.y; g[2] = cur.gf.z; g[3] = cur.gf.w; }
+            else { g[0] = (float)cur.gb[0]; g[1] = (float)cur.gb[1]; g[2] = (float)cur.gb[2]; g[3] = (float)cur.gb[3]; }
             if (a.thresh2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) g[q] *= dropout_scale(a.seed2, (uint32_t)(oidx + q), a.thresh2, a.inv_keep2);
-            const float4 y0 = *reinterpret_cast<const float4*>(a.y + in0);
-            float4 y1 = y0;
-            if (a.pool == 2) y1 = *reinterpret_cast<const float4*>(a.y + in0 + a.N);
+            const float4 y0 = cur.y0;
+            const float4 y1 = a.pool == 2 ? cur.y1 : y0;
             const float y0s[4] = {y0.x, y0.y, y0.z, y0.w}, y1s[4] = {y1.x, y1.y, y1.z, y1.w};
             float d0[4], d1[4];
 #pragma unroll
@@ -215,6 +226,8 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
                     if (a.pool == 2) *reinterpret_cast<float4*>(a.dy_f32 + in0 + a.N) = make_float4(d1[0], d1[1], d1[2], d1[3]);
                 }
             }
+            cur = nxt;
+            have = hn;
         }
     if (!APPLY) {
         // block reduction through plain LDS stores + a column walk.  (LDS float atomics with the
@@ -578,7 +591,7 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
     const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
     const size_t rows = (size_t)R * (S / pool);
     int grid = (int)((rows + rpb - 1) / rpb);
-    if (grid > 1024) grid = 1024;
+    { static const int cap = getenv("MM_BN_GRID") ? atoi(getenv("MM_BN_GRID")) : 768; if (grid > cap) grid = cap; }   // three workgroups per CU (sweep 256..1024: profiles/r03_bn_bwd_sweep.txt)
     // GELU with pool 1 / 2 (every BatchNorm of the encoders on the training path) is compiled in; anything else is generic
     if (act == MM_ACT_GELU && pool == 1) {
         if (apply) hipLaunchKernelGGL((bn_act_bwd_kernel<true, MM_ACT_GELU, 1>), dim3(grid), dim3(256), 0, st, a);
