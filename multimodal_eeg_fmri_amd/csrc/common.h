@@ -160,18 +160,21 @@ __device__ __forceinline__ void bn_dz_pair(const Args& a, float y0, float y1, fl
         return;
     }
     const float z1 = y1 * sc + sh;
-    float a0 = apply_act(z0, act), a1 = apply_act(z1, act);
     float m0 = 1.f, m1 = 1.f;
-    if (a.thresh) {
-        if (a.drop_first) {
-            m0 = dropout_scale(a.seed, i0, a.thresh, a.inv_keep);
-            m1 = dropout_scale(a.seed, i1, a.thresh, a.inv_keep);
-            a0 *= m0; a1 *= m1;
-        } else {
-            g *= dropout_scale(a.seed, io, a.thresh, a.inv_keep);
-        }
+    bool first;
+    if (a.thresh && a.drop_first) {
+        float a0 = apply_act(z0, act), a1 = apply_act(z1, act);
+        m0 = dropout_scale(a.seed, i0, a.thresh, a.inv_keep);
+        m1 = dropout_scale(a.seed, i1, a.thresh, a.inv_keep);
+        a0 *= m0; a1 *= m1;
+        first = a0 >= a1;                              // ties -> first (torch max_pool)
+    } else {
+        if (a.thresh) g *= dropout_scale(a.seed, io, a.thresh, a.inv_keep);
+        // GELU rises on [0, inf) and is negative below 0: when the larger pre-activation is >= 0 it holds the larger
+        // activation and nothing needs evaluating; only a pair of negative values does (the falling branch can win)
+        first = z0 >= z1;
+        if (act != MM_ACT_GELU || fmaxf(z0, z1) < 0.f) first = apply_act(z0, act) >= apply_act(z1, act);
     }
-    const bool first = a0 >= a1;                       // ties -> first (torch max_pool)
     // ONE derivative, at the winner (two selects of act_grad(z0) / act_grad(z1) evaluate both)
     const float d = g * (first ? m0 : m1) * act_grad(first ? z0 : z1, act);
     dz0 = first ? d : 0.f;

@@ -328,9 +328,16 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
                     if (z > zmax) { zmax = z; jmax = j; ymax = yv; }       // strict: first occurrence wins, as PyTorch
                     if (z < zmin) { zmin = z; jmin = j; ymin = yv; }
                 }
-                const float amax = apply_act(zmax, a.act), amin = apply_act(zmin, a.act);
-                const bool lo = amin > amax;
-                float v = lo ? amin : amax;
+                // GELU: with zmax >= 0 the largest pre-activation holds the largest activation (conv3d_l1.hip); the second
+                // evaluation is needed for an all-negative window only
+                const float amax = apply_act(zmax, a.act);
+                bool lo = false;
+                float v = amax;
+                if (a.act != MM_ACT_GELU || zmax < 0.f) {
+                    const float amin = apply_act(zmin, a.act);
+                    lo = amin > amax;
+                    v = lo ? amin : amax;
+                }
                 ys[c] = lo ? ymin : ymax;
                 args[c >> 2] |= (uint32_t)(lo ? jmin : jmax) << (8 * (c & 3));
                 if (a.thresh) v *= dropout_scale(a.seed, (uint32_t)(oidx + c), a.thresh, a.inv_keep);

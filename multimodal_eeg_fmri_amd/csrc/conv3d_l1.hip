@@ -166,21 +166,34 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                     const int oh = (h0 >> 1) + 2 * ip + ra, ow = (w0 >> 1) + 4 * wave + rb + 2 * lh, od = d0 >> 1;
                     const bool ok = FULLT || (oh < Ho && ow < Wo);
                     float y[8], z[8];
-                    float zmax = -INFINITY, zmin = INFINITY;
+                    float zmax = -INFINITY, zmin = INFINITY, ymax = 0.f;
                     int jmax = 0, jmin = 0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {           // j = (dd << 2) | (hh << 1) | ww
                         const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
                         y[j] = acc[ti][r] + bias;
                         z[j] = y[j] * sc + sh;
-                        if (z[j] > zmax) { zmax = z[j]; jmax = j; }       // strict: the first occurrence wins, as PyTorch
+                        if (z[j] > zmax) { zmax = z[j]; ymax = y[j]; jmax = j; }   // strict: the first occurrence wins, as PyTorch
                         if (z[j] < zmin) { zmin = z[j]; jmin = j; }
                     }
                     // GELU falls on (-inf, -0.75] and rises after it, so the window's largest activation sits at its largest
-                    // or at its smallest pre-activation: two evaluations, no divergent eight-way fallback (as pool3_bn_act)
-                    float best = gelu_erf(zmax);
-                    const float amin = gelu_erf(zmin);
-                    if (amin > best) { best = amin; jmax = jmin; }
+                    // or at its smallest pre-activation (as pool3_bn_act).  With zmax >= 0 it is the largest: GELU(zmax) >= 0
+                    // and anything below it is smaller (rising branch) or negative.  Only an all-negative window (1 in 256
+                    // for unit-normal pre-activations) needs the two evaluations - the backward modes then evaluate none
+                    // to find the winner, the forward one.
+                    float best = MODE == 1 ? gelu_erf(zmax) : 0.f;
+                    float zs = zmax, ys = ymax;
+                    if (zmax < 0.f) {
+                        if (MODE != 1) best = gelu_erf(zmax);
+                        const float amin = gelu_erf(zmin);
+                        if (amin > best) {
+                            best = amin; jmax = jmin; zs = zmin;
+                            ys = y[0];
+#pragma unroll
+                            for (int j = 1; j < 8; ++j)
+                                if (j == jmin) ys = y[j];
+                        }
+                    }
                     const size_t oidx = ((((size_t)b * Do + od) * Ho + oh) * Wo + ow) * 32 + lr;
                     if (MODE == 1) {
                         if (ok) {
@@ -190,10 +203,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                     } else {
                         float g = ok ? (float)a.dout[oidx] : 0.f;
                         if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)oidx, a.thresh, a.inv_keep);
-                        float zs = z[0], ys = y[0];
-#pragma unroll
-                        for (int j = 1; j < 8; ++j)
-                            if (j == jmax) { zs = z[j]; ys = y[j]; }
                         const float dzs = g * gelu_erf_grad(zs);
                         if (MODE == 2 || MODE == 4) {
                             acc1 += dzs;

@@ -90,9 +90,16 @@ __global__ void bn_act_fwd_kernel(BnActArgs a) {
             const float y1s[4] = {y1.x, y1.y, y1.z, y1.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v0 = bnact_one<ACT>(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), a.drop_first);
-                const float v1 = bnact_one<ACT>(a, y1s[q], scs[q], shs[q], (uint32_t)(in0 + a.N + q), a.drop_first);
-                float m = fmaxf(v0, v1);
+                float m;
+                const int act = ACT >= 0 ? ACT : a.act;
+                const float z0 = y0s[q] * scs[q] + shs[q], z1 = y1s[q] * scs[q] + shs[q];
+                if (act == MM_ACT_GELU && !(a.drop_first && a.thresh) && fmaxf(z0, z1) >= 0.f) {
+                    m = gelu_erf(fmaxf(z0, z1));        // the larger pre-activation, if >= 0, holds the larger GELU: one evaluation
+                } else {
+                    const float v0 = bnact_one<ACT>(a, y0s[q], scs[q], shs[q], (uint32_t)(in0 + q), a.drop_first);
+                    const float v1 = bnact_one<ACT>(a, y1s[q], scs[q], shs[q], (uint32_t)(in0 + a.N + q), a.drop_first);
+                    m = fmaxf(v0, v1);
+                }
                 if (!a.drop_first && a.thresh) m *= dropout_scale(a.seed, (uint32_t)(oidx + q), a.thresh, a.inv_keep);
                 o[q] = m;
             }

@@ -1,0 +1,6 @@
+#!/usr/bin/env bash
+set -uo pipefail
+root="${GRAFT_REPO_ROOT:-$(pwd)}"
+out="$root/gpurun_out"; mkdir -p "$out"; cd "$root"
+python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --fit-steps 0 --stamps 2>&1 | grep -v "^{" | grep -v amdgpu > "$out/r3_stamps31.txt"
+cat "$out/r3_stamps31.txt"
