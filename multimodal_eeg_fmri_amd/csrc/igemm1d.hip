@@ -687,18 +687,27 @@ __global__ void prep_many_kernel(PrepTable tab, int ndesc, float4* __restrict__ 
     while (t + 1 < ndesc && (int)blockIdx.x >= tab.first[t + 1]) ++t;      // (uniform: <= 64 scalar compares)
     const PrepDesc d = tab.d[t];
     const int blk = blockIdx.x - tab.first[t], nblk = tab.first[t + 1] - tab.first[t];
-    const int total_f = d.Cout * d.k * d.Cinp;
-    const int total_d = d.wd ? d.Cinp * d.k * d.Coutp : 0;
-#pragma unroll 4
-    for (int i = blk * blockDim.x + threadIdx.x; i < total_f + total_d; i += nblk * blockDim.x) {
-        if (i < total_f) {
-            const int c = i % d.Cinp, tap = (i / d.Cinp) % d.k, n = i / (d.Cinp * d.k);
-            d.wf[conv_image_index(d.Cout, d.k, d.Cinp, n, tap, c)] = (bf16)(c < d.Cin ? d.w[((size_t)n * d.Cin + c) * d.k + tap] : 0.f);
+    // one item = 8 consecutive elements of an image's innermost index (c of the forward image, n of the data-gradient
+    // image; both padded widths are multiples of 16 and both layouts keep an aligned group of 8 contiguous): two integer
+    // divisions and one 16-byte store per 8 elements (three divisions and a 2-byte store per ELEMENT made this launch -
+    // the first of the step, in front of both streams - VALU-bound at 10 us)
+    const int cg = d.Cinp / 8, ng = d.wd ? d.Coutp / 8 : 0;
+    const int items_f = d.Cout * d.k * cg, items_d = d.wd ? d.Cinp * d.k * ng : 0;
+    for (int i = blk * blockDim.x + threadIdx.x; i < items_f + items_d; i += nblk * blockDim.x) {
+        bf16x8 v;
+        if (i < items_f) {
+            const int c0 = (i % cg) * 8, r = i / cg, tap = r % d.k, n = r / d.k;
+            const float* src = d.w + ((size_t)n * d.Cin + c0) * d.k + tap;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)(c0 + j < d.Cin ? src[(size_t)j * d.k] : 0.f);
+            *reinterpret_cast<bf16x8*>(d.wf + conv_image_index(d.Cout, d.k, d.Cinp, n, tap, c0)) = v;
         } else {
-            const int e = i - total_f;
-            const int n = e % d.Coutp, tap = (e / d.Coutp) % d.k, c = e / (d.Coutp * d.k);
-            d.wd[conv_image_index(d.Cinp, d.k, d.Coutp, c, tap, n)] =
-                (bf16)((c < d.Cin && n < d.Cout) ? d.w[((size_t)n * d.Cin + c) * d.k + (d.k - 1 - tap)] : 0.f);
+            const int e = i - items_f;
+            const int n0 = (e % ng) * 8, r = e / ng, tap = r % d.k, c = r / d.k;
+            const float* src = d.w + ((size_t)n0 * d.Cin + c) * d.k + (d.k - 1 - tap);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)((c < d.Cin && n0 + j < d.Cout) ? src[(size_t)j * d.Cin * d.k] : 0.f);
+            *reinterpret_cast<bf16x8*>(d.wd + conv_image_index(d.Cinp, d.k, d.Coutp, c, tap, n0)) = v;
         }
     }
 }
