@@ -148,6 +148,14 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
                   void* out_bf16, float* out_f32, int R, int S, int N, int act, int pool,
                   int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
                   const uint32_t* seed_epoch, hipStream_t stream);
+/* the same pass for the last conv block of EnhancedERPEncoder (N = 128, no pooling) with the first
+ * TemporalTransformerBlock's norm1 (enhanced_models_v4.py:97-99, LayerNorm(128)) of every finished row fused in:
+ * out_f32 = the transformer input, ln_out_bf16 = norm1(out) (the QKV projection's operand), ln_stat [R*S][2] =
+ * mean, rstd (nullable; the backward's).  Replaces mm_bn_act_fwd + mm_layernorm_fwd. */
+int mm_bn_act_fwd_ln(const float* y, const float* scale, const float* shift, const float* pe, float* out_f32,
+                     int R, int S, int act, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
+                     const uint32_t* seed_epoch, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                     void* ln_out_bf16, float* ln_stat, hipStream_t stream);
 /* drop2 = the PositionalEncoding dropout applied AFTER the table add (:55)  * mm_bn_act_bwd_apply: sums = the accumulator workspace [32][2][N] as written by mm_bn_act_bwd_reduce
  * (sums_nrep = 32: the kernel adds the replicas up itself) or a compact fp32 [2][N] (sums_nrep = 1). */
 int mm_bn_act_bwd_reduce(const float* y, const float* out4, const void* dout_bf16,

@@ -53,6 +53,10 @@ struct BnActArgs {
     uint32_t thresh, seed; float inv_keep;
     uint32_t thresh2, seed2; float inv_keep2;
     const uint32_t* epoch;
+    // LayerNorm-128 of every finished row (the transformer stack's first norm1), N == 128 and pool == 1 only:
+    // 32 consecutive lanes hold one row
+    const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 0.f;
+    bf16* ln_out = nullptr; float* ln_stat = nullptr;
 };
 
 template <int ACT>
@@ -118,6 +122,19 @@ __global__ void bn_act_fwd_kernel(BnActArgs a) {
         if (a.out_bf16) {
             bf16x4 b = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
             *reinterpret_cast<bf16x4*>(a.out_bf16 + oidx) = b;
+        }
+        if (a.ln_out) {
+            // (host: N == 128, pool == 1, total a multiple of 32: every 32-lane group runs this together on one row;
+            //  arithmetic as epilogue_rows' fused LayerNorm in igemm1d.hip)
+            const float mean = half32_sum((o[0] + o[1]) + (o[2] + o[3])) * (1.f / 128.f);
+            const float d0 = o[0] - mean, d1 = o[1] - mean, d2 = o[2] - mean, d3 = o[3] - mean;
+            const float rstd = rsqrtf(half32_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.f / 128.f) + a.ln_eps);
+            const float4 g4 = *reinterpret_cast<const float4*>(a.ln_gamma + n4);
+            const float4 b4 = *reinterpret_cast<const float4*>(a.ln_beta + n4);
+            bf16x4 hv = {(bf16)(d0 * rstd * g4.x + b4.x), (bf16)(d1 * rstd * g4.y + b4.y),
+                         (bf16)(d2 * rstd * g4.z + b4.z), (bf16)(d3 * rstd * g4.w + b4.w)};
+            *reinterpret_cast<bf16x4*>(a.ln_out + oidx) = hv;
+            if (a.ln_stat && n4 == 0) { a.ln_stat[2 * (size_t)rs] = mean; a.ln_stat[2 * (size_t)rs + 1] = rstd; }
         }
     }
 }
@@ -562,20 +579,47 @@ int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, fl
     return mm_check_launch("bn_finalize");
 }
 
-int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe, void* out_bf16,
-                  float* out_f32, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
-                  uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, hipStream_t st) {
+static int bn_act_fwd_common(const float* y, const float* scale, const float* shift, const float* pe, void* out_bf16,
+                             float* out_f32, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
+                             uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch,
+                             const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, float* ln_stat,
+                             hipStream_t st) {
     MM_REQUIRE(y && scale && shift && (out_bf16 || out_f32), "bn_act_fwd: null");
     MM_REQUIRE(N % 4 == 0 && (pool == 1 || (pool == 2 && S % 2 == 0)), "bn_act_fwd: N%%4, pool");
     BnActArgs a{y, scale, shift, pe, (bf16*)out_bf16, out_f32, R, S, N, act, pool, drop_first,
                 thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
                 thresh_of(drop2_p), seed2, drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f, seed_epoch};
+    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.ln_out = (bf16*)ln_out; a.ln_stat = ln_stat;
     const size_t total = (size_t)R * (S / pool) * (N / 4);
     MM_REQUIRE(total < (1ull << 31), "bn_act_fwd: %zu vectors (32-bit indices)", total);
-    if (act == MM_ACT_GELU && pool == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 1>), dim3(grid_for(total)), dim3(256), 0, st, a);
-    else if (act == MM_ACT_GELU && pool == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 2>), dim3(grid_for(total)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((bn_act_fwd_kernel<>), dim3(grid_for(total)), dim3(256), 0, st, a);
+    int grid = grid_for(total);
+    if (ln_out) {
+        MM_REQUIRE(N == 128 && pool == 1 && ln_gamma && ln_beta, "bn_act_fwd_ln: N=%d (128) pool=%d (1)", N, pool);
+        // every 32-lane group must walk its rows together (cross-lane sums): total is a multiple of 32; a grid that
+        // covers it in whole passes keeps the loop trip count uniform inside a group
+        const size_t blocks = (total + 255) / 256;
+        if ((size_t)grid > blocks) grid = (int)blocks;
+    }
+    if (act == MM_ACT_GELU && pool == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if (act == MM_ACT_GELU && pool == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 2>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<>), dim3(grid), dim3(256), 0, st, a);
     return mm_check_launch("bn_act_fwd");
+}
+
+int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const float* pe, void* out_bf16,
+                  float* out_f32, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
+                  uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, hipStream_t st) {
+    return bn_act_fwd_common(y, scale, shift, pe, out_bf16, out_f32, R, S, N, act, pool, drop_first, drop_p, seed, drop2_p,
+                             seed2, seed_epoch, nullptr, nullptr, 0.f, nullptr, nullptr, st);
+}
+
+int mm_bn_act_fwd_ln(const float* y, const float* scale, const float* shift, const float* pe, float* out_f32, int R, int S,
+                     int act, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch,
+                     const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out_bf16, float* ln_stat,
+                     hipStream_t st) {
+    MM_REQUIRE(out_f32 && ln_out_bf16, "bn_act_fwd_ln: null output");
+    return bn_act_fwd_common(y, scale, shift, pe, nullptr, out_f32, R, S, 128, act, 1, 1, drop_p, seed, drop2_p, seed2,
+                             seed_epoch, ln_gamma, ln_beta, ln_eps, ln_out_bf16, ln_stat, st);
 }
 
 static int bn_bwd_common(bool apply, const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,

@@ -375,13 +375,16 @@ def additive_attn_mask(mask, L: int, like: torch.Tensor):
 # ------------------------------------------------------------------- stages
 def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=False, drop_p=0.0,
                 drop_first=True, pe=None, pe_drop_p=0.0, want_f32=False, want_bf16=True, need_dgrad=False,
-                save=None):
+                save=None, next_norm=None):
     """Conv1d -> BatchNorm1d -> act [-> MaxPool(2)] [-> Dropout] on (B, T, Cp) bf16.
 
     eval : one kernel (BN folded into the GEMM epilogue).
     train: GEMM (+bias, per-channel sum/sumsq) -> finalize -> BN/act/pool apply.
     eval with ``save`` (a backward will follow: frozen BatchNorm, saliency maps): the
     train-shaped pipeline with the RUNNING statistics and no statistic update.
+    ``next_norm`` (a LayerNorm(128) that consumes the fp32 output row-wise - the transformer stack's first norm1):
+    computed by the same launch when the block is 128 wide and un-pooled; the result comes back as ``out["prenorm"]``
+    = (bf16 rows, mean / rstd or None).
     Returns (out dict, saved-for-backward dict or None)."""
     save = training if save is None else save
     k = conv.kernel_size[0]
@@ -404,11 +407,20 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
     seed2 = _next_seed() if pe_drop_p > 0 else 0
     of = _empty((B, T // pool, cout), _F32, xb) if want_f32 else None
     ob = _empty((B, T // pool, cout), _BF, xb) if want_bf16 else None
-    _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, B, T, cout, ACT[act], pool,
-              1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2, EP())
+    prenorm = None
+    if next_norm is not None and cout == 128 and pool == 1 and want_f32 and not want_bf16 and drop_first \
+            and tuple(next_norm.normalized_shape) == (128,):
+        hn = _empty((B * T, cout), _BF, xb)
+        stn = _empty((B * T, 2), _F32, xb)
+        _hip.call("mm_bn_act_fwd_ln", y, out4[0], out4[1], pe, of, B, T, ACT[act], float(drop_p), seed,
+                  float(pe_drop_p), seed2, EP(), next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn)
+        prenorm = (hn, stn)
+    else:
+        _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, B, T, cout, ACT[act], pool,
+                  1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2, EP())
     saved = dict(xb=xb, y=y, out4=out4, act=act, pool=pool, drop_p=drop_p, seed=seed,
                  drop2=(float(pe_drop_p), seed2), drop_first=drop_first, conv=conv, bn=bn, train=training)
-    return {"f32": of, "bf16": ob, "pre": None}, saved
+    return {"f32": of, "bf16": ob, "pre": None, "prenorm": prenorm}, saved
 
 
 def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False,
@@ -517,15 +529,15 @@ def pe_table(pos_encoder, L: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------ EEG encoders
-def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool):
-    """shared tail of both EEG encoders: transformer stack -> mean pool -> Linear -> GELU"""
+def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool, prenorm=None):
+    """shared tail of both EEG encoders: transformer stack -> mean pool -> Linear -> GELU.
+    ``prenorm``: (norm1(h) bf16, stats) of the FIRST block when the producer of ``h`` already formed it."""
     blocks = []
     B, L, D = h.shape
     nblk = len(m.transformer_layers)
     # 64-bit fixed-point mean accumulator (one replica): the last block's GEMM epilogue adds into it
     pooled = _zeros((B, 2 * D), h) if nblk and L % 32 == 0 and D == 128 else None
     layers = list(m.transformer_layers)
-    prenorm = None
     for i, blk in enumerate(layers):
         if i < nblk - 1:                                 # the next block's norm1 rides in this block's last GEMM
             h, s, prenorm = transformer_block_fwd(h, blk, training, need_dgrad, save=save, prenorm=prenorm,
@@ -556,9 +568,10 @@ def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save
     L = r["bf16"].shape[1]
     r, s = conv_bn_act(r["bf16"], cl[9], cl[10], training=training, drop_p=p,
                        pe=pe_table(m.pos_encoder, L), pe_drop_p=(m.pos_encoder.dropout.p if training else 0.0),
-                       want_f32=True, want_bf16=False, need_dgrad=need_dgrad, save=save)
+                       want_f32=True, want_bf16=False, need_dgrad=need_dgrad, save=save,
+                       next_norm=m.transformer_layers[0].norm1 if len(m.transformer_layers) else None)
     saved.append(s)
-    out, blocks, s, h = _encoder_tail_impl(m, r["f32"], training, need_dgrad, save)
+    out, blocks, s, h = _encoder_tail_impl(m, r["f32"], training, need_dgrad, save, prenorm=r.get("prenorm"))
     return out, dict(convs=saved, blocks=blocks, head=s, x_shape=tuple(x.shape), tokens=h)
 
 

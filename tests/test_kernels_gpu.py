@@ -569,6 +569,32 @@ def test_conv3d_l1_tap_sums(B, D, H, W):
     torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()) + 1e-4)
 
 
+@pytest.mark.parametrize("R,S,p,p2", [(32, 512, 0.3, 0.1), (3, 37, 0.0, 0.0)])
+def test_bn_act_with_fused_first_layernorm(R, S, p, p2):
+    """mm_bn_act_fwd_ln = mm_bn_act_fwd (fp32 out, positional add, both dropouts) + mm_layernorm_fwd of its rows"""
+    hip = _hip()
+    N = 128
+    g = torch.Generator().manual_seed(R * S)
+    y = (torch.randn(R, S, N, generator=g) * 1.3 + 0.2).cuda()
+    sc, sh = (0.5 + torch.rand(N, generator=g)).cuda(), (torch.randn(N, generator=g) * 0.2).cuda()
+    pe = torch.randn(S, N, generator=g).cuda()
+    gam, bet = (0.5 + torch.rand(N, generator=g)).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    o_a = torch.full((R, S, N), float("nan"), device="cuda")
+    hip.call("mm_bn_act_fwd", y, sc, sh, pe, None, o_a, R, S, N, 1, 1, 1, p, 11, p2, 22, None)
+    h_a = torch.empty(R * S, N, dtype=torch.bfloat16, device="cuda")
+    st_a = torch.empty(R * S, 2, device="cuda")
+    hip.call("mm_layernorm_fwd", o_a.view(R * S, N), gam, bet, h_a, None, st_a, R * S, N, 1e-5)
+    o_b = torch.full((R, S, N), float("nan"), device="cuda")
+    h_b = torch.full((R * S, N), float("nan"), device="cuda").to(torch.bfloat16)
+    st_b = torch.full((R * S, 2), float("nan"), device="cuda")
+    hip.call("mm_bn_act_fwd_ln", y, sc, sh, pe, o_b, R, S, 1, p, 11, p2, 22, None, gam, bet, 1e-5, h_b, st_b)
+    assert torch.equal(o_a, o_b)
+    torch.testing.assert_close(st_b, st_a, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(h_b.float(), h_a.float(), rtol=1e-2, atol=1e-2)
+    ref = F.layer_norm(o_a.view(R * S, N).cpu(), (N,), gam.cpu(), bet.cpu(), 1e-5)
+    torch.testing.assert_close(h_b.float().cpu(), ref, rtol=1e-2, atol=2e-2)
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 
