@@ -296,14 +296,19 @@ def main():
     # (imports, capture), and the chip needs ~25 ms of this workload to settle - per-10-step event timings read 0.86, 0.84, 0.82
     # and then 0.815 ms per step (tools/r3/jitter.py).  A short --warmup would put that ramp inside a short timed region.
     precondition = 0 if args.profile else PRECONDITION_STEPS        # (profiler runs count kernels per step: keep their traces short)
+    import gc
+    # a generation-2 collection in the timed loop is a 20-30 ms host stall (seen 1 run in 8): collector frozen and off.
+    # Done BEFORE the conditioning / warm-up steps: the collection itself stalls the host for longer than the queued
+    # steps last, and a GPU that has idled >= 20 ms runs its next ~10 steps 4 % slower (tools/r3/jitter2.py: blocks of
+    # 10 steps after a synchronize 0.79 ms, after synchronize + 20 ms of sleep 0.83 ms) - with --steps 20 that was half
+    # the timed region.
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for i in range(precondition):
         tr.train_step(*dev_batches[i % NBATCH])
     for i in range(args.warmup):
         tr.train_step(*dev_batches[i % NBATCH])
-    import gc
-    gc.collect()
-    gc.freeze()                               # a generation-2 collection in the timed loop is a 20-30 ms host stall (seen 1 run in 8)
-    gc.disable()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -347,10 +352,10 @@ def main():
                 torch.cuda.current_stream().wait_event(ready[i % 2])
                 tr.train_step(*stage[i % 2])
                 consumed[i % 2].record()
-        h2d_loop(max(6, min(args.warmup, 20)))        # its own warm-up: copy stream, pinned copies, event pool (first use
-        gc.collect()                                    # of each costs milliseconds - more than a 20-step timed region)
+        gc.collect()                                    # (before the warm-up: no host stall between warm-up and timed loop)
         gc.disable()
-        sync()
+        h2d_loop(max(6, min(args.warmup, 20)))        # its own warm-up: copy stream, pinned copies, event pool (first use
+        sync()                                          # of each costs milliseconds - more than a 20-step timed region)
         t0 = time.perf_counter()
         h2d_loop(args.steps)
         sync()
