@@ -166,34 +166,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                     const int oh = (h0 >> 1) + 2 * ip + ra, ow = (w0 >> 1) + 4 * wave + rb + 2 * lh, od = d0 >> 1;
                     const bool ok = FULLT || (oh < Ho && ow < Wo);
                     float y[8], z[8];
-                    float zmax = -INFINITY, zmin = INFINITY, ymax = 0.f;
-                    int jmax = 0, jmin = 0;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {           // j = (dd << 2) | (hh << 1) | ww
                         const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
                         y[j] = acc[ti][r] + bias;
                         z[j] = y[j] * sc + sh;
-                        if (z[j] > zmax) { zmax = z[j]; ymax = y[j]; jmax = j; }   // strict: the first occurrence wins, as PyTorch
-                        if (z[j] < zmin) { zmin = z[j]; jmin = j; }
                     }
                     // GELU falls on (-inf, -0.75] and rises after it, so the window's largest activation sits at its largest
                     // or at its smallest pre-activation (as pool3_bn_act).  With zmax >= 0 it is the largest: GELU(zmax) >= 0
                     // and anything below it is smaller (rising branch) or negative.  Only an all-negative window (1 in 256
                     // for unit-normal pre-activations) needs the two evaluations - the backward modes then evaluate none
                     // to find the winner, the forward one.
-                    float best = MODE == 1 ? gelu_erf(zmax) : 0.f;
-                    float zs = zmax, ys = ymax;
-                    if (zmax < 0.f) {
-                        if (MODE != 1) best = gelu_erf(zmax);
+                    // The winner is the FIRST member that equals the extreme value (as PyTorch's max-pool): a max3 tree and
+                    // eight equality tests whose first-hit bookkeeping is lane-mask (scalar) work - tracking value, y and
+                    // index through eight compare / select steps for both extremes was a third of the VALU stream.
+                    float zsel = fmaxf(fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3])), fmaxf(fmaxf(z[4], z[5]), fmaxf(z[6], z[7])));
+                    float best = MODE == 1 ? gelu_erf(zsel) : 0.f;
+                    if (zsel < 0.f) {
+                        const float zmin = fminf(fminf(fminf(z[0], z[1]), fminf(z[2], z[3])), fminf(fminf(z[4], z[5]), fminf(z[6], z[7])));
+                        if (MODE != 1) best = gelu_erf(zsel);
                         const float amin = gelu_erf(zmin);
-                        if (amin > best) {
-                            best = amin; jmax = jmin; zs = zmin;
-                            ys = y[0];
-#pragma unroll
-                            for (int j = 1; j < 8; ++j)
-                                if (j == jmin) ys = y[j];
-                        }
+                        if (amin > best) { best = amin; zsel = zmin; }
                     }
+                    bool hit[8], found = false;
+                    float ys = y[0];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        hit[j] = !found && z[j] == zsel;
+                        found = found || hit[j];
+                        if (hit[j]) ys = y[j];
+                    }
+                    const float zs = zsel;
                     const size_t oidx = ((((size_t)b * Do + od) * Ho + oh) * Wo + ow) * 32 + lr;
                     if (MODE == 1) {
                         if (ok) {
@@ -214,14 +217,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                                 const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
                                 const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
                                 const bool in = FULLT || (d < a.D && h < a.H && w < a.W);
-                                dyf[ti >> 1][r >> 3][r & 7] = (bf16)((in && j == jmax) ? dzs : 0.f);
+                                dyf[ti >> 1][r >> 3][r & 7] = (bf16)((in && hit[j]) ? dzs : 0.f);
                                 xhf[ti >> 1][r >> 3][r & 7] = (bf16)(in ? (y[j] - mu) * rs : 0.f);
                             }
                         } else if (MODE == 3) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
-                                const float dzj = (j == jmax) ? dzs : 0.f;
+                                const float dzj = hit[j] ? dzs : 0.f;
                                 float dy = a.train ? sc * (dzj - c0 - (y[j] - mu) * rs * c1) : sc * dzj;
                                 const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
                                 if (!FULLT && !(d < a.D && h < a.H && w < a.W)) dy = 0.f;
