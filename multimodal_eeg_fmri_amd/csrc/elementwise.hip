@@ -642,7 +642,7 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
     const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
     const size_t rows = (size_t)R * (S / pool);
     int grid = (int)((rows + rpb - 1) / rpb);
-    { static const int cap = getenv("MM_BN_GRID") ? atoi(getenv("MM_BN_GRID")) : 768; if (grid > cap) grid = cap; }   // three workgroups per CU (sweep 256..1024: profiles/r03_bn_bwd_sweep.txt)
+    { static const int cap = getenv("MM_BN_GRID") ? atoi(getenv("MM_BN_GRID")) : 768; if (grid > cap) grid = cap; }   // three workgroups per CU (sweep 256..1024: profiles/r03_second_half_ab.txt)
     // GELU with pool 1 / 2 (every BatchNorm of the encoders on the training path) is compiled in; anything else is generic
     if (act == MM_ACT_GELU && pool == 1) {
         if (apply) hipLaunchKernelGGL((bn_act_bwd_kernel<true, MM_ACT_GELU, 1>), dim3(grid), dim3(256), 0, st, a);
