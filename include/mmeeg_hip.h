@@ -197,6 +197,17 @@ int mm_conv1d_dgrad_bn_reduce(const void* dy, const void* w_dgrad, int B, int T,
                               int pool, int drop_first, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                               hipStream_t stream);
 
+/* mm_linear_dgrad_ln_bwd for the FIRST transformer block of EnhancedERPEncoder, whose LayerNorm input is the last conv
+ * block's output (enhanced_models_v4.py:143-147: conv_layers[-1] -> pos_encoder -> transformer_layers[0].norm1): the rows dx
+ * (fp32) are that block's d(out), so its BatchNorm-backward reduce pass (mm_bn_act_bwd_reduce(y_below, out4_below, NULL, dx,
+ * sums_below, 1, M, 128, act, 1, 1, bn_drop_p, bn_seed, bn_drop2_p, bn_seed2, ...)) rides in the same launch.
+ * y_below (M, 128) fp32; sums_below = zeroed [32][2][128] workspace; drop2 = the PositionalEncoding dropout. */
+int mm_linear_dgrad_ln_bwd_bn_reduce(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                                     const float* gamma, const float* dres, float* dx, float* dgb_repl,
+                                     const uint32_t* seed_epoch, const float* y_below, const float* out4_below,
+                                     float* sums_below, int act, float bn_drop_p, uint32_t bn_seed, float bn_drop2_p,
+                                     uint32_t bn_seed2, hipStream_t stream);
+
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,
  * lse [B][H][L] fp32.  drop_p = attention-probability dropout (train mode).  The

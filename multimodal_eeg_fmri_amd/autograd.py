@@ -296,7 +296,7 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"]
 
 
-def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, drop_p, seed):
+def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, drop_p, seed, bn_below=None):
     """backward of ``Linear(LayerNorm(x))``: weight / bias gradients of the Linear (``h`` = LN(x) bf16 is its
     input), then d x = LN_backward(dy W) + dres.  Width 128 with M % 32 == 0 (the transformer blocks) runs
     the data-gradient GEMM with the LayerNorm backward as its epilogue; anything else takes two launches."""
@@ -307,6 +307,17 @@ def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, dro
         _, wd, cinp, coutp = ops.weights.get(weight, True)
         if coutp != dy.shape[1] or cinp != D:
             raise _hip.HipLibraryError(f"linear_ln_bwd: dY width {dy.shape[1]} / LN width {D} != weight image {coutp} x {cinp}")
+        if bn_below is not None and dx_bf16 is None and dx is not None and not _NO_BNRED:
+            # dx = the fp32 d(out) of the conv block below the stack: its BatchNorm-backward sums in the same launch
+            sb = bn_below["s"]
+            yb = sb["y"]
+            d2 = sb.get("drop2", (0.0, 0))
+            if yb.shape[2] == 128 and sb["pool"] == 1 and yb.shape[0] * yb.shape[1] == M:
+                sums_b = _zeros((REPL, 2, 128), yb)
+                _hip.call("mm_linear_dgrad_ln_bwd_bn_reduce", dy, wd, M, coutp, x, stat, ln.weight, dres, dx, dgb, ops.EP(),
+                          yb, sb["out4"], sums_b, ACT[sb["act"]], float(sb["drop_p"]), int(sb["seed"]), float(d2[0]), int(d2[1]))
+                bn_below["sums"] = sums_b
+                return
         _hip.call("mm_linear_dgrad_ln_bwd", dy, wd, M, coutp, x, stat, ln.weight, dres, dx, dx_bf16, dgb,
                   drop_p, seed, ops.EP())
         return
@@ -314,13 +325,15 @@ def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, dro
     _hip.call("mm_layernorm_bwd", dh, None, x, stat, ln.weight, dres, dx, dx_bf16, dgb, M, D, drop_p, seed, ops.EP())
 
 
-def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, emit_for=None):
+def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, emit_for=None, bn_below=None):
     """dx2 fp32 (M, D) -> (dx0 fp32 (M, D), bf16(dx0 * mask) or None).
 
     ``dy2`` = bf16(dx2 * dropout_mask(p, s3)) if the producer of dx2 already emitted it;
     ``emit_for`` = (p, seed) of the consumer of dx0 (the FFN2 mask of the block below):
     the last LayerNorm-backward then also writes that masked bf16 operand, so no
-    stand-alone cast/mask pass runs between GEMMs."""
+    stand-alone cast/mask pass runs between GEMMs.
+    ``bn_below`` = {"s": saved dict of the conv block whose output is this block's input}: the last launch also forms
+    that block's BatchNorm-backward sums (returned as ``bn_below["sums"]`` when the shapes allow the fusion)."""
     blk = s["blk"]
     p = s["p"]
     s1, s2, s3 = s["seeds"]
@@ -350,7 +363,7 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     ep, es = emit_for if emit_for is not None else (0.0, 0)
     dgb = _zeros((REPL, 2, D), dx2)
     _linear_ln_bwd(bag, dqkv.view(M, 3 * D), s["h1"], None, (at.in_proj_weight, at.in_proj_bias), s["x"], s["st1"],
-                   blk.norm1, dx1, dx0, emit, dgb, float(ep), int(es))
+                   blk.norm1, dx1, dx0, emit, dgb, float(ep), int(es), bn_below=bn_below)
     _ln_param_grads(bag, blk.norm1, dgb, D)
     return dx0, emit
 
@@ -409,13 +422,14 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     d = d.view(B * L, D)
     if dy2 is not None:
         dy2 = dy2.view(B * L, D)
+    c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
+    bn3 = {"s": c3}
     for i in range(len(blocks) - 1, -1, -1):
         below = (blocks[i - 1]["p"], blocks[i - 1]["seeds"][2]) if i > 0 else None
-        d, dy2 = transformer_block_bwd(bag, blocks[i], d, dy2=dy2, emit_for=below)
+        d, dy2 = transformer_block_bwd(bag, blocks[i], d, dy2=dy2, emit_for=below, bn_below=bn3 if i == 0 else None)
     if after_blocks is not None:
         after_blocks()
-    c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]
-    g, sm = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D), below=c2)
+    g, sm = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D), sums=bn3.get("sums"), below=c2)
     g, sm = conv_bn_act_bwd(bag, c2, dout_bf16=g, sums=sm, below=c1)
     if after_conv2 is not None:
         after_conv2()

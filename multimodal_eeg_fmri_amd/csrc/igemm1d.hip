@@ -33,6 +33,8 @@ struct BnRed {
     uint32_t thresh = 0, seed = 0;
     float inv_keep = 1.f;
     const uint32_t* epoch = nullptr;
+    uint32_t thresh2 = 0, seed2 = 0;   // the dropout BEHIND the block (PositionalEncoding's), applied to d(out) first:
+    float inv_keep2 = 1.f;             // epilogue_ln_bwd only (fp32 d(out))
 };
 
 struct EpiArgs {
@@ -330,6 +332,26 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
     const bool drop = EF_ON(EF_DROP, e.drop_thresh);
     const uint32_t dseed = drop ? mm_eff_seed(e.drop_seed, e.drop_epoch) : 0u;
     float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+    // BatchNorm-backward reduce of the conv block whose output (+ positional table, dropout) IS this LayerNorm's input:
+    // the rows leaving here are that block's fp32 d(out) (EnhancedERPEncoder: conv block 3 under the first transformer block)
+    const bool bnred = EF_ON(EF_BNRED, e.bn.y);
+    BnDz bn;
+    bn.act = ANY ? e.bn.act : (int)((FEAT >> 24) & 15u);
+    bn.pool = 1; bn.drop_first = 1; bn.thresh = e.bn.thresh; bn.inv_keep = e.bn.inv_keep;
+    bn.seed = bnred ? mm_eff_seed(e.bn.seed, e.bn.epoch) : 0u;
+    const uint32_t bseed2 = bnred ? mm_eff_seed(e.bn.seed2, e.bn.epoch) : 0u;
+    float4 by[BM / 8];
+    float bsc[4] = {0, 0, 0, 0}, bsh[4] = {0, 0, 0, 0}, bmu[4] = {0, 0, 0, 0}, brs[4] = {0, 0, 0, 0};
+    float t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+    if (bnred) {
+#pragma unroll
+        for (int k = 0; k < BM / 8; ++k)
+            by[k] = *reinterpret_cast<const float4*>(e.bn.y + ((size_t)b * T + t0 + rr + 8 * k) * 128 + cg * 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(e.bn.out4 + cg * 4), c1 = *reinterpret_cast<const float4*>(e.bn.out4 + 128 + cg * 4);
+        const float4 c2 = *reinterpret_cast<const float4*>(e.bn.out4 + 256 + cg * 4), c3 = *reinterpret_cast<const float4*>(e.bn.out4 + 384 + cg * 4);
+        bsc[0] = c0.x; bsc[1] = c0.y; bsc[2] = c0.z; bsc[3] = c0.w; bsh[0] = c1.x; bsh[1] = c1.y; bsh[2] = c1.z; bsh[3] = c1.w;
+        bmu[0] = c2.x; bmu[1] = c2.y; bmu[2] = c2.z; bmu[3] = c2.w; brs[0] = c3.x; brs[1] = c3.y; brs[2] = c3.z; brs[3] = c3.w;
+    }
 #pragma unroll
     for (int row = rr; row < BM; row += 8) {
         const size_t m = (size_t)b * T + t0 + row;
@@ -363,6 +385,30 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
                                              : o4[c]);
             *reinterpret_cast<bf16x4*>(e.out_bf16 + base) = ob;
         }
+        if (bnred) {
+            const float4 yv = by[(row - rr) / 8];
+            const float ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float g = o4[c];
+                if (e.bn.thresh2) g *= dropout_scale(bseed2, (uint32_t)(base + c), e.bn.thresh2, e.bn.inv_keep2);
+                float d0, d1;
+                bn_dz_pair<-1, 1>(bn, ys[c], ys[c], bsc[c], bsh[c], g, (uint32_t)(base + c), 0u, 0u, d0, d1);
+                t1[c] += d0;
+                t2[c] += d0 * ((ys[c] - bmu[c]) * brs[c]);
+            }
+        }
+    }
+    if (bnred) {
+        __syncthreads();                                   // every thread is done reading Cs
+        float* part = const_cast<float*>(Cs);              // [8 row groups][sum dz 128 | sum dz xhat 128]
+        *reinterpret_cast<float4*>(part + rr * 256 + cg * 4) = make_float4(t1[0], t1[1], t1[2], t1[3]);
+        *reinterpret_cast<float4*>(part + rr * 256 + 128 + cg * 4) = make_float4(t2[0], t2[1], t2[2], t2[3]);
+        __syncthreads();
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += part[r * 256 + tid];
+        acc_add<MM_ACC_GRAD>(acc_rep(e.bn.sums, blockIdx.x % MM_ACC_REPL, 256) + tid, s);
     }
     if (e.ln_dgb) {
         __syncthreads();                                   // every thread is done reading Cs
@@ -566,6 +612,7 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
             EPI_CASE(0x000800u)          // plain data gradient, bf16 out
             EPI_CASE(0x002d01u)          // data gradient + LayerNorm backward: skip gradient in, fp32 and masked bf16 out
             EPI_CASE(0x002401u)          // the same without the bf16 copy (first block)
+            EPI_CASE(0x1006401u)         // ... + the BatchNorm-backward reduce of the conv block below the stack (GELU)
             default: break;
         }
     } else if constexpr (BM == 64 && BN == 64 && KCT == 64) {
@@ -1247,9 +1294,9 @@ int mm_linear_fwd_ln(const void* x, const void* w, int M, int K, const float* bi
 // consumed LN(x) (dy (M, K) bf16, w = that Linear's dgrad image (128 rows of K)) with the LayerNorm
 // backward as its epilogue.  Same results as mm_conv1d_fwd followed by mm_layernorm_bwd, except that the
 // d(LN output) rows stay fp32 instead of a bf16 round trip.
-int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
-                           const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
-                           float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+static int linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                               const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
+                               float drop_p, uint32_t seed, const uint32_t* seed_epoch, const BnRed* bn, hipStream_t st) {
     MM_REQUIRE(dy && w && x && stat && gamma && (dx || dx_bf16), "linear_dgrad_ln_bwd: null");
     MM_REQUIRE(M > 0 && M % 32 == 0 && K > 0 && K % 16 == 0, "linear_dgrad_ln_bwd: M=%d (multiple of 32) K=%d (multiple of 16)", M, K);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_dgrad_ln_bwd: drop_p");
@@ -1266,6 +1313,7 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
     a.e.ln_x = x; a.e.ln_stat = stat; a.e.ln_gamma = gamma; a.e.ln_dgb = dgb_repl;
     a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
     a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
+    if (bn) a.e.bn = *bn;
     const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
     switch (kct) {
         case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);
@@ -1273,6 +1321,34 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
         case 64: return launch_fwd<32, 128, 1, 4, 64>(a, st);
         default: return launch_fwd<32, 128, 1, 4, 128>(a, st);
     }
+}
+
+int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                           const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
+                           float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+    return linear_dgrad_ln_bwd(dy, w, M, K, x, stat, gamma, dres, dx, dx_bf16, dgb_repl, drop_p, seed, seed_epoch, nullptr, st);
+}
+
+// mm_linear_dgrad_ln_bwd whose rows dx are the fp32 d(out) of a 128-channel, un-pooled conv block (Conv1d -> BatchNorm1d
+// -> act -> Dropout(p) -> + positional table -> Dropout(p2)): that block's BatchNorm-backward reduce pass rides in the same
+// launch.  y_below (M, 128) fp32, out4_below, sums_below (zeroed [32][2][128] workspace) and act / drop_p / seed / drop2_p /
+// seed2 as in mm_bn_act_bwd_reduce(y_below, out4_below, NULL, dx, sums_below, 1, M, 128, act, 1, 1, ...).
+int mm_linear_dgrad_ln_bwd_bn_reduce(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                                     const float* gamma, const float* dres, float* dx, float* dgb_repl,
+                                     const uint32_t* seed_epoch, const float* y_below, const float* out4_below,
+                                     float* sums_below, int act, float bn_drop_p, uint32_t bn_seed, float bn_drop2_p,
+                                     uint32_t bn_seed2, hipStream_t st) {
+    MM_REQUIRE(dx && y_below && out4_below && sums_below, "linear_dgrad_ln_bwd_bn_reduce: null");
+    MM_REQUIRE(bn_drop_p >= 0.f && bn_drop_p < 1.f && bn_drop2_p >= 0.f && bn_drop2_p < 1.f, "linear_dgrad_ln_bwd_bn_reduce: drop_p");
+    MM_REQUIRE((size_t)M * 128 < (1ull << 32), "linear_dgrad_ln_bwd_bn_reduce: 32-bit dropout indices");
+    BnRed bn;
+    bn.y = y_below; bn.out4 = out4_below; bn.sums = sums_below; bn.act = act; bn.pool = 1; bn.drop_first = 1;
+    bn.thresh = bn_drop_p > 0.f ? (uint32_t)((double)bn_drop_p * 4294967296.0) : 0u;
+    bn.seed = bn_seed; bn.inv_keep = bn_drop_p > 0.f ? 1.f / (1.f - bn_drop_p) : 1.f;
+    bn.thresh2 = bn_drop2_p > 0.f ? (uint32_t)((double)bn_drop2_p * 4294967296.0) : 0u;
+    bn.seed2 = bn_seed2; bn.inv_keep2 = bn_drop2_p > 0.f ? 1.f / (1.f - bn_drop2_p) : 1.f;
+    bn.epoch = seed_epoch;
+    return linear_dgrad_ln_bwd(dy, w, M, K, x, stat, gamma, dres, dx, nullptr, dgb_repl, 0.f, 0u, seed_epoch, &bn, st);
 }
 
 // rows of T per workgroup.  Atomic mode: every workgroup ends with 64 x 64 x taps fp32 atomics, so for

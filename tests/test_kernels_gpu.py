@@ -595,6 +595,41 @@ def test_bn_act_with_fused_first_layernorm(R, S, p, p2):
     torch.testing.assert_close(h_b.float().cpu(), ref, rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,K,p,p2,generic", [(16384, 384, 0.3, 0.1, False), (96, 384, 0.0, 0.0, False), (64, 128, 0.2, 0.3, True)])
+def test_linear_dgrad_ln_backward_with_fused_bn_backward_reduce(M, K, p, p2, generic, monkeypatch):
+    """mm_linear_dgrad_ln_bwd_bn_reduce = mm_linear_dgrad_ln_bwd (fp32 rows) + mm_bn_act_bwd_reduce of the 128-channel
+    conv block those rows are the d(out) of (incl. the positional-encoding dropout in front of it)."""
+    hip = _hip()
+    if generic:
+        monkeypatch.setenv("MM_EPI_GENERIC", "1")
+    g = torch.Generator().manual_seed(M + K)
+    w = torch.randn(K, 128, 1, generator=g) / math.sqrt(128)                # the Linear 128 -> K whose input is LN(x)
+    _, wd = _prep_w(hip, w, 128, K)
+    dy = (torch.randn(M, K, generator=g) * 0.1).cuda().to(torch.bfloat16)
+    x = torch.randn(M, 128, generator=g).cuda()
+    stat = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    gam = (0.5 + torch.rand(128, generator=g)).cuda()
+    dres = (torch.randn(M, 128, generator=g) * 0.1).cuda()
+    yb = (torch.randn(M, 128, generator=g) * 1.2 + 0.1).cuda()
+    out4 = torch.stack([0.5 + torch.rand(128, generator=g), torch.randn(128, generator=g) * 0.2,
+                        torch.randn(128, generator=g) * 0.1, 0.8 + 0.4 * torch.rand(128, generator=g)]).cuda().contiguous()
+    dx_a = torch.full((M, 128), float("nan"), device="cuda")
+    dgb_a = torch.zeros(32, 2, 128, device="cuda")
+    hip.call("mm_linear_dgrad_ln_bwd", dy, wd, M, K, x, stat, gam, dres, dx_a, None, dgb_a, 0.0, 0, None)
+    sums_a = torch.zeros(32, 2, 128, device="cuda")
+    hip.call("mm_bn_act_bwd_reduce", yb, out4, None, dx_a, sums_a, 1, M, 128, 1, 1, 1, p, 31, p2, 32, None)
+    dx_b = torch.full((M, 128), float("nan"), device="cuda")
+    dgb_b = torch.zeros(32, 2, 128, device="cuda")
+    sums_b = torch.zeros(32, 2, 128, device="cuda")
+    hip.call("mm_linear_dgrad_ln_bwd_bn_reduce", dy, wd, M, K, x, stat, gam, dres, dx_b, dgb_b, None, yb, out4, sums_b,
+             1, p, 31, p2, 32)
+    assert torch.equal(dx_a, dx_b) and torch.isfinite(dx_b).all()
+    assert torch.equal(dgb_a.view(torch.int32), dgb_b.view(torch.int32))
+    sa, sb = _grad(sums_a).cpu(), _grad(sums_b).cpu()
+    assert sa.abs().max() > 1e-3
+    torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()))
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 
