@@ -197,6 +197,15 @@ int mm_conv1d_dgrad_bn_reduce(const void* dy, const void* w_dgrad, int B, int T,
                               int pool, int drop_first, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                               hipStream_t stream);
 
+/* mm_linear_dgrad_ln_bwd of norm2 / linear1 with the attention out-projection's data gradient as a second GEMM in the
+ * same launch (TemporalTransformerBlock backward, enhanced_models_v4.py:99-103: x1 = x0 + dropout(out_proj(attn)),
+ * norm2(x1)): do_bf16 (M, 128) = dx_bf16 @ w2, w2 = out_proj's data-gradient weight image (128 x 128), dx_bf16 = the
+ * rows masked with out_proj's dropout (drop_p, seed).  Bit-identical to mm_conv1d_fwd(dx_bf16, w2, 1, M, 128, 128, 1, 0,
+ * ..., out_bf16 = do_bf16) after mm_linear_dgrad_ln_bwd. */
+int mm_linear_dgrad_ln_bwd_gemm2(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                                 const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
+                                 float drop_p, uint32_t seed, const uint32_t* seed_epoch, const void* w2, void* do_bf16,
+                                 hipStream_t stream);
 /* mm_linear_dgrad_ln_bwd for the FIRST transformer block of EnhancedERPEncoder, whose LayerNorm input is the last conv
  * block's output (enhanced_models_v4.py:143-147: conv_layers[-1] -> pos_encoder -> transformer_layers[0].norm1): the rows dx
  * (fp32) are that block's d(out), so its BatchNorm-backward reduce pass (mm_bn_act_bwd_reduce(y_below, out4_below, NULL, dx,

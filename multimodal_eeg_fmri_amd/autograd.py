@@ -238,6 +238,7 @@ def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *,
     return (r["f32"] if dx_f32 else r["bf16"]).view(M, cinp)
 
 
+_NO_GEMM2 = bool(os.environ.get("MM_NO_GEMM2"))     # A/B knob: the out-projection's data gradient as its own launch
 _NO_BNRED = bool(os.environ.get("MM_NO_BNRED"))     # A/B knob: the BatchNorm-backward reduce as its own launch
 
 
@@ -296,7 +297,7 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"]
 
 
-def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, drop_p, seed, bn_below=None):
+def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, drop_p, seed, bn_below=None, gemm2=None):
     """backward of ``Linear(LayerNorm(x))``: weight / bias gradients of the Linear (``h`` = LN(x) bf16 is its
     input), then d x = LN_backward(dy W) + dres.  Width 128 with M % 32 == 0 (the transformer blocks) runs
     the data-gradient GEMM with the LayerNorm backward as its epilogue; anything else takes two launches."""
@@ -318,6 +319,15 @@ def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, dro
                           yb, sb["out4"], sums_b, ACT[sb["act"]], float(sb["drop_p"]), int(sb["seed"]), float(d2[0]), int(d2[1]))
                 bn_below["sums"] = sums_b
                 return
+        if gemm2 is not None and dx_bf16 is not None and not _NO_GEMM2:
+            # ``gemm2`` = (128 x 128 data-gradient image, holder list): the data gradient of the Linear under this
+            # LayerNorm's skip path (the attention out-projection), computed from dx_bf16 before it leaves the workgroup
+            w2, holder = gemm2
+            do = _empty((M, 128), _BF, dy)
+            _hip.call("mm_linear_dgrad_ln_bwd_gemm2", dy, wd, M, coutp, x, stat, ln.weight, dres, dx, dx_bf16, dgb,
+                      drop_p, seed, ops.EP(), w2, do)
+            holder.append(do)
+            return
         _hip.call("mm_linear_dgrad_ln_bwd", dy, wd, M, coutp, x, stat, ln.weight, dres, dx, dx_bf16, dgb,
                   drop_p, seed, ops.EP())
         return
@@ -347,11 +357,22 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     dx1 = _empty((M, D), _F32, dx2)
     dyo = _empty((M, D), _BF, dx2)                      # bf16(dx1 * mask1): out-proj backward operand
     dgb = _zeros((REPL, 2, D), dx2)
+    # attention output projection:  x1 = x0 + drop(o Wo^T + bo): at width 128 its data gradient is a second GEMM inside the
+    # launch above it (FFN-1 data gradient + norm2 backward), fed by the masked rows before they leave the workgroup
+    holder = []
+    g2 = None
+    if D == 128 and M % 32 == 0:
+        _, wd_o, cinp_o, coutp_o = ops.weights.get(at.out_proj.weight, True)
+        if cinp_o == 128 and coutp_o == 128:
+            g2 = (wd_o, holder)
     _linear_ln_bwd(bag, dz, s["h2"], blk.linear1, None, s["x1"], s["st2"], blk.norm2, dx2, dx1, dyo, dgb,
-                   float(p), int(s1))
+                   float(p), int(s1), gemm2=g2)
     _ln_param_grads(bag, blk.norm2, dgb, D)
-    # attention output projection:  x1 = x0 + drop(o Wo^T + bo)
-    do = linear_bwd(bag, dyo, s["o"].view(M, D), at.out_proj.weight, at.out_proj.bias)
+    if holder:
+        do = holder[0]
+        linear_bwd(bag, dyo, s["o"].view(M, D), at.out_proj.weight, at.out_proj.bias, need_dx=False)
+    else:
+        do = linear_bwd(bag, dyo, s["o"].view(M, D), at.out_proj.weight, at.out_proj.bias)
     dqkv = _empty((B, L, 3 * D), _BF, dx2)
     delta = _empty((B, blk.nhead, L), _F32, dx2)
     dh = D // blk.nhead

@@ -73,6 +73,11 @@ struct EpiArgs {
     const float* lnf_beta;
     float lnf_eps;
     BnRed bn;
+    // second GEMM behind epilogue_ln_bwd (BM = 32, BN = 128): out2 (M, 128) bf16 = out_bf16 rows @ w2 (a 128 x 128 data-
+    // gradient weight image) - the data gradient of the Linear whose output, after dropout, was added to this LayerNorm's
+    // input (the attention out-projection under norm2): its operand never leaves the workgroup
+    const bf16* w2 = nullptr;
+    bf16* out2 = nullptr;
 };
 
 struct ConvArgs {
@@ -89,13 +94,14 @@ struct ConvArgs {
 // (FFN-1 forward, 8.4 M outputs: 25.7 us generic, 17.5 us specialised).
 enum : unsigned { EF_RES = 1, EF_PE = 2, EF_PRE = 4, EF_GRADZ = 8, EF_STATS = 16, EF_POOLOUT = 32, EF_LNF = 64, EF_POOL2 = 128,
                   EF_DROP = 256, EF_SCALE = 512, EF_F32 = 1024, EF_BF16 = 2048, EF_SHIFT = 4096, EF_LNBWD = 8192,
-                  EF_BNRED = 16384, EF_BNPOOL2 = 32768 /* bits 24-27: the fused BatchNorm-backward's activation */, EF_ANY = 0xFFFFFFFFu };
+                  EF_BNRED = 16384, EF_BNPOOL2 = 32768 /* bits 24-27: the fused BatchNorm-backward's activation */,
+                  EF_GEMM2 = 1u << 28, EF_ANY = 0xFFFFFFFFu };
 static unsigned epi_mask(const EpiArgs& e) {
     return (e.residual ? EF_RES : 0) | (e.pe ? EF_PE : 0) | (e.out_pre ? EF_PRE : 0) | (e.gradz ? EF_GRADZ : 0) | (e.stats ? EF_STATS : 0) |
            (e.pool_out ? EF_POOLOUT : 0) | (e.lnf_out ? EF_LNF : 0) | (e.pool == 2 ? EF_POOL2 : 0) | (e.drop_thresh ? EF_DROP : 0) |
            (e.scale ? EF_SCALE : 0) | (e.out_f32 ? EF_F32 : 0) | (e.out_bf16 ? EF_BF16 : 0) | (e.shift ? EF_SHIFT : 0) | (e.ln_x ? EF_LNBWD : 0) |
            ((unsigned)e.act << 16) | ((unsigned)(e.gradz ? e.gradz_act : 0) << 20) |
-           (e.bn.y ? (EF_BNRED | (e.bn.pool == 2 ? EF_BNPOOL2 : 0) | ((unsigned)e.bn.act << 24)) : 0);
+           (e.bn.y ? (EF_BNRED | (e.bn.pool == 2 ? EF_BNPOOL2 : 0) | ((unsigned)e.bn.act << 24)) : 0) | (e.w2 ? EF_GEMM2 : 0);
 }
 
 
@@ -314,9 +320,10 @@ __device__ __forceinline__ void epilogue_bn_reduce(const float* Cs, const EpiArg
 // dgrad GEMM -> LayerNorm backward in one pass (N == BN == 128, T % BM == 0: checked on the host).
 // 32 lanes own one row (4 columns each): the two row means are 5-step half-wave shuffles; every
 // thread keeps its 4 columns' dgamma / dbeta partial sums over the rows it walks.
+constexpr int A2S = 128 + KPAD;      // row stride (elements) of the second GEMM's LDS operand tile
 template <int BM, int BN, unsigned FEAT>
 __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
-                                                float* sstat) {
+                                                float* sstat, bf16* a2 = nullptr) {
     static_assert(BN == 128, "LayerNorm-128 epilogue");
     constexpr bool ANY = FEAT == EF_ANY;
 #define EF_ON(bit, runtime) (ANY ? (bool)(runtime) : ((FEAT & (bit)) != 0))
@@ -384,6 +391,7 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
                 ob[c] = (bf16)(drop ? o4[c] * dropout_scale(dseed, (uint32_t)(base + c), e.drop_thresh, e.drop_inv_keep)
                                              : o4[c]);
             *reinterpret_cast<bf16x4*>(e.out_bf16 + base) = ob;
+            if (a2) *reinterpret_cast<bf16x4*>(a2 + row * A2S + cg * 4) = ob;
         }
         if (bnred) {
             const float4 yv = by[(row - rr) / 8];
@@ -561,7 +569,32 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     __syncthreads();
     if constexpr (BM == 32 && BN == 128) {
         if ((FEAT == EF_ANY && a.e.ln_x) || (FEAT != EF_ANY && (FEAT & EF_LNBWD))) {
-            epilogue_ln_bwd<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, sstat);
+            const bool gemm2 = FEAT == EF_ANY ? a.e.w2 != nullptr : (FEAT & EF_GEMM2) != 0;
+            bf16* a2 = gemm2 ? reinterpret_cast<bf16*>(smem + (BM * LDC + 2 * BN) * sizeof(float)) : nullptr;   // behind the C tile
+            epilogue_ln_bwd<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, sstat, a2);
+            if (gemm2) {
+                // out2[32 rows][128] = a2[32][128] (bf16, this workgroup's finished rows) x w2: wave wn owns columns 32 wn ..,
+                // B fragments straight from the (L2-resident, 32 KB) weight image, k ascending as the main loop's
+                __syncthreads();
+                f32x16 c2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c2[r] = 0.f;
+                const bf16* wrow = a.e.w2 + (size_t)(wn * 32 + lr) * 128 + lh * 8;
+                bf16x8 bfr[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 16);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a2 + lr * A2S + ks * 16 + lh * 8);
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[ks], c2, 0, 0, 0);
+                }
+                bf16* orow = a.e.out2 + ((size_t)b * a.T + t0) * 128 + wn * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    orow[(size_t)row * 128] = (bf16)c2[r];
+                }
+            }
             return;
         }
     }
@@ -578,7 +611,8 @@ template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT, int TAPS = 0>
 int launch_fwd_feat(const ConvArgs& a, hipStream_t st) {
     const size_t stage = (size_t)(BM + a.taps - 1 + BN * a.taps) * (KCT + KPAD) * sizeof(bf16);
     const size_t ctile = (size_t)(BM * (BN + 4) + 2 * BN) * sizeof(float);
-    const size_t need = stage > ctile ? stage : ctile;
+    size_t need = stage > ctile ? stage : ctile;
+    if (a.e.w2 && need < ctile + (size_t)BM * A2S * sizeof(bf16)) need = ctile + (size_t)BM * A2S * sizeof(bf16);
     if (need > 160 * 1024) return mm_fail(MM_ERR_UNSUPPORTED, "conv1d_fwd: LDS %zu B > 160 KiB", need);
     auto kern = conv1d_fwd_kernel<BM, BN, WM, WN, KCT, FEAT, TAPS>;
     if (need > 64 * 1024)
@@ -611,6 +645,7 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
             EPI_CASE(0x001521u)          // last FFN-2 forward: ... and the mean over tokens instead of the LayerNorm
             EPI_CASE(0x000800u)          // plain data gradient, bf16 out
             EPI_CASE(0x002d01u)          // data gradient + LayerNorm backward: skip gradient in, fp32 and masked bf16 out
+            EPI_CASE(0x10002d01u)        // ... and the data gradient of the Linear under that LayerNorm's skip path (second GEMM)
             EPI_CASE(0x002401u)          // the same without the bf16 copy (first block)
             EPI_CASE(0x1006401u)         // ... + the BatchNorm-backward reduce of the conv block below the stack (GELU)
             default: break;
@@ -1296,8 +1331,10 @@ int mm_linear_fwd_ln(const void* x, const void* w, int M, int K, const float* bi
 // d(LN output) rows stay fp32 instead of a bf16 round trip.
 static int linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
                                const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
-                               float drop_p, uint32_t seed, const uint32_t* seed_epoch, const BnRed* bn, hipStream_t st) {
+                               float drop_p, uint32_t seed, const uint32_t* seed_epoch, const BnRed* bn, hipStream_t st,
+                               const void* w2 = nullptr, void* out2 = nullptr) {
     MM_REQUIRE(dy && w && x && stat && gamma && (dx || dx_bf16), "linear_dgrad_ln_bwd: null");
+    MM_REQUIRE(!w2 || (out2 && dx_bf16), "linear_dgrad_ln_bwd: the second GEMM needs the bf16 rows and an output");
     MM_REQUIRE(M > 0 && M % 32 == 0 && K > 0 && K % 16 == 0, "linear_dgrad_ln_bwd: M=%d (multiple of 32) K=%d (multiple of 16)", M, K);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear_dgrad_ln_bwd: drop_p");
     ConvArgs a;
@@ -1314,6 +1351,7 @@ static int linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, cons
     a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
     a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
     if (bn) a.e.bn = *bn;
+    a.e.w2 = (const bf16*)w2; a.e.out2 = (bf16*)out2;
     const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
     switch (kct) {
         case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);
@@ -1327,6 +1365,20 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
                            const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
                            float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
     return linear_dgrad_ln_bwd(dy, w, M, K, x, stat, gamma, dres, dx, dx_bf16, dgb_repl, drop_p, seed, seed_epoch, nullptr, st);
+}
+
+// mm_linear_dgrad_ln_bwd followed, inside the launch, by do = dx_bf16 @ w2 (M x 128 x 128): the data gradient of the
+// Linear(128 -> 128) whose dropped-out output entered this LayerNorm's input through the residual add (the attention
+// out-projection: x1 = x0 + drop(o Wo^T + bo), norm2(x1)) - dx_bf16 carries exactly that dropout mask (drop_p, seed).
+// w2 = that Linear's data-gradient weight image (128 rows of 128); do (M, 128) bf16, bit-identical to
+// mm_conv1d_fwd(dx_bf16, w2, ...) with a bf16 output.
+int mm_linear_dgrad_ln_bwd_gemm2(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
+                                 const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
+                                 float drop_p, uint32_t seed, const uint32_t* seed_epoch, const void* w2, void* do_bf16,
+                                 hipStream_t st) {
+    MM_REQUIRE(w2 && do_bf16 && dx_bf16, "linear_dgrad_ln_bwd_gemm2: null");
+    return linear_dgrad_ln_bwd(dy, w, M, K, x, stat, gamma, dres, dx, dx_bf16, dgb_repl, drop_p, seed, seed_epoch, nullptr, st,
+                               w2, do_bf16);
 }
 
 // mm_linear_dgrad_ln_bwd whose rows dx are the fp32 d(out) of a 128-channel, un-pooled conv block (Conv1d -> BatchNorm1d

@@ -630,6 +630,44 @@ def test_linear_dgrad_ln_backward_with_fused_bn_backward_reduce(M, K, p, p2, gen
     torch.testing.assert_close(sb, sa, rtol=1e-4, atol=1e-4 * float(sa.abs().max()))
 
 
+@pytest.mark.parametrize("M,K,p,generic", [(16384, 512, 0.3, False), (96, 512, 0.0, False), (64, 64, 0.2, True)])
+def test_linear_dgrad_ln_backward_with_second_gemm(M, K, p, generic, monkeypatch):
+    """mm_linear_dgrad_ln_bwd_gemm2: the rows masked for the out-projection's backward are multiplied by its data-gradient
+    image inside the launch - same dx, same masked rows, and do bit-identical to the separate data-gradient launch."""
+    hip = _hip()
+    if generic:
+        monkeypatch.setenv("MM_EPI_GENERIC", "1")
+    g = torch.Generator().manual_seed(M + K + 1)
+    w = torch.randn(K, 128, 1, generator=g) / math.sqrt(128)                # linear1: 128 -> K, input LN(x1)
+    _, wd = _prep_w(hip, w, 128, K)
+    wo = torch.randn(128, 128, 1, generator=g) / math.sqrt(128)             # out_proj: 128 -> 128
+    _, wdo = _prep_w(hip, wo, 128, 128)
+    dy = (torch.randn(M, K, generator=g) * 0.1).cuda().to(torch.bfloat16)
+    x = torch.randn(M, 128, generator=g).cuda()
+    stat = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    gam = (0.5 + torch.rand(128, generator=g)).cuda()
+    dres = (torch.randn(M, 128, generator=g) * 0.1).cuda()
+
+    def run(fused):
+        dx = torch.full((M, 128), float("nan"), device="cuda")
+        dxb = torch.full((M, 128), float("nan"), device="cuda").to(torch.bfloat16)
+        dgb = torch.zeros(32, 2, 128, device="cuda")
+        do = torch.full((M, 128), float("nan"), device="cuda").to(torch.bfloat16)
+        if fused:
+            hip.call("mm_linear_dgrad_ln_bwd_gemm2", dy, wd, M, K, x, stat, gam, dres, dx, dxb, dgb, p, 41, None, wdo, do)
+        else:
+            hip.call("mm_linear_dgrad_ln_bwd", dy, wd, M, K, x, stat, gam, dres, dx, dxb, dgb, p, 41, None)
+            hip.call("mm_conv1d_fwd", dxb, wdo, 1, M, 128, 128, 1, 0, None, None, 0, None, None, 1, None, None, do, None,
+                     0.0, 0, None, None, 0)
+        return dx, dxb, dgb, do
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+    assert torch.isfinite(b[3].float()).all() and b[3].float().abs().max() > 1e-3
+    assert torch.equal(a[3], b[3])
+    ref = (a[1].float().cpu() @ _bf(wo[:, :, 0])).to(torch.bfloat16).float()           # do = dyo @ Wo  (Wo: out x in)
+    torch.testing.assert_close(b[3].float().cpu(), ref, rtol=2e-2, atol=2e-3)
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 
