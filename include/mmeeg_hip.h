@@ -217,6 +217,17 @@ int mm_linear_dgrad_ln_bwd_bn_reduce(const void* dy, const void* w, int M, int K
                                      float* sums_below, int act, float bn_drop_p, uint32_t bn_seed, float bn_drop2_p,
                                      uint32_t bn_seed2, hipStream_t stream);
 
+/* The two BatchNorm-backward passes for a block whose d(out) is the backward of a mean over its S positions (the voxel
+ * encoder's last conv block under AdaptiveAvgPool3d(1) -> Linear): dout_rows (R, N) fp32 = ONE row per sample, every
+ * position's d(out) = dout_rows[r] * scale (scale = 1 / S).  Same results as mm_bn_act_bwd_reduce / _apply on the
+ * broadcast (R, S, N) tensor, which is never written or read (pool 1, no second dropout). */
+int mm_bn_act_bwd_reduce_bcast(const float* y, const float* out4, const float* dout_rows, float scale, float* sums_out,
+                               int R, int S, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                               hipStream_t stream);
+int mm_bn_act_bwd_apply_bcast(const float* y, const float* out4, const float* dout_rows, float scale, const float* sums,
+                              void* dy, int R, int S, int N, int act, float drop_p, uint32_t seed,
+                              const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t stream);
+
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,
  * lse [B][H][L] fp32.  drop_p = attention-probability dropout (train mode).  The

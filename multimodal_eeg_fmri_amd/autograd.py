@@ -238,6 +238,7 @@ def linear_bwd(bag: GradBag, dy: torch.Tensor, x: torch.Tensor, weight, bias, *,
     return (r["f32"] if dx_f32 else r["bf16"]).view(M, cinp)
 
 
+_NO_BCAST = bool(os.environ.get("MM_NO_BCAST"))     # A/B knob: the voxel head's gradient as a full (B, V, N) tensor
 _NO_GEMM2 = bool(os.environ.get("MM_NO_GEMM2"))     # A/B knob: the out-projection's data gradient as its own launch
 _NO_BNRED = bool(os.environ.get("MM_NO_BNRED"))     # A/B knob: the BatchNorm-backward reduce as its own launch
 
@@ -389,10 +390,22 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     return dx0, emit
 
 
-def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor, emit_for=None):
+def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor, emit_for=None, rows_only=False):
     """dout fp32 (B, H) -> d tokens fp32 (B, L, D); with ``emit_for`` = (p, seed) of the consumer also its
-    dropout-masked bf16 copy, returned as a pair (fused head only, else None)."""
+    dropout-masked bf16 copy, returned as a pair (fused head only, else None).
+    ``rows_only`` (fused head): returns (d pooled SUM fp32 (B, D), 1 / L) instead - every token's gradient is that row
+    times the scale, and a consumer that can take it in this form (mm_bn_act_bwd_*_bcast) saves the (B, L, D) tensor."""
     lin = s["lin"]
+    if s.get("fused") and rows_only and not _NO_BCAST:
+        B, L, D = s["B"], s["L"], s["D"]
+        N = lin.weight.shape[0]
+        dout = dout.contiguous()
+        dz = _empty((B, N), _BF, dout)
+        dp = _empty((B, 1, D), _F32, dout)
+        _hip.call("mm_pooled_head_bwd", dout, s["z"], lin.weight, dz, dp, None, B, 1, D, N, ACT[s["act"]],
+                  float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
+        linear_bwd(bag, dz, s["pooled"], lin.weight, lin.bias, need_dx=False)
+        return dp.view(B, D), 1.0 / L
     if s.get("fused"):
         B, L, D = s["B"], s["L"], s["D"]
         N = lin.weight.shape[0]
@@ -641,6 +654,12 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
         # the apply passes sum the workspace's replicas themselves (no compaction launch between the two passes)
         _hip.call("mm_pool3d_bn_act_bwd_apply", y, s["arg"], out4, dout, sums, dy, B, D, H, W, N, gelu,
                   float(s["drop_p"]), int(s["seed"]), ops.EP(), train, REPL)
+    elif isinstance(dout, tuple):                       # (one fp32 row per sample, scale): pooled_head_bwd(rows_only=True)
+        rows, scale = dout
+        _hip.call("mm_bn_act_bwd_reduce_bcast", y, out4, rows, float(scale), sums, B, D * H * W, N, gelu,
+                  float(s["drop_p"]), int(s["seed"]), ops.EP())
+        _hip.call("mm_bn_act_bwd_apply_bcast", y, out4, rows, float(scale), sums, dy, B, D * H * W, N, gelu,
+                  float(s["drop_p"]), int(s["seed"]), ops.EP(), train, REPL)
     else:
         args = (B, D * H * W, N, gelu, 1, 1, float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         _hip.call("mm_bn_act_bwd_reduce", y, out4, None, dout, sums, *args)
@@ -701,8 +720,9 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
 def volume_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor):
     """backward of ops._vol_forward_impl (train mode, or eval with frozen BatchNorm); dout fp32 (B, out_dim).
     Returns d / d volume (fp32, the input's shape) when the forward was run with need_dx, else None."""
-    d = pooled_head_bwd(bag, sv["head"], dout)                # fp32 (B, V, N)
-    g = conv3d_bn_act_bwd(bag, sv["convs"][2], d)
+    last = sv["convs"][2]
+    d = pooled_head_bwd(bag, sv["head"], dout, rows_only=not last["pool"])     # fp32 (B, V, N), or (row per sample, 1 / V)
+    g = conv3d_bn_act_bwd(bag, last, d)
     g = conv3d_bn_act_bwd(bag, sv["convs"][1], g)
     if sv["convs"][0].get("l1"):
         conv3d_l1_bwd(bag, sv["convs"][0], g)

@@ -154,6 +154,10 @@ struct BnBwdArgs {
     uint32_t thresh2, seed2; float inv_keep2;
     const uint32_t* epoch;
     int sums_nrep;               // apply: sums is [sums_nrep][2][N]; the block reduces the replicas itself
+    // d(out) that is the same row for every position of a sample (the backward of a mean over positions): dout_f32 is
+    // [R][N] and every element is multiplied by bcast_scale (1 / positions); pool == 1 only
+    int bcast = 0;
+    float bcast_scale = 1.f;
 };
 
 template <bool APPLY, int ACT = -1, int POOL = 0>
@@ -180,7 +184,8 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
     size_t row = (size_t)blockIdx.x * rows_per_blk + ri;
     auto load = [&](size_t r, In& v) __attribute__((always_inline)) {
         const size_t in0 = r * a.pool * a.N + n4, oidx = r * a.N + n4;
-        if (a.dout_f32) v.gf = *reinterpret_cast<const float4*>(a.dout_f32 + oidx);
+        if (a.bcast) v.gf = *reinterpret_cast<const float4*>(a.dout_f32 + (size_t)((unsigned)r / (unsigned)a.S) * a.N + n4);
+        else if (a.dout_f32) v.gf = *reinterpret_cast<const float4*>(a.dout_f32 + oidx);
         else v.gb = *reinterpret_cast<const bf16x4*>(a.dout_bf16 + oidx);
         v.y0 = *reinterpret_cast<const float4*>(a.y + in0);
         if (a.pool == 2) v.y1 = *reinterpret_cast<const float4*>(a.y + in0 + a.N);
@@ -210,7 +215,8 @@ __global__ void bn_act_bwd_kernel(BnBwdArgs a) {
             const size_t in0 = row * a.pool * a.N + n4;             // (r * S + so * pool) = row * pool: no division
             const size_t oidx = row * a.N + n4;
             float g[4];
-            if (a.dout_f32) { g[0] = cur.gf.x; g[1] = cur.gf.y; g[2] = cur.gf.z; g[3] = cur.gf.w; }
+            if (a.bcast) { g[0] = cur.gf.x * a.bcast_scale; g[1] = cur.gf.y * a.bcast_scale; g[2] = cur.gf.z * a.bcast_scale; g[3] = cur.gf.w * a.bcast_scale; }
+            else if (a.dout_f32) { g[0] = cur.gf.x; g[1] = cur.gf.y; g[2] = cur.gf.z; g[3] = cur.gf.w; }
             else { g[0] = (float)cur.gb[0]; g[1] = (float)cur.gb[1]; g[2] = (float)cur.gb[2]; g[3] = (float)cur.gb[3]; }
             if (a.thresh2)
 #pragma unroll
@@ -625,8 +631,10 @@ int mm_bn_act_fwd_ln(const float* y, const float* scale, const float* shift, con
 static int bn_bwd_common(bool apply, const float* y, const float* out4, const void* dout_bf16, const float* dout_f32,
                          const float* sums_in, float* sums_out, void* dy, float* dy_f32, int R, int S, int N, int act,
                          int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
-                         const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t st) {
+                         const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t st, int bcast = 0,
+                         float bcast_scale = 1.f) {
     MM_REQUIRE(y && out4 && (dout_bf16 || dout_f32), "bn_act_bwd: null");
+    MM_REQUIRE(!bcast || (dout_f32 && pool == 1 && (size_t)R * S < (1ull << 32)), "bn_act_bwd: broadcast d(out) needs fp32 rows and pool 1");
     MM_REQUIRE(sums_nrep == 1 || sums_nrep == MM_REPL, "bn_act_bwd: sums_nrep = 1 (compact fp32) or %d (the reduce pass's workspace)", MM_REPL);
     MM_REQUIRE(N % 4 == 0 && N <= 1024 && (N / 4) <= 256, "bn_act_bwd: N");
     BnBwdArgs a;
@@ -639,6 +647,7 @@ static int bn_bwd_common(bool apply, const float* y, const float* out4, const vo
     a.thresh2 = thresh_of(drop2_p); a.seed2 = seed2; a.inv_keep2 = drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f;
     a.epoch = seed_epoch;
     a.sums_nrep = sums_nrep;
+    a.bcast = bcast; a.bcast_scale = bcast_scale;
     const int rpb = 256 / (N / 4) > 0 ? 256 / (N / 4) : 1;
     const size_t rows = (size_t)R * (S / pool);
     int grid = (int)((rows + rpb - 1) / rpb);
@@ -670,6 +679,24 @@ int mm_bn_act_bwd_apply(const float* y, const float* out4, const void* dout_bf16
     MM_REQUIRE((dy || dy_f32) && (!train || sums), "bn_act_bwd_apply: null");
     return bn_bwd_common(true, y, out4, dout_bf16, dout_f32, sums, nullptr, dy, dy_f32, R, S, N, act, pool,
                          drop_first, drop_p, seed, drop2_p, seed2, seed_epoch, train, sums_nrep, st);
+}
+
+// The two passes for a block whose d(out) is the backward of a mean over its S positions (AdaptiveAvgPool -> Linear head
+// on top of the last conv block of the voxel encoder): dout_rows (R, N) fp32 holds ONE row per sample, every position's
+// d(out) is dout_rows[r] * scale (scale = 1 / S).  The (R, S, N) broadcast tensor is never written or read.
+int mm_bn_act_bwd_reduce_bcast(const float* y, const float* out4, const float* dout_rows, float scale, float* sums_out, int R,
+                               int S, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(sums_out && dout_rows, "bn_act_bwd_reduce_bcast: null");
+    return bn_bwd_common(false, y, out4, nullptr, dout_rows, nullptr, sums_out, nullptr, nullptr, R, S, N, act, 1, 1, drop_p, seed,
+                         0.f, 0u, seed_epoch, 1, 1, st, 1, scale);
+}
+
+int mm_bn_act_bwd_apply_bcast(const float* y, const float* out4, const float* dout_rows, float scale, const float* sums,
+                              void* dy, int R, int S, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                              int train, int sums_nrep, hipStream_t st) {
+    MM_REQUIRE(dy && dout_rows && (!train || sums), "bn_act_bwd_apply_bcast: null");
+    return bn_bwd_common(true, y, out4, nullptr, dout_rows, sums, nullptr, dy, nullptr, R, S, N, act, 1, 1, drop_p, seed, 0.f, 0u,
+                         seed_epoch, train, sums_nrep, st, 1, scale);
 }
 
 #define LN_DISPATCH(D, CALL)                                   \

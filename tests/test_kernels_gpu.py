@@ -668,6 +668,31 @@ def test_linear_dgrad_ln_backward_with_second_gemm(M, K, p, generic, monkeypatch
     torch.testing.assert_close(b[3].float().cpu(), ref, rtol=2e-2, atol=2e-3)
 
 
+@pytest.mark.parametrize("R,S,N,p", [(32, 512, 128, 0.3), (3, 40, 48, 0.0)])
+def test_bn_act_backward_with_one_dout_row_per_sample(R, S, N, p):
+    """mm_bn_act_bwd_reduce_bcast / _apply_bcast = the ordinary passes on the (R, S, N) tensor whose every position holds
+    the sample's row times 1 / S (the backward of a mean over positions): same accumulator words, same dy."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(R * S + N)
+    y = (torch.randn(R, S, N, generator=g) * 1.3 + 0.2).cuda()
+    out4 = torch.stack([0.5 + torch.rand(N, generator=g), torch.randn(N, generator=g) * 0.2,
+                        torch.randn(N, generator=g) * 0.1, 0.8 + 0.4 * torch.rand(N, generator=g)]).cuda().contiguous()
+    rows = torch.randn(R, N, generator=g).cuda()
+    scale = 1.0 / S
+    full = (rows * torch.tensor(scale, dtype=torch.float32, device="cuda")).view(R, 1, N).expand(R, S, N).contiguous()
+    sums_a = torch.zeros(32, 2, N, device="cuda")
+    dy_a = torch.empty(R, S, N, dtype=torch.bfloat16, device="cuda")
+    args = (R, S, N, 1, 1, 1, p, 51, 0.0, 0, None)
+    hip.call("mm_bn_act_bwd_reduce", y, out4, None, full, sums_a, *args)
+    hip.call("mm_bn_act_bwd_apply", y, out4, None, full, sums_a, dy_a, None, *args, 1, 32)
+    sums_b = torch.zeros(32, 2, N, device="cuda")
+    dy_b = torch.full((R, S, N), float("nan"), device="cuda").to(torch.bfloat16)
+    hip.call("mm_bn_act_bwd_reduce_bcast", y, out4, rows, scale, sums_b, R, S, N, 1, p, 51, None)
+    hip.call("mm_bn_act_bwd_apply_bcast", y, out4, rows, scale, sums_b, dy_b, R, S, N, 1, p, 51, None, 1, 32)
+    assert torch.equal(sums_a.view(torch.int32), sums_b.view(torch.int32))
+    assert torch.equal(dy_a, dy_b) and torch.isfinite(dy_b.float()).all()
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 
