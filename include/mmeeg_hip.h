@@ -201,11 +201,12 @@ int mm_conv1d_dgrad_bn_reduce(const void* dy, const void* w_dgrad, int B, int T,
  * same launch (TemporalTransformerBlock backward, enhanced_models_v4.py:99-103: x1 = x0 + dropout(out_proj(attn)),
  * norm2(x1)): do_bf16 (M, 128) = dx_bf16 @ w2, w2 = out_proj's data-gradient weight image (128 x 128), dx_bf16 = the
  * rows masked with out_proj's dropout (drop_p, seed).  Bit-identical to mm_conv1d_fwd(dx_bf16, w2, 1, M, 128, 128, 1, 0,
- * ..., out_bf16 = do_bf16) after mm_linear_dgrad_ln_bwd. */
+ * ..., out_bf16 = do_bf16) after mm_linear_dgrad_ln_bwd.  dres_rows_per_sample > 0: dres holds ONE row per that many
+ * consecutive rows (mm_pooled_head_bwd_rows), 0: a row per row. */
 int mm_linear_dgrad_ln_bwd_gemm2(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
                                  const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
                                  float drop_p, uint32_t seed, const uint32_t* seed_epoch, const void* w2, void* do_bf16,
-                                 hipStream_t stream);
+                                 int dres_rows_per_sample, hipStream_t stream);
 /* mm_linear_dgrad_ln_bwd for the FIRST transformer block of EnhancedERPEncoder, whose LayerNorm input is the last conv
  * block's output (enhanced_models_v4.py:143-147: conv_layers[-1] -> pos_encoder -> transformer_layers[0].norm1): the rows dx
  * (fp32) are that block's d(out), so its BatchNorm-backward reduce pass (mm_bn_act_bwd_reduce(y_below, out4_below, NULL, dx,
@@ -227,6 +228,13 @@ int mm_bn_act_bwd_reduce_bcast(const float* y, const float* out4, const float* d
 int mm_bn_act_bwd_apply_bcast(const float* y, const float* out4, const float* dout_rows, float scale, const float* sums,
                               void* dy, int R, int S, int N, int act, float drop_p, uint32_t seed,
                               const uint32_t* seed_epoch, int train, int sums_nrep, hipStream_t stream);
+
+/* mm_pooled_head_bwd (the backward of x.mean(dim=1) -> output_proj, enhanced_models_v4.py:161-167) without the fp32
+ * (B, L, D) token gradients: rows_out (B, D) = the one row every token of a sample receives; dx_bf16 (B, L, D) = that row
+ * under the consumer's dropout mask, as mm_pooled_head_bwd writes it. */
+int mm_pooled_head_bwd_rows(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* rows_out,
+                            void* dx_bf16, int B, int L, int D, int N, int act, float drop_p, uint32_t seed,
+                            float emit_drop_p, uint32_t emit_seed, const uint32_t* seed_epoch, hipStream_t stream);
 
 /* ---- multi-head self-attention, head_dim 32 (nn.MultiheadAttention,
  * enhanced_models_v4.py:71-73, 99).  qkv [B][L][3E] bf16 -> out [B][L][E] bf16,

@@ -298,7 +298,8 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     return ops.igemm(dy, wd, k, k - 1 - pad, cinp)["bf16"]
 
 
-def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, drop_p, seed, bn_below=None, gemm2=None):
+def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, drop_p, seed, bn_below=None, gemm2=None,
+                   res_rows=0):
     """backward of ``Linear(LayerNorm(x))``: weight / bias gradients of the Linear (``h`` = LN(x) bf16 is its
     input), then d x = LN_backward(dy W) + dres.  Width 128 with M % 32 == 0 (the transformer blocks) runs
     the data-gradient GEMM with the LayerNorm backward as its epilogue; anything else takes two launches."""
@@ -326,7 +327,7 @@ def _linear_ln_bwd(bag, dy, h, lin, wb, x, stat, ln, dres, dx, dx_bf16, dgb, dro
             w2, holder = gemm2
             do = _empty((M, 128), _BF, dy)
             _hip.call("mm_linear_dgrad_ln_bwd_gemm2", dy, wd, M, coutp, x, stat, ln.weight, dres, dx, dx_bf16, dgb,
-                      drop_p, seed, ops.EP(), w2, do)
+                      drop_p, seed, ops.EP(), w2, do, int(res_rows))
             holder.append(do)
             return
         _hip.call("mm_linear_dgrad_ln_bwd", dy, wd, M, coutp, x, stat, ln.weight, dres, dx, dx_bf16, dgb,
@@ -349,8 +350,18 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     p = s["p"]
     s1, s2, s3 = s["seeds"]
     B, L = s["B"], s["L"]
-    M, D = dx2.shape
     at = blk.self_attn
+    res_rows = 0
+    if isinstance(dx2, tuple):                          # (one fp32 row per sample (B, D), tokens per sample): pooled_head_bwd
+        rows, per = dx2
+        M, D = dy2.shape
+        _, _, ci, co = ops.weights.get(at.out_proj.weight, True)
+        if D == 128 and M % 32 == 0 and ci == 128 and co == 128 and not _NO_GEMM2:
+            dx2, res_rows = rows, per                   # the LayerNorm-backward launch reads the row (res_rows)
+        else:                                           # no consumer for the row form: materialise the token gradients
+            dx2 = rows.view(-1, 1, D).expand(-1, per, D).reshape(M, D).contiguous()
+    else:
+        M, D = dx2.shape
     # FFN second linear:  x2 = x1 + drop(g W2^T + b2);  g = drop(act(z))
     if dy2 is None:
         dy2 = _mask_cast(g_f32=dx2, drop_p=p, seed=s3)
@@ -367,7 +378,7 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
         if cinp_o == 128 and coutp_o == 128:
             g2 = (wd_o, holder)
     _linear_ln_bwd(bag, dz, s["h2"], blk.linear1, None, s["x1"], s["st2"], blk.norm2, dx2, dx1, dyo, dgb,
-                   float(p), int(s1), gemm2=g2)
+                   float(p), int(s1), gemm2=g2, res_rows=res_rows)
     _ln_param_grads(bag, blk.norm2, dgb, D)
     if holder:
         do = holder[0]
@@ -396,7 +407,7 @@ def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor, emit_for=None, ro
     ``rows_only`` (fused head): returns (d pooled SUM fp32 (B, D), 1 / L) instead - every token's gradient is that row
     times the scale, and a consumer that can take it in this form (mm_bn_act_bwd_*_bcast) saves the (B, L, D) tensor."""
     lin = s["lin"]
-    if s.get("fused") and rows_only and not _NO_BCAST:
+    if s.get("fused") and rows_only and emit_for is None and not _NO_BCAST:
         B, L, D = s["B"], s["L"], s["D"]
         N = lin.weight.shape[0]
         dout = dout.contiguous()
@@ -406,6 +417,18 @@ def pooled_head_bwd(bag: GradBag, s: dict, dout: torch.Tensor, emit_for=None, ro
                   float(s["drop_p"]), int(s["seed"]), 0.0, 0, ops.EP())
         linear_bwd(bag, dz, s["pooled"], lin.weight, lin.bias, need_dx=False)
         return dp.view(B, D), 1.0 / L
+    if s.get("fused") and rows_only and emit_for is not None and not _NO_BCAST:
+        # the chain's form: masked bf16 tokens for the consumer's GEMMs + the one fp32 row per sample for its skip path
+        B, L, D = s["B"], s["L"], s["D"]
+        N = lin.weight.shape[0]
+        dout = dout.contiguous()
+        dz = _empty((B, N), _BF, dout)
+        rows = _empty((B, D), _F32, dout)
+        emit = _empty((B, L, D), _BF, dout)
+        _hip.call("mm_pooled_head_bwd_rows", dout, s["z"], lin.weight, dz, rows, emit, B, L, D, N, ACT[s["act"]],
+                  float(s["drop_p"]), int(s["seed"]), float(emit_for[0]), int(emit_for[1]), ops.EP())
+        linear_bwd(bag, dz, s["pooled"], lin.weight, lin.bias, need_dx=False)
+        return (rows, L), emit
     if s.get("fused"):
         B, L, D = s["B"], s["L"], s["D"]
         N = lin.weight.shape[0]
@@ -449,11 +472,14 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     blocks = sv["blocks"]
     dy2 = None
     if blocks:                                       # the head's backward also writes the top block's masked operand
-        d, dy2 = pooled_head_bwd(bag, sv["head"], dout, emit_for=(blocks[-1]["p"], blocks[-1]["seeds"][2]))
+        d, dy2 = pooled_head_bwd(bag, sv["head"], dout, emit_for=(blocks[-1]["p"], blocks[-1]["seeds"][2]), rows_only=True)
     else:
         d = pooled_head_bwd(bag, sv["head"], dout)
-    B, L, D = d.shape
-    d = d.view(B * L, D)
+    if isinstance(d, tuple):                         # (row per sample, tokens per sample): the top block reads the row
+        B, L, D = dy2.shape
+    else:
+        B, L, D = d.shape
+        d = d.view(B * L, D)
     if dy2 is not None:
         dy2 = dy2.view(B * L, D)
     c3, c2, c1 = sv["convs"][2], sv["convs"][1], sv["convs"][0]

@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(256) void pooled_head_bwd_kernel(const float* __res
                                                              float* __restrict__ dx, bf16* __restrict__ dx_bf16, int L, int D,
                                                              int N, int rows_per_wg, int act, uint32_t thresh, float inv_keep,
                                                              uint32_t seed, uint32_t thresh2, float inv_keep2, uint32_t seed2,
-                                                             const uint32_t* __restrict__ epoch) {
+                                                             const uint32_t* __restrict__ epoch, float* __restrict__ rows_out) {
     __shared__ float dz[1024];
     __shared__ __attribute__((aligned(16))) float dp[1024];
     const int b = blockIdx.x, l0 = blockIdx.y * rows_per_wg;
@@ -1316,6 +1316,7 @@ __global__ __launch_bounds__(256) void pooled_head_bwd_kernel(const float* __res
             for (int q = 0; q < 4; ++q) acc[q] += dz[n + q] * W[(size_t)(n + q) * D + k];
         }
         dp[k] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * invL;
+        if (rows_out && blockIdx.y == 0) rows_out[(size_t)b * D + k] = dp[k];     // the ONE row every token of the sample receives
     }
     __syncthreads();
     const int vec = D / 4;                                  // float4 groups per row
@@ -1672,9 +1673,10 @@ int mm_pooled_head_fwd(const float* pooled, const float* pooled_acc, const float
     return mm_check_launch("pooled_head_fwd");
 }
 
-int mm_pooled_head_bwd(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* dx, void* dx_bf16,
-                       int B, int L, int D, int N, int act, float drop_p, uint32_t seed, float emit_drop_p,
-                       uint32_t emit_seed, const uint32_t* seed_epoch, hipStream_t st) {
+static int pooled_head_bwd_common(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* dx,
+                                  void* dx_bf16, float* rows_out, int B, int L, int D, int N, int act, float drop_p,
+                                  uint32_t seed, float emit_drop_p, uint32_t emit_seed, const uint32_t* seed_epoch,
+                                  hipStream_t st) {
     MM_REQUIRE(dout && z_pre_bf16 && W && (dx || dx_bf16) && B > 0 && L > 0, "pooled_head_bwd: null");
     MM_REQUIRE(D > 0 && D <= 1024 && D % 4 == 0 && N > 0 && N <= 1024 && N % 4 == 0, "pooled_head_bwd: D=%d N=%d", D, N);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f && emit_drop_p >= 0.f && emit_drop_p < 1.f, "pooled_head_bwd: drop_p");
@@ -1683,8 +1685,26 @@ int mm_pooled_head_bwd(const float* dout, const void* z_pre_bf16, const float* W
     const uint32_t t2 = emit_drop_p > 0.f ? (uint32_t)((double)emit_drop_p * 4294967296.0) : 0u;
     hipLaunchKernelGGL(pooled_head_bwd_kernel, dim3(B, (L + rows - 1) / rows), dim3(256), 0, st, dout, (const bf16*)z_pre_bf16, W,
                        (bf16*)dz_bf16, dx, (bf16*)dx_bf16, L, D, N, rows, act, t1, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, seed,
-                       t2, emit_drop_p > 0.f ? 1.f / (1.f - emit_drop_p) : 1.f, emit_seed, seed_epoch);
+                       t2, emit_drop_p > 0.f ? 1.f / (1.f - emit_drop_p) : 1.f, emit_seed, seed_epoch, rows_out);
     return mm_check_launch("pooled_head_bwd");
+}
+
+int mm_pooled_head_bwd(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* dx, void* dx_bf16,
+                       int B, int L, int D, int N, int act, float drop_p, uint32_t seed, float emit_drop_p,
+                       uint32_t emit_seed, const uint32_t* seed_epoch, hipStream_t st) {
+    return pooled_head_bwd_common(dout, z_pre_bf16, W, dz_bf16, dx, dx_bf16, nullptr, B, L, D, N, act, drop_p, seed, emit_drop_p,
+                                  emit_seed, seed_epoch, st);
+}
+
+// mm_pooled_head_bwd without the fp32 (B, L, D) token gradients: every token of sample b receives rows_out[b] (B, D), so a
+// consumer that takes the row (mm_linear_dgrad_ln_bwd_gemm2's dres_rows_per_sample, mm_bn_act_bwd_*_bcast) needs only that;
+// dx_bf16 (B, L, D) = the rows under the consumer's dropout mask (emit_drop_p, emit_seed), as before.
+int mm_pooled_head_bwd_rows(const float* dout, const void* z_pre_bf16, const float* W, void* dz_bf16, float* rows_out,
+                            void* dx_bf16, int B, int L, int D, int N, int act, float drop_p, uint32_t seed,
+                            float emit_drop_p, uint32_t emit_seed, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(rows_out && dx_bf16, "pooled_head_bwd_rows: null");
+    return pooled_head_bwd_common(dout, z_pre_bf16, W, dz_bf16, nullptr, dx_bf16, rows_out, B, L, D, N, act, drop_p, seed,
+                                  emit_drop_p, emit_seed, seed_epoch, st);
 }
 
 int mm_drop_path(const float* x, float* out, int64_t B, int64_t inner, float drop_p, uint32_t seed,

@@ -78,6 +78,7 @@ struct EpiArgs {
     // input (the attention out-projection under norm2): its operand never leaves the workgroup
     const bf16* w2 = nullptr;
     bf16* out2 = nullptr;
+    int res_rows = 0;            // epilogue_ln_bwd: > 0 = `residual` is (M / res_rows, 128): one row for res_rows consecutive rows
 };
 
 struct ConvArgs {
@@ -366,7 +367,8 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
         const float4 a4 = *reinterpret_cast<const float4*>(Cs + row * LDC + cg * 4);
         const float4 xv = *reinterpret_cast<const float4*>(e.ln_x + base);
         float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EF_ON(EF_RES, e.residual)) rv = *reinterpret_cast<const float4*>(e.residual + base);
+        if (EF_ON(EF_RES, e.residual))
+            rv = *reinterpret_cast<const float4*>(e.residual + (e.res_rows ? (size_t)((unsigned)m / (unsigned)e.res_rows) * 128 + cg * 4 : base));
         const float2 st = *reinterpret_cast<const float2*>(e.ln_stat + 2 * m);
         const float dyv[4] = {a4.x + sh[0], a4.y + sh[1], a4.z + sh[2], a4.w + sh[3]};
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, rs[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -1332,7 +1334,7 @@ int mm_linear_fwd_ln(const void* x, const void* w, int M, int K, const float* bi
 static int linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
                                const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
                                float drop_p, uint32_t seed, const uint32_t* seed_epoch, const BnRed* bn, hipStream_t st,
-                               const void* w2 = nullptr, void* out2 = nullptr) {
+                               const void* w2 = nullptr, void* out2 = nullptr, int res_rows = 0) {
     MM_REQUIRE(dy && w && x && stat && gamma && (dx || dx_bf16), "linear_dgrad_ln_bwd: null");
     MM_REQUIRE(!w2 || (out2 && dx_bf16), "linear_dgrad_ln_bwd: the second GEMM needs the bf16 rows and an output");
     MM_REQUIRE(M > 0 && M % 32 == 0 && K > 0 && K % 16 == 0, "linear_dgrad_ln_bwd: M=%d (multiple of 32) K=%d (multiple of 16)", M, K);
@@ -1352,6 +1354,8 @@ static int linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, cons
     a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
     if (bn) a.e.bn = *bn;
     a.e.w2 = (const bf16*)w2; a.e.out2 = (bf16*)out2;
+    MM_REQUIRE(res_rows >= 0 && (!res_rows || (dres && M % res_rows == 0 && (size_t)M < (1ull << 32))), "linear_dgrad_ln_bwd: res_rows=%d", res_rows);
+    a.e.res_rows = res_rows;
     const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
     switch (kct) {
         case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);
@@ -1371,14 +1375,15 @@ int mm_linear_dgrad_ln_bwd(const void* dy, const void* w, int M, int K, const fl
 // Linear(128 -> 128) whose dropped-out output entered this LayerNorm's input through the residual add (the attention
 // out-projection: x1 = x0 + drop(o Wo^T + bo), norm2(x1)) - dx_bf16 carries exactly that dropout mask (drop_p, seed).
 // w2 = that Linear's data-gradient weight image (128 rows of 128); do (M, 128) bf16, bit-identical to
-// mm_conv1d_fwd(dx_bf16, w2, ...) with a bf16 output.
+// mm_conv1d_fwd(dx_bf16, w2, ...) with a bf16 output.  dres_rows_per_sample > 0: dres is (M / that, 128) - ONE skip-gradient
+// row for that many consecutive rows (the backward of a mean over a sample's tokens, mm_pooled_head_bwd_rows).
 int mm_linear_dgrad_ln_bwd_gemm2(const void* dy, const void* w, int M, int K, const float* x, const float* stat,
                                  const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgb_repl,
                                  float drop_p, uint32_t seed, const uint32_t* seed_epoch, const void* w2, void* do_bf16,
-                                 hipStream_t st) {
+                                 int dres_rows_per_sample, hipStream_t st) {
     MM_REQUIRE(w2 && do_bf16 && dx_bf16, "linear_dgrad_ln_bwd_gemm2: null");
     return linear_dgrad_ln_bwd(dy, w, M, K, x, stat, gamma, dres, dx, dx_bf16, dgb_repl, drop_p, seed, seed_epoch, nullptr, st,
-                               w2, do_bf16);
+                               w2, do_bf16, dres_rows_per_sample);
 }
 
 // mm_linear_dgrad_ln_bwd whose rows dx are the fp32 d(out) of a 128-channel, un-pooled conv block (Conv1d -> BatchNorm1d

@@ -654,7 +654,7 @@ def test_linear_dgrad_ln_backward_with_second_gemm(M, K, p, generic, monkeypatch
         dgb = torch.zeros(32, 2, 128, device="cuda")
         do = torch.full((M, 128), float("nan"), device="cuda").to(torch.bfloat16)
         if fused:
-            hip.call("mm_linear_dgrad_ln_bwd_gemm2", dy, wd, M, K, x, stat, gam, dres, dx, dxb, dgb, p, 41, None, wdo, do)
+            hip.call("mm_linear_dgrad_ln_bwd_gemm2", dy, wd, M, K, x, stat, gam, dres, dx, dxb, dgb, p, 41, None, wdo, do, 0)
         else:
             hip.call("mm_linear_dgrad_ln_bwd", dy, wd, M, K, x, stat, gam, dres, dx, dxb, dgb, p, 41, None)
             hip.call("mm_conv1d_fwd", dxb, wdo, 1, M, 128, 128, 1, 0, None, None, 0, None, None, 1, None, None, do, None,
@@ -691,6 +691,44 @@ def test_bn_act_backward_with_one_dout_row_per_sample(R, S, N, p):
     hip.call("mm_bn_act_bwd_apply_bcast", y, out4, rows, scale, sums_b, dy_b, R, S, N, 1, p, 51, None, 1, 32)
     assert torch.equal(sums_a.view(torch.int32), sums_b.view(torch.int32))
     assert torch.equal(dy_a, dy_b) and torch.isfinite(dy_b.float()).all()
+
+
+def test_pooled_head_backward_row_form_and_row_residual():
+    """mm_pooled_head_bwd_rows: the one fp32 row per sample instead of the (B, L, D) token gradients (same dz, same masked
+    bf16 tokens); mm_linear_dgrad_ln_bwd_gemm2 fed with that row (dres_rows_per_sample = L) = fed with the expanded tensor."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(5)
+    B, L, D, N = 4, 64, 128, 128
+    dout = torch.randn(B, N, generator=g).cuda()
+    z = torch.randn(B, N, generator=g).cuda().to(torch.bfloat16)
+    W = (torch.randn(N, D, generator=g) / math.sqrt(D)).cuda()
+    dz_a = torch.empty(B, N, dtype=torch.bfloat16, device="cuda"); dz_b = torch.empty_like(dz_a)
+    dx = torch.empty(B, L, D, device="cuda")
+    em_a = torch.empty(B, L, D, dtype=torch.bfloat16, device="cuda"); em_b = torch.full_like(em_a, float("nan"))
+    rows = torch.full((B, D), float("nan"), device="cuda")
+    hip.call("mm_pooled_head_bwd", dout, z, W, dz_a, dx, em_a, B, L, D, N, 1, 0.3, 61, 0.2, 62, None)
+    hip.call("mm_pooled_head_bwd_rows", dout, z, W, dz_b, rows, em_b, B, L, D, N, 1, 0.3, 61, 0.2, 62, None)
+    assert torch.equal(dz_a, dz_b) and torch.equal(em_a, em_b)
+    assert torch.equal(rows, dx[:, 0, :]) and torch.equal(rows.view(B, 1, D).expand(B, L, D), dx)
+    M, K = B * L, 512
+    w = torch.randn(K, 128, 1, generator=g) / math.sqrt(128)
+    _, wd = _prep_w(hip, w, 128, K)
+    _, wdo = _prep_w(hip, torch.randn(128, 128, 1, generator=g) / math.sqrt(128), 128, 128)
+    dy = (torch.randn(M, K, generator=g) * 0.1).cuda().to(torch.bfloat16)
+    x = torch.randn(M, 128, generator=g).cuda()
+    stat = torch.stack([x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    gam = (0.5 + torch.rand(128, generator=g)).cuda()
+    outs = []
+    for dres, per in ((dx.view(M, D).contiguous(), 0), (rows, L)):
+        o = [torch.full((M, 128), float("nan"), device="cuda"), torch.empty(M, 128, dtype=torch.bfloat16, device="cuda"),
+             torch.zeros(32, 2, 128, device="cuda"), torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")]
+        hip.call("mm_linear_dgrad_ln_bwd_gemm2", dy, wd, M, K, x, stat, gam, dres, o[0], o[1], o[2], 0.1, 63, None, wdo, o[3], per)
+        outs.append(o)
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    with pytest.raises(hip.HipLibraryError):                      # rows per sample must divide M
+        hip.call("mm_linear_dgrad_ln_bwd_gemm2", dy, wd, M, K, x, stat, gam, rows, outs[0][0], outs[0][1], outs[0][2], 0.1, 63, None,
+                 wdo, outs[0][3], 7)
 
 
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
