@@ -465,7 +465,7 @@ class _ModuleFn(torch.autograd.Function):
 
 
 def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = False, after_blocks=None,
-                    after_conv2=None):
+                    after_conv2=None, after_conv3=None):
     """backward of ops._erp_forward_impl (train mode); dout fp32 (B, H).  ``after_blocks()`` is called
     once the transformer stack's backward has been issued, ``after_conv2()`` once the second conv block's
     has (a trainer hands the reductions / weight gradients collected so far to another stream there)."""
@@ -490,6 +490,8 @@ def erp_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool = 
     if after_blocks is not None:
         after_blocks()
     g, sm = conv_bn_act_bwd(bag, c3, dout_f32=d.view(B, L, D), sums=bn3.get("sums"), below=c2)
+    if after_conv3 is not None:
+        after_conv3()
     g, sm = conv_bn_act_bwd(bag, c2, dout_bf16=g, sums=sm, below=c1)
     if after_conv2 is not None:
         after_conv2()

@@ -22,6 +22,7 @@ this keeps that step structure.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -211,8 +212,15 @@ class BridgeTrainer(nn.Module):
             def split_convs():
                 split()
                 bag.defer_conv_wgrads = False
-            bag.defer_conv_wgrads = True
-            erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split, after_conv2=split_convs)   # longer chain first (see _seg_forward)
+            # MM_CONV_WGRADS_HANDED: 1 = block 2's only (default: block 3's weight gradient stays on the chain), 2 = blocks 3
+            # and 2 (round 2 / early round 3, when the chain was the later stream), 0 = none.  Which stream ends later
+            # decides: 0.773-0.776 / 0.782-0.799 / 0.789-0.793 ms per step for 1 / 2 / 0 (profiles/r03_second_half_ab.txt)
+            handed_convs = int(os.environ.get("MM_CONV_WGRADS_HANDED", "1"))
+            bag.defer_conv_wgrads = handed_convs >= 2
+
+            def conv3_done():
+                bag.defer_conv_wgrads = handed_convs >= 1
+            erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split, after_conv2=split_convs, after_conv3=conv3_done)   # longer chain first (see _seg_forward)
             bag.flush(dz.device)
             self._stamp(8)
             with torch.cuda.stream(self._side):
