@@ -379,9 +379,10 @@ class BridgeTrainer(nn.Module):
         if (ce and cf and eeg.dtype == torch.float32 and fmri.dtype == torch.float32 and eeg.is_cuda and fmri.is_cuda
                 and eeg.is_contiguous() and fmri.is_contiguous() and eeg.numel() % 4 == 0 and fmri.numel() % 4 == 0
                 and (eeg.data_ptr() | fmri.data_ptr()) % 16 == 0):
-            # ONE launch: EEG batch packed into the first convolution's bf16 operand (+ its fp32 copy), fMRI batch copied
+            # ONE launch: EEG batch packed into the first convolution's bf16 operand, fMRI batch copied
             Bx, Cx, Tx = eeg.shape
-            _hip.call("mm_stage_inputs", eeg, c["xb"], c["eeg"], Bx, Cx, Tx, c["xb"].shape[2], c["fmri"], fmri, fmri.numel())
+            # (no fp32 copy of the EEG batch: the captured step reads the packed operand only - c["eeg"] gives it its shape)
+            _hip.call("mm_stage_inputs", eeg, c["xb"], None, Bx, Cx, Tx, c["xb"].shape[2], c["fmri"], fmri, fmri.numel())
         else:                                               # each input on its own: a loader may fill only one in place
             if ce:
                 c["eeg"].copy_(eeg)
