@@ -197,6 +197,14 @@ int mm_conv1d_dgrad_bn_reduce(const void* dy, const void* w_dgrad, int B, int T,
                               int pool, int drop_first, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                               hipStream_t stream);
 
+/* mm_linear_fwd_ln (the last Linear of a TemporalTransformerBlock with the NEXT block's norm1 fused,
+ * enhanced_models_v4.py:97-107) followed, inside the launch, by that next block's self_attn in_proj on the LayerNorm rows:
+ * out2_bf16 (M, n2) = ln_out_bf16 @ w2^T + bias2, w2 = in_proj's forward weight image (n2 rows of 128, n2 % 128 == 0).
+ * Bit-identical to mm_conv1d_fwd(ln_out_bf16, w2, 1, M, 128, n2, 1, 0, NULL, bias2, ..., out_bf16 = out2_bf16). */
+int mm_linear_fwd_ln_gemm2(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
+                           float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                           const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out_bf16, float* ln_stat,
+                           const void* w2, const float* bias2, int n2, void* out2_bf16, hipStream_t stream);
 /* mm_linear_dgrad_ln_bwd of norm2 / linear1 with the attention out-projection's data gradient as a second GEMM in the
  * same launch (TemporalTransformerBlock backward, enhanced_models_v4.py:99-103: x1 = x0 + dropout(out_proj(attn)),
  * norm2(x1)): do_bf16 (M, 128) = dx_bf16 @ w2, w2 = out_proj's data-gradient weight image (128 x 128), dx_bf16 = the

@@ -78,6 +78,8 @@ struct EpiArgs {
     // input (the attention out-projection under norm2): its operand never leaves the workgroup
     const bf16* w2 = nullptr;
     bf16* out2 = nullptr;
+    const float* bias2 = nullptr;   // (n2) added to the second GEMM's columns (nullptr = 0)
+    int n2 = 128;                   // its output width: w2 is n2 rows of 128 (a multiple of 128)
     int res_rows = 0;            // epilogue_ln_bwd: > 0 = `residual` is (M / res_rows, 128): one row for res_rows consecutive rows
 };
 
@@ -111,7 +113,7 @@ static unsigned epi_mask(const EpiArgs& e) {
 // residual / positional loads and all stores are 16-byte, row-contiguous.
 template <int BM, int BN, unsigned FEAT>
 __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
-                                              int n0, int N, float* sstat) {
+                                              int n0, int N, float* sstat, bf16* a2 = nullptr) {
     // no implicit FMA contraction in here: which multiply-adds get fused would depend on what a specialisation folds
     // away, and the variants of one op must agree bit for bit (tests compare them); the two intended FMAs are explicit
 #pragma clang fp contract(off)
@@ -194,6 +196,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
                 bf16x4 hv = {(bf16)(d0 * rstd * g4.x + b4.x), (bf16)(d1 * rstd * g4.y + b4.y),
                              (bf16)(d2 * rstd * g4.z + b4.z), (bf16)(d3 * rstd * g4.w + b4.w)};
                 *reinterpret_cast<bf16x4*>(e.lnf_out + oi) = hv;
+                if (a2) *reinterpret_cast<bf16x4*>(a2 + r0 * (128 + KPAD) + cg * 4) = hv;     // operand tile of the second GEMM
                 if (e.lnf_stat && cg == 0) {
                     const size_t m = (size_t)b * To + t;
                     e.lnf_stat[2 * m] = mean; e.lnf_stat[2 * m + 1] = rstd;
@@ -435,6 +438,34 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
 #undef EF_ON
 }
 
+// out2[32 rows][n2] = a2[32][128] (bf16 rows this workgroup has just finished, in LDS) x w2 (+ bias2): wave wn owns columns
+// 128 j + 32 wn .. of every 128-column group j; B fragments straight from the L2-resident weight image, k ascending as the
+// main loop's, fp32 accumulate, one rounding to bf16 - bit-identical to a launch of its own on the same rows.
+__device__ __forceinline__ void second_gemm(const bf16* a2, const EpiArgs& e, size_t row0, int wn, int lr, int lh) {
+    bf16x8 af[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(a2 + lr * A2S + ks * 16 + lh * 8);
+    for (int j = 0; j < e.n2 / 128; ++j) {
+        const int n = 128 * j + 32 * wn + lr;
+        const bf16* wrow = e.w2 + (size_t)n * 128 + lh * 8;
+        bf16x8 bfr[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 16);
+        f32x16 c2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c2[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfr[ks], c2, 0, 0, 0);
+        const float bias = e.bias2 ? e.bias2[n] : 0.f;
+        bf16* orow = e.out2 + row0 * e.n2 + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            orow[(size_t)row * e.n2] = (bf16)(e.bias2 ? c2[r] + bias : c2[r]);
+        }
+    }
+}
+
 // FEAT: epilogue combination (EF_ANY = all run-time); TAPS > 0: compiled for that tap count (1 = the Linear layers)
 template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT, int TAPS>
 __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
@@ -575,27 +606,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
             bf16* a2 = gemm2 ? reinterpret_cast<bf16*>(smem + (BM * LDC + 2 * BN) * sizeof(float)) : nullptr;   // behind the C tile
             epilogue_ln_bwd<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, sstat, a2);
             if (gemm2) {
-                // out2[32 rows][128] = a2[32][128] (bf16, this workgroup's finished rows) x w2: wave wn owns columns 32 wn ..,
-                // B fragments straight from the (L2-resident, 32 KB) weight image, k ascending as the main loop's
                 __syncthreads();
-                f32x16 c2;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c2[r] = 0.f;
-                const bf16* wrow = a.e.w2 + (size_t)(wn * 32 + lr) * 128 + lh * 8;
-                bf16x8 bfr[8];
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 16);
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(a2 + lr * A2S + ks * 16 + lh * 8);
-                    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[ks], c2, 0, 0, 0);
-                }
-                bf16* orow = a.e.out2 + ((size_t)b * a.T + t0) * 128 + wn * 32 + lr;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    orow[(size_t)row * 128] = (bf16)c2[r];
-                }
+                second_gemm(a2, a.e, (size_t)b * a.T + t0, wn, lr, lh);
             }
             return;
         }
@@ -603,6 +615,17 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     if constexpr (BM == 64 && BN == 64) {
         if ((FEAT == EF_ANY && a.e.bn.y) || (FEAT != EF_ANY && (FEAT & EF_BNRED))) {
             epilogue_bn_reduce<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout);
+            return;
+        }
+    }
+    if constexpr (BM == 32 && BN == 128) {
+        // forward: the LayerNorm rows of the fused next pre-norm (EF_LNF) feed a second GEMM (the next block's QKV projection)
+        const bool gemm2 = FEAT == EF_ANY ? a.e.w2 != nullptr : (FEAT & EF_GEMM2) != 0;
+        if (gemm2) {
+            bf16* a2 = reinterpret_cast<bf16*>(smem + (BM * LDC + 2 * BN) * sizeof(float));
+            epilogue_rows<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat, a2);
+            __syncthreads();
+            second_gemm(a2, a.e, (size_t)b * a.T + t0, wn, lr, lh);
             return;
         }
     }
@@ -644,6 +667,7 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
         constexpr int LT = 1;
         if (a.taps == 1) switch (m) {
             EPI_CASE(0x001541u)          // out-proj / FFN-2 forward: bias, dropout, residual, fp32 out, LayerNorm of the result
+            EPI_CASE(0x10001541u)        // ... and the next block's QKV projection of those LayerNorm rows (second GEMM)
             EPI_CASE(0x001521u)          // last FFN-2 forward: ... and the mean over tokens instead of the LayerNorm
             EPI_CASE(0x000800u)          // plain data gradient, bf16 out
             EPI_CASE(0x002d01u)          // data gradient + LayerNorm backward: skip gradient in, fp32 and masked bf16 out
@@ -1282,7 +1306,8 @@ int mm_conv1d_dgrad_bn_reduce(const void* dy, const void* w_dgrad, int B, int T,
 static int linear128_fwd(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
                          float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, float* pool_out,
                          int rows_per_group, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out,
-                         float* ln_stat, hipStream_t st) {
+                         float* ln_stat, hipStream_t st, const void* w2 = nullptr, const float* bias2 = nullptr, int n2 = 0,
+                         void* out2 = nullptr) {
     MM_REQUIRE(x && w && out_f32 && M > 0 && M % 32 == 0 && K > 0 && K % 16 == 0, "linear128_fwd: M=%d (x32) K=%d (x16)", M, K);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear128_fwd: drop_p");
     MM_REQUIRE(!pool_out || (rows_per_group > 0 && rows_per_group % 32 == 0 && M % rows_per_group == 0),
@@ -1302,6 +1327,10 @@ static int linear128_fwd(const void* x, const void* w, int M, int K, const float
     a.e.pool_out = pool_out; a.e.pool_rows = pool_out ? rows_per_group : 0;
     a.e.pool_scale = pool_out ? 1.f / (float)rows_per_group : 0.f;
     a.e.lnf_out = (bf16*)ln_out; a.e.lnf_stat = ln_stat; a.e.lnf_gamma = ln_gamma; a.e.lnf_beta = ln_beta; a.e.lnf_eps = ln_eps;
+    if (w2) {
+        MM_REQUIRE(ln_out && out2 && n2 > 0 && n2 % 128 == 0, "linear128_fwd: the second GEMM needs the LayerNorm rows, an output and n2 %% 128 == 0 (n2=%d)", n2);
+        a.e.w2 = (const bf16*)w2; a.e.bias2 = bias2; a.e.n2 = n2; a.e.out2 = (bf16*)out2;
+    }
     const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
     switch (kct) {
         case 16: return launch_fwd<32, 128, 1, 4, 16>(a, st);
@@ -1325,6 +1354,18 @@ int mm_linear_fwd_ln(const void* x, const void* w, int M, int K, const float* bi
     MM_REQUIRE(ln_out_bf16, "linear_fwd_ln: null ln_out");
     return linear128_fwd(x, w, M, K, bias, residual, out_f32, drop_p, seed, seed_epoch, nullptr, 0, ln_gamma, ln_beta, ln_eps,
                          ln_out_bf16, ln_stat, st);
+}
+
+// mm_linear_fwd_ln followed, inside the launch, by out2 = ln_out @ w2^T + bias2 (M x 128 x n2): the projection that
+// consumes the fused LayerNorm's rows (the next TemporalTransformerBlock's in_proj: n2 = 384).  w2 = that Linear's forward
+// weight image (n2 rows of 128); bit-identical to mm_conv1d_fwd(ln_out, w2, 1, M, 128, n2, 1, 0, NULL, bias2, ..., bf16 out).
+int mm_linear_fwd_ln_gemm2(const void* x, const void* w, int M, int K, const float* bias, const float* residual, float* out_f32,
+                           float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* ln_gamma, const float* ln_beta,
+                           float ln_eps, void* ln_out_bf16, float* ln_stat, const void* w2, const float* bias2, int n2,
+                           void* out2_bf16, hipStream_t st) {
+    MM_REQUIRE(ln_out_bf16 && w2 && out2_bf16, "linear_fwd_ln_gemm2: null");
+    return linear128_fwd(x, w, M, K, bias, residual, out_f32, drop_p, seed, seed_epoch, nullptr, 0, ln_gamma, ln_beta, ln_eps,
+                         ln_out_bf16, ln_stat, st, w2, bias2, n2, out2_bf16);
 }
 
 // dx = LayerNorm128_backward(dy @ W^T) + dres in one launch: the data-gradient GEMM of the Linear that

@@ -14,6 +14,7 @@ Conventions
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -124,6 +125,7 @@ def _zeros(shape, like, dtype=_F32):
     return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
+_NO_QKV_FUSE = bool(os.environ.get("MM_NO_QKV_FUSE"))     # A/B knob: the next block's QKV projection as its own launch
 _seed_state = {"base": 0x1234567, "step": 0, "epoch": None}
 
 
@@ -425,23 +427,28 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
 
 def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool = False,
                           save: Optional[bool] = None, pool_out: Optional[torch.Tensor] = None,
-                          prenorm=None, next_norm=None, mask=None):
+                          prenorm=None, next_norm=None, mask=None, next_blk=None):
     """x fp32 (B, L, d) -> fp32 (B, L, d); returns (out, saved).  ``training``
     switches dropout on; ``save`` (default = training) keeps what backward needs.
     ``pool_out`` (zeroed fp32 (B, d)): the second FFN Linear also accumulates the mean over time of
     the block's output there (the encoder's pooling step, fused into that GEMM's epilogue).
     Width 128: every LayerNorm but the stack's first is computed in the epilogue of the GEMM that produces
     its input (``prenorm`` = (norm1(x) bf16, stats) handed in by the block below, ``next_norm`` = the next
-    block's norm1, whose output is then returned in ``saved['next_prenorm']`` / as third result)."""
+    block's norm1, whose output is then returned in ``saved['next_prenorm']`` / as third result).  With ``next_blk`` the
+    same launch also runs that block's QKV projection on those rows (a second GEMM: the third result then carries the
+    packed q | k | v as its third element)."""
     B, L, D = x.shape
     M = B * L
     save = training if save is None else save
     p = blk.dropout.p if training else 0.0
     x2 = x.view(M, D)
     fuse_ln = D == 128 and M % 32 == 0
-    h1, st1 = prenorm if prenorm is not None else layernorm(x2, blk.norm1, save)
-    qkv = linear_rows(h1, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias,
-                      need_dgrad=need_dgrad)["bf16"]
+    h1, st1 = prenorm[:2] if prenorm is not None else layernorm(x2, blk.norm1, save)
+    if prenorm is not None and len(prenorm) > 2:            # the block below already projected its fused LayerNorm rows
+        qkv = prenorm[2]
+    else:
+        qkv = linear_rows(h1, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias,
+                          need_dgrad=need_dgrad)["bf16"]
     pa = float(blk.self_attn.dropout) if training else 0.0      # attention-probability dropout
     sa = _next_seed() if pa > 0 else 0
     o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save, pa, sa, mask)
@@ -473,9 +480,22 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
         x2o = _empty((M, D), _F32, x)
         hn = _empty((M, D), _BF, x)
         stn = _empty((M, 2), _F32, x) if save else None
-        _hip.call("mm_linear_fwd_ln", f1["bf16"], wf, M, cinp, blk.linear2.bias, x1, x2o, float(p), int(s3), EP(),
-                  next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn)
-        nxt = (hn, stn)
+        wq = None
+        if next_blk is not None and not _NO_QKV_FUSE:
+            wq, _, cq, _ = weights.get(next_blk.self_attn.in_proj_weight, need_dgrad)
+            if cq != 128 or next_blk.self_attn.in_proj_weight.shape[0] % 128:
+                wq = None
+        if wq is not None:
+            nq = next_blk.self_attn.in_proj_weight.shape[0]
+            qn = _empty((M, nq), _BF, x)
+            _hip.call("mm_linear_fwd_ln_gemm2", f1["bf16"], wf, M, cinp, blk.linear2.bias, x1, x2o, float(p), int(s3), EP(),
+                      next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn, wq, next_blk.self_attn.in_proj_bias,
+                      nq, qn)
+            nxt = (hn, stn, qn)
+        else:
+            _hip.call("mm_linear_fwd_ln", f1["bf16"], wf, M, cinp, blk.linear2.bias, x1, x2o, float(p), int(s3), EP(),
+                      next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn)
+            nxt = (hn, stn)
     else:
         x2o = linear_rows(f1["bf16"], blk.linear2.weight, blk.linear2.bias, residual=x1, out_f32=True,
                           out_bf16=False, drop_p=p, seed=s3, need_dgrad=need_dgrad)["f32"]
@@ -541,7 +561,7 @@ def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool, preno
     for i, blk in enumerate(layers):
         if i < nblk - 1:                                 # the next block's norm1 rides in this block's last GEMM
             h, s, prenorm = transformer_block_fwd(h, blk, training, need_dgrad, save=save, prenorm=prenorm,
-                                                  next_norm=layers[i + 1].norm1)
+                                                  next_norm=layers[i + 1].norm1, next_blk=layers[i + 1])
         else:
             h, s = transformer_block_fwd(h, blk, training, need_dgrad, save=save, pool_out=pooled, prenorm=prenorm)
         blocks.append(s)

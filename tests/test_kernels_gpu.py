@@ -731,6 +731,43 @@ def test_pooled_head_backward_row_form_and_row_residual():
                  wdo, outs[0][3], 7)
 
 
+@pytest.mark.parametrize("M,K,p,generic", [(16384, 512, 0.3, False), (96, 128, 0.0, False), (64, 64, 0.2, True)])
+def test_linear_forward_with_fused_layernorm_and_next_projection(M, K, p, generic, monkeypatch):
+    """mm_linear_fwd_ln_gemm2: the fused LayerNorm's rows go through the next block's QKV projection inside the launch -
+    q | k | v bit-identical to the projection as a launch of its own, everything else unchanged."""
+    hip = _hip()
+    if generic:
+        monkeypatch.setenv("MM_EPI_GENERIC", "1")
+    g = torch.Generator().manual_seed(M + K + 2)
+    w = torch.randn(128, K, 1, generator=g) / math.sqrt(K)
+    wf, _ = _prep_w(hip, w, K)
+    wq = torch.randn(384, 128, 1, generator=g) / math.sqrt(128)
+    wqf, _ = _prep_w(hip, wq, 128)
+    bq = torch.randn(384, generator=g).cuda() * 0.1
+    x = (torch.randn(M, K, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    bias = torch.randn(128, generator=g).cuda() * 0.1
+    res = torch.randn(M, 128, generator=g).cuda()
+    gam, bet = (0.5 + torch.rand(128, generator=g)).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+
+    def run(fused):
+        o = torch.full((M, 128), float("nan"), device="cuda")
+        h = torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")
+        st = torch.empty(M, 2, device="cuda")
+        q = torch.full((M, 384), float("nan"), device="cuda").to(torch.bfloat16)
+        if fused:
+            hip.call("mm_linear_fwd_ln_gemm2", x, wf, M, K, bias, res, o, p, 71, None, gam, bet, 1e-5, h, st, wqf, bq, 384, q)
+        else:
+            hip.call("mm_linear_fwd_ln", x, wf, M, K, bias, res, o, p, 71, None, gam, bet, 1e-5, h, st)
+            hip.call("mm_conv1d_fwd", h, wqf, 1, M, 128, 384, 1, 0, None, bq, 0, None, None, 1, None, None, q, None,
+                     0.0, 0, None, None, 0)
+        return o, h, st, q
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.isfinite(b[3].float()).all() and torch.equal(a[3], b[3])
+    ref = (a[1].float().cpu() @ _bf(wq[:, :, 0]).t() + bq.cpu()).to(torch.bfloat16).float()
+    torch.testing.assert_close(b[3].float().cpu(), ref, rtol=2e-2, atol=2e-2)
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 
