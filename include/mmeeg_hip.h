@@ -205,6 +205,15 @@ int mm_linear_fwd_ln_gemm2(const void* x, const void* w, int M, int K, const flo
                            float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                            const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out_bf16, float* ln_stat,
                            const void* w2, const float* bias2, int n2, void* out2_bf16, hipStream_t stream);
+/* ... and with an epilogue on the second GEMM: the attention out-projection (+ residual, dropout, norm2 fused) followed by
+ * the first FFN Linear on norm2's rows - out2_bf16 (M, n2) = dropout(act2(ln_out @ w2^T + bias2)), pre2_bf16 (nullable) =
+ * its bf16 pre-activation (enhanced_models_v4.py:99-105).  Bit-identical to mm_conv1d_fwd(ln_out_bf16, w2, 1, M, 128, n2,
+ * 1, 0, NULL, bias2, act2, ..., out_bf16 = out2_bf16, out_pre = pre2_bf16, drop2_p, seed2, seed_epoch, ...). */
+int mm_linear_fwd_ln_gemm2_act(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
+                               float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                               const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out_bf16,
+                               float* ln_stat, const void* w2, const float* bias2, int n2, void* out2_bf16,
+                               void* pre2_bf16, int act2, float drop2_p, uint32_t seed2, hipStream_t stream);
 /* mm_linear_dgrad_ln_bwd of norm2 / linear1 with the attention out-projection's data gradient as a second GEMM in the
  * same launch (TemporalTransformerBlock backward, enhanced_models_v4.py:99-103: x1 = x0 + dropout(out_proj(attn)),
  * norm2(x1)): do_bf16 (M, 128) = dx_bf16 @ w2, w2 = out_proj's data-gradient weight image (128 x 128), dx_bf16 = the

@@ -80,6 +80,9 @@ struct EpiArgs {
     bf16* out2 = nullptr;
     const float* bias2 = nullptr;   // (n2) added to the second GEMM's columns (nullptr = 0)
     int n2 = 128;                   // its output width: w2 is n2 rows of 128 (a multiple of 128)
+    int act2 = 0;                   // activation of the second GEMM's output, then dropout (thresh2 / seed2 / inv_keep2, index
+    uint32_t thresh2 = 0, seed2 = 0; float inv_keep2 = 1.f;      // row * n2 + column as a launch of its own would use)
+    bf16* pre2 = nullptr;           // pre-activation copy (M, n2) bf16 (nullptr = none)
     int res_rows = 0;            // epilogue_ln_bwd: > 0 = `residual` is (M / res_rows, 128): one row for res_rows consecutive rows
 };
 
@@ -442,6 +445,7 @@ __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& 
 // 128 j + 32 wn .. of every 128-column group j; B fragments straight from the L2-resident weight image, k ascending as the
 // main loop's, fp32 accumulate, one rounding to bf16 - bit-identical to a launch of its own on the same rows.
 __device__ __forceinline__ void second_gemm(const bf16* a2, const EpiArgs& e, size_t row0, int wn, int lr, int lh) {
+#pragma clang fp contract(off)
     bf16x8 af[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(a2 + lr * A2S + ks * 16 + lh * 8);
@@ -458,10 +462,25 @@ __device__ __forceinline__ void second_gemm(const bf16* a2, const EpiArgs& e, si
         for (int ks = 0; ks < 8; ++ks) c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfr[ks], c2, 0, 0, 0);
         const float bias = e.bias2 ? e.bias2[n] : 0.f;
         bf16* orow = e.out2 + row0 * e.n2 + n;
+        if (!e.act2 && !e.thresh2 && !e.pre2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            orow[(size_t)row * e.n2] = (bf16)(e.bias2 ? c2[r] + bias : c2[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                orow[(size_t)row * e.n2] = (bf16)(e.bias2 ? c2[r] + bias : c2[r]);
+            }
+        } else {
+            // bias -> pre-activation copy -> activation -> dropout, the arithmetic of epilogue_rows (FFN-1 forward)
+            const uint32_t dseed = e.thresh2 ? mm_eff_seed(e.seed2, e.drop_epoch) : 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const size_t idx = (row0 + row) * e.n2 + n;
+                const float v = e.bias2 ? c2[r] + bias : c2[r];
+                if (e.pre2) e.pre2[idx] = (bf16)v;
+                float val = apply_act(v, e.act2);
+                if (e.thresh2) val = __builtin_fmaf(val, dropout_scale(dseed, (uint32_t)idx, e.thresh2, e.inv_keep2), 0.f);
+                orow[(size_t)row * e.n2] = (bf16)val;
+            }
         }
     }
 }
@@ -1307,7 +1326,7 @@ static int linear128_fwd(const void* x, const void* w, int M, int K, const float
                          float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, float* pool_out,
                          int rows_per_group, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out,
                          float* ln_stat, hipStream_t st, const void* w2 = nullptr, const float* bias2 = nullptr, int n2 = 0,
-                         void* out2 = nullptr) {
+                         void* out2 = nullptr, int act2 = 0, float drop2_p = 0.f, uint32_t seed2 = 0, void* pre2 = nullptr) {
     MM_REQUIRE(x && w && out_f32 && M > 0 && M % 32 == 0 && K > 0 && K % 16 == 0, "linear128_fwd: M=%d (x32) K=%d (x16)", M, K);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "linear128_fwd: drop_p");
     MM_REQUIRE(!pool_out || (rows_per_group > 0 && rows_per_group % 32 == 0 && M % rows_per_group == 0),
@@ -1329,7 +1348,11 @@ static int linear128_fwd(const void* x, const void* w, int M, int K, const float
     a.e.lnf_out = (bf16*)ln_out; a.e.lnf_stat = ln_stat; a.e.lnf_gamma = ln_gamma; a.e.lnf_beta = ln_beta; a.e.lnf_eps = ln_eps;
     if (w2) {
         MM_REQUIRE(ln_out && out2 && n2 > 0 && n2 % 128 == 0, "linear128_fwd: the second GEMM needs the LayerNorm rows, an output and n2 %% 128 == 0 (n2=%d)", n2);
+        MM_REQUIRE(drop2_p >= 0.f && drop2_p < 1.f && (size_t)M * n2 < (1ull << 32), "linear128_fwd: second GEMM dropout / 32-bit indices");
         a.e.w2 = (const bf16*)w2; a.e.bias2 = bias2; a.e.n2 = n2; a.e.out2 = (bf16*)out2;
+        a.e.act2 = act2; a.e.pre2 = (bf16*)pre2;
+        a.e.thresh2 = drop2_p > 0.f ? (uint32_t)((double)drop2_p * 4294967296.0) : 0u;
+        a.e.seed2 = seed2; a.e.inv_keep2 = drop2_p > 0.f ? 1.0f / (1.0f - drop2_p) : 1.f;
     }
     const int kct = (K % 128 == 0) ? 128 : (K % 64 == 0 ? 64 : (K % 32 == 0 ? 32 : 16));
     switch (kct) {
@@ -1366,6 +1389,20 @@ int mm_linear_fwd_ln_gemm2(const void* x, const void* w, int M, int K, const flo
     MM_REQUIRE(ln_out_bf16 && w2 && out2_bf16, "linear_fwd_ln_gemm2: null");
     return linear128_fwd(x, w, M, K, bias, residual, out_f32, drop_p, seed, seed_epoch, nullptr, 0, ln_gamma, ln_beta, ln_eps,
                          ln_out_bf16, ln_stat, st, w2, bias2, n2, out2_bf16);
+}
+
+// mm_linear_fwd_ln_gemm2 with an epilogue on the second GEMM: out2 = dropout(act(ln_out @ w2^T + bias2)), pre2 (nullable) =
+// the bf16 pre-activation - the first FFN Linear (128 -> n2 = 512, GELU, Dropout) on the rows of the norm2 that the attention
+// out-projection's launch has just formed.  Bit-identical to mm_conv1d_fwd(ln_out, w2, 1, M, 128, n2, 1, 0, NULL, bias2, act,
+// ..., out_bf16 = out2, out_pre = pre2, drop2_p, seed2, seed_epoch, ...).
+int mm_linear_fwd_ln_gemm2_act(const void* x, const void* w, int M, int K, const float* bias, const float* residual,
+                               float* out_f32, float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* ln_gamma,
+                               const float* ln_beta, float ln_eps, void* ln_out_bf16, float* ln_stat, const void* w2,
+                               const float* bias2, int n2, void* out2_bf16, void* pre2_bf16, int act2, float drop2_p,
+                               uint32_t seed2, hipStream_t st) {
+    MM_REQUIRE(ln_out_bf16 && w2 && out2_bf16, "linear_fwd_ln_gemm2_act: null");
+    return linear128_fwd(x, w, M, K, bias, residual, out_f32, drop_p, seed, seed_epoch, nullptr, 0, ln_gamma, ln_beta, ln_eps,
+                         ln_out_bf16, ln_stat, st, w2, bias2, n2, out2_bf16, act2, drop2_p, seed2, pre2_bf16);
 }
 
 // dx = LayerNorm128_backward(dy @ W^T) + dres in one launch: the data-gradient GEMM of the Linear that

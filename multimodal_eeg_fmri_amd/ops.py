@@ -125,6 +125,8 @@ def _zeros(shape, like, dtype=_F32):
     return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
+_NO_FFN1_FUSE = not os.environ.get("MM_FFN1_FUSE")        # the first FFN Linear inside the out-projection's launch: measured, not
+                                                           # faster (2-byte column stores of 2 x 16 MB) - off unless MM_FFN1_FUSE=1
 _NO_QKV_FUSE = bool(os.environ.get("MM_NO_QKV_FUSE"))     # A/B knob: the next block's QKV projection as its own launch
 _seed_state = {"base": 0x1234567, "step": 0, "epoch": None}
 
@@ -453,21 +455,36 @@ def transformer_block_fwd(x: torch.Tensor, blk, training: bool, need_dgrad: bool
     sa = _next_seed() if pa > 0 else 0
     o, lse = attention(qkv.view(B, L, 3 * D), blk.nhead, save, pa, sa, mask)
     s1 = _next_seed() if p > 0 else 0
+    f1 = None
+    s2 = None
     if fuse_ln:
         wf, _, cinp, _ = weights.get(blk.self_attn.out_proj.weight, need_dgrad)
         x1 = _empty((M, D), _F32, x)
         h2 = _empty((M, D), _BF, x)
         st2 = _empty((M, 2), _F32, x) if save else None
-        _hip.call("mm_linear_fwd_ln", o.view(M, D), wf, M, cinp, blk.self_attn.out_proj.bias, x2, x1, float(p), int(s1),
-                  EP(), blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), h2, st2)
+        w1, _, c1, _ = weights.get(blk.linear1.weight, need_dgrad)
+        n1 = blk.linear1.weight.shape[0]
+        if c1 == 128 and n1 % 128 == 0 and M * n1 < (1 << 32) and not _NO_FFN1_FUSE:
+            # the first FFN Linear (GELU, Dropout, pre-activation copy) runs on norm2's rows inside the out-projection's launch
+            s2 = _next_seed() if p > 0 else 0
+            g1 = _empty((M, n1), _BF, x)
+            z1 = _empty((M, n1), _BF, x) if save else None
+            _hip.call("mm_linear_fwd_ln_gemm2_act", o.view(M, D), wf, M, cinp, blk.self_attn.out_proj.bias, x2, x1, float(p),
+                      int(s1), EP(), blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), h2, st2, w1, blk.linear1.bias,
+                      n1, g1, z1, ACT[blk._act], float(p), int(s2))
+            f1 = {"bf16": g1, "pre": z1, "f32": None}
+        else:
+            _hip.call("mm_linear_fwd_ln", o.view(M, D), wf, M, cinp, blk.self_attn.out_proj.bias, x2, x1, float(p), int(s1),
+                      EP(), blk.norm2.weight, blk.norm2.bias, float(blk.norm2.eps), h2, st2)
     else:
         x1 = linear_rows(o.view(M, D), blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias,
                          residual=x2, out_f32=True, out_bf16=False, drop_p=p, seed=s1,
                          need_dgrad=need_dgrad)["f32"]
         h2, st2 = layernorm(x1, blk.norm2, save)
-    s2 = _next_seed() if p > 0 else 0
-    f1 = linear_rows(h2, blk.linear1.weight, blk.linear1.bias, act=blk._act, out_pre=save,
-                     drop_p=p, seed=s2, need_dgrad=need_dgrad)
+    if f1 is None:
+        s2 = _next_seed() if p > 0 else 0
+        f1 = linear_rows(h2, blk.linear1.weight, blk.linear1.bias, act=blk._act, out_pre=save,
+                         drop_p=p, seed=s2, need_dgrad=need_dgrad)
     s3 = _next_seed() if p > 0 else 0
     nxt = None
     if pool_out is not None:

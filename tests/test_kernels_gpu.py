@@ -768,6 +768,45 @@ def test_linear_forward_with_fused_layernorm_and_next_projection(M, K, p, generi
     torch.testing.assert_close(b[3].float().cpu(), ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,K,p,generic", [(16384, 128, 0.3, False), (96, 128, 0.0, False), (64, 64, 0.2, True)])
+def test_linear_forward_with_fused_layernorm_and_first_ffn_linear(M, K, p, generic, monkeypatch):
+    """mm_linear_fwd_ln_gemm2_act: out-projection + norm2, then Linear(128 -> 512) + GELU + dropout on norm2's rows in the
+    same launch - activation and pre-activation bit-identical to the Linear as a launch of its own."""
+    hip = _hip()
+    if generic:
+        monkeypatch.setenv("MM_EPI_GENERIC", "1")
+    g = torch.Generator().manual_seed(M + K + 3)
+    wf, _ = _prep_w(hip, torch.randn(128, K, 1, generator=g) / math.sqrt(K), K)
+    w1 = torch.randn(512, 128, 1, generator=g) / math.sqrt(128)
+    w1f, _ = _prep_w(hip, w1, 128)
+    b1 = torch.randn(512, generator=g).cuda() * 0.1
+    x = (torch.randn(M, K, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    bias = torch.randn(128, generator=g).cuda() * 0.1
+    res = torch.randn(M, 128, generator=g).cuda()
+    gam, bet = (0.5 + torch.rand(128, generator=g)).cuda(), (torch.randn(128, generator=g) * 0.1).cuda()
+
+    def run(fused):
+        o = torch.full((M, 128), float("nan"), device="cuda")
+        h = torch.empty(M, 128, dtype=torch.bfloat16, device="cuda")
+        st = torch.empty(M, 2, device="cuda")
+        a1 = torch.full((M, 512), float("nan"), device="cuda").to(torch.bfloat16)
+        z1 = torch.full((M, 512), float("nan"), device="cuda").to(torch.bfloat16)
+        if fused:
+            hip.call("mm_linear_fwd_ln_gemm2_act", x, wf, M, K, bias, res, o, p, 81, None, gam, bet, 1e-5, h, st, w1f, b1, 512,
+                     a1, z1, 1, p, 82)
+        else:
+            hip.call("mm_linear_fwd_ln", x, wf, M, K, bias, res, o, p, 81, None, gam, bet, 1e-5, h, st)
+            hip.call("mm_conv1d_fwd", h, w1f, 1, M, 128, 512, 1, 0, None, b1, 1, None, None, 1, None, None, a1, z1,
+                     p, 82, None, None, 0)
+        return o, h, st, a1, z1
+    a, b = run(False), run(True)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert torch.isfinite(b[3].float()).all() and torch.isfinite(b[4].float()).all()
+    zref = (a[1].float().cpu() @ _bf(w1[:, :, 0]).t() + b1.cpu())
+    torch.testing.assert_close(b[4].float().cpu(), zref.to(torch.bfloat16).float(), rtol=2e-2, atol=2e-2)
+
+
 def _vol_cl(x):           # (B,C,D,H,W) -> channels-last bf16 on GPU
     return x.permute(0, 2, 3, 4, 1).contiguous().cuda().to(torch.bfloat16)
 

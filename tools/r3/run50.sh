@@ -1,18 +1,18 @@
 #!/usr/bin/env bash
-# next block's QKV projection as a second GEMM behind FFN-2 + fused norm1: tests, A/B (MM_NO_QKV_FUSE=1 = own launch)
+# next block's QKV projection as a second GEMM behind FFN-2 + fused norm1: tests, A/B (MM_NO_FFN1_FUSE=1 = own launch)
 set -uo pipefail
 root="${GRAFT_REPO_ROOT:-$(pwd)}"
 out="$root/gpurun_out"; mkdir -p "$out"; cd "$root"
-timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > "$out/r3_t50.log" 2>&1
-echo "rc=$?" >> "$out/r3_t50.log"
-tail -4 "$out/r3_t50.log"
-grep -q "rc=0" "$out/r3_t50.log" || exit 1
-rm -f "$out/r3_ab50.log"
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > "$out/r3_t51.log" 2>&1
+echo "rc=$?" >> "$out/r3_t51.log"
+tail -4 "$out/r3_t51.log"
+grep -q "rc=0" "$out/r3_t51.log" || exit 1
+rm -f "$out/r3_ab51.log"
 for rep in 1 2 3; do
   for v in 1 0; do
-    if [ $v = 1 ]; then export MM_NO_QKV_FUSE=1; else unset MM_NO_QKV_FUSE; fi
-    echo "== no_qkv_fuse=$v (rep $rep)" >> "$out/r3_ab50.log"
-    python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --fit-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['final_loss'])" >> "$out/r3_ab50.log"
+    if [ $v = 1 ]; then export MM_NO_FFN1_FUSE=1; else unset MM_NO_FFN1_FUSE; fi
+    echo "== no_ffn1_fuse=$v (rep $rep)" >> "$out/r3_ab51.log"
+    python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --fit-steps 0 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['final_loss'])" >> "$out/r3_ab51.log"
   done
 done
-cat "$out/r3_ab50.log"
+cat "$out/r3_ab51.log"
