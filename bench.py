@@ -31,7 +31,7 @@ EEG_CH, EEG_T, VOL = 64, 1024, (32, 32, 32)
 PMC_SUMMARY = "profiles/r03_pmc_wres_c2.summary.txt"
 PMC_SUMMARY_C4 = "profiles/r03_pmc_wres_c4.summary.txt"
 # rocprofv3 --kernel-trace of this command (profiles/run_prof.sh): the kernel's mean duration inside the replayed step
-PROFILE_IN_STEP = {"source": "profiles/r03_step_kernel_summary.txt", "avg_launch_ms": 0.0239}
+PROFILE_IN_STEP = {"source": "profiles/r03_step_kernel_summary.txt", "avg_launch_ms": 0.0223}
 
 
 def pmc_traffic_bytes(path=None):
