@@ -21,6 +21,7 @@ namespace {
 
 
 constexpr int KPAD = 8;       // +16 B per LDS row
+constexpr int A2S = 128 + KPAD; // row stride (elements) of the second GEMM's LDS operand tile (32 rows of 128 bf16)
 
 // BatchNorm-backward reduce pass of the layer BELOW, fused behind the data-gradient GEMM that produces that layer's
 // d(out) (epilogue_bn_reduce): the tile's bf16 d(out) values are routed through dropout / pool / act' exactly as
@@ -199,7 +200,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, const EpiArgs& e,
                 bf16x4 hv = {(bf16)(d0 * rstd * g4.x + b4.x), (bf16)(d1 * rstd * g4.y + b4.y),
                              (bf16)(d2 * rstd * g4.z + b4.z), (bf16)(d3 * rstd * g4.w + b4.w)};
                 *reinterpret_cast<bf16x4*>(e.lnf_out + oi) = hv;
-                if (a2) *reinterpret_cast<bf16x4*>(a2 + r0 * (128 + KPAD) + cg * 4) = hv;     // operand tile of the second GEMM
+                if (a2) *reinterpret_cast<bf16x4*>(a2 + r0 * A2S + cg * 4) = hv;              // operand tile of the second GEMM
                 if (e.lnf_stat && cg == 0) {
                     const size_t m = (size_t)b * To + t;
                     e.lnf_stat[2 * m] = mean; e.lnf_stat[2 * m + 1] = rstd;
@@ -327,7 +328,6 @@ __device__ __forceinline__ void epilogue_bn_reduce(const float* Cs, const EpiArg
 // dgrad GEMM -> LayerNorm backward in one pass (N == BN == 128, T % BM == 0: checked on the host).
 // 32 lanes own one row (4 columns each): the two row means are 5-step half-wave shuffles; every
 // thread keeps its 4 columns' dgamma / dbeta partial sums over the rows it walks.
-constexpr int A2S = 128 + KPAD;      // row stride (elements) of the second GEMM's LDS operand tile
 template <int BM, int BN, unsigned FEAT>
 __device__ __forceinline__ void epilogue_ln_bwd(const float* Cs, const EpiArgs& e, int tid, int b, int t0, int T,
                                                 float* sstat, bf16* a2 = nullptr) {
