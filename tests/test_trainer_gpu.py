@@ -312,6 +312,44 @@ def test_training_is_bit_reproducible(mode, shape):
     assert torch.equal(s1, s2)
 
 
+def test_fused_launches_train_exactly_as_their_separate_forms(monkeypatch):
+    """Round 3's launch fusions are re-arrangements, not approximations: with the second-GEMM forms (out-projection data
+    gradient, next block's QKV projection, first FFN Linear), the one-row-per-sample head gradients and either hand-over
+    of the conv weight gradients switched, six steps at the C2 shape (dropout on, hipGraph) give BIT-IDENTICAL losses and
+    parameters; the BatchNorm-reduce epilogues regroup fp32 partial sums, so they are held to rounding level."""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    from multimodal_eeg_fmri_amd import autograd, ops
+    batches = [synthetic_pairs(32, 64, 1024, (32, 32, 32), seed=300 + i) for i in range(2)]
+
+    def run(env=None, **knobs):
+        if env:
+            monkeypatch.setenv(*env)
+        for k, v in knobs.items():
+            mod, name = (ops, k[4:]) if k.startswith("ops_") else (autograd, k)
+            monkeypatch.setattr(mod, name, v)
+        ops.set_seed_epoch(None)
+        ops.set_dropout_seed(4321)
+        torch.manual_seed(0)
+        tr = BridgeTrainer(eeg_channels=64, dropout=0.2, lr=1e-3).train()
+        losses = [tr.train_step(*batches[i % 2])["loss"].clone() for i in range(6)]
+        torch.cuda.synchronize()
+        params = torch.cat([p.detach().flatten() for m in (tr.eeg_encoder, tr.fmri_encoder, tr.head) for p in m.parameters()]).clone()
+        ops.set_seed_epoch(None)
+        monkeypatch.undo()
+        return torch.stack(losses), params
+    l0, p0 = run()
+    assert torch.isfinite(l0).all()
+    for knobs in (dict(_NO_GEMM2=True), dict(ops__NO_QKV_FUSE=True), dict(_NO_BCAST=True), dict(ops__NO_FFN1_FUSE=False),
+                  dict(_NO_GEMM2=True, _NO_BCAST=True, ops__NO_QKV_FUSE=True)):
+        l1, p1 = run(**knobs)
+        assert torch.equal(l0, l1) and torch.equal(p0, p1), knobs
+    l2, p2 = run(env=("MM_CONV_WGRADS_HANDED", "2"))
+    assert torch.equal(l0, l2) and torch.equal(p0, p2)
+    l3, p3 = run(_NO_BNRED=True)
+    torch.testing.assert_close(l3, l0, rtol=2e-4, atol=2e-4)
+    assert ((p3 - p0).norm() / p0.norm()).item() < 2e-3
+
+
 def test_graph_mode_draws_new_dropout_masks_each_replay():
     from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
     from multimodal_eeg_fmri_amd import ops
