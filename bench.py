@@ -3,7 +3,14 @@
 step (EEG temporal encoder + fMRI voxel encoder + projection bridge + InfoNCE,
 forward + backward + clip + AdamW) per "step", 32 (EEG-epoch, fMRI-volume)
 pairs per GPU of synthetic 64-ch x 1024-sample EEG and 32^3-voxel fMRI
-(BASELINE.json configs[1]; configs[2] at --gpus 8).
+(BASELINE.json configs[1]; configs[2] at --gpus 8).  `--config c4` runs the same
+step on 64 x 64 x 48 volumes (configs[3]), `--config c5` with the multi-scale
+STFT front-end + power encoder as the EEG branch (configs[4]).
+
+`python bench.py --gpus N` without a launcher starts its own N ranks (one per
+GPU, `torch.distributed.run`) BEFORE anything touches the GPU, relays rank 0's
+line and exits non-zero if a rank fails; under `torch.distributed.run` (RANK /
+WORLD_SIZE set) it is one of those ranks.
 
 Prints ONE JSON line (rank 0).  `value` = pairs/sec of the whole job, inputs
 resident in HBM.  `roofline` is for the layer-2 3-D conv implicit-GEMM kernel,
@@ -17,21 +24,123 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def self_launch(n: int) -> int:
+    """`bench.py --gpus N` started without a launcher: this process becomes the parent of N ranks and never touches the
+    GPU (no torch import, no HIP call; nothing is re-exec'ed).  Rank 0's JSON line is relayed on stdout, everything else
+    the ranks print goes to stderr; the exit code is the job's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{"):
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited 0 without a result line\n")
+        return 1
+    return rc
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _ap = argparse.ArgumentParser(add_help=False)
+    _ap.add_argument("--gpus", type=int, default=1)
+    _n = _ap.parse_known_args()[0].gpus
+    if _n > 1:
+        sys.exit(self_launch(_n))
+
+import torch  # noqa: E402  (after the self-launch decision: the parent of a multi-rank job never loads it)
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # dense, /opt/skills/guides/MI355X_MICROARCH.md
 PAIRS_PER_GPU = 32
 PRECONDITION_STEPS = 300                # untimed steps in front of the --warmup steps (clock conditioning, ~0.25 s)
-EEG_CH, EEG_T, VOL = 64, 1024, (32, 32, 32)
+EEG_CH, EEG_T = 64, 1024
+STFT = dict(n_ffts=(64, 128), hop=32)   # BASELINE config #5 / SURVEY.md 8(d)
 
+# --config: which BASELINE configuration the step runs on (c2 is the one `metric` is quoted on; c4 / c5 are extra legs)
+CONFIGS = {
+    "c2": dict(vol=(32, 32, 32), eeg="erp",
+               workload="C2 bridge train step: 64ch x 1024 EEG (EnhancedERPEncoder) + 32^3 fMRI (3-D conv encoder) + "
+                        "projection bridge + InfoNCE, fwd+bwd+clip+AdamW"),
+    "c4": dict(vol=(64, 64, 48), eeg="erp",
+               workload="C4 bridge train step: 64ch x 1024 EEG (EnhancedERPEncoder) + full-resolution 64x64x48 fMRI (3-D conv "
+                        "encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW"),
+    "c5": dict(vol=(32, 32, 32), eeg="stft",
+               workload="C5 bridge train step: raw 64ch x 1024 EEG -> multi-scale STFT power (n_fft 64 + 128, hop 32, z-scored) -> "
+                        "EnhancedPowerEncoder + 32^3 fMRI (3-D conv encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW"),
+}
 
 PMC_SUMMARY = "profiles/r03_pmc_wres_c2.summary.txt"
 PMC_SUMMARY_C4 = "profiles/r03_pmc_wres_c4.summary.txt"
-# rocprofv3 --kernel-trace of this command (profiles/run_prof.sh): the kernel's mean duration inside the replayed step
-PROFILE_IN_STEP = {"source": "profiles/r03_step_kernel_summary.txt", "avg_launch_ms": 0.0223}
+# rocprofv3 --kernel-trace of this command (profiles/run_prof.sh): per-kernel mean durations inside the replayed step
+PROFILE_STEP_SUMMARIES = ("profiles/r04_step_kernel_summary.txt", "profiles/r03_step_kernel_summary.txt")
+
+
+def conv3_flops(cin, cout, vox):
+    return 2.0 * cin * cout * 27 * vox
+
+
+def family_flops(vol, pairs):
+    """the six dense 3-D convolution GEMMs of one step (layer 2 at vol/2, layer 3 at vol/4: forward, data gradient,
+    weight gradient): name -> (FLOPs per launch, kernel-summary pattern (name prefix, grid))"""
+    v2 = pairs * (vol[0] // 2) * (vol[1] // 2) * (vol[2] // 2)
+    v3 = v2 // 8
+    l2, l3 = conv3_flops(32, 64, v2), conv3_flops(64, 128, v3)
+    return {"L2 fwd": l2, "L3 fwd": l3, "L3 dgrad": l3, "L2 dgrad": l2, "L2 wgrad": l2, "L3 wgrad": l3}
+
+
+def step_flops(cfg, pairs):
+    """algorithmic FLOPs of one training step (forward per pair, backward = 2 x forward)"""
+    T, C, d, ff = EEG_T, EEG_CH, 128, 512
+
+    def blocks(L):
+        return 2 * (2 * L * d * 3 * d + 4 * L * L * d + 2 * L * d * d + 2 * 2 * L * d * ff)
+    if cfg["eeg"] == "erp":
+        eeg = 2 * T * 64 * C * 7 + 2 * T * 128 * 64 * 5 + 2 * (T // 2) * d * 128 * 3 + blocks(T // 2) + 2 * d * d
+    else:
+        frames = T // STFT["hop"] + 1
+        cs = C * sum(n // 2 + 1 for n in STFT["n_ffts"])
+        eeg = 2 * frames * 64 * cs * (3 + 5 + 7) + 2 * frames * d * 192 + blocks(frames) + 2 * d * d
+    v = cfg["vol"][0] * cfg["vol"][1] * cfg["vol"][2]
+    vox = conv3_flops(1, 32, v) + conv3_flops(32, 64, v // 8) + conv3_flops(64, 128, v // 64) + 2 * 128 * 64
+    return 3.0 * pairs * (eeg + vox)
+
+
+def profile_family_us(vol=(32, 32, 32)):
+    """mean in-step durations (us) of the family's six launches parsed from the committed rocprofv3 kernel table
+    (profiles/summarize.py output); None when no summary is committed or a row is missing"""
+    import re
+    if tuple(vol) != (32, 32, 32):
+        return None, None
+    pats = {"L2 fwd": r"conv3d_wres_kernel\s", "L3 fwd": r"conv3d_stream_kernel<64, 128,", "L3 dgrad": r"conv3d_stream_kernel<128, 64,",
+            "L2 dgrad": r"conv3d_stream_kernel<64, 32,", "L2 wgrad": r"conv3d_wgrad_kernel\s+grid=\(41,", "L3 wgrad": r"conv3d_wgrad_kernel\s+grid=\(10,"}
+    for path in PROFILE_STEP_SUMMARIES:
+        try:
+            text = open(os.path.join(ROOT, path)).read()
+        except OSError:
+            continue
+        out = {}
+        for k, pat in pats.items():
+            m = re.search(pat + r".*?avg=\s*([0-9.]+)us", text)
+            if m:
+                out[k] = float(m.group(1))
+        if len(out) == len(pats):
+            return out, path
+    return None, None
 
 
 def pmc_traffic_bytes(path=None):
@@ -70,10 +179,17 @@ def cgroup_cpu_limit():
         return None
 
 
-def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
+def make_eeg_encoder(kind: str, dropout: float):
+    """the EEG branch of a --config (None = the trainer's default EnhancedERPEncoder)"""
+    if kind == "erp":
+        return None
+    from multimodal_eeg_fmri_amd.crossmodal_v4_enhancements import MultiScaleSTFTPowerEncoder
+    return MultiScaleSTFTPowerEncoder(EEG_CH, STFT["n_ffts"], STFT["hop"], 128, 2, 4, dropout)
+
+
+def cpu_baseline(pairs: int, cfg, steps: int = 5, warmup: int = 2):
     """oracle/ training step on the host (checker code, reported baseline only): every core of the affinity mask,
     2 warm-up + 5 timed steps, CPU model stated."""
-    import torch.nn.functional as F
     from oracle import ref_functional as RF
     import multimodal_eeg_fmri_amd.enhanced_models_v4 as E
     import multimodal_eeg_fmri_amd.fmri_utils as Fm
@@ -85,8 +201,8 @@ def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
     cores = max(1, min(affinity, int(quota + 0.5))) if quota else affinity
     torch.set_num_threads(cores)
     torch.manual_seed(0)
-    mods = {"e.": E.EnhancedERPEncoder(EEG_CH, 128, 2, 4, 0.0), "f.": Fm.fMRIVolumeEncoder3D(1, 64, dropout=0.0),
-            "h.": Bu.EEGfMRIContrastiveBridge(dropout=0.0)}
+    enc = make_eeg_encoder(cfg["eeg"], 0.0) or E.EnhancedERPEncoder(EEG_CH, 128, 2, 4, 0.0)
+    mods = {"e.": enc, "f.": Fm.fMRIVolumeEncoder3D(1, 64, dropout=0.0), "h.": Bu.EEGfMRIContrastiveBridge(dropout=0.0)}
     sd = {}
     for pre, m in mods.items():
         for k, v in m.state_dict().items():
@@ -95,11 +211,14 @@ def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
     opt = torch.optim.AdamW(leaves, lr=1e-4, weight_decay=1e-4)
     g = torch.Generator().manual_seed(1234)
     eeg = torch.randn(pairs, EEG_CH, EEG_T, generator=g)
-    vol = torch.randn(pairs, 1, *VOL, generator=g)
+    vol = torch.randn(pairs, 1, *cfg["vol"], generator=g)
 
     def step():
         opt.zero_grad()
-        fe = RF.erp_encoder(sd, eeg, "e.", train=True)
+        if cfg["eeg"] == "erp":
+            fe = RF.erp_encoder(sd, eeg, "e.", train=True)
+        else:
+            fe = RF.stft_power_encoder(sd, eeg, STFT["n_ffts"], STFT["hop"], "e.encoder.", train=True)
         ff = RF.volume_encoder3d(sd, vol, "f.", train=True)
         ze, zf = RF.contrastive_head(sd, fe, ff, "h.bridge.")
         loss = RF.clip_loss(ze, zf, ze, zf, sd["h.logit_scale"].exp())[0]
@@ -120,14 +239,15 @@ def cpu_baseline(pairs: int, steps: int = 5, warmup: int = 2):
     step()
     dt1 = time.perf_counter() - t0
     torch.set_num_threads(cores)
-    c1 = cpu_baseline_c1_lite()
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "affinity_cores": affinity, "cgroup_cpu_limit": quota,
-            "sample": f"{steps} timed + {warmup} warm-up full training steps of {pairs} pairs "
-                      f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step, torch threads = {cores} = min(affinity mask "
-                      f"{affinity}, container CPU quota {quota if quota else 'none'})",
-            "one_thread": {"value": pairs / dt1, "unit": "pairs/s", "sample": f"1 step, {dt1:.1f} s"},
-            "c1_lite": c1}
+    out = {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+           "affinity_cores": affinity, "cgroup_cpu_limit": quota,
+           "sample": f"{steps} timed + {warmup} warm-up full training steps of {pairs} pairs "
+                     f"(same shapes), fp32 torch CPU oracle, {dt:.2f} s/step, torch threads = {cores} = min(affinity mask "
+                     f"{affinity}, container CPU quota {quota if quota else 'none'})",
+           "one_thread": {"value": pairs / dt1, "unit": "pairs/s", "sample": f"1 step, {dt1:.1f} s"}}
+    if cfg is CONFIGS["c2"]:
+        out["c1_lite"] = cpu_baseline_c1_lite()
+    return out
 
 
 def cpu_baseline_c1_lite(steps: int = 20):
@@ -161,10 +281,11 @@ def cpu_baseline_c1_lite(steps: int = 20):
             f"samples, fp32 torch CPU oracle, {dt * 1e3:.1f} ms/step"}
 
 
-def standalone_wres(B: int, D: int, H: int, W: int, launches: int = 20, rounds: int = 7):
+def standalone_wres(B: int, D: int, H: int, W: int, min_launches: int = 200, min_ms: float = 15.0, rounds: int = 5):
     """the roofline kernel alone (layer 2 of the voxel encoder, 32 -> 64 channels, bf16 out + BatchNorm sums) at volume
-    (B, D, H, W): `launches` back-to-back launches between two HIP events on the launch stream, behind a device-side
-    sleep so that the host's enqueue time is not in the bracket; per-launch mean of each round -> min / mean / max."""
+    (B, D, H, W): per round at least `min_launches` back-to-back launches AND at least `min_ms` of device time between two
+    HIP events on the launch stream (sustained clocks, not a burst - the rocprofv3 trace mean is the figure to agree with),
+    behind a device-side sleep so that the host's enqueue time is not in the bracket; per-launch mean of each round."""
     import math
     from multimodal_eeg_fmri_amd import _hip
     Cin, Cout = 32, 64
@@ -178,38 +299,67 @@ def standalone_wres(B: int, D: int, H: int, W: int, launches: int = 20, rounds: 
 
     def fn():
         _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, bias, stats, None, out)
-    for _ in range(10):
-        fn()
-    torch.cuda.synchronize()
-    per = []
-    for _ in range(rounds):
+
+    def round_of(n):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(int(4.0e6))
         a.record()
-        for _ in range(launches):
+        for _ in range(n):
             fn()
         b.record()
         torch.cuda.synchronize()
-        per.append(a.elapsed_time(b) / launches)
-    flops = 2.0 * B * D * H * W * Cin * Cout * 27
+        return a.elapsed_time(b) / n
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    launches = max(min_launches, int(min_ms / max(round_of(50), 1e-4)) + 1)
+    per = [round_of(launches) for _ in range(rounds)]
+    flops = conv3_flops(Cin, Cout, B * D * H * W)
     mean = sum(per) / len(per)
     return {"flops_per_launch": flops, "avg_launch_ms": mean, "min_launch_ms": min(per), "max_launch_ms": max(per),
             "achieved": flops / (mean * 1e-3) / 1e12, "frac": flops / (mean * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
             "launches": launches * rounds,
-            "method": f"{rounds} rounds of {launches} back-to-back launches between two HIP events on the launch stream "
-                      "(launch-to-launch gaps included), inputs resident"}
+            "method": f"{rounds} rounds of {launches} back-to-back launches ({launches * mean:.1f} ms each) between two HIP events "
+                      "on the launch stream (launch-to-launch gaps included), inputs resident"}
 
 
-def fit_and_retrieve(steps: int, lr: float = 3e-4, dropout: float = 0.1, held_out_batches: int = 8):
+def voxel_encoder_only(vol, pairs: int, dropout: float, iters: int = 20):
+    """BASELINE config #4 as it is worded - the 3-D conv encoder alone: forward + backward of fMRIVolumeEncoder3D through
+    its public autograd surface on `pairs` volumes, HIP events around `iters` iterations behind a device-side sleep"""
+    import multimodal_eeg_fmri_amd.fmri_utils as Fm
+    torch.manual_seed(0)
+    enc = Fm.fMRIVolumeEncoder3D(1, 64, dropout=dropout).cuda().train()
+    x = torch.randn(pairs, 1, *vol, device="cuda")
+    dout = torch.randn(pairs, 64, device="cuda")
+    for _ in range(3):
+        enc(x).backward(dout)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(2.0e7))
+    a.record()
+    for _ in range(iters):
+        enc(x).backward(dout)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    v = vol[0] * vol[1] * vol[2]
+    fl = 3.0 * pairs * (conv3_flops(1, 32, v) + conv3_flops(32, 64, v // 8) + conv3_flops(64, 128, v // 64))
+    return {"volumes_per_s": pairs / (ms * 1e-3), "ms_per_iteration": ms, "iterations": iters, "pairs": pairs,
+            "mfma_frac_of_peak": fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "flops_per_iteration": fl,
+            "what": "fMRIVolumeEncoder3D forward + backward (eager, public autograd surface), no optimizer"}
+
+
+def fit_and_retrieve(steps: int, cfg, lr: float = 3e-4, dropout: float = 0.1, held_out_batches: int = 8):
     """Second half of BASELINE's metric (contrastive top-1 retrieval), untimed: a fresh trainer (same
     kernels, same hipGraph step; dropout 0.1 - at the timed run's 0.3 the same number of steps only reaches
     ~0.17) is fitted on fresh synthetic pairs (every step a new batch drawn on the GPU from the
     shared-latent generator of SURVEY.md 8d), then scored on batches it has never seen."""
     from multimodal_eeg_fmri_amd import ops
     from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    VOL = cfg["vol"]
     torch.manual_seed(0)
     ops.set_dropout_seed(20260)                                  # the figure must not depend on what drew masks earlier in the process
-    tr = BridgeTrainer(eeg_channels=EEG_CH, dropout=dropout, lr=lr).train()
+    tr = BridgeTrainer(eeg_channels=EEG_CH, dropout=dropout, lr=lr, eeg_encoder=make_eeg_encoder(cfg["eeg"], dropout)).train()
     gm = torch.Generator().manual_seed(99)                       # the fixed mixing matrices of synthetic_pairs()
     A_e = torch.randn(EEG_CH, 16, generator=gm).cuda()
     A_f = (torch.randn(VOL[0] * VOL[1] * VOL[2], 16, generator=gm) / 4.0).cuda()
@@ -223,7 +373,7 @@ def fit_and_retrieve(steps: int, lr: float = 3e-4, dropout: float = 0.1, held_ou
     # the reference's schedule (CosineAnnealingWarmup, run_training_lite.py:176 / crossmodal_v4_enhancements.py:55-78): linear
     # warm-up over the first 5 %, cosine decay to 1 % of the base rate; the rate is a device word the captured step reads,
     # rewritten every 50 steps.  (At a constant 3e-4 the held-out figure of one 6 000-step run swung between 0.43 and 0.96
-    # with the dropout seeds alone - tools/r3/fit_check3.py - i.e. it measured where the noisy tail of training happened to stop.)
+    # with the dropout seeds alone - profiles/scripts/r3/fit_check3.py - i.e. it measured where the noisy tail of training happened to stop.)
     import math
     warm = max(1, steps // 20)
     t0 = time.perf_counter()
@@ -252,18 +402,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE configuration of the step: c2 (the one the "
+                    "metric is quoted on), c4 (64x64x48 volumes), c5 (multi-scale STFT front-end + power encoder as the EEG branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.3)
     ap.add_argument("--profile", action="store_true", help="skip the post-region event-timing steps (for rocprofv3 runs)")
-    ap.add_argument("--fit-steps", type=int, default=6000, help="untimed steps on FRESH synthetic pairs after the timed "
-                    "region, for the held-out top-1 retrieval figure (0 = skip; single-GPU runs only)")
+    ap.add_argument("--fit-steps", type=int, default=None, help="untimed steps on FRESH synthetic pairs after the timed "
+                    "region, for the held-out top-1 retrieval figure (0 = skip; single-GPU runs only; default 6000 for c2, 0 otherwise)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic: in-graph phase stamps of the step (adds 13 tiny nodes; "
                     "prints a phase table to stderr, the JSON line is then not a valid benchmark)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    VOL = cfg["vol"]
+    if args.fit_steps is None:
+        args.fit_steps = 6000 if args.config == "c2" else 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: start it as `python bench.py --gpus "
+                         f"{args.gpus}` (it launches its own ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}")
     # one rank per GPU (RCCL).  MM_DIST_BACKEND=gloo is the one-GPU rehearsal of the N > 1 code path:
     # several ranks then share a device (LOCAL_RANK modulo the device count) and exchange over gloo.
     backend = os.environ.get("MM_DIST_BACKEND", "nccl")
@@ -280,12 +439,12 @@ def main():
             from tools import gloo_staging           # one-GPU rehearsal of the N > 1 path (tests only)
             gloo_staging.install()
         group = dist.group.WORLD
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from multimodal_eeg_fmri_amd import ops
     from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
     torch.manual_seed(0)                      # identical initial weights on every rank
-    tr = BridgeTrainer(eeg_channels=EEG_CH, dropout=args.dropout, group=group).train()
+    tr = BridgeTrainer(eeg_channels=EEG_CH, dropout=args.dropout, group=group,
+                       eeg_encoder=make_eeg_encoder(cfg["eeg"], args.dropout)).train()
     eeg, fmri = synthetic_pairs(PAIRS_PER_GPU, EEG_CH, EEG_T, VOL, seed=1234 + rank)
     if args.stamps:
         tr.stamps = torch.zeros(16, dtype=torch.int64, device="cuda")
@@ -295,6 +454,18 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        if world > 1:
+            import torch.distributed as dist
+            if backend == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX)
+                t = h
+        return t.item()
 
     # a fresh synthetic batch every step: NBATCH pre-drawn batches cycle through the captured step's static input
     # buffers.  `value` (the contract's figure) keeps the inputs resident in HBM: the batches sit on the device and
@@ -306,12 +477,12 @@ def main():
     tr.train_step(eeg, fmri)                  # capture (not a warm-up step: lazy initialisation, graph capture)
     # clock conditioning (untimed, disclosed as `preconditioning_steps`): the process has kept the GPU nearly idle for seconds
     # (imports, capture), and the chip needs ~25 ms of this workload to settle - per-10-step event timings read 0.86, 0.84, 0.82
-    # and then 0.815 ms per step (tools/r3/jitter.py).  A short --warmup would put that ramp inside a short timed region.
+    # and then 0.815 ms per step (profiles/scripts/r3/jitter.py).  A short --warmup would put that ramp inside a short timed region.
     precondition = 0 if args.profile else PRECONDITION_STEPS        # (profiler runs count kernels per step: keep their traces short)
     import gc
     # a generation-2 collection in the timed loop is a 20-30 ms host stall (seen 1 run in 8): collector frozen and off.
     # Done BEFORE the conditioning / warm-up steps: the collection itself stalls the host for longer than the queued
-    # steps last, and a GPU that has idled >= 20 ms runs its next ~10 steps 4 % slower (tools/r3/jitter2.py: blocks of
+    # steps last, and a GPU that has idled >= 20 ms runs its next ~10 steps 4 % slower (profiles/scripts/r3/jitter2.py: blocks of
     # 10 steps after a synchronize 0.79 ms, after synchronize + 20 ms of sleep 0.83 ms) - with --steps 20 that was half
     # the timed region.
     gc.collect()
@@ -330,54 +501,16 @@ def main():
     gc.enable()
     loss_timed = out["loss"].item()           # read before any other step overwrites the trainer's result buffer
     tr_capture_mode = tr.capture_mode
-    t = torch.tensor([dt], device="cuda")
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
+    dt = max_over_ranks(dt)
 
-    # the same loop with every batch coming from pinned host memory: H2D into a staging pair on a copy stream
-    # (12.6 MB per step), overlapped with the previous step; reported beside `value`, never as `value`
-    dt_h2d = None
+    # the same loop fed from the host (a real training loop's rate; reported beside `value`, never as `value`)
+    h2d = None
     if not args.profile:
-        host = [(e.cpu().pin_memory(), f.cpu().pin_memory()) for e, f in dev_batches]
-        stage = [(torch.empty_like(dev_batches[0][0]), torch.empty_like(dev_batches[0][1])) for _ in range(2)]
-        copy_s = torch.cuda.Stream()
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        consumed = [torch.cuda.Event(), torch.cuda.Event()]
-
-        def upload(i):
-            b = i % 2
-            with torch.cuda.stream(copy_s):
-                copy_s.wait_event(consumed[b])               # the step that read this staging pair is done with it
-                stage[b][0].copy_(host[i % NBATCH][0], non_blocking=True)
-                stage[b][1].copy_(host[i % NBATCH][1], non_blocking=True)
-                ready[b].record(copy_s)
-        for b in range(2):
-            consumed[b].record()
-
-        def h2d_loop(n):
-            upload(0)
-            for i in range(n):
-                if i + 1 < n:
-                    upload(i + 1)
-                torch.cuda.current_stream().wait_event(ready[i % 2])
-                tr.train_step(*stage[i % 2])
-                consumed[i % 2].record()
         gc.collect()                                    # (before the warm-up: no host stall between warm-up and timed loop)
         gc.disable()
-        h2d_loop(max(6, min(args.warmup, 20)))        # its own warm-up: copy stream, pinned copies, event pool (first use
-        sync()                                          # of each costs milliseconds - more than a 20-step timed region)
-        t0 = time.perf_counter()
-        h2d_loop(args.steps)
-        sync()
-        dt_h2d = time.perf_counter() - t0
+        h2d = host_fed_loop(tr, dev_batches, args.steps, max(6, min(args.warmup, 20)), sync)
         gc.enable()
-        t = torch.tensor([dt_h2d], device="cuda")
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_h2d = t.item()
+        h2d["seconds"] = max_over_ranks(h2d["seconds"])
     eeg, fmri = dev_batches[0]
     if args.stamps and rank == 0:
         acc = torch.zeros(16, dtype=torch.float64)
@@ -390,18 +523,24 @@ def main():
             print(f"  {name:22s} {acc[i].item() / 20:8.1f} us", file=sys.stderr)
 
     # roofline line: the timed steps are hipGraph replays (no host code runs inside them; HIP cannot record timing
-    # events from inside a replay: hipEventRecordWithFlags(external) is rejected on ROCm 7.2), so the layer-2 conv3d
-    # kernel is bracketed with HIP events on its launch stream in a few extra steps of the SAME tape run eagerly right
+    # events from inside a replay: hipEventRecordWithFlags(external) is rejected on ROCm 7.2), so the 3-D convolution
+    # GEMMs are bracketed with HIP events on their launch stream in a few extra steps of the SAME tape run eagerly right
     # after the timed region (same kernels, the other stream busy as in the real step).  Eager launches are host-bound
     # (~30 us of Python per launch against ~10 us kernels): each step is queued behind a device-side sleep, so that
     # the whole step sits in the stream queues before the GPU starts and the events see device time, not host gaps.
-    kt = kt_raw = kt_pair = None
+    # A bracket also holds the event pair's own ~5 us: `frac` is that UNCORRECTED figure (a lower bound, and what the
+    # rocprofv3 trace of the same command agrees with); the figure with an empty bracket subtracted is secondary.
+    FAMILY = (("L2 fwd", "conv3d_fwd_c32"), ("L3 fwd", "conv3d_fwd_c64"), ("L3 dgrad", "conv3d_dgrad_c128"),
+              ("L2 dgrad", "conv3d_dgrad_c64"), ("L2 wgrad", "conv3d_wgrad_c32"), ("L3 wgrad", "conv3d_wgrad_c64"))
+    kt_raw = kt_pair = None
     kt_all = []
-    rf_c2 = rf_c4 = None
+    fam_ms = {}
+    rf_c2 = rf_c4 = enc_only = None
     if not args.profile:
         tr.mode = "manual"
         tr.train_step(eeg, fmri)
-        ops.kernel_timer.reset("conv3d_fwd_c32")
+        for _, key in FAMILY:
+            ops.kernel_timer.reset(key)
         ops.kernel_timer.reset("event_pair_c32")
         for _ in range(16):
             torch.cuda._sleep(int(2.0e7))                    # ~10 ms of device spin: covers the host's enqueue time
@@ -410,59 +549,87 @@ def main():
         kt_all = ops.kernel_timer.all_ms("conv3d_fwd_c32")
         kt_raw = sum(kt_all) / len(kt_all)
         kt_pair = ops.kernel_timer.mean_ms("event_pair_c32")      # an empty event bracket on the same stream, same steps
-        kt = kt_raw - kt_pair                                     # the kernel's share of its bracket
+        fam_ms = {name: ops.kernel_timer.mean_ms(key) for name, key in FAMILY}
         if rank == 0:
             # the same kernel alone: the C2 shape, and BASELINE config #4 (64 x 64 x 48 volumes -> layer 2 at 32 x 32 x 24)
             rf_c2 = standalone_wres(PAIRS_PER_GPU, 16, 16, 16)
             rf_c4 = standalone_wres(PAIRS_PER_GPU, 32, 32, 24)
+            if args.config == "c4":
+                enc_only = voxel_encoder_only(VOL, PAIRS_PER_GPU, args.dropout)
+    coll_us = tr.time_collectives(PAIRS_PER_GPU) if world > 1 else None          # collective: every rank takes part
     ev = tr.evaluate(eeg, fmri)
     fit = None
     if world == 1 and args.fit_steps > 0 and not args.profile:
-        fit = fit_and_retrieve(args.fit_steps)
+        fit = fit_and_retrieve(args.fit_steps, cfg)
     if rank != 0:
         return
     global_batch = PAIRS_PER_GPU * world
-    # layer-2 conv3d forward: M = 32 * 16^3, N = 64, K = 27 * 32
-    flops = 2.0 * PAIRS_PER_GPU * 16 ** 3 * 64 * 27 * 32
-    achieved = flops / (kt * 1e-3) / 1e12 if kt else None
+    ms_per_step = dt / args.steps * 1e3
+    # layer-2 conv3d forward: M = 32 * (vol / 2)^3 voxels, N = 64, K = 27 * 32
+    fam_fl = family_flops(VOL, PAIRS_PER_GPU)
+    flops = fam_fl["L2 fwd"]
+    v2 = tuple(v // 2 for v in VOL)
+
+    def tf(fl, ms):
+        return fl / (ms * 1e-3) / 1e12 if ms else None
+    achieved = tf(flops, kt_raw)
+    if world == 1:
+        execution = "hipGraph replay (one graph, two streams)"
+    elif tr_capture_mode and tr_capture_mode.startswith("one graph"):
+        execution = (f"{tr_capture_mode}: all-gather of embeddings; all-reduce of the gradient bucket per finished layer group "
+                     f"({', '.join(g[0] for g in reversed(tr.groups))}), all but the last beside the EEG backward")
+    else:
+        execution = f"{tr_capture_mode}: all-gather of embeddings after the forward segment; ONE all-reduce of the whole bucket after the backward segment"
+    sfl = step_flops(cfg, PAIRS_PER_GPU)
     line = {
         "metric": "pairs_per_sec_per_node", "value": global_batch * args.steps / dt, "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preconditioning_steps": precondition,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": "C2 bridge train step: 64ch x 1024 EEG (EnhancedERPEncoder) + 32^3 fMRI "
-                               "(3-D conv encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW",
+        "config": {"workload": cfg["workload"], "baseline_config": args.config, "volume": list(VOL),
                    "pairs_per_gpu": PAIRS_PER_GPU, "global_batch": global_batch, "parallelism": f"dp{world}",
-                   "dropout": args.dropout, "mfma_operands": "bf16", "accumulate": "fp32",
-                   "execution": "hipGraph replay" if world == 1 else
-                   f"{tr_capture_mode} (all-gather of embeddings; all-reduce of the fMRI third of the gradient bucket beside the "
-                   "EEG backward, of the remainder after it)"},
+                   "dropout": args.dropout, "mfma_operands": "bf16", "accumulate": "fp32", "execution": execution},
         "top1_retrieval_acc": {"eeg_to_fmri": ev["top1_e2f"].item(), "fmri_to_eeg": ev["top1_f2e"].item(),
                                "chance": 1.0 / global_batch, "note": "on the training batch after the timed steps",
                                "held_out_after_fit": fit},
         "final_loss": loss_timed,
-        "value_with_input_transfer": (global_batch * args.steps / dt_h2d) if dt_h2d else None,
-        "input_transfer": "every step's batch copied from pinned host memory (12.6 MB) on a copy stream into a staging pair, "
-                          "overlapped with the previous step; `value` keeps the batches resident in HBM",
-        "roofline": {"kernel": "conv3d_wres_kernel (layer 2: 32->64 ch @16^3, implicit GEMM M=131072 N=64 K=864)",
+        # the whole step against the MFMA roof: algorithmic FLOPs of one step (SURVEY.md 8(d) formulas) / step time / 2.5 PF
+        "step_mfma_frac": sfl / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "step_flops": sfl,
+        "value_with_input_transfer": (global_batch * args.steps / h2d["seconds"]) if h2d else None,
+        "input_transfer": h2d,
+        "roofline": {"kernel": f"conv3d_wres_kernel (layer 2: 32->64 ch @{v2[0]}x{v2[1]}x{v2[2]}, implicit GEMM "
+                               f"M={PAIRS_PER_GPU * v2[0] * v2[1] * v2[2]} N=64 K=864)",
                      "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / PEAK_BF16_MFMA_TFLOPS) if achieved else None,
-                     "flops_per_launch": flops, "avg_launch_ms": kt,
-                     "event_bracket_ms": kt_raw if kt else None, "empty_event_bracket_ms": kt_pair if kt else None,
-                     # spread over the bracketed launches (each minus the mean empty bracket), and the uncorrected bound:
-                     # frac_raw_bracket counts the event pair's own ~5 us as kernel time (a lower bound on the fraction)
-                     "min_launch_ms": (min(kt_all) - kt_pair) if kt else None,
-                     "max_launch_ms": (max(kt_all) - kt_pair) if kt else None,
+                     "flops_per_launch": flops, "avg_launch_ms": kt_raw,
+                     "min_launch_ms": min(kt_all) if kt_all else None, "max_launch_ms": max(kt_all) if kt_all else None,
                      "launches_bracketed": len(kt_all),
-                     "frac_raw_bracket": (flops / (kt_raw * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS) if kt else None,
-                     "profile_in_step": PROFILE_IN_STEP,
+                     # secondary: the same brackets minus the mean EMPTY bracket (what a pair of event records costs alone)
+                     "empty_event_bracket_ms": kt_pair,
+                     "frac_minus_empty_bracket": (tf(flops, kt_raw - kt_pair) / PEAK_BF16_MFMA_TFLOPS) if kt_raw else None,
                      # HBM bytes per launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2 gfx950 correction
                      # and WRITE_SIZE in separate passes, profiles/run_pmc_wres.sh); algorithmic = 8.4 + 16.8 + 0.1 MB
-                     "traffic": pmc_traffic_bytes(), "traffic_source": PMC_SUMMARY, "algorithmic_bytes": 25.3e6,
-                     "note": "measured inside the training step (other stream busy); stand-alone and config-#4 figures: "
-                             "profiles/README.md"},
+                     "traffic": pmc_traffic_bytes() if args.config != "c4" else pmc_traffic_bytes(PMC_SUMMARY_C4),
+                     "traffic_source": PMC_SUMMARY if args.config != "c4" else PMC_SUMMARY_C4,
+                     "algorithmic_bytes": 25.3e6 if args.config != "c4" else 151.1e6,
+                     "note": "measured inside the training step (other stream busy), uncorrected event bracket; stand-alone and "
+                             "config-#4 figures: roofline_c2_standalone / roofline_c4"},
     }
+    if fam_ms and all(fam_ms.values()):
+        tot_fl, tot_ms = sum(fam_fl.values()), sum(fam_ms.values())
+        prof, prof_src = profile_family_us(VOL)
+        line["roofline_family"] = {
+            "what": "the six dense 3-D convolution GEMM launches of one step (layers 2 and 3: forward, data gradient, weight "
+                    "gradient), event-bracketed inside the training step like `roofline` (uncorrected)",
+            "bound": "mfma", "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "flops": tot_fl, "sum_launch_ms": tot_ms,
+            "achieved": tf(tot_fl, tot_ms), "frac": tf(tot_fl, tot_ms) / PEAK_BF16_MFMA_TFLOPS,
+            "frac_minus_empty_bracket": tf(tot_fl, tot_ms - 6 * kt_pair) / PEAK_BF16_MFMA_TFLOPS,
+            "per_launch": {k: {"ms": fam_ms[k], "flops": fam_fl[k], "frac": tf(fam_fl[k], fam_ms[k]) / PEAK_BF16_MFMA_TFLOPS}
+                           for k in fam_fl},
+            "profile_in_step": None if prof is None else {
+                "source": prof_src, "avg_launch_us": prof,
+                "frac": tot_fl / (sum(prof.values()) * 1e-6) / 1e12 / PEAK_BF16_MFMA_TFLOPS}}
     if rf_c2:
         line["roofline_c2_standalone"] = dict(rf_c2, kernel="conv3d_wres_kernel alone at the C2 shape (B=32, 16^3)", bound="mfma",
                                               peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", traffic=pmc_traffic_bytes(),
@@ -472,9 +639,56 @@ def main():
                                                  "@32x32x24, B=32, implicit GEMM M=786432 N=64 K=864", bound="mfma",
                                    peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", traffic=pmc_traffic_bytes(PMC_SUMMARY_C4),
                                    traffic_source=PMC_SUMMARY_C4, algorithmic_bytes=151.1e6)
+    if enc_only:
+        line["voxel_encoder_only"] = enc_only
+    if world > 1:
+        line["rccl_ranks"] = world if backend == "nccl" else 0
+        line["dist_backend"] = "RCCL (torch.distributed nccl)" if backend == "nccl" else f"{backend} (one-GPU rehearsal: ranks share a device)"
+        line["capture_mode"] = tr_capture_mode
+        line["gradient_bucket_groups"] = [{"name": n, "ready": r, "MB": (hi - lo) * 4 / 1e6} for n, r, lo, hi in tr.groups]
+        line["collectives_us"] = coll_us
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(PAIRS_PER_GPU)
-    print(json.dumps(line))
+        line["cpu_baseline"] = cpu_baseline(PAIRS_PER_GPU, cfg)
+    print(json.dumps(line), flush=True)
+
+
+def host_fed_loop(tr, dev_batches, steps, warm, sync):
+    """every step's batch comes from pinned host memory: H2D into a staging pair on a copy stream (12.6 MB per step),
+    overlapped with the previous step; -> {seconds, description}"""
+    NB = len(dev_batches)
+    host = [(e.cpu().pin_memory(), f.cpu().pin_memory()) for e, f in dev_batches]
+    stage = [(torch.empty_like(dev_batches[0][0]), torch.empty_like(dev_batches[0][1])) for _ in range(2)]
+    copy_s = torch.cuda.Stream()
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def upload(i):
+        b = i % 2
+        with torch.cuda.stream(copy_s):
+            copy_s.wait_event(consumed[b])               # the step that read this staging pair is done with it
+            stage[b][0].copy_(host[i % NB][0], non_blocking=True)
+            stage[b][1].copy_(host[i % NB][1], non_blocking=True)
+            ready[b].record(copy_s)
+    for b in range(2):
+        consumed[b].record()
+
+    def loop(n):
+        upload(0)
+        for i in range(n):
+            if i + 1 < n:
+                upload(i + 1)
+            torch.cuda.current_stream().wait_event(ready[i % 2])
+            tr.train_step(*stage[i % 2])
+            consumed[i % 2].record()
+    loop(warm)            # its own warm-up: copy stream, pinned copies, event pool (first use of each costs milliseconds)
+    sync()
+    t0 = time.perf_counter()
+    loop(steps)
+    sync()
+    nbytes = sum(t.numel() * t.element_size() for t in host[0])
+    return {"seconds": time.perf_counter() - t0, "bytes_per_step": nbytes,
+            "how": "every step's batch copied from pinned host memory on a copy stream into a staging pair, overlapped with the "
+                   "previous step; `value` keeps the batches resident in HBM"}
 
 
 if __name__ == "__main__":

@@ -328,6 +328,14 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
                  const void* dout, const float* sums, float* stats, void* out, float* dw_tapmajor,
                  float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
                  const uint32_t* seed_epoch, hipStream_t stream);
+/* mode 1 (the forward) with one more output: arg u8 [B][D/2][H/2][W/2][32] = which member of each 2x2x2 pooling
+ * window won, j = (dd << 2) | (hh << 1) | ww (the convention of mm_pool3d_bn_act_fwd's `arg`).  The training path
+ * recomputes the winners in its backward and never stores them; this entry point lets a caller inspect the routing
+ * (the parity tests evaluate the fp32 oracle with the HIP path's routing: an arg-max flip between two near-equal
+ * window members is then not counted as a gradient error). */
+int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias, const float* out4, void* out,
+                             void* arg, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
+                             const uint32_t* seed_epoch, hipStream_t stream);
 /* Training backward of the same layer in ONE recompute pass (replaces modes 2 + 3): BatchNorm's
  * backward is linear in the two sums S1 = sum dz, S2 = sum dz * xhat, so
  *   dW = scale * (A1 - (S1/M) * T - (S2/M) * A3),  A1 = x^T dz, A3 = x^T xhat, T[tap] = sum_v x[v + tap].

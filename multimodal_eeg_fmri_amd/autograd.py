@@ -707,8 +707,11 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
             _hip.call("mm_conv3d_wgrad_slots", B, D, H, W, cinp_x, N, ctypes.addressof(out))
             slots = _SLOTS[key] = int(out.value)
         ws = _empty((slots, N, 27, cinp_x), _F32, y)           # one writer per element: no atomics, no memset
+        end = ops.kernel_timer.bracket(f"conv3d_wgrad_c{cinp_x}")     # (bench.py's roofline_family; off by default)
         _hip.call("mm_conv3d_wgrad", dy, xv, ws, dbr, B, D, H, W, cinp_x, N, cinp_x,
                   27 * cinp_x, 1, cinp_x, slots, N * 27 * cinp_x, 1)
+        if end is not None:
+            end.record()
         _scatter_into(dw, ws, N, cin, 27, cinp_x, slots)
         if db is not None:
             _reduce_into(db, dbr, N, N)
@@ -717,7 +720,10 @@ def conv3d_bn_act_bwd(bag: GradBag, s: dict, dout, need_dx=True):
     _, wd, cinp, coutp = ops.weights.get(conv.weight, True)
     assert coutp == N
     dx = _empty((B, D, H, W, cinp), _BF, y)
+    end = ops.kernel_timer.bracket(f"conv3d_dgrad_c{N}")
     _hip.call("mm_conv3d_fwd", dy, wd, B, D, H, W, N, cinp, None, None, None, dx)
+    if end is not None:
+        end.record()
     return dx
 
 

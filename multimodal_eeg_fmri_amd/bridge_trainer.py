@@ -7,11 +7,14 @@ packed L2-normalised embeddings (global contrastive negatives), fused
 similarity/InfoNCE forward+backward on this rank's rows of the gathered batch
 (every rank evaluates all rows, so no reduce-scatter of column gradients is
 issued), encoder backward, the all-reduce of the flat fp32 gradient bucket in
-two parts - the fMRI encoder's third as soon as its (shorter) backward has
-finished, on that branch's stream, hidden beside the rest of the EEG backward;
-the remainder after the chain - and the fused clip+AdamW on the flat parameter
-bucket.  At world size > 1 the whole step, collectives included, is ONE
-hipGraph when the backend's collectives can be captured (RCCL), else three
+one piece per FINISHED LAYER GROUP (``groups``: the fMRI encoder as soon as its
+shorter backward is done; transformer stack + heads, then conv blocks 3-2, as
+soon as their handed-over weight-gradient sums have been flushed on the side
+stream; only conv block 1 - 0.1 MB - after the chain), each an asynchronous
+collective the optimizer alone waits for, and the fused clip+AdamW on the flat
+parameter bucket.  At world size > 1 the whole step, collectives included, is
+ONE hipGraph when the backend's collectives can be captured (RCCL) - all ranks
+agree on that outcome before any replay (``dp.agree_on_capture``) - else three
 graph segments around two eager collectives (``capture_mode`` says which).
 BatchNorm statistics stay per-rank (the reference has no SyncBN; SURVEY.md
 section 8e).
@@ -29,7 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip, dp, ops
-from .autograd import GradBag, contrastive_embed_bwd, deferred, erp_encoder_bwd, volume_encoder_bwd
+from .autograd import GradBag, contrastive_embed_bwd, deferred, erp_encoder_bwd, power_encoder_bwd, volume_encoder_bwd
 from .bridge_utils import EEGfMRIContrastiveBridge
 from .enhanced_models_v4 import EnhancedERPEncoder
 from .fmri_utils import fMRIVolumeEncoder3D
@@ -40,9 +43,22 @@ class BridgeTrainer(nn.Module):
     def __init__(self, eeg_channels: int = 64, hidden_dim: int = 128, fmri_dim: int = 64,
                  bridge_dim: int = 128, dropout: float = 0.3, lr: float = 1e-4,
                  weight_decay: float = 1e-4, grad_clip: float = 1.0, betas=(0.9, 0.999),
-                 eps: float = 1e-8, group=None, device="cuda", mode: str = "graph"):
+                 eps: float = 1e-8, group=None, device="cuda", mode: str = "graph", eeg_encoder: Optional[nn.Module] = None):
+        """``eeg_encoder``: the EEG branch when it is not the default ``EnhancedERPEncoder(eeg_channels, hidden_dim, 2, 4,
+        dropout)`` - an ``EnhancedPowerEncoder`` (enhanced_models_v4.py:196-285) or a ``MultiScaleSTFTPowerEncoder``
+        (BASELINE config #5: raw EEG -> multi-scale STFT power -> a4); it must end in ``hidden_dim`` features."""
         super().__init__()
-        self.eeg_encoder = EnhancedERPEncoder(eeg_channels, hidden_dim, 2, 4, dropout)
+        self.eeg_encoder = EnhancedERPEncoder(eeg_channels, hidden_dim, 2, 4, dropout) if eeg_encoder is None else eeg_encoder
+        from .crossmodal_v4_enhancements import MultiScaleSTFTPowerEncoder
+        from .enhanced_models_v4 import EnhancedPowerEncoder
+        if isinstance(self.eeg_encoder, EnhancedERPEncoder):
+            self._eeg_kind = "erp"
+        elif isinstance(self.eeg_encoder, MultiScaleSTFTPowerEncoder):
+            self._eeg_kind = "stft"
+        elif isinstance(self.eeg_encoder, EnhancedPowerEncoder):
+            self._eeg_kind = "power"
+        else:
+            raise TypeError(f"BridgeTrainer: no tape for an EEG encoder of type {type(self.eeg_encoder).__name__}")
         self.fmri_encoder = fMRIVolumeEncoder3D(1, fmri_dim, dropout=dropout)
         self.head = EEGfMRIContrastiveBridge(hidden_dim, fmri_dim, bridge_dim, dropout)
         self.to(device)
@@ -66,12 +82,36 @@ class BridgeTrainer(nn.Module):
         for name, p in br.named_parameters():
             if not (name.startswith("eeg_proj") or name.startswith("fmri_proj")):
                 p.requires_grad_(False)
-        # bucket order: EEG encoder | projection heads | logit scale | fMRI encoder.  The fMRI encoder's slice is the
-        # tail, so "the part whose gradients are final first" is one contiguous range [fmri_lo, n)
+        # bucket order = the order in which gradients are NOT yet final, i.e. the reverse of when each layer group's
+        # all-reduce can start (`_seg_backward`): conv block 1 (last kernel of the chain) | conv blocks 2-3 (final once
+        # the second hand-over has been flushed) | transformer stack + encoder head + projection heads + logit scale
+        # (first hand-over) | fMRI encoder (its own, shorter backward).  Each group is one contiguous range of the
+        # flat bucket, the fMRI encoder's the tail [fmri_lo, n).
         head_params = [p for p in br.parameters() if p.requires_grad] + [self.head.logit_scale]
-        train_params = list(self.eeg_encoder.parameters()) + head_params + list(self.fmri_encoder.parameters())
-        self.bucket = FlatBucket(train_params)
-        self.fmri_lo = self.bucket.n - sum(p.numel() for p in self.fmri_encoder.parameters() if p.requires_grad)
+        if self._eeg_kind == "erp":
+            cl = self.eeg_encoder.conv_layers
+            conv1 = list(cl[0].parameters()) + list(cl[1].parameters())
+            conv23 = [p for i in (4, 5, 9, 10) for p in cl[i].parameters()]
+            seen = {id(p) for p in conv1 + conv23}
+            rest = [p for p in self.eeg_encoder.parameters() if id(p) not in seen]
+            layout = [("eeg conv block 1", "main", conv1), ("eeg conv blocks 2-3", "handed1", conv23),
+                      ("eeg transformer stack + heads", "handed0", rest + head_params)]
+        else:
+            layout = [("eeg encoder + heads", "main", list(self.eeg_encoder.parameters()) + head_params)]
+        layout.append(("fmri encoder", "fmri", list(self.fmri_encoder.parameters())))
+        # MM_DP_GROUPS=2 (A/B knob): the round-3 split - the fMRI slice early, everything else after the chain
+        if os.environ.get("MM_DP_GROUPS", "4") == "2" and len(layout) > 2:
+            layout = [("eeg encoder + heads", "main", [p for _, _, ps in layout[:-1] for p in ps]), layout[-1]]
+        self.bucket = FlatBucket([p for _, _, ps in layout for p in ps])
+        self.groups = []                              # (name, ready point, lo, hi) over the flat bucket, in bucket order
+        off = 0
+        for name, ready, ps in layout:
+            k = sum(p.numel() for p in ps if p.requires_grad)
+            self.groups.append((name, ready, off, off + k))
+            off += k
+        assert off == self.bucket.n
+        self.fmri_lo = self.groups[-1][2]
+        self._works = []                              # asynchronous all-reduces of the running step (waited for by the optimizer)
         self.capture_mode = None                      # "one graph" | "one graph + captured RCCL collectives" | "3 segments + 2 eager collectives"
         self.bucket.state[2] = lr
         # {loss, top-1 e->f, top-1 f->e, d loss / d logit_scale} of the last step: owned by this trainer
@@ -163,7 +203,7 @@ class BridgeTrainer(nn.Module):
         # The EEG branch is the longer chain, so it is issued FIRST: a hipGraph replay writes its
         # kernel packets in capture order at ~4.6 us per node, and the branch captured second
         # cannot start before the host has written every packet of the first (profiles/README.md).
-        fe, sv_e = ops._erp_forward_impl(self.eeg_encoder, eeg, True, True, xb=xb)
+        fe, sv_e = self._eeg_forward(eeg, xb)
         self._stamp(2)
         with torch.cuda.stream(self._side):
             self._stamp(3)
@@ -173,6 +213,16 @@ class BridgeTrainer(nn.Module):
         z, sv_h = ops.contrastive_embed_impl(self.head.bridge, fe, ff, True)
         self._stamp(5)
         return z, (sv_e, sv_f, sv_h)
+
+    def _eeg_forward(self, eeg, xb):
+        enc = self.eeg_encoder
+        if self._eeg_kind == "erp":
+            return ops._erp_forward_impl(enc, eeg, True, True, xb=xb)
+        if self._eeg_kind == "power":
+            return ops._power_forward_impl(enc, xb if xb is not None else ops.pack_nct(eeg), True, False)
+        # config #5: the parameter-free multi-scale STFT power front-end (z-scored per sample), then a4
+        spec = ops.stft_front_end(eeg, enc.n_ffts, enc.hop, enc.normalize)
+        return ops._power_forward_impl(enc.encoder, spec, True, False)
 
     def _seg_loss(self, z_all, scal, dz):
         """symmetric InfoNCE of this rank's rows against the gathered batch, gradient w.r.t. ITS rows only
@@ -185,10 +235,19 @@ class BridgeTrainer(nn.Module):
         _hip.call("mm_clip_loss_own_rows", z_all, ls, scal, dz, ws, B, z_all.shape[0], N2 // 2, dp.rank(self.group) * B)
         self._stamp(6)
 
-    def _seg_backward(self, saved, dz, scal, reduce_fmri: bool = False):
-        """``reduce_fmri``: all-reduce the fMRI encoder's slice of the gradient bucket on the side stream as soon as that
-        branch's backward and its reductions are done (~160 us before the EEG chain ends at C2)"""
+    def _reduce_group(self, ready: str):
+        """all-reduce (asynchronous: the issuing stream does not wait) every bucket range whose gradients are final at
+        ``ready``; the handles are waited for by `_seg_optimizer`.  Host issue order = collective order on every rank."""
+        for name, rdy, lo, hi in self.groups:
+            if rdy == ready and hi > lo:
+                self._works.append(dp.allreduce_sum_(self.bucket.g[lo:hi], self.group, async_op=True))
+
+    def _seg_backward(self, saved, dz, scal, reduce: bool = False):
+        """``reduce``: all-reduce every layer group of the gradient bucket as soon as it is final - the fMRI encoder's
+        after that branch's backward, the transformer stack's and conv blocks 3-2's after their handed-over sums were
+        flushed on the side stream (all three hidden beside the EEG chain), conv block 1's after the chain"""
         sv_e, sv_f, sv_h = saved
+        self._works = []
         bag = GradBag()
         with deferred(bag, dz.device):           # ONE batched reduction after both branches joined
             # d loss / d logit_scale (scal[3]) rides in the same batched reduction launch
@@ -220,8 +279,14 @@ class BridgeTrainer(nn.Module):
 
             def conv3_done():
                 bag.defer_conv_wgrads = handed_convs >= 1
-            erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split, after_conv2=split_convs, after_conv3=conv3_done)   # longer chain first (see _seg_forward)
+            finish = None
+            if self._eeg_kind == "erp":
+                erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split, after_conv2=split_convs, after_conv3=conv3_done)   # longer chain first (see _seg_forward)
+            else:
+                _, finish = power_encoder_bwd(bag, sv_e, dfe)
             bag.flush(dz.device)
+            if finish is not None:
+                finish()                         # the merged 192-channel conv / BatchNorm gradients back into the six real parameters
             self._stamp(8)
             with torch.cuda.stream(self._side):
                 self._stamp(9)
@@ -229,19 +294,28 @@ class BridgeTrainer(nn.Module):
                 with deferred(bag_f, dz.device):     # hidden beside the rest of the EEG backward
                     volume_encoder_bwd(bag_f, sv_f, dff)
                 self._stamp(10)
-                if reduce_fmri:
-                    dp.allreduce_sum_(self.bucket.g[self.fmri_lo:], self.group)
-                for hb, ev in handed:
+                if reduce:
+                    self._reduce_group("fmri")
+                for i, (hb, ev) in enumerate(handed):
                     self._side.wait_event(ev)
                     hb.flush(dz.device)
+                    if reduce:
+                        self._reduce_group(f"handed{i}")
                 self._stamp(13)
+            if reduce:
+                self._reduce_group("main")       # issued last on the host: the collectives run in issue order
             main.wait_stream(self._side)
         self._stamp(11)
         self._bags = getattr(self, "_bags", [])[-12:] + [bag, bag_f] + [hb for hb, _ in handed]   # keep descriptor tables alive
 
-    def _seg_optimizer(self, fmri_reduced: bool = False):
-        b = self.bucket
-        dp.allreduce_sum_(b.g[:self.fmri_lo] if fmri_reduced else b.g, self.group)
+    def _seg_optimizer(self, reduced: bool = False):
+        """``reduced``: the backward issued the per-group all-reduces (wait for them); else ONE all-reduce of the whole bucket"""
+        if reduced:
+            for w in self._works:
+                dp.wait(w)
+            self._works = []
+        else:
+            dp.allreduce_sum_(self.bucket.g, self.group)
         self._seg_adamw()
 
     def _seg_adamw(self):
@@ -270,9 +344,9 @@ class BridgeTrainer(nn.Module):
         z_all = dp.gather_embeddings(z, self.group)
         scal, dz = self._scal, ops._empty(tuple(z.shape), torch.float32, z)
         self._seg_loss(z_all, scal, dz)
-        early = self.world > 1
-        self._seg_backward(saved, dz, scal, reduce_fmri=early)
-        self._seg_optimizer(fmri_reduced=early)
+        early = dp.active(self.group)
+        self._seg_backward(saved, dz, scal, reduce=early)
+        self._seg_optimizer(reduced=early)
         return {"loss": scal[0], "top1_e2f": scal[1], "top1_f2e": scal[2]}
 
     # ---- hipGraph capture ------------------------------------------------------
@@ -280,7 +354,8 @@ class BridgeTrainer(nn.Module):
         dev = eeg.device
         world = self.world
         c = {"eeg": eeg.clone(), "fmri": fmri.clone(), "epoch": torch.zeros(1, dtype=torch.int32, device=dev)}
-        c["xb"] = ops.pack_nct(c["eeg"])                         # static packed EEG operand: refilled before every replay
+        # static packed EEG operand, refilled before every replay (the STFT front-end reads the raw fp32 batch instead)
+        c["xb"] = ops.pack_nct(c["eeg"]) if self._eeg_kind != "stft" else None
         ops.set_seed_epoch(c["epoch"])
         # warm-up outside capture (lazy inits, allocator priming) on a snapshot of the
         # training state, so that the first replay is really step 1
@@ -318,9 +393,11 @@ class BridgeTrainer(nn.Module):
         if not dist_step:
             def whole():
                 z, saved = self._seg_forward(c["eeg"], c["fmri"], xb=c["xb"])
+                c["z"] = z
                 c["dz"] = ops._empty(tuple(z.shape), torch.float32, z)
                 self._seg_loss(z, c["scal"], c["dz"])
                 self._seg_backward(saved, c["dz"], c["scal"])
+                self._grad_probe()
                 self._seg_adamw()
             record(whole)
             self.capture_mode = "one graph"
@@ -338,45 +415,71 @@ class BridgeTrainer(nn.Module):
                 self._seg_loss(c["z_all"], c["scal"], c["dz"])
                 self._seg_backward(c["saved"], c["dz"], c["scal"])
             record(seg2)
-            record(self._seg_adamw)
+
+            def seg3():
+                self._grad_probe()
+                self._seg_adamw()
+            record(seg3)
         c["graphs"] = graphs
         self._cap = c
 
+    def _grad_probe(self):
+        """``self.grad_probe`` (a flat fp32 tensor the size of the bucket, set by a test BEFORE the first graph step):
+        the step copies its finished gradients there just before clip + AdamW clears them - one more node, the
+        arithmetic untouched - so that a replayed step's gradients can be compared with the oracle's"""
+        probe = getattr(self, "grad_probe", None)
+        if probe is not None:
+            probe.copy_(self.bucket.g)
+
     def _capture_with_collectives(self, c, record, B, N2, world, dev) -> bool:
-        """the N > 1 step as ONE hipGraph: all-gather of the embeddings, the fMRI slice's all-reduce on the side branch
-        and the remainder's all-reduce on the chain are graph nodes (no replay gaps, no host in the step).  Returns
-        False - nothing recorded - when the backend refuses the capture; the caller then records the three segments."""
+        """the N > 1 step as ONE hipGraph: the all-gather of the embeddings and the all-reduce of every layer group of the
+        gradient bucket (side branch / chain, `_seg_backward`) are graph nodes (no replay gaps, no host in the step).
+        Every rank then reports its outcome and ALL take the same form (`dp.agree_on_capture`): the graph, or - only when
+        every rank was refused before a collective had been enqueued - the three segments (returns False, nothing
+        recorded); a mixed outcome raises on every rank, so the job exits non-zero instead of hanging."""
         c["z_all"] = torch.empty(world * B, N2, device=dev)
         # the communicator must exist before the capture starts (its lazy initialisation is not capturable)
         dp.all_gather_into(c["z_all"], torch.zeros(B, N2, device=dev), self.group)
-        dp.allreduce_sum_(torch.zeros(8, device=dev), self.group)
+        dp.wait(dp.allreduce_sum_(torch.zeros(8, device=dev), self.group, async_op=True))
         torch.cuda.synchronize()
 
         def whole_dp():
             z, saved = self._seg_forward(c["eeg"], c["fmri"], xb=c["xb"])
+            c["z"] = z
             c["dz"] = ops._empty((B, N2), torch.float32, z)
             dp.all_gather_into(c["z_all"], z, self.group)
             self._seg_loss(c["z_all"], c["scal"], c["dz"])
-            self._seg_backward(saved, c["dz"], c["scal"], reduce_fmri=True)
-            self._seg_optimizer(fmri_reduced=True)
+            self._seg_backward(saved, c["dz"], c["scal"], reduce=True)
+            for w in self._works:
+                dp.wait(w)
+            self._works = []
+            self._grad_probe()
+            self._seg_adamw()
+        issued0 = dp.issued
+        err = None
         try:
             # thread-local capture mode: the process group's watchdog thread polls its events while this thread captures
             record(whole_dp, mode="thread_local")
+        except Exception as e:  # noqa: BLE001 - any refusal (RCCL, the caching allocator, a host sync)
+            err = e
+        verdict = dp.agree_on_capture(err is None, dp.issued - issued0, self.group)      # raises on a mixed outcome
+        if verdict == "captured":
             return True
-        except Exception as e:  # noqa: BLE001 - any refusal (RCCL, the caching allocator, a host sync) -> segments
-            import warnings
-            warnings.warn(f"collectives not captured into the step's hipGraph ({type(e).__name__}: {e}); using three segments")
-            torch.cuda.synchronize()
-            ops.arena.end()
-            ops.weights_changed()
-            return False
+        import warnings
+        warnings.warn(f"collectives not captured into the step's hipGraph on any rank ({type(err).__name__}: {err}); "
+                      "all ranks use three graph segments around two eager collectives")
+        torch.cuda.synchronize()
+        self._works = []
+        ops.arena.end()
+        ops.weights_changed()
+        return False
 
     def _step_graph(self, eeg, fmri):
         if self._cap is None or self._cap["eeg"].shape != eeg.shape or self._cap["fmri"].shape != fmri.shape:
             self._capture(eeg, fmri)
         c = self._cap
         ce, cf = eeg.data_ptr() != c["eeg"].data_ptr(), fmri.data_ptr() != c["fmri"].data_ptr()
-        if (ce and cf and eeg.dtype == torch.float32 and fmri.dtype == torch.float32 and eeg.is_cuda and fmri.is_cuda
+        if (c["xb"] is not None and ce and cf and eeg.dtype == torch.float32 and fmri.dtype == torch.float32 and eeg.is_cuda and fmri.is_cuda
                 and eeg.is_contiguous() and fmri.is_contiguous() and eeg.numel() % 4 == 0 and fmri.numel() % 4 == 0
                 and (eeg.data_ptr() | fmri.data_ptr()) % 16 == 0):
             # ONE launch: EEG batch packed into the first convolution's bf16 operand, fMRI batch copied
@@ -388,8 +491,9 @@ class BridgeTrainer(nn.Module):
                 c["eeg"].copy_(eeg)
             if cf:
                 c["fmri"].copy_(fmri)
-            Bx, Cx, Tx = c["eeg"].shape
-            _hip.call("mm_pack_nct_bf16", c["eeg"], c["xb"], Bx, Cx, Tx, c["xb"].shape[2])
+            if c["xb"] is not None:
+                Bx, Cx, Tx = c["eeg"].shape
+                _hip.call("mm_pack_nct_bf16", c["eeg"], c["xb"], Bx, Cx, Tx, c["xb"].shape[2])
         g = c["graphs"]
         if len(g) == 1:
             g[0].replay()
@@ -400,6 +504,35 @@ class BridgeTrainer(nn.Module):
             dp.allreduce_sum_(self.bucket.g, self.group)
             g[2].replay()                                              # clip + AdamW
         return {"loss": c["scal"][0], "top1_e2f": c["scal"][1], "top1_f2e": c["scal"][2]}
+
+    def time_collectives(self, batch: int, iters: int = 50) -> Dict[str, float]:
+        """microseconds per call of every collective one step issues, each alone at its message size (HIP events on the
+        current stream around ``iters`` back-to-back calls; collective: every rank of the group must call it).  What the
+        step pays is less: all but the all-gather and the last group run beside the backward."""
+        if not dp.active(self.group):
+            return {}
+        dev = self.bucket.g.device
+        N2 = 2 * self.head.bridge.bridge_dim
+        z = torch.zeros(batch, N2, device=dev)
+        z_all = torch.empty(self.world * batch, N2, device=dev)
+        cases = [(f"all_gather embeddings ({batch}x{N2} fp32 per rank)", lambda: dp.all_gather_into(z_all, z, self.group))]
+        for name, _, lo, hi in self.groups:
+            buf = torch.zeros(hi - lo, device=dev)
+            cases.append((f"all_reduce {name} ({(hi - lo) * 4 / 1e6:.2f} MB)",
+                          lambda buf=buf: dp.wait(dp.allreduce_sum_(buf, self.group, async_op=True))))
+        out = {}
+        for name, fn in cases:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            out[name] = a.elapsed_time(b) / iters * 1e3
+        return out
 
     def input_buffers(self):
         """the static (eeg, fmri) tensors the captured step reads, or None before the first graph step:

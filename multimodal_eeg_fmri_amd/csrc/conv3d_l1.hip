@@ -39,6 +39,7 @@ struct L1Args {
     const float* sums;     // [2][32]                           (mode 3)
     float* stats;          // mode 0: [2][32];  mode 2: sums_out
     bf16* out;             // mode 1
+    uint8_t* arg;          // mode 1, optional: the pooling window's winner j = (dd << 2) | (hh << 1) | ww per output element
     float* dw;             // mode 3: [27][32] (tap-major, channel-contiguous atomics); mode 4: A1
     float* dw3;            // mode 4: A3, same layout
     float* dbias;          // mode 3
@@ -202,6 +203,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                         if (ok) {
                             if (a.thresh) best *= dropout_scale(a.seed, (uint32_t)oidx, a.thresh, a.inv_keep);
                             a.out[oidx] = (bf16)best;
+                            if (a.arg) {                        // inspection output (parity tests): which member won
+                                int js = 0;
+#pragma unroll
+                                for (int j = 1; j < 8; ++j) js = hit[j] ? j : js;
+                                a.arg[oidx] = (uint8_t)js;
+                            }
                         }
                     } else {
                         float g = ok ? (float)a.dout[oidx] : 0.f;
@@ -435,7 +442,7 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     MM_REQUIRE(mode != 3 || (dw_tapmajor && (!train || sums)), "conv3d_l1: dw/sums");
     L1Args a;
     a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = sums;
-    a.stats = stats; a.out = (bf16*)out; a.dw = dw_tapmajor; a.dw3 = nullptr; a.dbias = dbias;
+    a.stats = stats; a.out = (bf16*)out; a.arg = nullptr; a.dw = dw_tapmajor; a.dw3 = nullptr; a.dbias = dbias;
     a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
     a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)B * D * H * W);
@@ -454,6 +461,25 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
         default: hipLaunchKernelGGL((conv3d_l1_kernel<3, true>), dim3(grid), dim3(256), 0, st, a); break;
     }
     return mm_check_launch("conv3d_l1");
+}
+
+int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias, const float* out4, void* out, void* arg,
+                             int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
+                             const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(x && wimg && out4 && out && arg && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_fwd_winners: null/invalid");
+    MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_fwd_winners: D,H,W must be even (MaxPool3d(2))");
+    L1Args a;
+    a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = nullptr; a.sums = nullptr;
+    a.stats = nullptr; a.out = (bf16*)out; a.arg = (uint8_t*)arg; a.dw = nullptr; a.dw3 = nullptr; a.dbias = nullptr;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
+    a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.inv_count = 1.f / ((float)B * D * H * W);
+    a.epoch = seed_epoch;
+    const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
+    const int grid = ntiles < 1024 ? ntiles : 1024;
+    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<1, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3d_l1_kernel<1, false>), dim3(grid), dim3(256), 0, st, a);
+    return mm_check_launch("conv3d_l1_fwd_winners");
 }
 
 static int l1_tapsum_grid(int B, int D, int H, int W) {
@@ -477,7 +503,7 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_bwd: D,H,W must be even (MaxPool3d(2))");
     L1Args a;
     a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = nullptr;
-    a.stats = sums_out; a.out = nullptr; a.dw = a1; a.dw3 = a3; a.dbias = nullptr;
+    a.stats = sums_out; a.out = nullptr; a.arg = nullptr; a.dw = a1; a.dw3 = a3; a.dbias = nullptr;
     a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
     a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)B * D * H * W);

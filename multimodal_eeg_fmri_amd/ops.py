@@ -258,7 +258,7 @@ class _WeightCache:
 
     def get(self, w: torch.Tensor, need_dgrad: bool, key=None):
         owner = w if key is None else key          # the nn.Parameter the image belongs to
-        if self._rec is not None:
+        if self._rec is not None and not getattr(owner, "_mm_transient", False):
             self._rec.append((owner, None if key is None else tuple(w.shape), bool(need_dgrad)))
         k = id(owner)
         ver = (owner.data_ptr(), owner._version, self._gen, tuple(w.shape))
@@ -566,9 +566,10 @@ def pe_table(pos_encoder, L: int) -> torch.Tensor:
 
 
 # ------------------------------------------------------------ EEG encoders
-def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool, prenorm=None):
+def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool, prenorm=None, stages=None):
     """shared tail of both EEG encoders: transformer stack -> mean pool -> Linear -> GELU.
-    ``prenorm``: (norm1(h) bf16, stats) of the FIRST block when the producer of ``h`` already formed it."""
+    ``prenorm``: (norm1(h) bf16, stats) of the FIRST block when the producer of ``h`` already formed it.
+    ``stages`` (dict, inspection only): receives a copy of the residual stream after every block (``block<i>``)."""
     blocks = []
     B, L, D = h.shape
     nblk = len(m.transformer_layers)
@@ -582,33 +583,50 @@ def _encoder_tail_impl(m, h, training: bool, need_dgrad: bool, save: bool, preno
         else:
             h, s = transformer_block_fwd(h, blk, training, need_dgrad, save=save, pool_out=pooled, prenorm=prenorm)
         blocks.append(s)
+        if stages is not None:
+            stages[f"block{i}"] = h.clone()
     out, s = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=m.drop_p, need_dgrad=need_dgrad,
                              save=save, pooled_f32=pooled)
     return out, blocks, s, h
 
 
-def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None, xb=None):
+def _erp_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None, xb=None, stages=None):
     """EnhancedERPEncoder forward; returns (features fp32 (B, H), saved list).
     ``save`` (default = training): keep what a backward needs (eval + save = frozen BatchNorm).
-    ``xb``: ``pack_nct(x)`` when the caller already holds it (a trainer stages its inputs packed)."""
+    ``xb``: ``pack_nct(x)`` when the caller already holds it (a trainer stages its inputs packed).
+    ``stages`` (dict, inspection only - the parity tests hold the HIP path's intermediate activations against the
+    reference's, enhanced_models_v4.py:169-193): receives channels-last copies of what the path materialises - ``conv1``
+    / ``conv2`` (bf16 (B, T, C)), ``pos`` (fp32, conv block 3 + positional table, one launch) and ``block<i>`` - plus
+    ``conv3``, which the fused launch never forms: one EXTRA launch of the same kernel without the table."""
     cl = m.conv_layers
     save = training if save is None else save
     p = m.drop_p if training else 0.0
     if xb is None:
         xb = pack_nct(x)
     saved = []
+    saved_in = []                                        # conv block outputs (for ``stages``)
     r, s = conv_bn_act(xb, cl[0], cl[1], training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
+    saved_in.append(r["bf16"])
     r, s = conv_bn_act(r["bf16"], cl[4], cl[5], pool=2, training=training, drop_p=p,
                        drop_first=False, need_dgrad=need_dgrad, save=save)
     saved.append(s)
+    saved_in.append(r["bf16"])
     L = r["bf16"].shape[1]
     r, s = conv_bn_act(r["bf16"], cl[9], cl[10], training=training, drop_p=p,
                        pe=pe_table(m.pos_encoder, L), pe_drop_p=(m.pos_encoder.dropout.p if training else 0.0),
                        want_f32=True, want_bf16=False, need_dgrad=need_dgrad, save=save,
                        next_norm=m.transformer_layers[0].norm1 if len(m.transformer_layers) else None)
     saved.append(s)
-    out, blocks, s, h = _encoder_tail_impl(m, r["f32"], training, need_dgrad, save, prenorm=r.get("prenorm"))
+    if stages is not None:
+        stages["conv1"], stages["conv2"] = saved_in[0].clone(), saved_in[1].clone()
+        stages["pos"] = r["f32"].clone()
+        if not save:                                     # (the fused eval launch: BatchNorm folded into the GEMM epilogue)
+            wf3 = weights.get(cl[9].weight, need_dgrad)[0]
+            o4 = bn_fold_eval(cl[10], cl[9].bias)
+            stages["conv3"] = igemm(saved_in[1], wf3, cl[9].kernel_size[0], cl[9].padding[0], cl[9].out_channels,
+                                    scale=o4[0], shift=o4[1], act="gelu", out_f32=True, out_bf16=False)["f32"]
+    out, blocks, s, h = _encoder_tail_impl(m, r["f32"], training, need_dgrad, save, prenorm=r.get("prenorm"), stages=stages)
     return out, dict(convs=saved, blocks=blocks, head=s, x_shape=tuple(x.shape), tokens=h)
 
 
@@ -723,9 +741,10 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     return out, saved
 
 
-def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float, save=None):
+def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float, save=None, winners=None):
     """fused first layer on the raw fp32 volume (B, 1, D, H, W); see conv3d_l1.hip.  ``save`` without ``training``:
-    frozen BatchNorm (running statistics), a backward will follow."""
+    frozen BatchNorm (running statistics), a backward will follow.  ``winners`` (list, inspection only): receives the
+    u8 (B, D/2, H/2, W/2, 32) tensor of pooling-window winners the forward launch then also writes."""
     save = training if save is None else save
     B, _, D, H, W = x.shape
     wimg = weights.get(conv.weight.view(32, 27, 1), False, key=conv.weight)[0]
@@ -744,16 +763,22 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     else:
         out4 = bn_fold_eval(bn, conv.bias)
         bias = None
-    _hip.call("mm_conv3d_l1", 1, x, wimg, bias, out4, None, None, None, out, None, None,
-              B, D, H, W, 1 if training else 0, float(p), seed, EP())
+    if winners is not None:
+        arg = _empty(tuple(out.shape), torch.uint8, x)
+        _hip.call("mm_conv3d_l1_fwd_winners", x, wimg, bias, out4, out, arg, B, D, H, W, 1 if training else 0, float(p), seed, EP())
+        winners.append(arg)
+    else:
+        _hip.call("mm_conv3d_l1", 1, x, wimg, bias, out4, None, None, None, out, None, None,
+                  B, D, H, W, 1 if training else 0, float(p), seed, EP())
     saved = dict(l1=True, x=x, wimg=wimg, out4=out4, drop_p=p, seed=seed, conv=conv, bn=bn, train=training) if save else None
     return out, saved
 
 
-def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None, need_dx: bool = False):
+def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save=None, need_dx: bool = False, winners=None):
     """``save`` (default = training): keep what a backward needs; eval + save = frozen BatchNorm.  ``need_dx``: the
     caller wants d / d volume - layer 1 then runs as an ordinary implicit GEMM on the channel-padded volume (the
-    fused layer-1 kernels never form its data gradient)."""
+    fused layer-1 kernels never form its data gradient).  ``winners`` (list, inspection only; needs ``save``): receives
+    the two max-pool layers' window winners, u8 channels-last, j = (dd << 2) | (hh << 1) | ww."""
     save = training if save is None else save
     cl = m.conv_layers
     p = m.drop_p
@@ -761,13 +786,17 @@ def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save
     B, C, D, H, W = x.shape
     x = x.contiguous()
     if C == 1 and cl[0].out_channels == 32 and D % 2 == 0 and H % 2 == 0 and W % 2 == 0 and not need_dx:
-        h, s = conv3d_l1_bn_act(x, cl[0], cl[1], training=training, drop_p=p, save=save)
+        h, s = conv3d_l1_bn_act(x, cl[0], cl[1], training=training, drop_p=p, save=save, winners=winners)
     else:
         h, s = conv3d_bn_act(pack_volume(x), cl[0], cl[1], pool=True, training=training, drop_p=p,
                              need_dgrad=need_dgrad or need_dx, save=save)
     saved.append(s)
     h, s = conv3d_bn_act(h, cl[5], cl[6], pool=True, training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
+    if winners is not None:
+        if len(winners) == 0:                            # layer 1 took the generic path: its winners are saved like layer 2's
+            winners.append(saved[0]["arg"])
+        winners.append(s["arg"])
     h, s = conv3d_bn_act(h, cl[10], cl[11], pool=False, training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
     out, hs = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
@@ -947,8 +976,16 @@ def _mlp_bn_act(x, lin, bn, act, drop_p, training):
         from . import small_autograd as sa
         return sa.linear_bn_act(x, lin, bn, act, drop_p)
     if torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
-        raise NotImplementedError("backward through an eval-mode BatchNorm1d MLP head is not built; use no_grad or train()")
+        # eval mode with a backward to follow: frozen BatchNorm (running statistics, no update), dropout off
+        from . import small_autograd as sa
+        return sa.linear_bn_act(x, lin, bn, act, 0.0, frozen=True)
     return small_linear(_f32c(x), lin, act=act, bn=bn)[0]
+
+
+def small_autograd_linear(x, lin, act="none", drop_p=0.0):
+    """differentiable fp32 Linear (+ activation, dropout) on (B, K) rows: small_autograd.linear"""
+    from . import small_autograd as sa
+    return sa.linear(x, lin, act, drop_p)
 
 
 def _v4_classifier(cl, fused, p, training):
@@ -1097,6 +1134,9 @@ def bn_classifier_forward(seq, fused, drop_p, training):
     if training:
         from . import small_autograd as sa
         return sa.linear(sa.linear_bn_act(fused, seq[0], seq[1], "gelu", drop_p), seq[4])
+    if torch.is_grad_enabled() and (fused.requires_grad or seq[0].weight.requires_grad):
+        from . import small_autograd as sa                   # eval + backward: frozen BatchNorm, dropout off
+        return sa.linear(sa.linear_bn_act(fused, seq[0], seq[1], "gelu", 0.0, frozen=True), seq[4])
     with torch.no_grad():
         h, _ = small_linear(_f32c(fused), seq[0], act="gelu", bn=seq[1])
         out, _ = small_linear(h, seq[4])
@@ -1203,6 +1243,7 @@ def _power_merged_train(m):
     F = torch.nn.functional
     cat = lambda ts: torch.cat([t.detach() for t in ts], dim=0).contiguous()    # noqa: E731
     w = cat([F.pad(s[0].weight.detach(), ((7 - s[0].kernel_size[0]) // 2,) * 2) for s in seqs])
+    w._mm_transient = True        # rebuilt every step: a trainer's recorded weight list must not hold on to this one
     conv = _Merged(weight=w.requires_grad_(any(s[0].weight.requires_grad for s in seqs)),
                    bias=cat([s[0].bias for s in seqs]).requires_grad_(any(s[0].bias.requires_grad for s in seqs)),
                    kernel_size=(7,), padding=(3,), in_channels=seqs[0][0].in_channels, out_channels=192)

@@ -48,15 +48,23 @@ class SmallLinearFn(torch.autograd.Function):
 
 
 class BNRowsActFn(torch.autograd.Function):
-    """y = dropout(act(BatchNorm1d_train(x))) on fp32 (B, N); updates running stats."""
+    """y = dropout(act(BatchNorm1d(x))) on fp32 (B, N).  Train mode: batch statistics, running stats updated.
+    ``frozen`` (eval mode with a backward to follow - saliency / fine-tuning through a classifier head,
+    crossmodal_v4_enhancements.py:909-915): running statistics, no update, no dropout; the backward is
+    dx = scale * dz with the parameter gradients dbeta = sum dz, dgamma = sum dz * xhat."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, act, drop_p):
+    def forward(ctx, x, gamma, beta, bn, act, drop_p, frozen=False):
         x = _f(x)
         B, N = x.shape
-        stats = _zeros((REPL, 2, N), x)
-        _hip.call("mm_colstats", x, stats, B, N)                 # replica 0
-        out4 = ops.bn_finalize_train(bn, stats, B)
+        if frozen:
+            out4 = ops.bn_fold_eval(bn, None)
+            drop_p = 0.0
+        else:
+            stats = _zeros((REPL, 2, N), x)
+            _hip.call("mm_colstats", x, stats, B, N)                 # replica 0
+            out4 = ops.bn_finalize_train(bn, stats, B)
+        ctx.frozen = bool(frozen)
         seed = ops._next_seed() if drop_p > 0 else 0
         y = _empty((B, N), _F32, x)
         _hip.call("mm_bn_act_fwd", x, out4[0], out4[1], None, None, y, 1, B, N, ACT[act], 1, 1,
@@ -77,14 +85,14 @@ class BNRowsActFn(torch.autograd.Function):
         _hip.call("mm_bn_act_bwd_reduce", x, out4, None, dy, sums, *args)
         sc = _compact(sums, 2 * N)
         dx = _empty((B, N), _F32, x)
-        _hip.call("mm_bn_act_bwd_apply", x, out4, None, dy, sc, None, dx, *args, 1, 1)
+        _hip.call("mm_bn_act_bwd_apply", x, out4, None, dy, sc, None, dx, *args, 0 if ctx.frozen else 1, 1)
         bag = GradBag()
         gg, gb = bag.target(bn.weight), bag.target(bn.bias)
         if gb is not None:
             _hip.call("mm_reduce_replicas", sc, gb, N, 1, N)
         if gg is not None:
             _hip.call("mm_reduce_replicas", sc.data_ptr() + 4 * N, gg, N, 1, N)
-        return dx, bag.result(bn.weight), bag.result(bn.bias), None, None, None
+        return dx, bag.result(bn.weight), bag.result(bn.bias), None, None, None, None
 
 
 class MulFn(torch.autograd.Function):
@@ -189,9 +197,9 @@ def linear(x, lin, act="none", drop_p=0.0):
     return SmallLinearFn.apply(x, lin.weight, lin.bias, act, float(drop_p))
 
 
-def linear_bn_act(x, lin, bn, act, drop_p):
-    """Linear -> BatchNorm1d(train) -> act -> Dropout"""
-    return BNRowsActFn.apply(linear(x, lin), bn.weight, bn.bias, bn, act, float(drop_p))
+def linear_bn_act(x, lin, bn, act, drop_p, frozen: bool = False):
+    """Linear -> BatchNorm1d (train: batch statistics; ``frozen``: running statistics, differentiable) -> act -> Dropout"""
+    return BNRowsActFn.apply(linear(x, lin), bn.weight, bn.bias, bn, act, float(drop_p), bool(frozen))
 
 
 class LayerNormFn(torch.autograd.Function):

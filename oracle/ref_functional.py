@@ -358,17 +358,28 @@ def smart_fusion_v4(sd: SD, erp, pw, p: str = "", nhead: int = 4, train: bool = 
 # EXTENSIONS named by north_star, absent from the reference
 # ("parity unpinned by reference"; definitions in DESIGN.md)
 # ==========================================================================
+def max_pool3d_routed(h, route):
+    """MaxPool3d(2) with the window member to take GIVEN (``route`` (B, C, D/2, H/2, W/2) int64, member index
+    (dd << 2) | (hh << 1) | ww): what max-pooling computes whenever ``route`` is its own arg-max.  The parity tests pass
+    the routing the HIP path took, so that a flip between two near-equal window members (bf16 operands) is not counted
+    as a gradient error of everything below the pool."""
+    B, C, D, H, W = h.shape
+    win = h.reshape(B, C, D // 2, 2, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, C, D // 2, H // 2, W // 2, 8)
+    return win.gather(-1, route.unsqueeze(-1)).squeeze(-1)
+
+
 def volume_encoder3d(sd: SD, x, p: str = "", train: bool = False,
-                     stages: Optional[dict] = None):
+                     stages: Optional[dict] = None, route=None):
     """a-X1: Conv3d(1->32)-BN-GELU-MaxPool2 / Conv3d(32->64)-BN-GELU-MaxPool2 /
-    Conv3d(64->128)-BN-GELU / global-avg-pool / Linear(128->64)-GELU."""
+    Conv3d(64->128)-BN-GELU / global-avg-pool / Linear(128->64)-GELU.
+    ``route`` = (route1, route2): evaluate the two max-pools with given window members (`max_pool3d_routed`)."""
     c = p + "conv_layers."
     h = gelu(_bn(sd, c + "1.", F.conv3d(x, sd[c + "0.weight"], sd[c + "0.bias"], padding=1), train))
-    h = F.max_pool3d(h, 2)
+    h = F.max_pool3d(h, 2) if route is None else max_pool3d_routed(h, route[0])
     if stages is not None:
         stages["conv1"] = h
     h = gelu(_bn(sd, c + "6.", F.conv3d(h, sd[c + "5.weight"], sd[c + "5.bias"], padding=1), train))
-    h = F.max_pool3d(h, 2)
+    h = F.max_pool3d(h, 2) if route is None else max_pool3d_routed(h, route[1])
     if stages is not None:
         stages["conv2"] = h
     h = gelu(_bn(sd, c + "11.", F.conv3d(h, sd[c + "10.weight"], sd[c + "10.bias"], padding=1), train))

@@ -18,6 +18,7 @@ import multimodal_eeg_fmri_amd.enhanced_models_v4 as E
 import multimodal_eeg_fmri_amd.fmri_utils as Fm
 from multimodal_eeg_fmri_amd.config import Config, set_seed
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -305,3 +306,107 @@ def test_hand_scheduled_conv3d_kernel_keeps_the_accumulator_file_to_itself():
             bad.append(line.strip())
     assert not bad, bad[:5]
     assert text.count("#ASMSTART") >= 10
+
+
+def test_lite_disk_datasets_vs_reference_golden(tmp_path):
+    """EEGDatasetERP / EEGDatasetPW / EEGDatasetCONN + aggregate_features (run_training_lite.py:62-259): every item tuple
+    and every per-subject aggregate bit-equal to what the REFERENCE's classes produced on the same MATLAB-v5 tree
+    (tests/golden/f3_lite_datasets.npz, written by oracle/make_goldens_r4.py; the tree is rebuilt from the fixture).
+    Covers: variable-name search and the first-variable fallback, matrix -> strict upper triangle vs flatten, the second
+    glob pattern (and the duplicates it yields), the "1_Hz" / "11_Hz" substring match, an unreadable file, an absent
+    subject, labels missing for a subject.  The HDF5 (MATLAB v7.3) branch is UNPINNED: h5py is not in the image."""
+    from oracle.make_goldens_r4 import ARGS, flatten, run_datasets, write_tree
+    import multimodal_eeg_fmri_amd.run_training_lite as R
+    fx = np.load(os.path.join(GOLDEN, "f3_lite_datasets.npz"), allow_pickle=False)
+    tree = {}
+    for i, rel in enumerate(fx["paths"]):
+        var = str(fx[f"file_{i}_var"])
+        tree[str(rel)] = {var: fx[f"file_{i}_arr"]} if var else None
+    write_tree(str(tmp_path), tree)
+    got = flatten(*run_datasets(R, str(tmp_path)))
+    keys = [str(k) for k in fx["expected_keys"]]
+    assert list(got) == keys
+    for i, k in enumerate(keys):
+        want = fx[f"exp_{i}"]
+        assert got[k].shape == want.shape and got[k].dtype == want.dtype and np.array_equal(got[k], want), k
+    # the glue of main(): aggregates -> one 2-D sample per subject present everywhere (subject 4 has no files)
+    ds = R.EEGDatasetERP(ARGS["subjects"], ARGS["bands"], ARGS["freqs"], tmp_path / "erp", labels=ARGS["labels"])
+    item = ds[0]
+    assert isinstance(item[0], torch.Tensor) and item[0].dtype == torch.float32 and item[0].shape == (4, 16) and len(item) == 5
+    agg = {k: R.aggregate_features(d, k)[0] for k, d in run_datasets(R, str(tmp_path))[0].items()}
+    tri = R.AggregatedTriModalDataset(agg["erp"], agg["pw"], agg["conn"], ARGS["labels"])
+    assert [s["subject"] for s in tri.samples] == [1, 2, 3] and tri[0]["erp"].shape == (4, 16) and tri[0]["conn"].shape == (15,)
+
+
+def test_built_library_has_no_half_selecting_packed_fp32():
+    """profiles/r03_packed_fp32_ab.txt / r04_packed_fp32_isa.txt: compiler-formed `v_pk_{fma,mul,add}_f32` whose `op_sel:`
+    modifier makes the LOW result lane read the HIGH register of an operand pair (`v_pk_fma_f32 v[28:29], v[28:29],
+    v[22:23], v[18:19] op_sel:[0,1,1]`: the BatchNorm scale / shift of an odd column broadcast from the high half) gave
+    run-to-run different sums inside the two-stream training graph.  The guard used to be a build flag alone
+    (-fno-slp-vectorize); this audits what was actually BUILT: every gfx950 code object of libmmeeg_hip.so is
+    disassembled and no packed-fp32 instruction may carry an `op_sel:` modifier (`op_sel_hi:` - the broadcast of an inline
+    constant or an SGPR, e.g. `v_pk_add_f32 v[0:1], v[2:3], 0 op_sel_hi:[1,0]` - is a different encoding and stays
+    allowed, as do the plain register-pair `v_pk_add_f32` of conv3d_wres's hand-written K loop)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    assert os.path.exists(_hip.lib_path()), "run __graft_entry__.build() first"
+    with tempfile.TemporaryDirectory() as tmp:
+        lib = shutil.copy(_hip.lib_path(), os.path.join(tmp, "lib.so"))       # --offloading writes next to its input
+        subprocess.run([objdump, "--offloading", lib], check=True, capture_output=True, cwd=tmp)
+        bundles = [f for f in os.listdir(tmp) if f.endswith("gfx950")]
+        assert len(bundles) >= 9, bundles
+        packed, bad, kernels = 0, [], 0
+        for f in bundles:
+            dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            cur = ""
+            for line in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+                if m:
+                    cur = m.group(1)
+                    kernels += 1
+                    continue
+                if re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+                    packed += 1
+                    if re.search(r"\bop_sel:\[", line):
+                        bad.append((cur[:80], line.split("//")[0].strip()))
+    assert kernels > 100, kernels                     # the disassembly really covered the library
+    assert packed >= 100, packed                      # ... down to the instruction level (conv3d_wres's hand-written pairs)
+    assert not bad, bad[:5]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """under a launcher whose WORLD_SIZE differs from --gpus the bench stops with a message before any GPU call (no assert
+    trace, no hang)"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "launches its own ranks" in r.stderr
+
+
+def test_bench_self_launch_relays_a_failing_rank():
+    """`python bench.py --gpus 2` without a launcher becomes the parent of its own two ranks (torch.distributed.run) and
+    exits NON-ZERO when they fail - which they must here, where there is no GPU - without printing a result line.  The
+    parent itself never imports torch: it cannot have touched the GPU."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    probe = ("import runpy, sys; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1']\n"
+             "import subprocess\n"
+             "real = subprocess.Popen\n"
+             "def spy(cmd, **kw):\n"
+             "    assert 'torch' not in sys.modules, 'the parent imported torch before launching its ranks'\n"
+             "    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '2'\n"
+             "    assert '--master-addr' in cmd and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'\n"
+             "    return real(cmd, **kw)\n"
+             "subprocess.Popen = spy\n"
+             f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: the ranks would run")
+    assert r.returncode != 0, r.stdout[-800:] + r.stderr[-800:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "AssertionError" not in r.stderr, r.stderr[-1500:]

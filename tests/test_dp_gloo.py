@@ -52,13 +52,16 @@ def _worker(rank, world, port, B, N, out_q):
         z.backward(dz_local)                                         # into this rank's "encoder"
         gw = (h.grad * h_all[rank * B:(rank + 1) * B]).sum(0)        # d/dw on this rank
         flat = gw.clone()
-        # the flat bucket goes out in parts (bridge_trainer: the branch that finishes first is reduced
-        # while the other still runs); the parts are disjoint views, so the result is the one all-reduce
-        cut = flat.numel() // 3
-        works = [dp.allreduce_sum_(flat[:cut], dist.group.WORLD, async_op=True),
-                 dp.allreduce_sum_(flat[cut:], dist.group.WORLD, async_op=True)]
+        # the flat bucket goes out in one asynchronous piece per finished layer group (bridge_trainer._reduce_group: the
+        # fMRI tail first, conv block 1's head of the bucket last), waited for only by the optimizer; the pieces are
+        # disjoint views that tile the bucket, so the result is the one all-reduce
+        n = flat.numel()
+        cuts = [0, n // 8, n // 3, 2 * n // 3, n]
+        works = [dp.allreduce_sum_(flat[lo:hi], dist.group.WORLD, async_op=True)
+                 for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:])))]
+        assert all(wk is not None for wk in works)
         for wk in works:
-            wk.wait()
+            dp.wait(wk)
         flat /= world                                                # grad_scale = 1/world in the AdamW kernel
         losses = [torch.zeros(()) for _ in range(world)]
         dist.all_gather(losses, loss_r.detach())
@@ -109,3 +112,96 @@ def test_trainer_bucket_puts_the_fmri_slice_last():
         off = (p._mm_grad.data_ptr() - base) // 4
         assert off + p.numel() <= tr.fmri_lo
     assert b.g[:tr.fmri_lo].numel() + b.g[tr.fmri_lo:].numel() == b.n
+
+
+def test_trainer_bucket_is_laid_out_by_finished_layer_group():
+    """one contiguous range of the flat bucket per layer group, in the reverse of the order in which the backward finishes
+    them: conv block 1 | conv blocks 2-3 | transformer stack + encoder head + projection heads + logit scale | fMRI
+    encoder; the ranges tile the bucket, every parameter's gradient sink lies inside its group's range, and each group
+    names the point of the backward at which it is reduced (host logic; no kernels run)."""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer
+    tr = BridgeTrainer(eeg_channels=8, device="cpu", mode="manual")
+    b = tr.bucket
+    assert [g[1] for g in tr.groups] == ["main", "handed1", "handed0", "fmri"]
+    assert tr.groups[0][2] == 0 and tr.groups[-1][3] == b.n
+    assert all(a[3] == c[2] for a, c in zip(tr.groups, tr.groups[1:]))            # contiguous, no gap, no overlap
+    assert all(hi > lo for _, _, lo, hi in tr.groups)
+    base = b.g.data_ptr()
+    cl = tr.eeg_encoder.conv_layers
+    members = {
+        "main": list(cl[0].parameters()) + list(cl[1].parameters()),
+        "handed1": [p for i in (4, 5, 9, 10) for p in cl[i].parameters()],
+        "handed0": list(tr.eeg_encoder.transformer_layers.parameters()) + list(tr.eeg_encoder.output_proj.parameters())
+        + list(tr.head.bridge.eeg_proj.parameters()) + list(tr.head.bridge.fmri_proj.parameters()) + [tr.head.logit_scale],
+        "fmri": list(tr.fmri_encoder.parameters()),
+    }
+    total = 0
+    for name, ready, lo, hi in tr.groups:
+        for p in members[ready]:
+            off = (p._mm_grad.data_ptr() - base) // 4
+            assert lo <= off and off + p.numel() <= hi, (name, off, lo, hi)
+        assert sum(p.numel() for p in members[ready]) == hi - lo, name
+        total += hi - lo
+    assert total == b.n
+
+
+def test_trainer_accepts_the_config5_eeg_branch():
+    """BridgeTrainer(eeg_encoder=...): the STFT front-end + power encoder (BASELINE config #5) and a bare EnhancedPowerEncoder
+    as the EEG branch get a two-group bucket (EEG side | fMRI encoder); an encoder without a tape is refused (host logic)."""
+    import torch.nn as nn
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer
+    from multimodal_eeg_fmri_amd.crossmodal_v4_enhancements import MultiScaleSTFTPowerEncoder
+    from multimodal_eeg_fmri_amd.enhanced_models_v4 import EnhancedPowerEncoder
+    for enc, kind in ((MultiScaleSTFTPowerEncoder(4, (16, 32), 8, 128, 1, 4, 0.1), "stft"), (EnhancedPowerEncoder(8, 128, 1, 4, 0.1), "power")):
+        tr = BridgeTrainer(device="cpu", mode="manual", eeg_encoder=enc)
+        assert tr._eeg_kind == kind and [g[1] for g in tr.groups] == ["main", "fmri"]
+        assert tr.groups[0][2] == 0 and tr.groups[0][3] == tr.groups[1][2] == tr.fmri_lo and tr.groups[1][3] == tr.bucket.n
+        assert all(getattr(p, "_mm_grad", None) is not None for p in enc.parameters())
+    with pytest.raises(TypeError):
+        BridgeTrainer(device="cpu", eeg_encoder=nn.Linear(4, 128))
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multimodal_eeg_fmri_amd import dp
+    try:
+        out = []
+        g = dist.group.WORLD
+        out.append(dp.agree_on_capture(True, 5, g))                       # every rank captured
+        out.append(dp.agree_on_capture(False, 0, g))                      # every rank refused before any collective
+        for ok, enq in (((rank == 0), 5 if rank == 0 else 0),             # one rank failed, cleanly - but its peer captured
+                        (False, 1 if rank == 1 else 0)):                  # all failed, one of them after a collective
+            try:
+                dp.agree_on_capture(ok, enq, g)
+                out.append("no error")
+            except RuntimeError as e:
+                out.append("raised" if "aborting the job" in str(e) else str(e))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_capture_form():
+    """the fallback from the one-graph step to the segmented form must be a GROUP decision.  All captured ->
+    "captured"; all refused before a collective was enqueued -> "segments" on every rank; anything mixed (a rank failed
+    while another captured, or a failure after a collective had been handed to the backend) -> RuntimeError on EVERY
+    rank, so the job exits non-zero instead of issuing different collective sequences."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r] == ["captured", "segments", "raised", "raised"], got
+    from multimodal_eeg_fmri_amd import dp
+    assert dp.agree_on_capture(True, 3, None) == "captured" and dp.agree_on_capture(False, 0, None) == "segments"
+    with pytest.raises(RuntimeError):
+        dp.agree_on_capture(False, 2, None)

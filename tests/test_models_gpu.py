@@ -42,6 +42,34 @@ def test_a3_erp_encoder_eval_vs_golden(golden, tag):
     assert rel_err(y, want) < 2e-2
 
 
+@pytest.mark.parametrize("tag", ["c1", "c2"])
+def test_a3_erp_encoder_stages_vs_golden(golden, tag):
+    """the six intermediate activations the reference golden holds (enhanced_models_v4.py:169-193: after each conv block,
+    after the positional add, after each transformer block) against what the HIP path materialises at the same points
+    (``stages=`` hook of ops._erp_forward_impl): bf16 conv-block outputs <= 1.5e-2 rel-L2 (bf16 operands + one bf16 rounding
+    of the stored activation), the fp32 residual stream <= 1e-2, cosine per sample >= 1 - 1e-4 everywhere."""
+    from multimodal_eeg_fmri_amd import ops
+    fx = golden(f"a3_erp_{tag}.npz")
+    B, C, T = (int(v) for v in fx["shape"])
+    m = build(E.EnhancedERPEncoder, int(fx["seed"]), C, 128, 2, 4, 0.3).eval().cuda()
+    x = seeded_randn(int(fx["x_seed"]), B, C, T).cuda()
+    stages = {}
+    with torch.no_grad():
+        out, _ = ops._erp_forward_impl(m, x, False, False, stages=stages)
+    assert cos_min(out.cpu(), torch.as_tensor(fx["out"])) >= 1 - COS_TOL
+    stride = int(fx["stride"])                           # the fixture keeps every stride-th time step / token of a stage
+    for name, tol in (("conv1", 1.5e-2), ("conv2", 1.5e-2), ("conv3", 1.5e-2), ("pos", 1e-2), ("block0", 1e-2), ("block1", 1e-2)):
+        want = torch.as_tensor(fx[f"stage_{name}"])
+        got = stages[name].float().cpu()
+        if name.startswith("conv"):                      # reference layout (B, C, T); the HIP path is channels-last
+            got = got[..., :want.shape[1]].permute(0, 2, 1)[:, :, ::stride]
+        else:
+            got = got[:, ::stride, :]
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        assert cos_min(got, want) >= 1 - COS_TOL, (name, cos_min(got, want))
+        assert rel_err(got, want) < tol, (name, rel_err(got, want))
+
+
 def _grad_check(name, got, want, rel_tol):
     e = rel_err(got, want)
     assert e < rel_tol, f"{name}: rel err {e:.3e}"
@@ -152,6 +180,47 @@ def test_volume_encoder_train_grads_vs_oracle():
     assert len(no_pool) == 6
     wnp = _worst(no_pool, g32)
     assert wnp[1] <= 5e-2, ("layer 3 / head vs the unmodified fp32 oracle", wnp)
+
+
+@pytest.mark.parametrize("shape,seed", [((4, 1, 16, 16, 16), 37), ((2, 1, 32, 32, 32), 38)])
+def test_volume_encoder_grads_vs_unmodified_fp32_oracle_with_hip_routing(shape, seed):
+    """the 2e-1 bound of layers 1-2 against plain fp32 was max-pool arg-max flips (two near-equal window
+    members swap under bf16 operands and a whole gradient entry moves).  Here the UNMODIFIED fp32 oracle - no operand
+    rounding anywhere - is evaluated with the two pools routed as the HIP path routed them (its saved / exported window
+    winners, ops._vol_forward_impl(winners=...)): EVERY parameter gradient, layers 1 and 2 included, <= 5e-2 rel-L2.
+    The routing itself must be a genuine arg-max of the oracle's own pre-pool activations up to near-ties: at most 2 %
+    of the windows differ, and where they do the two members are within 2 % of the activation scale."""
+    from multimodal_eeg_fmri_amd import ops
+    m = build(Fm.fMRIVolumeEncoder3D, seed, dropout=0.0).train()
+    x = seeded_randn(100 + seed, *shape)
+    gy = seeded_randn(200 + seed, shape[0], 64)
+    mg = build(Fm.fMRIVolumeEncoder3D, seed, dropout=0.0).train().cuda()
+    y = mg(x.cuda())
+    y.backward(gy.cuda())
+    winners = []
+    mw = build(Fm.fMRIVolumeEncoder3D, seed, dropout=0.0).train().cuda()         # same seed -> same weights, fresh BN buffers
+    with torch.no_grad():
+        out_w, _ = ops._vol_forward_impl(mw, x.cuda(), True, True, winners=winners)
+    assert torch.equal(out_w, y.detach())                                         # the inspected forward IS the product forward
+    route = tuple(w.long().permute(0, 4, 1, 2, 3).contiguous().cpu() for w in winners)
+    assert len(route) == 2 and route[0].shape[1] == 32 and route[1].shape[1] == 64
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    stages = {}
+    out = RF.volume_encoder3d(sd, x, train=True, route=route, stages=stages)
+    out.backward(gy)
+    want = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    assert cos_min(y.detach().cpu(), out.detach()) >= 1 - COS_TOL
+    w = _worst(mg.named_parameters(), want)
+    assert w[1] <= 5e-2, ("every layer vs the unmodified fp32 oracle routed as the HIP path", w)
+    # the routing is the oracle's own arg-max except at near-ties
+    with torch.no_grad():
+        free = RF.volume_encoder3d({k: v.detach() for k, v in sd.items()}, x, train=True, stages=(st2 := {}))
+    for name in ("conv1", "conv2"):
+        a, b = stages[name].detach(), st2[name]
+        differ = (a != b)
+        assert differ.float().mean().item() <= 2e-2, (name, differ.float().mean().item())
+        if differ.any():
+            assert ((b - a)[differ].abs().max() / b.abs().max()).item() <= 2e-2, name
 
 
 def test_volume_encoder_train_grads_at_config4_size_vs_oracle():
@@ -355,6 +424,40 @@ def test_run_training_lite_main_trains_on_gpu(tmp_path, monkeypatch):
     cfg.synthetic["subjects"] = 24
     res = R.main(cfg, max_epochs=3)
     assert len(res) == 2 and all(0.0 <= r["Accuracy"] <= 1.0 for r in res)
+
+
+def test_run_training_lite_main_trains_from_a_disk_tree(tmp_path, monkeypatch):
+    """the reference's own route through main() (run_training_lite.py:360-396): label CSV + three directories of per-file
+    .mat features -> EEGDatasetERP / PW / CONN -> per-subject aggregates -> the cross-validated Lite loop, on a synthetic
+    tree with BASELINE config #1's encoder shapes (8 ch x 256 samples; 465 connectivity features = the strict upper triangle of 31 x 31)."""
+    from scipy.io import savemat
+    import multimodal_eeg_fmri_amd.run_training_lite as R
+    from multimodal_eeg_fmri_amd.config import Config
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(3)
+    root = tmp_path / "data"
+    for d in ("erp", "pw", "conn"):
+        (root / d).mkdir(parents=True)
+    rows = ["subject,label"]
+    for subj in range(1, 17):
+        y = subj % 2
+        rows.append(f"{subj},{3 if y else 1}")                    # load_labels(binary=True): <= 1 -> 0, else 1
+        shift = 0.5 * (2 * y - 1)
+        for f in ("1_Hz", "2_Hz"):
+            savemat(root / "erp" / f"ERP_sub{subj:03d}_alpha_{f}.mat", {"ERP": rng.standard_normal((8, 256)) + shift})
+            savemat(root / "pw" / f"pw_sub{subj:03d}_alpha_{f}.mat", {"powspctrm": rng.standard_normal((8, 256)) - shift})
+        for c in ("open", "close"):
+            m = rng.standard_normal((31, 31)) + shift
+            savemat(root / "conn" / f"conn_sub{subj:03d}_alpha_{c}.mat", {"conn": m + m.T})
+    (root / "labels.csv").write_text("\n".join(rows) + "\n")
+    cfg = Config(None)
+    cfg.eeg_path_erp, cfg.eeg_path_pw, cfg.eeg_path_conn, cfg.label_path = root / "erp", root / "pw", root / "conn", root / "labels.csv"
+    cfg.subject_list, cfg.bands, cfg.eeg_segments = list(range(1, 17)), {"alpha": "Alpha"}, ["1_Hz", "2_Hz"]
+    cfg.n_splits, cfg.learning_rate = 2, 2e-3
+    res = R.main(cfg, max_epochs=3)                               # source="auto": the directories exist -> disk
+    assert len(res) == 2 and all(0.0 <= r["Accuracy"] <= 1.0 for r in res)
+    ds = R.load_disk_dataset(cfg)
+    assert len(ds) == 16 and ds[0]["erp"].shape == (8, 256) and ds[0]["pw"].shape == (8, 256) and ds[0]["conn"].shape == (465,)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 512), (2, 64, 1024)])       # second: BASELINE config #5 (6 272 conv input channels)

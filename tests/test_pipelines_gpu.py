@@ -266,3 +266,47 @@ def test_a8_drop_path_per_sample_mask_and_backward():
     y2 = layer(xin.detach())
     assert not torch.equal(y2 > 0, y > 0)                   # a fresh mask per call
     assert layer.eval()(x) is x
+
+
+def test_eval_mode_batchnorm_mlp_head_backward_vs_torch():
+    """backward through an eval-mode BatchNorm1d MLP head (the classifier form of
+    crossmodal_v4_enhancements.py:909-915: Linear -> BatchNorm1d -> GELU -> Dropout -> Linear) used to raise.  Eval mode
+    with a backward to follow = frozen BatchNorm (running statistics, no update) and dropout off: logits, d / d input
+    and every parameter gradient against torch autograd of the same modules on the CPU (fp32 kernels: 1e-4 / 1e-3),
+    through ops._mlp_bn_act (V4 classifier) and ops.bn_classifier_forward (Lite classifier)."""
+    import torch.nn as nn
+    from multimodal_eeg_fmri_amd import ops
+    torch.manual_seed(5)
+    seq = nn.Sequential(nn.Linear(96, 48), nn.BatchNorm1d(48), nn.GELU(), nn.Dropout(0.4), nn.Linear(48, 2))
+    with torch.no_grad():
+        seq[1].running_mean.copy_(torch.randn(48) * 0.3)
+        seq[1].running_var.copy_(1.0 + 0.5 * torch.rand(48))
+        seq[1].weight.copy_(1.0 + 0.2 * torch.randn(48))
+        seq[1].bias.copy_(0.1 * torch.randn(48))
+    seq.eval()
+    x = torch.randn(16, 96)
+    gy = torch.randn(16, 2)
+    import copy
+    ref = copy.deepcopy(seq)
+    xr = x.clone().requires_grad_(True)
+    out_r = ref(xr)
+    out_r.backward(gy)
+    seq = seq.cuda()
+    stats0 = (seq[1].running_mean.clone(), seq[1].running_var.clone(), seq[1].num_batches_tracked.clone())
+    for fn in ("lite", "v4"):
+        for p in seq.parameters():
+            p.grad = None
+        xg = x.cuda().requires_grad_(True)
+        if fn == "lite":
+            out = ops.bn_classifier_forward(seq, xg, 0.4, False)
+        else:
+            out = ops.small_autograd_linear(ops._mlp_bn_act(xg, seq[0], seq[1], "gelu", 0.4, False), seq[4])
+        out.backward(gy.cuda())
+        torch.testing.assert_close(out.detach().cpu(), out_r.detach(), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-5)
+        for (n, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+            torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-3, atol=1e-5, msg=f"{fn}: {n}")
+        assert torch.equal(seq[1].running_mean, stats0[0]) and torch.equal(seq[1].running_var, stats0[1])
+        assert torch.equal(seq[1].num_batches_tracked, stats0[2])
+    with torch.no_grad():                                   # and the plain eval forward is the same function
+        torch.testing.assert_close(ops.bn_classifier_forward(seq, x.cuda(), 0.4, False).cpu(), out_r.detach(), rtol=1e-4, atol=1e-5)

@@ -105,6 +105,57 @@ def test_c2_shaped_train_step_vs_oracle():
     assert worst32f[1] <= 2e-1, ("voxel encoder vs fp32 oracle", worst32f)
 
 
+def test_c2_graph_step_at_the_benchmarked_batch_vs_oracle():
+    """the step bench.py times - B = 32, hipGraph replay, two streams - against the CPU oracle (the tests above
+    run B = 4 on the eager tape).  Dropout 0 (the reference's RNG stream cannot be matched; the masked-oracle test covers
+    p = 0.3 on the tape).  One replayed step from the initial weights: loss 1e-3, both L2-normalised embeddings cos >=
+    1 - 1e-4 vs the fp32 oracle, every parameter gradient of the flat bucket (copied out by the step's ``grad_probe``
+    node just before clip + AdamW clears it) <= 6e-2 rel-L2 vs the oracle with bf16-rounded GEMM operands, and the
+    parameters after the step = torch.optim.AdamW + clip_grad_norm_(1.0) applied to the PROBED gradients (1e-6)."""
+    import torch.nn.functional as F
+    from multimodal_eeg_fmri_amd import ops
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    ops.set_seed_epoch(None)
+    torch.manual_seed(0)
+    tr = BridgeTrainer(eeg_channels=64, dropout=0.0, mode="graph").train()
+    eeg, fmri = synthetic_pairs(32, 64, 1024, (32, 32, 32), seed=4323)
+    l32, ze32, zf32, _ = _oracle_step(tr, eeg, fmri, emulate=False)
+    _, _, _, g16 = _oracle_step(tr, eeg, fmri, emulate=True)
+    p0 = tr.bucket.p.detach().clone()
+    tr.grad_probe = torch.zeros_like(tr.bucket.g)
+    out = tr.train_step(eeg, fmri)
+    torch.cuda.synchronize()
+    assert tr.capture_mode == "one graph" and len(tr._cap["graphs"]) == 1
+    z = tr._cap["z"]
+    N = tr.head.bridge.bridge_dim
+    cos_e = F.cosine_similarity(z[:, :N].cpu().double(), ze32.double(), dim=1).min().item()
+    cos_f = F.cosine_similarity(z[:, N:].cpu().double(), zf32.double(), dim=1).min().item()
+    assert cos_e >= 1 - 1e-4 and cos_f >= 1 - 1e-4, (cos_e, cos_f)
+    assert abs(out["loss"].item() - l32) <= 1e-3 * max(1.0, abs(l32)), (out["loss"].item(), l32)
+    named = {}
+    for pre, m in (("e.", tr.eeg_encoder), ("f.", tr.fmri_encoder), ("h.", tr.head)):
+        named.update({pre + k: v for k, v in m.named_parameters()})
+    base = tr.bucket.g.data_ptr()
+    worst, checked = ("", 0.0), 0
+    for n, p in named.items():
+        sink = getattr(p, "_mm_grad", None)
+        if sink is None or n not in g16 or g16[n].norm() < 1e-5:
+            continue
+        off = (sink.data_ptr() - base) // 4
+        got = tr.grad_probe[off:off + p.numel()].cpu().view(g16[n].shape).double()
+        worst = max(worst, (n, ((got - g16[n].double()).norm() / g16[n].double().norm()).item()), key=lambda t: t[1])
+        checked += 1
+    assert checked >= 50, checked
+    assert worst[1] <= 6e-2, ("graph-replayed B = 32 step vs the bf16-operand oracle", worst)
+    # the optimizer half of the same replay, on the probed gradients
+    ref = p0.cpu().clone().requires_grad_(True)
+    ref.grad = tr.grad_probe.cpu().clone()
+    torch.nn.utils.clip_grad_norm_([ref], 1.0)
+    opt = torch.optim.AdamW([ref], lr=tr.lr, weight_decay=tr.weight_decay, betas=tr.betas, eps=tr.eps)
+    opt.step()
+    torch.testing.assert_close(tr.bucket.p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
 def test_projection_heads_with_dropout_match_masked_oracle():
     """both projection heads' nn.Dropout (bridge_utils.py:34-45) at p = 0.3 in ONE launch each way
     (mm_proj_heads_fwd / _bwd): embeddings, loss and every gradient against the CPU oracle evaluated with the same
@@ -388,21 +439,33 @@ def test_segmented_step_through_rccl_with_one_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_two_ranks_share_the_gpu_over_gloo():
-    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per
-    process), except that both ranks share this GPU and exchange over gloo (MM_DIST_BACKEND): the
-    N > 1 timing / reduction / JSON path must run and report whole-job throughput."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_share_the_gpu_over_gloo(launcher):
+    """bench.py at N = 2 both ways the driver may start it - `python bench.py --gpus 2` with no launcher (it then starts
+    its own ranks before touching the GPU and relays rank 0's line) and under torch.distributed.run - except that both
+    ranks share this GPU and exchange over gloo (MM_DIST_BACKEND): the N > 1 timing / reduction / JSON path must run,
+    report whole-job throughput and carry the N > 1 fields."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MM_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "4", "--warmup", "2"],
-                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29517"] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 64 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert line["rccl_ranks"] == 0 and line["capture_mode"] == "3 segments + 2 eager collectives"      # gloo rehearsal
+    assert len(line["gradient_bucket_groups"]) == 4 and len(line["collectives_us"]) == 5
+    assert abs(sum(g["MB"] for g in line["gradient_bucket_groups"]) - 3.4) < 0.2

@@ -72,17 +72,24 @@ def run_rccl_world1():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        from multimodal_eeg_fmri_amd import dp
         from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+        # a world of one rank still hands EVERY collective of the step to RCCL (without this the all-reduces
+        # were skipped and only the all-gather was ever a graph node)
+        dp.FORCE_COLLECTIVES = True
         eeg, fmri = synthetic_pairs(8, 16, 256, (16, 16, 16), seed=1234)
         res = {}
+        issued = {}
         for tag, group, force, cap in (("one graph", None, False, "1"), ("captured RCCL", dist.group.WORLD, True, "1"),
                                        ("segments + RCCL", dist.group.WORLD, True, "0")):
             os.environ["MM_DP_CAPTURE"] = cap
             torch.manual_seed(0)
             tr = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-3, group=group).train()
             tr.force_segments = force
+            n0 = dp.issued
             ls = [tr.train_step(eeg, fmri)["loss"].item() for _ in range(6)]
             torch.cuda.synchronize()
+            issued[tag] = dp.issued - n0
             res[tag] = (ls, tr.bucket.p.detach().cpu().clone(), len(tr._cap["graphs"]), tr.capture_mode)
             if force:                                   # what bench.py does after its timed region at N > 1
                 tr.mode = "manual"
@@ -91,7 +98,8 @@ def run_rccl_world1():
                 assert ev["loss"].item() == ev["loss"].item()
         a, b, cg = res["one graph"], res["segments + RCCL"], res["captured RCCL"]
         rel = ((a[1] - b[1]).norm() / a[1].norm()).item()
-        return {"graphs": (a[2], b[2]), "losses": (a[0], b[0]), "param_rel": rel,
+        return {"graphs": (a[2], b[2]), "losses": (a[0], b[0]), "param_rel": rel, "collectives_issued": issued,
+                "groups": [g[0] for g in tr.groups],
                 # the N > 1 step with its collectives recorded into the graph (falls back to segments if RCCL refuses):
                 "captured": {"mode": cg[3], "graphs": cg[2], "losses": cg[0],
                              "param_rel_vs_one_graph": ((a[1] - cg[1]).norm() / a[1].norm()).item(),
@@ -109,7 +117,9 @@ def time_rccl_world1(steps=200):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        from multimodal_eeg_fmri_amd import dp
         from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+        dp.FORCE_COLLECTIVES = True
         eeg, fmri = synthetic_pairs(32, 64, 1024, (32, 32, 32), seed=1234)
         out = {}
         for tag, group, force, cap in (("one graph", None, False, "1"), ("one graph + captured RCCL collectives", dist.group.WORLD, True, "1"),
@@ -141,6 +151,12 @@ if __name__ == "__main__":
         r = run_rccl_world1()
         print(r)
         assert r["graphs"] == (1, 3), r
+        # the captured form: the warm-up pair outside the capture (2) + 2 eager warm-up steps and the capture pass, each with
+        # the all-gather and one all-reduce per layer group (replays issue nothing from the host)
+        ngroups = len(r["groups"])
+        assert r["captured"]["mode"] == "one graph + captured RCCL collectives", r
+        assert r["collectives_issued"]["captured RCCL"] == 2 + 3 * (1 + ngroups), r
+        assert r["captured"]["bit_identical_to_segments"], r
         assert r["captured"]["param_rel_vs_one_graph"] < 1e-2, r
         assert r["param_rel"] < 1e-2, r
         for i, (x, y) in enumerate(zip(*r["losses"])):      # (tolerances from before the step became bit-reproducible; kept loose: RCCL owns the reduction order)
