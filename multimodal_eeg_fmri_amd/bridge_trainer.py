@@ -353,9 +353,23 @@ class BridgeTrainer(nn.Module):
     def _capture(self, eeg, fmri):
         dev = eeg.device
         world = self.world
-        c = {"eeg": eeg.clone(), "fmri": fmri.clone(), "epoch": torch.zeros(1, dtype=torch.int32, device=dev)}
-        # static packed EEG operand, refilled before every replay (the STFT front-end reads the raw fp32 batch instead)
-        c["xb"] = ops.pack_nct(c["eeg"]) if self._eeg_kind != "stft" else None
+        c = {"epoch": torch.zeros(1, dtype=torch.int32, device=dev)}
+        # the step's static inputs are two views of ONE flat buffer `c["in"]` = [EEG operand | fMRI volumes fp32], so that a
+        # host-fed loop fills them with a single copy (`train_step_packed`).  EEG operand: the first convolution's packed
+        # bf16 (B, T, Cp) image (the STFT front-end reads the raw fp32 batch instead and keeps that)
+        stft = self._eeg_kind == "stft"
+        Bx, Cx, Tx = eeg.shape
+        n_e = eeg.numel() * 4 if stft else Bx * Tx * ops.cpad(Cx) * 2
+        c["in"] = torch.empty(n_e + fmri.numel() * 4, dtype=torch.uint8, device=dev)
+        c["fmri"] = c["in"][n_e:].view(torch.float32).view(fmri.shape)
+        c["fmri"].copy_(fmri)
+        if stft:
+            c["eeg"], c["xb"] = c["in"][:n_e].view(torch.float32).view(eeg.shape), None
+            c["eeg"].copy_(eeg)
+        else:
+            c["eeg"] = eeg.clone()                      # (shape carrier / in-place loader target; the graph reads c["xb"])
+            c["xb"] = c["in"][:n_e].view(torch.bfloat16).view(Bx, Tx, ops.cpad(Cx))
+            _hip.call("mm_pack_nct_bf16", c["eeg"], c["xb"], Bx, Cx, Tx, c["xb"].shape[2])
         ops.set_seed_epoch(c["epoch"])
         # warm-up outside capture (lazy inits, allocator priming) on a snapshot of the
         # training state, so that the first replay is really step 1
@@ -494,6 +508,10 @@ class BridgeTrainer(nn.Module):
             if c["xb"] is not None:
                 Bx, Cx, Tx = c["eeg"].shape
                 _hip.call("mm_pack_nct_bf16", c["eeg"], c["xb"], Bx, Cx, Tx, c["xb"].shape[2])
+        return self._replay()
+
+    def _replay(self):
+        c = self._cap
         g = c["graphs"]
         if len(g) == 1:
             g[0].replay()
@@ -504,6 +522,42 @@ class BridgeTrainer(nn.Module):
             dp.allreduce_sum_(self.bucket.g, self.group)
             g[2].replay()                                              # clip + AdamW
         return {"loss": c["scal"][0], "top1_e2f": c["scal"][1], "top1_f2e": c["scal"][2]}
+
+    # ---- host-fed input path ---------------------------------------------------
+    def pack_host_batch(self, eeg: torch.Tensor, fmri: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """CPU side of the host-fed loop (a data loader's job, off the step's critical path): one (EEG, fMRI) batch as
+        ONE flat pinned byte buffer in the layout of the step's static inputs - the EEG epochs already in the first
+        convolution's operand format (channels-last (B, T, Cp) bf16, zero-padded channels: half the bytes of fp32, and
+        no pack launch on the device; raw fp32 for the STFT front-end) followed by the fp32 volumes.  Round-to-nearest-
+        even on the host = what mm_pack_nct_bf16 does on the device: the step's arithmetic is bit-identical.
+        Reference counterpart: the ``.to(device)`` of each batch, run_training_lite.py:480-481."""
+        eeg, fmri = eeg.detach().cpu().float(), fmri.detach().cpu().float().contiguous()
+        if self._eeg_kind == "stft":
+            e_bytes = eeg.contiguous().view(-1).view(torch.uint8)
+        else:
+            B, C, T = eeg.shape
+            cp = ops.cpad(C)
+            xb = torch.zeros(B, T, cp, dtype=torch.bfloat16)
+            xb[:, :, :C] = eeg.permute(0, 2, 1)
+            e_bytes = xb.view(-1).view(torch.uint8)
+        f_bytes = fmri.view(-1).view(torch.uint8)
+        n = e_bytes.numel() + f_bytes.numel()
+        if out is None:
+            out = torch.empty(n, dtype=torch.uint8).pin_memory()
+        out[:e_bytes.numel()].copy_(e_bytes)
+        out[e_bytes.numel():].copy_(f_bytes)
+        return out
+
+    def train_step_packed(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """one graph-replayed step on a batch that is already in the packed layout of `pack_host_batch` and on the device
+        (a staging buffer an H2D copy filled): ONE device-to-device copy into the static inputs, then the replay"""
+        if self._cap is None:
+            raise RuntimeError("train_step_packed: run one train_step(eeg, fmri) first (it captures the step and fixes the shapes)")
+        c = self._cap
+        if flat.dtype != torch.uint8 or flat.numel() != c["in"].numel() or not flat.is_cuda:
+            raise ValueError(f"train_step_packed: expected a device uint8 buffer of {c['in'].numel()} bytes")
+        c["in"].copy_(flat, non_blocking=True)
+        return self._replay()
 
     def time_collectives(self, batch: int, iters: int = 50) -> Dict[str, float]:
         """microseconds per call of every collective one step issues, each alone at its message size (HIP events on the

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Where does the host-fed training loop lose its time?  (value_with_input_transfer was 30 % below value
+although 12.6 MB per step is far below PCIe.)  Measures, on one GPU:
+  1. pinned H2D copy bandwidth at the sizes involved (one copy at a time, HIP events);
+  2. the C2 training loop: resident batches | two fp32 H2D copies + stage kernel (round 3) | ONE packed copy (bf16 EEG
+     operand + fp32 volumes, 8.4 MB) + one D2D | the copies alone in the same event structure | the packed loop with the
+     H2D issued but never waited for (diagnostic: what the cross-stream dependency itself costs).
+usage: python tools/h2d_probe.py [steps]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def bandwidth():
+    print("== pinned host -> device, one copy at a time")
+    for mb in (1.0, 4.2, 8.4, 12.6, 33.6, 134.0):
+        n = int(mb * 1e6)
+        h = torch.empty(n, dtype=torch.uint8).pin_memory()
+        d = torch.empty(n, dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            d.copy_(h, non_blocking=True)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 20
+        print(f"  {mb:7.1f} MB: {ms * 1e3:8.1f} us  {n / ms / 1e6:7.2f} GB/s")
+
+
+def loops(steps):
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    torch.manual_seed(0)
+    tr = BridgeTrainer(eeg_channels=64, dropout=0.3).train()
+    NB = 4
+    dev = [synthetic_pairs(32, 64, 1024, (32, 32, 32), seed=1234 + 1000 * i) for i in range(NB)]
+    tr.train_step(*dev[0])
+    for i in range(300):
+        tr.train_step(*dev[i % NB])
+    torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()
+
+    def timed(name, body, warm=20):
+        body(warm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        body(steps)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print(f"  {name:78s} {dt * 1e3:7.4f} ms/step  {32 / dt:9.0f} pairs/s", flush=True)
+        return dt
+
+    print(f"== C2 training loop, {steps} steps each")
+    base = timed("resident batches (mm_stage_inputs + replay)", lambda n: [tr.train_step(*dev[i % NB]) for i in range(n)])
+    host = [(e.cpu().pin_memory(), f.cpu().pin_memory()) for e, f in dev]
+    packed = [tr.pack_host_batch(e, f) for e, f in dev]
+    copy_s = torch.cuda.Stream()
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+    stage2 = [(torch.empty_like(dev[0][0]), torch.empty_like(dev[0][1])) for _ in range(2)]
+    stage1 = [torch.empty(packed[0].numel(), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    for b in range(2):
+        consumed[b].record()
+
+    def loop_two(n, train=True):
+        def up(i):
+            b = i % 2
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(consumed[b])
+                stage2[b][0].copy_(host[i % NB][0], non_blocking=True)
+                stage2[b][1].copy_(host[i % NB][1], non_blocking=True)
+                ready[b].record(copy_s)
+        up(0)
+        for i in range(n):
+            if i + 1 < n:
+                up(i + 1)
+            torch.cuda.current_stream().wait_event(ready[i % 2])
+            if train:
+                tr.train_step(*stage2[i % 2])
+            consumed[i % 2].record()
+
+    def loop_one(n, train=True, wait=True):
+        def up(i):
+            b = i % 2
+            with torch.cuda.stream(copy_s):
+                if wait:
+                    copy_s.wait_event(consumed[b])
+                stage1[b].copy_(packed[i % NB], non_blocking=True)
+                ready[b].record(copy_s)
+        up(0)
+        for i in range(n):
+            if i + 1 < n:
+                up(i + 1)
+            if wait:
+                torch.cuda.current_stream().wait_event(ready[i % 2])
+            if train:
+                tr.train_step_packed(stage1[i % 2])
+            consumed[i % 2].record()
+
+    timed("round 3: two fp32 H2D copies (12.6 MB) + stage kernel + replay", loop_two)
+    timed("   the same event / copy structure without the training step", lambda n: loop_two(n, False))
+    timed("ONE packed H2D copy (bf16 EEG operand + fp32 volumes, 8.4 MB) + one D2D + replay", loop_one)
+    timed("   the same event / copy structure without the training step", lambda n: loop_one(n, False))
+    timed("   packed copy issued but never waited for (diagnostic: races on purpose)", lambda n: loop_one(n, True, False))
+    timed("resident packed buffers (train_step_packed on a device copy: D2D + replay)",
+          lambda n: [tr.train_step_packed(stage1[i % 2]) for i in range(n)])
+    timed("resident batches again", lambda n: [tr.train_step(*dev[i % NB]) for i in range(n)])
+    # same packed loop, H2D on the MAIN stream (no second stream, no events): copy and step serialised
+    def serial(n):
+        for i in range(n):
+            stage1[0].copy_(packed[i % NB], non_blocking=True)
+            tr.train_step_packed(stage1[0])
+    timed("packed copy on the step's own stream (serialised, no events)", serial)
+    return base
+
+
+if __name__ == "__main__":
+    bandwidth()
+    loops(int(sys.argv[1]) if len(sys.argv) > 1 else 200)

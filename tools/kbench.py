@@ -294,8 +294,43 @@ def split_case():
         print(f"{name:28s} {timeit(g.replay, iters=10):8.1f} us  (4 x [QKV linear, attention fwd, out-proj])")
 
 
+def l1_case(B=32, D=32, H=32, W=32, p=0.3):
+    """the three training passes of the fused first voxel layer (conv3d_l1.hip) at the C2 shape: statistics (mode 0),
+    forward (mode 1), one-pass backward (mode 4 + combine).  FLOPs per pass = 2 * 27 * 32 * voxels = 1.81 GF at C2;
+    compulsory bytes: 4.2 MB fp32 volume in (+ 8.4 MB bf16 pooled output for the forward / pooled gradient in for the backward)."""
+    import multimodal_eeg_fmri_amd.fmri_utils as Fm
+    torch.manual_seed(0)
+    enc = Fm.fMRIVolumeEncoder3D(1, 64, dropout=p).cuda().train()
+    conv, bn = enc.conv_layers[0], enc.conv_layers[1]
+    x = torch.randn(B, 1, D, H, W, device="cuda")
+    out, s = ops.conv3d_l1_bn_act(x, conv, bn, training=True, drop_p=p)
+    wimg, out4 = s["wimg"], s["out4"]
+    stats = torch.zeros(32, 2, 32, device="cuda")
+    dout = torch.randn(out.shape, device="cuda").to(BF)
+    sums, a1, a3 = torch.zeros(32, 2, 32, device="cuda"), torch.zeros(32, 27, 32, device="cuda"), torch.zeros(32, 27, 32, device="cuda")
+    tapsum = torch.zeros(32, 32, device="cuda")
+    _hip.call("mm_conv3d_l1_tapsum", x, tapsum, B, D, H, W)
+    dw, db = torch.zeros(32, 1, 3, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
+    fl = 2.0 * 27 * 32 * B * D * H * W
+    t0 = timeit(lambda: _hip.call("mm_conv3d_l1", 0, x, wimg, conv.bias, None, None, None, stats, None, None, None,
+                                  B, D, H, W, 1, 0.0, 0, None))
+    t1 = timeit(lambda: _hip.call("mm_conv3d_l1", 1, x, wimg, conv.bias, out4, None, None, None, out, None, None,
+                                  B, D, H, W, 1, float(p), 123, None))
+    t4 = timeit(lambda: _hip.call("mm_conv3d_l1_bwd", x, wimg, conv.bias, out4, dout, sums, a1, a3, tapsum, 1, dw, db,
+                                  B, D, H, W, 1, float(p), 123, None))
+    tt = timeit(lambda: _hip.call("mm_conv3d_l1_tapsum", x, tapsum, B, D, H, W))
+    inb, outb = x.numel() * 4, out.numel() * 2
+    for name, t, byts in (("stats  (mode 0)", t0, inb), ("forward (mode 1)", t1, inb + outb), ("backward (mode 4 + combine)", t4, inb + outb),
+                          ("tap sums", tt, inb)):
+        print(f"conv3d_l1 {name:28s} B={B} {D}x{H}x{W}: {t:7.1f} us  {fl / t / 1e6:6.1f} TF/s (of 157 fp32 / 2500 bf16)  "
+              f"{byts / 1e6:5.1f} MB compulsory -> {byts / t / 1e6:6.2f} TB/s of 8")
+
+
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    if flt in ("l1", "pmcl1"):
+        l1_case()
+        return
     if "floor" in flt:
         floor_case()
     M = 32 * 512
