@@ -375,10 +375,14 @@ def volume_encoder3d(sd: SD, x, p: str = "", train: bool = False,
     ``route`` = (route1, route2): evaluate the two max-pools with given window members (`max_pool3d_routed`)."""
     c = p + "conv_layers."
     h = gelu(_bn(sd, c + "1.", F.conv3d(x, sd[c + "0.weight"], sd[c + "0.bias"], padding=1), train))
+    if stages is not None:
+        stages["act1"] = h                                  # (before the pool)
     h = F.max_pool3d(h, 2) if route is None else max_pool3d_routed(h, route[0])
     if stages is not None:
         stages["conv1"] = h
     h = gelu(_bn(sd, c + "6.", F.conv3d(h, sd[c + "5.weight"], sd[c + "5.bias"], padding=1), train))
+    if stages is not None:
+        stages["act2"] = h
     h = F.max_pool3d(h, 2) if route is None else max_pool3d_routed(h, route[1])
     if stages is not None:
         stages["conv2"] = h

@@ -188,8 +188,8 @@ def test_volume_encoder_grads_vs_unmodified_fp32_oracle_with_hip_routing(shape, 
     members swap under bf16 operands and a whole gradient entry moves).  Here the UNMODIFIED fp32 oracle - no operand
     rounding anywhere - is evaluated with the two pools routed as the HIP path routed them (its saved / exported window
     winners, ops._vol_forward_impl(winners=...)): EVERY parameter gradient, layers 1 and 2 included, <= 5e-2 rel-L2.
-    The routing itself must be a genuine arg-max of the oracle's own pre-pool activations up to near-ties: at most 2 %
-    of the windows differ, and where they do the two members are within 2 % of the activation scale."""
+    The routing itself must be a genuine arg-max of the oracle's own pre-pool activations up to near-ties: in at most
+    2 % of the windows the member taken is not the oracle's maximum, and then it is within 2 % of the activation scale of it."""
     from multimodal_eeg_fmri_amd import ops
     m = build(Fm.fMRIVolumeEncoder3D, seed, dropout=0.0).train()
     x = seeded_randn(100 + seed, *shape)
@@ -212,15 +212,15 @@ def test_volume_encoder_grads_vs_unmodified_fp32_oracle_with_hip_routing(shape, 
     assert cos_min(y.detach().cpu(), out.detach()) >= 1 - COS_TOL
     w = _worst(mg.named_parameters(), want)
     assert w[1] <= 5e-2, ("every layer vs the unmodified fp32 oracle routed as the HIP path", w)
-    # the routing is the oracle's own arg-max except at near-ties
-    with torch.no_grad():
-        free = RF.volume_encoder3d({k: v.detach() for k, v in sd.items()}, x, train=True, stages=(st2 := {}))
-    for name in ("conv1", "conv2"):
-        a, b = stages[name].detach(), st2[name]
-        differ = (a != b)
-        assert differ.float().mean().item() <= 2e-2, (name, differ.float().mean().item())
-        if differ.any():
-            assert ((b - a)[differ].abs().max() / b.abs().max()).item() <= 2e-2, name
+    # the routing is the oracle's own arg-max except at near-ties: per pooled element, the member the HIP path took holds
+    # the window maximum of the ORACLE's pre-pool activations up to a small gap
+    for act, r in (("act1", route[0]), ("act2", route[1])):
+        a = stages[act].detach()
+        taken = RF.max_pool3d_routed(a, r)
+        best = F.max_pool3d(a, 2)
+        gap = (best - taken) / a.abs().max()
+        assert (gap > 0).float().mean().item() <= 2e-2, (act, (gap > 0).float().mean().item())
+        assert gap.max().item() <= 2e-2, (act, gap.max().item())
 
 
 def test_volume_encoder_train_grads_at_config4_size_vs_oracle():

@@ -52,9 +52,10 @@ def loops(steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         body(steps)
+        t_host = time.perf_counter() - t0                      # the host has ISSUED everything (it runs ahead of the GPU)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        print(f"  {name:78s} {dt * 1e3:7.4f} ms/step  {32 / dt:9.0f} pairs/s", flush=True)
+        print(f"  {name:78s} {dt * 1e3:7.4f} ms/step  {32 / dt:9.0f} pairs/s   (host issue {t_host / steps * 1e3:6.3f} ms/step)", flush=True)
         return dt
 
     print(f"== C2 training loop, {steps} steps each")
@@ -104,6 +105,30 @@ def loops(steps):
                 tr.train_step_packed(stage1[i % 2])
             consumed[i % 2].record()
 
+    def loop_deep(n, depth=4):
+        """packed copies into a ring of `depth` staging buffers, issued depth - 1 steps ahead: the buffer-reuse guard is then
+        always an already-completed event (no real cross-queue dependency on the copy stream)"""
+        ring = [torch.empty(packed[0].numel(), dtype=torch.uint8, device="cuda") for _ in range(depth)]
+        rdy = [torch.cuda.Event() for _ in range(depth)]
+        con = [torch.cuda.Event() for _ in range(depth)]
+        for e in con:
+            e.record()
+
+        def up(i):
+            b = i % depth
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(con[b])
+                ring[b].copy_(packed[i % NB], non_blocking=True)
+                rdy[b].record(copy_s)
+        for i in range(min(depth - 1, n)):
+            up(i)
+        for i in range(n):
+            if i + depth - 1 < n:
+                up(i + depth - 1)
+            torch.cuda.current_stream().wait_event(rdy[i % depth])
+            tr.train_step_packed(ring[i % depth])
+            con[i % depth].record()
+
     timed("round 3: two fp32 H2D copies (12.6 MB) + stage kernel + replay", loop_two)
     timed("   the same event / copy structure without the training step", lambda n: loop_two(n, False))
     timed("ONE packed H2D copy (bf16 EEG operand + fp32 volumes, 8.4 MB) + one D2D + replay", loop_one)
@@ -111,6 +136,8 @@ def loops(steps):
     timed("   packed copy issued but never waited for (diagnostic: races on purpose)", lambda n: loop_one(n, True, False))
     timed("resident packed buffers (train_step_packed on a device copy: D2D + replay)",
           lambda n: [tr.train_step_packed(stage1[i % 2]) for i in range(n)])
+    timed("ONE packed copy, ring of 4 staging buffers, copies issued 3 steps ahead", loop_deep)
+    timed("ONE packed copy, ring of 3 staging buffers, copies issued 2 steps ahead", lambda n: loop_deep(n, 3))
     timed("resident batches again", lambda n: [tr.train_step(*dev[i % NB]) for i in range(n)])
     # same packed loop, H2D on the MAIN stream (no second stream, no events): copy and step serialised
     def serial(n):
