@@ -336,19 +336,29 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
 int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias, const float* out4, void* out,
                              void* arg, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
                              const uint32_t* seed_epoch, hipStream_t stream);
+/* Training forward of the same layer without a statistics pass over the convolution: the Gram matrix of the im2col
+ * matrix, G[t][t'] = sum over output voxels of xcol[v][t] * xcol[v][t'] for the 27 taps plus a column of ones (bf16-
+ * rounded, zero-padded volume - what the convolution sees), holds everything the layer needs from the input:
+ *   sum_v y_n = w_n . S + M b_n,  sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2   (S[t] = G[t][27], M = G[27][27])
+ * and, in the backward, A3[t][n] = sum_v xcol[v][t] xhat[v][n] = rstd_n ((G w_n)[t] + (b_n - mean_n) S[t]).
+ * mm_conv3d_l1_gram: gram = ZEROED accumulator workspace [32][32][32] (activation-statistics scale).
+ * mm_conv3d_l1_gram_stats: -> stats (ZEROED accumulator workspace [32][2][32], replica 0 written: {sum y, sum y^2} of
+ * conv + bias, the input of mm_bn_finalize) and gram_compact fp32 [28][32] (nullable; kept for mm_conv3d_l1_bwd). */
+int mm_conv3d_l1_gram(const float* x, float* gram, int B, int D, int H, int W, hipStream_t stream);
+int mm_conv3d_l1_gram_stats(const float* gram, const void* wimg, const float* bias, float* stats, float* gram_compact,
+                            hipStream_t stream);
 /* Training backward of the same layer in ONE recompute pass (replaces modes 2 + 3): BatchNorm's
  * backward is linear in the two sums S1 = sum dz, S2 = sum dz * xhat, so
- *   dW = scale * (A1 - (S1/M) * T - (S2/M) * A3),  A1 = x^T dz, A3 = x^T xhat, T[tap] = sum_v x[v + tap].
+ *   dW = scale * (A1 - (S1/M) * S - (S2/M) * A3),  A1 = x^T dz, S and A3 from gram_compact (above).
  * Zeroed accumulator workspaces: sums_out [32][2][32] (also the BatchNorm parameter
- * gradients: dbeta = S1, dgamma = S2), a1 / a3 [32][27][32], tapsum [32][32].  dw (PyTorch layout
- * [32][1][3][3][3]) and dbias are ADDED to (dbias only when train == 0; it is identically 0 otherwise).
- * T depends on the input volume alone: mm_conv3d_l1_tapsum may fill it earlier (e.g. during the forward pass,
- * off the backward chain) and the backward is then called with tapsum_ready = 1. */
+ * gradients: dbeta = S1, dgamma = S2), a1 [32][27][32].  dw (PyTorch layout [32][1][3][3][3]) and dbias are ADDED to
+ * (dbias only when train == 0; it is identically 0 otherwise).  gram_compact may be NULL when train == 0 (frozen
+ * BatchNorm: the two correction terms vanish). */
 int mm_conv3d_l1_tapsum(const float* x, float* tapsum, int B, int D, int H, int W, hipStream_t stream);
 int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
-                     float* sums_out, float* a1, float* a3, float* tapsum, int tapsum_ready, float* dw,
-                     float* dbias, int B, int D, int H, int W, int train, float drop_p, uint32_t seed,
-                     const uint32_t* seed_epoch, hipStream_t stream);
+                     float* sums_out, float* a1, const float* gram_compact, float* dw, float* dbias, int B, int D,
+                     int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                     hipStream_t stream);
 /* dst[c][r] += fp32(sum over replicas of src[rep][r][c]); src = gradient accumulator workspace [32][R][C], nrep = 16 */
 int mm_transpose_add(const float* src, float* dst, int R, int C, int nrep, hipStream_t stream);
 

@@ -733,20 +733,16 @@ def conv3d_l1_bwd(bag: GradBag, s: dict, dout: torch.Tensor):
     conv, bn, x = s["conv"], s["bn"], s["x"]
     B, _, D, H, W = x.shape
     train = 1 if s.get("train", True) else 0
-    # one recompute pass: S1/S2, A1 = x^T dz, A3 = x^T xhat; BatchNorm's backward is linear in S1, S2
+    # one recompute pass: S1 / S2 and A1 = x^T dz; BatchNorm's backward is linear in S1, S2, and its two correction terms
+    # come from the forward pass's compact Gram matrix (csrc/conv3d_l1.hip)
     sums = _zeros((REPL, 2, 32), x)
-    a1 = _zeros((REPL, 27, 32), x)
-    a3 = _zeros((REPL, 27, 32), x)
-    tapsum = s.get("tapsum")                         # filled during the forward pass when the tape asked for it
-    ready = tapsum is not None
-    if not ready:
-        tapsum = _zeros((REPL, 32), x)
     dw = bag.target(conv.weight)
     if dw is None:                                   # frozen conv weight: the sums alone (BatchNorm gradients)
         _hip.call("mm_conv3d_l1", 2, x, s["wimg"], conv.bias, s["out4"], dout, None, sums, None, None, None,
                   B, D, H, W, train, float(s["drop_p"]), int(s["seed"]), ops.EP())
     else:
-        _hip.call("mm_conv3d_l1_bwd", x, s["wimg"], conv.bias, s["out4"], dout, sums, a1, a3, tapsum, 1 if ready else 0,
+        a1 = _zeros((REPL, 27, 32), x)
+        _hip.call("mm_conv3d_l1_bwd", x, s["wimg"], conv.bias, s["out4"], dout, sums, a1, s.get("gramc") if train else None,
                   dw, bag.target(conv.bias), B, D, H, W, train, float(s["drop_p"]), int(s["seed"]), ops.EP())
     _bn_param_grads(bag, bn, sums, 32, nrep=REPL)
 

@@ -1,27 +1,34 @@
 // First layer of the 3-D voxel encoder: Conv3d(1 -> 32, k3, p1) + BatchNorm3d +
 // GELU + MaxPool3d(2) [+ Dropout] on single-channel fp32 volumes, fused.
 //
-// With Cin = 1 the GEMM K is just the 27 taps, so the layer is HBM/VALU-bound,
-// not MFMA-bound.  The pre-BN activation (32x the input, 134 MB fp32 at the C2
-// config) is never written: every pass recomputes the convolution from the
-// 4 MB input (8 bf16 MFMAs per 128 voxels) and keeps only per-channel sums:
-//   mode 0  stats        : sum / sumsq of y = conv + bias           (train fwd 1)
-//   mode 1  apply        : BN -> GELU -> 2x2x2 max -> dropout -> bf16 (fwd 2 / eval)
-//   mode 2  bwd reduce   : S1 = sum dz, S2 = sum dz*xhat
-//   mode 3  bwd apply    : dy = BN'(dz) for every voxel, dW[tap][n] += x^T dy,
-//                          dbias += sum dy     (second MFMA: the dy accumulator
-//                          tile is the B operand, the im2col gather the A operand)
-//   mode 4  bwd, one pass: BN' is linear in the two sums of mode 2, so the weight gradient is
-//                          dW = sc (A1 - c0 S - c1 A3) with A1 = x^T dz, A3 = x^T xhat,
-//                          S[tap] = sum_v x[v + tap] (l1_tapsum_kernel), c0 = S1/M, c1 = S2/M.
-//                          One recompute of the convolution yields S1, S2, A1 and A3 (the two
-//                          products share their gathered A fragments); l1_combine_kernel finishes.
-//                          Replaces modes 2 + 3 (two recomputes) in training.
-// One wave owns a 2 x 8 x 8 block of conv outputs (= 1 x 4 x 4 pooled voxels) x
-// 32 channels: all 8 members of every pooling window sit in the same lane.
-// GELU is evaluated once per window when max(z) >= 0 (GELU is monotone on
-// [-0.7518, inf) and negative left of 0, so the window max is GELU(max z));
-// otherwise on all 8 members.  Both branches are exact.
+// With Cin = 1 the GEMM K is just the 27 taps: 8 bf16 MFMAs per 128 voxels, i.e. the layer is bound by its
+// VALU epilogue and by load latency, not by MFMA or HBM (profiles/r04_pmc_l1.summary.txt: VALU 50-65 % of the
+// kernel time, waves waiting 37-55 %, 10-33 MB of HBM traffic).  The pre-BN activation (32x the input, 134 MB
+// fp32 at the C2 config) is never written: every pass recomputes the convolution from the 4 MB input.
+//
+// Training forward:
+//   gram   G = Xcol^T Xcol over all output voxels (Xcol = the im2col matrix, 27 taps + a column of ones): ONE
+//          32x32 MFMA accumulator per wave for the whole kernel, no epilogue.  Everything the layer needs to know
+//          about the input beyond the convolution itself is in G:
+//            sum_v y_n   = w_n . S + M b_n                       (S[t] = G[t][ones], M = G[ones][ones])
+//            sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2     -> BatchNorm statistics (l1_gram_stats_kernel)
+//            A3[t][n] = sum_v xcol[v][t] xhat[v][n] = rstd_n ((G w_n)[t] + (b_n - mean_n) S[t])   (backward)
+//          It replaces the statistics pass (mode 0: a full recompute with a per-channel epilogue) AND the tap-sum
+//          kernel, and takes the second MFMA product out of the backward.
+//   mode 1 apply        : BN -> GELU -> 2x2x2 max -> dropout -> bf16
+// Training backward (one recompute pass, mode 4): BatchNorm's backward is linear in S1 = sum dz, S2 = sum dz xhat, so
+//   dW = sc (A1 - c0 S - c1 A3),  A1 = x^T dz,  c0 = S1 / M, c1 = S2 / M: the pass yields S1, S2 and A1 (one MFMA
+//   product with the sparse dz fragments), l1_combine_kernel finishes from the compact Gram matrix.
+// Kept for callers of the C ABI / frozen-weight paths: mode 0 (statistics by recompute), mode 2 (S1, S2 only),
+// mode 3 (two-pass weight gradient), l1_tapsum_kernel.
+//
+// One wave owns a 2 x 8 x 8 block of conv outputs (= 1 x 4 x 4 pooled voxels) x 32 channels: all 8 members of
+// every pooling window sit in the same lane.  A workgroup (4 waves) walks tiles of 2 x 8 x 32 voxels persistently;
+// the halo of tile i + 1 is fetched into registers while tile i is computed and parked in the other half of a
+// double-buffered LDS halo (one barrier per tile); the per-thread halo addressing (6 elements) is computed once
+// per kernel, not per tile (it was ~250 of mode 1's ~860 VALU instructions per tile).
+// GELU is evaluated once per window when max(z) >= 0 (GELU is monotone on [-0.7518, inf) and negative left of 0,
+// so the window max is GELU(max z)); otherwise at the largest and the smallest member.  Both branches are exact.
 #include "common.h"
 
 namespace {
@@ -29,20 +36,22 @@ namespace {
 constexpr int HP = 36;                 // halo row pitch (34 used)
 constexpr int HROWS1 = 4 * 10;         // (2+2) depth x (8+2) height rows
 constexpr int HSZ = HROWS1 * HP;
+constexpr int NH = (HROWS1 * 34 + 255) / 256;      // halo elements per thread (6)
+constexpr int GN = 28;                 // Gram matrix order: 27 taps + the column of ones
 
 struct L1Args {
     const float* x;        // [B][D][H][W]
     const bf16* wimg;      // [32][32] (n, tap; taps 27..31 zero)
     const float* bias;     // [32] or nullptr (eval: folded into out4 shift)
-    const float* out4;     // [4][32] scale, shift, mean, rstd  (modes 1-3)
-    const bf16* dout;      // [B][D/2][H/2][W/2][32]            (modes 2-3)
+    const float* out4;     // [4][32] scale, shift, mean, rstd  (modes 1-4)
+    const bf16* dout;      // [B][D/2][H/2][W/2][32]            (modes 2-4)
     const float* sums;     // [2][32]                           (mode 3)
-    float* stats;          // mode 0: [2][32];  mode 2: sums_out
+    float* stats;          // mode 0: [2][32];  modes 2, 4: sums_out
     bf16* out;             // mode 1
-    uint8_t* arg;          // mode 1, optional: the pooling window's winner j = (dd << 2) | (hh << 1) | ww per output element
-    float* dw;             // mode 3: [27][32] (tap-major, channel-contiguous atomics); mode 4: A1
-    float* dw3;            // mode 4: A3, same layout
+    uint8_t* arg;          // mode 1 with ARG: the pooling window's winner j = (dd << 2) | (hh << 1) | ww per output element
+    float* dw;             // mode 3: [27][32] (tap-major, channel-contiguous); mode 4: A1
     float* dbias;          // mode 3
+    float* gram;           // gram kernel: accumulator workspace [32][32] (tap, tap)
     int B, D, H, W, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
     const uint32_t* epoch;
@@ -54,14 +63,64 @@ __device__ __forceinline__ int tap_off(int tap) {          // halo offset of tap
     return kd * 10 * HP + kh * HP + kw;
 }
 
+// ---- halo staging: the (2+2) x (8+2) x (32+2) input block of a tile, bf16, zero outside the volume -----------------
+// per-thread plan, computed once: element i = tid + 256 q -> offset relative to the tile's first voxel and a packed
+// descriptor (bits 0-11 LDS index, 12-13 depth row, 14-17 height row, 18-23 column; sign bit: no such element)
+struct HaloPlan { int roff[NH]; int pk[NH]; };
+
+__device__ __forceinline__ void halo_plan(HaloPlan& p, int tid, int H, int W) {
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+        const int i = tid + q * 256;
+        const int hw = i % 34, hr = i / 34, hd = hr / 10, hh = hr % 10;
+        p.roff[q] = ((hd - 1) * H + (hh - 1)) * W + (hw - 1);
+        p.pk[q] = i < HROWS1 * 34 ? ((hr * HP + hw) | (hd << 12) | (hh << 14) | (hw << 18)) : (int)0x80000000;
+    }
+}
+// all loads of a tile's halo in flight at once, branch-free (an out-of-volume element reads the tile's first voxel and
+// is replaced by zero): xb = &x[b][d0][h0][w0]
+__device__ __forceinline__ void halo_load(float (&hv)[NH], const float* __restrict__ xb, const HaloPlan& p,
+                                          int d0, int h0, int w0, int D, int H, int W) {
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+        const int pk = p.pk[q];
+        const unsigned d = (unsigned)(d0 - 1 + ((pk >> 12) & 3)), h = (unsigned)(h0 - 1 + ((pk >> 14) & 15)),
+                       w = (unsigned)(w0 - 1 + ((pk >> 18) & 63));
+        const bool ok = pk >= 0 && d < (unsigned)D && h < (unsigned)H && w < (unsigned)W;
+        const float v = xb[ok ? p.roff[q] : 0];
+        hv[q] = ok ? v : 0.f;
+    }
+}
+__device__ __forceinline__ void halo_store(unsigned short* __restrict__ hb, const HaloPlan& p, const float (&hv)[NH]) {
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+        const bf16 b = (bf16)hv[q];
+        if (p.pk[q] >= 0) hb[p.pk[q] & 0xFFF] = *reinterpret_cast<const unsigned short*>(&b);
+    }
+}
+struct TileCoord { int b, d0, h0, w0; };
+__device__ __forceinline__ TileCoord tile_coord(int tile, int tw, int th, int td) {
+    TileCoord c;
+    int q = tile;
+    c.w0 = (q % tw) * 32; q /= tw;
+    c.h0 = (q % th) * 8; q /= th;
+    c.d0 = (q % td) * 2; q /= td;
+    c.b = q;
+    return c;
+}
+__device__ __forceinline__ const float* tile_ptr(const float* x, const TileCoord& c, int D, int H, int W) {
+    return x + ((((size_t)c.b * D + c.d0) * H + c.h0) * W + c.w0);
+}
+
 // FULLT: H % 8 == 0 and W % 32 == 0, i.e. every 2 x 8 x 32 tile lies inside the volume: the per-voxel bounds tests
-// (three compares and the index arithmetic behind them, per voxel and channel) are compiled out
-template <int MODE, bool FULLT = false>
-__global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // two waves per SIMD: <= 256 registers
+// (three compares and the index arithmetic behind them, per voxel and channel) are compiled out.
+// ARG (mode 1): also write the window winners (inspection output of the parity tests, mm_conv3d_l1_fwd_winners).
+template <int MODE, bool FULLT = false, bool ARG = false>
+__global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Args a) {   // statistics / forward: three waves per SIMD (<= 168 registers), backward two
     a.seed = mm_eff_seed(a.seed, a.epoch);
-    __shared__ __attribute__((aligned(16))) unsigned short halo[HSZ];
+    __shared__ __attribute__((aligned(16))) unsigned short halo[2][HSZ];
     __shared__ float red[4][32];
-    __shared__ float wred[4][27][32];
+    __shared__ float wred[(MODE == 3 || MODE == 4) ? 4 : 1][27][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int tw = (a.W + 31) / 32, th = (a.H + 7) / 8, td = a.D / 2;
@@ -84,41 +143,33 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
         sc = a.out4[lr]; sh = a.out4[32 + lr]; mu = a.out4[64 + lr]; rs = a.out4[96 + lr];
         if (MODE == 3 && a.train) { c0 = a.sums[lr] * a.inv_count; c1 = a.sums[32 + lr] * a.inv_count; }   // compact sums
     }
+    // z = (acc + bias) sc + sh = acc sc + shb: ONE FMA per voxel and channel in every pass (forward and backward must
+    // form z identically - the window winner is decided on it)
+    const float shb = fmaf(bias, sc, sh);
     float acc1 = 0.f, acc2 = 0.f;          // per-lane channel sums (modes 0, 2, 4) / dbias (mode 3)
-    f32x16 dwacc, dwacc3;                  // modes 3, 4: D[tap][n]
+    f32x16 dwacc;                          // modes 3, 4: D[tap][n]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dwacc[r] = 0.f; dwacc3[r] = 0.f; }
-    const int my_tap_off = tap_off(lr);    // mode 3: A row = tap lr
+    for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+    const int my_tap_off = tap_off(lr);    // modes 3, 4: A row = tap lr
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int q = tile;
-        const int w0 = (q % tw) * 32; q /= tw;
-        const int h0 = (q % th) * 8; q /= th;
-        const int d0 = (q % td) * 2; q /= td;
-        const int b = q;
-        __syncthreads();
-        {   // all loads of the halo are in flight before the first LDS write (a load -> store loop
-            // pays one global round trip per pass: six per tile)
-            constexpr int NH = (HROWS1 * 34 + 255) / 256;
-            float hv[NH];
-#pragma unroll
-            for (int q = 0; q < NH; ++q) {
-                const int i = tid + q * 256;
-                const int hw = i % 34, hr = i / 34;
-                const int hd = hr / 10, hh = hr % 10;
-                const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-                hv[q] = 0.f;
-                if (i < HROWS1 * 34 && d >= 0 && d < a.D && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                    hv[q] = a.x[(((size_t)b * a.D + d) * a.H + h) * a.W + w];
-            }
-#pragma unroll
-            for (int q = 0; q < NH; ++q) {
-                const int i = tid + q * 256;
-                const bf16 hb = (bf16)hv[q];
-                if (i < HROWS1 * 34) halo[(i / 34) * HP + i % 34] = *reinterpret_cast<const unsigned short*>(&hb);
-            }
+    HaloPlan plan;
+    halo_plan(plan, tid, a.H, a.W);
+    float hv[NH];
+    int tile = blockIdx.x, buf = 0;
+    if (tile < ntiles) {
+        const TileCoord c = tile_coord(tile, tw, th, td);
+        halo_load(hv, tile_ptr(a.x, c, a.D, a.H, a.W), plan, c.d0, c.h0, c.w0, a.D, a.H, a.W);
+    }
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const TileCoord tc = tile_coord(tile, tw, th, td);
+        const int b = tc.b, d0 = tc.d0, h0 = tc.h0, w0 = tc.w0;
+        unsigned short* hb = halo[buf];
+        halo_store(hb, plan, hv);
+        __syncthreads();                                    // (the other buffer's readers passed the previous barrier)
+        if (tile + (int)gridDim.x < ntiles) {               // next tile's halo: in flight during this tile's compute
+            const TileCoord c = tile_coord(tile + gridDim.x, tw, th, td);
+            halo_load(hv, tile_ptr(a.x, c, a.D, a.H, a.W), plan, c.d0, c.h0, c.w0, a.D, a.H, a.W);
         }
-        __syncthreads();
         const int wbase = 8 * wave;                         // this wave's w-block inside the tile
         // ---- conv: acc[i] (rows m = 32 i + ..., voxel = (m>>6, (m>>3)&7, m&7))
         f32x16 acc[4];
@@ -132,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
             for (int s = 0; s < 2; ++s) {
                 union { unsigned short u[8]; bf16x8 v; } fr;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) fr.u[j] = halo[vb + foff[s][j]];
+                for (int j = 0; j < 8; ++j) fr.u[j] = hb[vb + foff[s][j]];
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, wf[s], acc[i], 0, 0, 0);
             }
         }
@@ -152,11 +203,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
             continue;
         }
         // ---- pooled windows: (ip, ra, rb) -> regs {r0, r0+1, r0+4, r0+5} of tiles ip and ip+2
-        // dy (mode 3) / dz and xhat (mode 4) fragments of the two conv tiles ip, ip + 2 that one pass of
-        // the ip loop completes; their weight-gradient MFMAs run at the end of that pass, so only two
-        // tiles' fragments are ever live (all four: 316 VGPRs in mode 4 = one wave per SIMD)
+        // dy (mode 3) / dz (mode 4) fragments of the two conv tiles ip, ip + 2 that one pass of the ip loop completes;
+        // their weight-gradient MFMAs run at the end of that pass, so only two tiles' fragments are ever live
         bf16x8 dyf[2][2];
-        bf16x8 xhf[2][2];
+        // flat index of this lane's first pooled output of the tile (32-bit: the host checks the tensor size)
+        const uint32_t obase = ((((uint32_t)b * Do + (d0 >> 1)) * Ho + (h0 >> 1)) * Wo + (w0 >> 1) + 4 * wave + 2 * lh) * 32 + lr;
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip) {
 #pragma unroll
@@ -164,23 +215,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb) {
                     const int r0 = 8 * ra + 2 * rb;
-                    const int oh = (h0 >> 1) + 2 * ip + ra, ow = (w0 >> 1) + 4 * wave + rb + 2 * lh, od = d0 >> 1;
+                    const int oh = (h0 >> 1) + 2 * ip + ra, ow = (w0 >> 1) + 4 * wave + rb + 2 * lh;
                     const bool ok = FULLT || (oh < Ho && ow < Wo);
-                    float y[8], z[8];
+                    float z[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {           // j = (dd << 2) | (hh << 1) | ww
                         const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
-                        y[j] = acc[ti][r] + bias;
-                        z[j] = y[j] * sc + sh;
+                        z[j] = fmaf(acc[ti][r], sc, shb);
                     }
                     // GELU falls on (-inf, -0.75] and rises after it, so the window's largest activation sits at its largest
                     // or at its smallest pre-activation (as pool3_bn_act).  With zmax >= 0 it is the largest: GELU(zmax) >= 0
                     // and anything below it is smaller (rising branch) or negative.  Only an all-negative window (1 in 256
                     // for unit-normal pre-activations) needs the two evaluations - the backward modes then evaluate none
                     // to find the winner, the forward one.
-                    // The winner is the FIRST member that equals the extreme value (as PyTorch's max-pool): a max3 tree and
-                    // eight equality tests whose first-hit bookkeeping is lane-mask (scalar) work - tracking value, y and
-                    // index through eight compare / select steps for both extremes was a third of the VALU stream.
+                    // The winner is the FIRST member that equals the extreme value (as PyTorch's max-pool).
                     float zsel = fmaxf(fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3])), fmaxf(fmaxf(z[4], z[5]), fmaxf(z[6], z[7])));
                     float best = MODE == 1 ? gelu_erf(zsel) : 0.f;
                     if (zsel < 0.f) {
@@ -189,55 +237,60 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                         const float amin = gelu_erf(zmin);
                         if (amin > best) { best = amin; zsel = zmin; }
                     }
-                    bool hit[8], found = false;
-                    float ys = y[0];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        hit[j] = !found && z[j] == zsel;
-                        found = found || hit[j];
-                        if (hit[j]) ys = y[j];
-                    }
-                    const float zs = zsel;
-                    const size_t oidx = ((((size_t)b * Do + od) * Ho + oh) * Wo + ow) * 32 + lr;
+                    const uint32_t oidx = obase + ((uint32_t)(2 * ip + ra) * Wo + rb) * 32;
                     if (MODE == 1) {
                         if (ok) {
-                            if (a.thresh) best *= dropout_scale(a.seed, (uint32_t)oidx, a.thresh, a.inv_keep);
+                            if (a.thresh) best *= dropout_scale(a.seed, oidx, a.thresh, a.inv_keep);
                             a.out[oidx] = (bf16)best;
-                            if (a.arg) {                        // inspection output (parity tests): which member won
-                                int js = 0;
+                            if (ARG) {                          // which member won (first hit)
+                                int js = 7;
 #pragma unroll
-                                for (int j = 1; j < 8; ++j) js = hit[j] ? j : js;
+                                for (int j = 6; j >= 0; --j) js = z[j] == zsel ? j : js;
                                 a.arg[oidx] = (uint8_t)js;
                             }
                         }
-                    } else {
-                        float g = ok ? (float)a.dout[oidx] : 0.f;
-                        if (a.thresh) g *= dropout_scale(a.seed, (uint32_t)oidx, a.thresh, a.inv_keep);
-                        const float dzs = g * gelu_erf_grad(zs);
-                        if (MODE == 2 || MODE == 4) {
-                            acc1 += dzs;
-                            acc2 += dzs * (ys - mu) * rs;
+                        continue;
+                    }
+                    // backward modes: the winner's index (first hit, as the forward) and its pre-BatchNorm value
+                    int js = 7;
+#pragma unroll
+                    for (int j = 6; j >= 0; --j) js = z[j] == zsel ? j : js;
+                    float g = ok ? (float)a.dout[oidx] : 0.f;
+                    if (a.thresh) g *= dropout_scale(a.seed, oidx, a.thresh, a.inv_keep);
+                    const float dzs = g * gelu_erf_grad(zsel);
+                    if (MODE == 2 || MODE == 4) {
+                        // xhat of the winner: its accumulator value (+ bias) is at hand; going back from z would need a division
+                        float aw = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                            aw = js == j ? acc[ti][r] : aw;
                         }
-                        if (MODE == 4) {
+                        acc1 += dzs;
+                        acc2 += dzs * (aw + bias - mu) * rs;
+                    }
+                    if (MODE == 4) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                        for (int j = 0; j < 8; ++j) {
+                            const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                            bool in = true;
+                            if (!FULLT) {
                                 const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
-                                const bool in = FULLT || (d < a.D && h < a.H && w < a.W);
-                                dyf[ti >> 1][r >> 3][r & 7] = (bf16)((in && hit[j]) ? dzs : 0.f);
-                                xhf[ti >> 1][r >> 3][r & 7] = (bf16)(in ? (y[j] - mu) * rs : 0.f);
+                                in = d < a.D && h < a.H && w < a.W;
                             }
-                        } else if (MODE == 3) {
+                            dyf[ti >> 1][r >> 3][r & 7] = (bf16)((in && js == j) ? dzs : 0.f);
+                        }
+                    } else if (MODE == 3) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
-                                const float dzj = hit[j] ? dzs : 0.f;
-                                float dy = a.train ? sc * (dzj - c0 - (y[j] - mu) * rs * c1) : sc * dzj;
-                                const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
-                                if (!FULLT && !(d < a.D && h < a.H && w < a.W)) dy = 0.f;
-                                acc1 += dy;
-                                dyf[ti >> 1][r >> 3][r & 7] = (bf16)dy;
-                            }
+                        for (int j = 0; j < 8; ++j) {
+                            const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                            const float dzj = js == j ? dzs : 0.f;
+                            const float y = acc[ti][r] + bias;
+                            float dy = a.train ? sc * (dzj - c0 - (y - mu) * rs * c1) : sc * dzj;
+                            const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
+                            if (!FULLT && !(d < a.D && h < a.H && w < a.W)) dy = 0.f;
+                            acc1 += dy;
+                            dyf[ti >> 1][r >> 3][r & 7] = (bf16)dy;
                         }
                     }
                 }
@@ -254,10 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
                         for (int j = 0; j < 8; ++j) {
                             const int m = 32 * ti + 16 * s + 8 * (j >> 2) + 4 * lh + (j & 3);
                             const int vb = ((m >> 6) * 10 + ((m >> 3) & 7)) * HP + (m & 7) + wbase;
-                            fr.u[j] = halo[vb + my_tap_off];
+                            fr.u[j] = hb[vb + my_tap_off];
                         }
                         dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, dyf[tq][s], dwacc, 0, 0, 0);
-                        if (MODE == 4) dwacc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, xhf[tq][s], dwacc3, 0, 0, 0);
                     }
             }
         }
@@ -285,26 +337,144 @@ __global__ __launch_bounds__(256, 2) void conv3d_l1_kernel(L1Args a) {     // tw
         }
     }
     if (MODE == 3 || MODE == 4) {
+        __syncthreads();
 #pragma unroll
-        for (int pass = 0; pass < (MODE == 4 ? 2 : 1); ++pass) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {                            // every wave parks its tile: no LDS atomics
-                const int tap = (r & 3) + 8 * (r >> 2) + 4 * lh;      // D row
-                if (tap < 27) wred[wave][tap][lr] = pass ? dwacc3[r] : dwacc[r];
-            }
-            __syncthreads();
-            mm_acc_t* dwr = acc_rep(pass ? a.dw3 : a.dw, blockIdx.x % MM_ACC_REPL, 27 * 32);
-            for (int i = tid; i < 27 * 32; i += 256)
-                acc_add<MM_ACC_GRAD>(&dwr[i], ((&wred[0][0][0])[i] + (&wred[1][0][0])[i]) + ((&wred[2][0][0])[i] + (&wred[3][0][0])[i]));
+        for (int r = 0; r < 16; ++r) {                            // every wave parks its tile: no LDS atomics
+            const int tap = (r & 3) + 8 * (r >> 2) + 4 * lh;      // D row
+            if (tap < 27) wred[wave][tap][lr] = dwacc[r];
         }
+        __syncthreads();
+        mm_acc_t* dwr = acc_rep(a.dw, blockIdx.x % MM_ACC_REPL, 27 * 32);
+        for (int i = tid; i < 27 * 32; i += 256)
+            acc_add<MM_ACC_GRAD>(&dwr[i], ((&wred[0][0][0])[i] + (&wred[1][0][0])[i]) + ((&wred[2][0][0])[i] + (&wred[3][0][0])[i]));
+    }
+}
+
+// G[t][t'] = sum over output voxels v of xcol[v][t] xcol[v][t'] for the 27 taps and the constant column 27 (ones):
+// the Gram matrix of the im2col matrix of the zero-padded, bf16-rounded volume.  A wave owns 2 x 8 x 8 voxels per tile
+// = 8 MFMA K-steps of 16 voxels; the A operand (row = tap lr, k = 8 consecutive voxels of one row) and the B operand
+// (k = voxel, column = tap lr) of G += Xcol^T Xcol are the SAME registers.  One accumulator for the whole kernel.
+template <bool FULLT>
+__global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned short halo[2][HSZ];
+    __shared__ float gred[4][GN][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int tw = (a.W + 31) / 32, th = (a.H + 7) / 8, td = a.D / 2;
+    const int ntiles = a.B * td * th * tw;
+    const int my_tap_off = tap_off(lr);
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.f;
+    HaloPlan plan;
+    halo_plan(plan, tid, a.H, a.W);
+    float hv[NH];
+    int tile = blockIdx.x, buf = 0;
+    if (tile < ntiles) {
+        const TileCoord c = tile_coord(tile, tw, th, td);
+        halo_load(hv, tile_ptr(a.x, c, a.D, a.H, a.W), plan, c.d0, c.h0, c.w0, a.D, a.H, a.W);
+    }
+    const unsigned short one = 0x3F80;                      // bf16(1.0)
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const TileCoord tc = tile_coord(tile, tw, th, td);
+        unsigned short* hb = halo[buf];
+        halo_store(hb, plan, hv);
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) {
+            const TileCoord c = tile_coord(tile + gridDim.x, tw, th, td);
+            halo_load(hv, tile_ptr(a.x, c, a.D, a.H, a.W), plan, c.d0, c.h0, c.w0, a.D, a.H, a.W);
+        }
+        const int wbase = 8 * wave;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            // K-step s: voxels m = 16 s + 8 lh + j, j = 0..7: depth s >> 2, row (2 s + lh) & 7, columns wbase + j
+            const int hrow = (2 * s + lh) & 7;
+            const int vb = ((s >> 2) * 10 + hrow) * HP + wbase;
+            union { unsigned short u[8]; bf16x8 v; } fr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned short e = hb[vb + j + my_tap_off];     // (rows 27..31 read the voxel itself: replaced below)
+                e = lr < 27 ? e : (lr == 27 ? one : (unsigned short)0);
+                if (!FULLT) {                                   // an output voxel outside the volume contributes nothing
+                    const bool in = tc.h0 + hrow < a.H && tc.w0 + wbase + j < a.W;
+                    e = in ? e : (unsigned short)0;
+                }
+                fr.u[j] = e;
+            }
+            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, fr.v, g, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                // D[m][n]: column n = lr, row m = (r & 3) + 8 (r >> 2) + 4 lh
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < GN) gred[wave][m][lr] = g[r];
+    }
+    __syncthreads();
+    mm_acc_t* gw = acc_rep(a.gram, blockIdx.x % MM_ACC_REPL, 32 * 32);
+    for (int i = tid; i < GN * 32; i += 256) {
+        const int m = i >> 5, n = i & 31;
+        if (n < GN)
+            acc_add<MM_ACC_STAT>(&gw[m * 32 + n], (gred[0][m][n] + gred[1][m][n]) + (gred[2][m][n] + gred[3][m][n]));
+    }
+}
+
+// BatchNorm statistics of y = conv + bias from the Gram matrix (one workgroup): stats[n] = sum_v y_n, stats[32 + n] =
+// sum_v y_n^2 as fixed-point accumulators (replica 0 of a zeroed workspace, the form mm_bn_finalize reads), and the
+// compact fp32 matrix gc[GN][32] (rows = taps + ones row, columns 0..27) the backward's combine step uses.
+__global__ __launch_bounds__(1024) void l1_gram_stats_kernel(const float* __restrict__ gram, const bf16* __restrict__ wimg,
+                                                             const float* __restrict__ bias, float* __restrict__ stats,
+                                                             float* __restrict__ gc) {
+    __shared__ double G[GN][GN + 1];
+    __shared__ float wsh[32][28];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    if (tid < GN * 32) {
+        const int m = tid >> 5, n = tid & 31;
+        if (n < GN) {
+            const mm_acc_t s = acc_sum(gram, 32 * 32, (size_t)m * 32 + n);
+            const float f = acc_val<MM_ACC_STAT>(s);          // NaN when a replica is poisoned / the sum out of range
+            if (f != f) atomicOr(&bad, 1);
+            G[m][n] = (double)s * (1.0 / (double)(1ull << MM_ACC_STAT));
+            if (gc) gc[m * 32 + n] = f;
+        } else if (gc) gc[m * 32 + n] = 0.f;
+    } else if (tid < GN * 32 + 32 * 27) {
+        const int i = tid - GN * 32;                            // the bf16 weights the convolution multiplies with
+        wsh[i / 27][i % 27] = (float)wimg[(i / 27) * 32 + i % 27];
+    }
+    __syncthreads();
+    // thread (n, t) forms row t of w_n^T G w_n in double; the 27 rows of a channel are then summed in a fixed order
+    __shared__ double rowsum[32][28];
+    if (tid < 32 * 27) {
+        const int n = tid / 27, t = tid % 27;
+        double row = 0.0;
+        for (int u = 0; u < 27; ++u) row += G[t][u] * (double)wsh[n][u];
+        rowsum[n][t] = (double)wsh[n][t] * row;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int n = tid;
+        const double b = bias ? (double)bias[n] : 0.0, M = G[27][27];
+        double ws = 0.0, wgw = 0.0;
+        for (int t = 0; t < 27; ++t) {
+            ws += (double)wsh[n][t] * G[t][27];
+            wgw += rowsum[n][t];
+        }
+        const double s1 = ws + M * b, s2 = wgw + 2.0 * b * ws + M * b * b;
+        mm_acc_t* out = reinterpret_cast<mm_acc_t*>(stats);     // replica 0 (whole values, one writer: the contract of acc_encode)
+        const double f1 = s1 * (double)(1ull << MM_ACC_STAT), f2 = s2 * (double)(1ull << MM_ACC_STAT), lim = 2305843009213693952.0;   // 2^61
+        out[n] = (!bad && fabs(f1) < lim) ? (mm_acc_t)llrint(f1) : MM_ACC_POISON;
+        out[32 + n] = (!bad && fabs(f2) < lim) ? (mm_acc_t)llrint(f2) : MM_ACC_POISON;
     }
 }
 
 // S[tap] = sum over output voxels v of x~[v + tap - 1] (zero padded, bf16-rounded as the conv sees it):
 // input voxel u = (d, h, w) feeds tap (kd, kh, kw) iff u - (k - 1) is inside the volume, i.e. the
 // indicator factorises per axis.  Per (b, d, h) row: three row sums (all w, all but the last, all but
-// the first) and nine conditional adds of them - 27 adds per ROW, not per voxel.
+// the first) and nine conditional adds of them - 27 adds per ROW, not per voxel.  (The training path takes S from the
+// Gram matrix; this kernel serves callers of mm_conv3d_l1_tapsum.)
 // W % 4 == 0: eight lanes share a row (one float4 each per 32 voxels: a wave reads 8 rows x 128 contiguous bytes
 // per instruction; a thread per row read 64 different cache lines per instruction and took 12 us for 4 MB), the
 // row sum is a 3-step shuffle and lane 0 of the group keeps the tap sums.  Otherwise: a thread per row.
@@ -389,27 +559,39 @@ __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict_
     }
 }
 
-// dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1   (all inputs: fixed-point accumulators x MM_ACC_REPL)
-__global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __restrict__ a3, const float* __restrict__ tapsum,
-                                  const float* __restrict__ sums, const float* __restrict__ out4, float* __restrict__ dw,
-                                  float* __restrict__ dbias, float inv_count, int train) {
+// dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1, with S[tap] = gc[tap][27] and
+// A3[tap][n] = rstd_n ((G w_n)[tap] + (b_n - mean_n) S[tap]) from the compact Gram matrix gc (l1_gram_stats_kernel);
+// a1 / sums: fixed-point accumulators x MM_ACC_REPL.  gc may be null when train == 0 (c0 = c1 = 0: frozen BatchNorm).
+__global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __restrict__ gc, const bf16* __restrict__ wimg,
+                                  const float* __restrict__ bias, const float* __restrict__ sums, const float* __restrict__ out4,
+                                  float* __restrict__ dw, float* __restrict__ dbias, float inv_count, int train) {
     // one output per 16 lanes, one replica per lane: a single load round trip + (integer) shuffle sums
-    // (the serial replica loop was five dependent-latency chains: 11 us on 4 workgroups)
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, r = threadIdx.x & 15;
     if (i >= 32 * 27) return;
     const int n = i / 27, tap = i % 27;
-    const mm_acc_t *q1 = reinterpret_cast<const mm_acc_t*>(a1), *q3 = reinterpret_cast<const mm_acc_t*>(a3),
-                   *qt = reinterpret_cast<const mm_acc_t*>(tapsum), *qs = reinterpret_cast<const mm_acc_t*>(sums);
-    mm_acc_t iA1 = q1[(size_t)r * 864 + tap * 32 + n], iA3 = q3[(size_t)r * 864 + tap * 32 + n];
-    mm_acc_t iSt = qt[r * 32 + tap], is0 = qs[r * 64 + n], is1 = qs[r * 64 + 32 + n];
-    iA1 = acc_sum_lanes16(iA1); iA3 = acc_sum_lanes16(iA3); iSt = acc_sum_lanes16(iSt);
-    is0 = acc_sum_lanes16(is0); is1 = acc_sum_lanes16(is1);
+    const mm_acc_t *q1 = reinterpret_cast<const mm_acc_t*>(a1), *qs = reinterpret_cast<const mm_acc_t*>(sums);
+    mm_acc_t iA1 = q1[(size_t)r * 864 + tap * 32 + n], is0 = qs[r * 64 + n], is1 = qs[r * 64 + 32 + n];
+    // (G w_n)[tap]: 27 products, two per lane over the 16 lanes, summed in a fixed (butterfly) order
+    float gw = 0.f;
+    if (train) {
+        const int u0 = r, u1 = r + 16;
+        gw = gc[tap * 32 + u0] * (float)wimg[n * 32 + u0];
+        if (u1 < 27) gw += gc[tap * 32 + u1] * (float)wimg[n * 32 + u1];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) gw += __shfl_xor(gw, o, 64);
+    }
+    iA1 = acc_sum_lanes16(iA1); is0 = acc_sum_lanes16(is0); is1 = acc_sum_lanes16(is1);
     if (r) return;
-    const float A1 = acc_val<MM_ACC_GRAD>(iA1), A3 = acc_val<MM_ACC_GRAD>(iA3), St = acc_val<MM_ACC_STAT>(iSt);
+    const float A1 = acc_val<MM_ACC_GRAD>(iA1);
     const float s0 = acc_val<MM_ACC_GRAD>(is0), s1 = acc_val<MM_ACC_GRAD>(is1);
-    const float sc = out4[n];
-    const float c0 = train ? s0 * inv_count : 0.f, c1 = train ? s1 * inv_count : 0.f;
-    dw[i] += sc * (A1 - c0 * St - c1 * A3);
+    const float sc = out4[n], mu = out4[64 + n], rs = out4[96 + n];
+    float corr = 0.f;
+    if (train) {
+        const float St = gc[tap * 32 + 27], b = bias ? bias[n] : 0.f;
+        const float A3 = rs * (gw + (b - mu) * St);
+        corr = s0 * inv_count * St + s1 * inv_count * A3;
+    }
+    dw[i] += sc * (A1 - corr);
     if (tap == 0 && dbias && !train) dbias[n] += sc * s0;      // train: sum dy == 0 identically
 }
 
@@ -424,6 +606,21 @@ __global__ void transpose_add_kernel(const float* __restrict__ src, float* __res
 
 inline uint32_t thresh_l1(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 
+inline void l1_fill(L1Args& a, const float* x, const void* wimg, const float* bias, const float* out4, int B, int D, int H,
+                    int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch) {
+    a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = nullptr; a.sums = nullptr;
+    a.stats = nullptr; a.out = nullptr; a.arg = nullptr; a.dw = nullptr; a.dbias = nullptr; a.gram = nullptr;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
+    a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    a.inv_count = 1.f / ((float)B * D * H * W);
+    a.epoch = seed_epoch;
+}
+inline int l1_tiles(int B, int D, int H, int W) { return B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32); }
+// persistent grids: `per_cu` resident workgroups on each of the 256 CUs (the register budget of the instance decides)
+inline int l1_grid(int ntiles, int per_cu) { const int cap = 256 * per_cu; return ntiles < cap ? ntiles : cap; }
+// pooled output indices are formed in 32 bits (they also seed the dropout hash)
+inline bool l1_fits(int B, int D, int H, int W) { return (double)B * D * H * W * 4.0 < 2147483648.0; }
+
 }  // namespace
 
 extern "C" {
@@ -434,6 +631,7 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
                  hipStream_t st) {
     MM_REQUIRE(x && wimg && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1: null/invalid");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1: D,H,W must be even (MaxPool3d(2))");
+    MM_REQUIRE(l1_fits(B, D, H, W), "conv3d_l1: more than 2^31 pooled output elements");
     MM_REQUIRE(mode >= 0 && mode <= 3, "conv3d_l1: mode");  /* mode 4 has its own entry point */
     MM_REQUIRE(mode == 0 ? stats != nullptr : out4 != nullptr, "conv3d_l1: stats/out4");
     MM_REQUIRE(mode != 1 || out, "conv3d_l1: out");
@@ -441,24 +639,20 @@ int mm_conv3d_l1(int mode, const float* x, const void* wimg, const float* bias, 
     MM_REQUIRE(mode != 2 || stats, "conv3d_l1: sums_out");
     MM_REQUIRE(mode != 3 || (dw_tapmajor && (!train || sums)), "conv3d_l1: dw/sums");
     L1Args a;
-    a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = sums;
-    a.stats = stats; a.out = (bf16*)out; a.arg = nullptr; a.dw = dw_tapmajor; a.dw3 = nullptr; a.dbias = dbias;
-    a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
-    a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    a.inv_count = 1.f / ((float)B * D * H * W);
-    a.epoch = seed_epoch;
-    const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
-    const int grid = ntiles < 1024 ? ntiles : 1024;
+    l1_fill(a, x, wimg, bias, out4, B, D, H, W, train, drop_p, seed, seed_epoch);
+    a.dout = (const bf16*)dout; a.sums = sums; a.stats = stats; a.out = (bf16*)out; a.dw = dw_tapmajor; a.dbias = dbias;
+    const int ntiles = l1_tiles(B, D, H, W);
     const bool full = H % 8 == 0 && W % 32 == 0;
+    const int g3 = l1_grid(ntiles, 3), g2 = l1_grid(ntiles, 2);
     switch (mode * 2 + (full ? 1 : 0)) {
-        case 0: hipLaunchKernelGGL((conv3d_l1_kernel<0, false>), dim3(grid), dim3(256), 0, st, a); break;
-        case 1: hipLaunchKernelGGL((conv3d_l1_kernel<0, true>), dim3(grid), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((conv3d_l1_kernel<1, false>), dim3(grid), dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((conv3d_l1_kernel<1, true>), dim3(grid), dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((conv3d_l1_kernel<2, false>), dim3(grid), dim3(256), 0, st, a); break;
-        case 5: hipLaunchKernelGGL((conv3d_l1_kernel<2, true>), dim3(grid), dim3(256), 0, st, a); break;
-        case 6: hipLaunchKernelGGL((conv3d_l1_kernel<3, false>), dim3(grid), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((conv3d_l1_kernel<3, true>), dim3(grid), dim3(256), 0, st, a); break;
+        case 0: hipLaunchKernelGGL((conv3d_l1_kernel<0, false>), dim3(g3), dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((conv3d_l1_kernel<0, true>), dim3(g3), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((conv3d_l1_kernel<1, false>), dim3(g3), dim3(256), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((conv3d_l1_kernel<1, true>), dim3(g3), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((conv3d_l1_kernel<2, false>), dim3(g2), dim3(256), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((conv3d_l1_kernel<2, true>), dim3(g2), dim3(256), 0, st, a); break;
+        case 6: hipLaunchKernelGGL((conv3d_l1_kernel<3, false>), dim3(g2), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv3d_l1_kernel<3, true>), dim3(g2), dim3(256), 0, st, a); break;
     }
     return mm_check_launch("conv3d_l1");
 }
@@ -468,18 +662,33 @@ int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias
                              const uint32_t* seed_epoch, hipStream_t st) {
     MM_REQUIRE(x && wimg && out4 && out && arg && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_fwd_winners: null/invalid");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_fwd_winners: D,H,W must be even (MaxPool3d(2))");
+    MM_REQUIRE(l1_fits(B, D, H, W), "conv3d_l1_fwd_winners: more than 2^31 pooled output elements");
     L1Args a;
-    a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = nullptr; a.sums = nullptr;
-    a.stats = nullptr; a.out = (bf16*)out; a.arg = (uint8_t*)arg; a.dw = nullptr; a.dw3 = nullptr; a.dbias = nullptr;
-    a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
-    a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    a.inv_count = 1.f / ((float)B * D * H * W);
-    a.epoch = seed_epoch;
-    const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
-    const int grid = ntiles < 1024 ? ntiles : 1024;
-    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<1, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3d_l1_kernel<1, false>), dim3(grid), dim3(256), 0, st, a);
+    l1_fill(a, x, wimg, bias, out4, B, D, H, W, train, drop_p, seed, seed_epoch);
+    a.out = (bf16*)out; a.arg = (uint8_t*)arg;
+    const int grid = l1_grid(l1_tiles(B, D, H, W), 3);
+    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<1, true, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3d_l1_kernel<1, false, true>), dim3(grid), dim3(256), 0, st, a);
     return mm_check_launch("conv3d_l1_fwd_winners");
+}
+
+int mm_conv3d_l1_gram(const float* x, float* gram, int B, int D, int H, int W, hipStream_t st) {
+    MM_REQUIRE(x && gram && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_gram: null/invalid");
+    MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_gram: D,H,W must be even (MaxPool3d(2))");
+    L1Args a;
+    l1_fill(a, x, nullptr, nullptr, nullptr, B, D, H, W, 1, 0.f, 0, nullptr);
+    a.gram = gram;
+    const int grid = l1_grid(l1_tiles(B, D, H, W), 3);
+    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((l1_gram_kernel<true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((l1_gram_kernel<false>), dim3(grid), dim3(256), 0, st, a);
+    return mm_check_launch("conv3d_l1_gram");
+}
+
+int mm_conv3d_l1_gram_stats(const float* gram, const void* wimg, const float* bias, float* stats, float* gram_compact,
+                            hipStream_t st) {
+    MM_REQUIRE(gram && wimg && stats, "conv3d_l1_gram_stats: null");
+    hipLaunchKernelGGL(l1_gram_stats_kernel, dim3(1), dim3(1024), 0, st, gram, (const bf16*)wimg, bias, stats, gram_compact);
+    return mm_check_launch("conv3d_l1_gram_stats");
 }
 
 static int l1_tapsum_grid(int B, int D, int H, int W) {
@@ -496,26 +705,21 @@ int mm_conv3d_l1_tapsum(const float* x, float* tapsum, int B, int D, int H, int 
 }
 
 int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
-                     float* sums_out, float* a1, float* a3, float* tapsum, int tapsum_ready, float* dw, float* dbias, int B,
+                     float* sums_out, float* a1, const float* gram_compact, float* dw, float* dbias, int B,
                      int D, int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                      hipStream_t st) {
-    MM_REQUIRE(x && wimg && out4 && dout && sums_out && a1 && a3 && tapsum && dw && B > 0, "conv3d_l1_bwd: null/invalid");
+    MM_REQUIRE(x && wimg && out4 && dout && sums_out && a1 && dw && B > 0, "conv3d_l1_bwd: null/invalid");
+    MM_REQUIRE(!train || gram_compact, "conv3d_l1_bwd: train-mode BatchNorm needs the compact Gram matrix of the forward pass");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_bwd: D,H,W must be even (MaxPool3d(2))");
+    MM_REQUIRE(l1_fits(B, D, H, W), "conv3d_l1_bwd: more than 2^31 pooled output elements");
     L1Args a;
-    a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = (const bf16*)dout; a.sums = nullptr;
-    a.stats = sums_out; a.out = nullptr; a.arg = nullptr; a.dw = a1; a.dw3 = a3; a.dbias = nullptr;
-    a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
-    a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    a.inv_count = 1.f / ((float)B * D * H * W);
-    a.epoch = seed_epoch;
-    const int ntiles = B * (D / 2) * ceil_div(H, 8) * ceil_div(W, 32);
-    if (!tapsum_ready)
-        hipLaunchKernelGGL(l1_tapsum_kernel, dim3(l1_tapsum_grid(B, D, H, W)), dim3(256), 0,
-                           st, x, tapsum, B, D, H, W);
-    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<4, true>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3d_l1_kernel<4, false>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 16, 256)), dim3(256), 0, st, a1, a3, tapsum, sums_out, out4, dw,
-                       dbias, a.inv_count, train);
+    l1_fill(a, x, wimg, bias, out4, B, D, H, W, train, drop_p, seed, seed_epoch);
+    a.dout = (const bf16*)dout; a.stats = sums_out; a.dw = a1;
+    const int grid = l1_grid(l1_tiles(B, D, H, W), 2);
+    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3d_l1_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 16, 256)), dim3(256), 0, st, a1, gram_compact,
+                       (const bf16*)wimg, bias, sums_out, out4, dw, dbias, a.inv_count, train);
     return mm_check_launch("conv3d_l1_bwd");
 }
 

@@ -751,10 +751,15 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     out = _empty((B, D // 2, H // 2, W // 2, 32), _BF, x)
     p = drop_p if training else 0.0
     seed = _next_seed() if p > 0 else 0
+    gramc = None
     if training:
+        # BatchNorm statistics from the Gram matrix of the im2col matrix (no per-channel pass over the convolution):
+        # csrc/conv3d_l1.hip.  The compact matrix is kept: the backward's weight-gradient correction terms come from it.
+        gram = _zeros((REPL, 32, 32), x)
+        _hip.call("mm_conv3d_l1_gram", x, gram, B, D, H, W)
         stats = _zeros((REPL, 2, 32), x)
-        _hip.call("mm_conv3d_l1", 0, x, wimg, conv.bias, None, None, None, stats, None, None, None,
-                  B, D, H, W, 1, 0.0, 0, None)
+        gramc = _empty((28, 32), _F32, x)
+        _hip.call("mm_conv3d_l1_gram_stats", gram, wimg, conv.bias, stats, gramc)
         out4 = bn_finalize_train(bn, stats, B * D * H * W)
         bias = conv.bias
     elif save:
@@ -770,7 +775,7 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     else:
         _hip.call("mm_conv3d_l1", 1, x, wimg, bias, out4, None, None, None, out, None, None,
                   B, D, H, W, 1 if training else 0, float(p), seed, EP())
-    saved = dict(l1=True, x=x, wimg=wimg, out4=out4, drop_p=p, seed=seed, conv=conv, bn=bn, train=training) if save else None
+    saved = dict(l1=True, x=x, wimg=wimg, out4=out4, drop_p=p, seed=seed, conv=conv, bn=bn, train=training, gramc=gramc) if save else None
     return out, saved
 
 
@@ -800,11 +805,6 @@ def _vol_forward_impl(m, x: torch.Tensor, training: bool, need_dgrad: bool, save
     h, s = conv3d_bn_act(h, cl[10], cl[11], pool=False, training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
     saved.append(s)
     out, hs = pooled_head_fwd(h, m.output_proj[2], training=training, drop_p=p, need_dgrad=need_dgrad, save=save)
-    if training and saved[0] is not None and saved[0].get("l1") and cl[0].weight.requires_grad:
-        # per-tap input sums of the layer-1 weight gradient depend on the volume alone: taken here, where the
-        # fMRI stream has slack, instead of at the head of the layer-1 backward
-        saved[0]["tapsum"] = _zeros((REPL, 32), x)
-        _hip.call("mm_conv3d_l1_tapsum", x, saved[0]["tapsum"], B, D, H, W)
     return out, dict(convs=saved, head=hs, x_shape=tuple(x.shape), need_dx=need_dx)
 
 

@@ -307,22 +307,25 @@ def l1_case(B=32, D=32, H=32, W=32, p=0.3):
     wimg, out4 = s["wimg"], s["out4"]
     stats = torch.zeros(32, 2, 32, device="cuda")
     dout = torch.randn(out.shape, device="cuda").to(BF)
-    sums, a1, a3 = torch.zeros(32, 2, 32, device="cuda"), torch.zeros(32, 27, 32, device="cuda"), torch.zeros(32, 27, 32, device="cuda")
+    sums, a1 = torch.zeros(32, 2, 32, device="cuda"), torch.zeros(32, 27, 32, device="cuda")
+    gram, gramc = torch.zeros(32, 32, 32, device="cuda"), s["gramc"]
     tapsum = torch.zeros(32, 32, device="cuda")
-    _hip.call("mm_conv3d_l1_tapsum", x, tapsum, B, D, H, W)
     dw, db = torch.zeros(32, 1, 3, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
     fl = 2.0 * 27 * 32 * B * D * H * W
+    tg = timeit(lambda: _hip.call("mm_conv3d_l1_gram", x, gram, B, D, H, W))
+    tgs = timeit(lambda: _hip.call("mm_conv3d_l1_gram_stats", gram, wimg, conv.bias, stats, gramc))
     t0 = timeit(lambda: _hip.call("mm_conv3d_l1", 0, x, wimg, conv.bias, None, None, None, stats, None, None, None,
                                   B, D, H, W, 1, 0.0, 0, None))
     t1 = timeit(lambda: _hip.call("mm_conv3d_l1", 1, x, wimg, conv.bias, out4, None, None, None, out, None, None,
                                   B, D, H, W, 1, float(p), 123, None))
-    t4 = timeit(lambda: _hip.call("mm_conv3d_l1_bwd", x, wimg, conv.bias, out4, dout, sums, a1, a3, tapsum, 1, dw, db,
+    t4 = timeit(lambda: _hip.call("mm_conv3d_l1_bwd", x, wimg, conv.bias, out4, dout, sums, a1, gramc, dw, db,
                                   B, D, H, W, 1, float(p), 123, None))
     tt = timeit(lambda: _hip.call("mm_conv3d_l1_tapsum", x, tapsum, B, D, H, W))
     inb, outb = x.numel() * 4, out.numel() * 2
-    for name, t, byts in (("stats  (mode 0)", t0, inb), ("forward (mode 1)", t1, inb + outb), ("backward (mode 4 + combine)", t4, inb + outb),
-                          ("tap sums", tt, inb)):
-        print(f"conv3d_l1 {name:28s} B={B} {D}x{H}x{W}: {t:7.1f} us  {fl / t / 1e6:6.1f} TF/s (of 157 fp32 / 2500 bf16)  "
+    for name, t, byts in (("Gram matrix (training stats)", tg, inb), ("stats from Gram (1 workgroup)", tgs, 0),
+                          ("stats by recompute (mode 0, ABI)", t0, inb), ("forward (mode 1)", t1, inb + outb),
+                          ("backward (mode 4 + combine)", t4, inb + outb), ("tap sums (ABI)", tt, inb)):
+        print(f"conv3d_l1 {name:34s} B={B} {D}x{H}x{W}: {t:7.1f} us  {fl / t / 1e6:6.1f} TF/s (of 157 fp32 / 2500 bf16)  "
               f"{byts / 1e6:5.1f} MB compulsory -> {byts / t / 1e6:6.2f} TB/s of 8")
 
 
