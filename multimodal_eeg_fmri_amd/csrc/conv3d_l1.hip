@@ -440,10 +440,9 @@ __global__ __launch_bounds__(1024) void l1_gram_stats_kernel(const float* __rest
             G[m][n] = (double)s * (1.0 / (double)(1ull << MM_ACC_STAT));
             if (gc) gc[m * 32 + n] = f;
         } else if (gc) gc[m * 32 + n] = 0.f;
-    } else if (tid < GN * 32 + 32 * 27) {
-        const int i = tid - GN * 32;                            // the bf16 weights the convolution multiplies with
-        wsh[i / 27][i % 27] = (float)wimg[(i / 27) * 32 + i % 27];
     }
+    if (tid < 32 * 27)                                          // the bf16 weights the convolution multiplies with
+        wsh[tid / 27][tid % 27] = (float)wimg[(tid / 27) * 32 + tid % 27];
     __syncthreads();
     // thread (n, t) forms row t of w_n^T G w_n in double; the 27 rows of a channel are then summed in a fixed order
     __shared__ double rowsum[32][28];
