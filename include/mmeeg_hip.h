@@ -341,12 +341,19 @@ int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias
  * rounded, zero-padded volume - what the convolution sees), holds everything the layer needs from the input:
  *   sum_v y_n = w_n . S + M b_n,  sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2   (S[t] = G[t][27], M = G[27][27])
  * and, in the backward, A3[t][n] = sum_v xcol[v][t] xhat[v][n] = rstd_n ((G w_n)[t] + (b_n - mean_n) S[t]).
- * mm_conv3d_l1_gram: gram = ZEROED accumulator workspace [32][32][32] (activation-statistics scale).
+ * mm_conv3d_l1_gram: gram = ZEROED accumulator workspace [32][32][32] (activation-statistics scale); G is symmetric and
+ * only its upper triangle (t <= t') is accumulated.
  * mm_conv3d_l1_gram_stats: -> stats (ZEROED accumulator workspace [32][2][32], replica 0 written: {sum y, sum y^2} of
  * conv + bias, the input of mm_bn_finalize) and gram_compact fp32 [28][32] (nullable; kept for mm_conv3d_l1_bwd). */
 int mm_conv3d_l1_gram(const float* x, float* gram, int B, int D, int H, int W, hipStream_t stream);
+ * mm_conv3d_l1_gram_finalize: the same kernel carrying mm_bn_finalize's train-mode step for the layer (same fixed-point
+ * sums, same arithmetic: out4 [4][32] = scale, shift (WITHOUT the conv bias: the apply pass adds it), mean, rstd; the
+ * running-statistic update with momentum and the unbiased variance; batches_tracked += 1) - one launch instead of two. */
 int mm_conv3d_l1_gram_stats(const float* gram, const void* wimg, const float* bias, float* stats, float* gram_compact,
                             hipStream_t stream);
+int mm_conv3d_l1_gram_finalize(const float* gram, const void* wimg, const float* bias, const float* gamma,
+                               const float* beta, float* run_mean, float* run_var, float* out4, float* gram_compact,
+                               float count, float momentum, float eps, void* batches_tracked, hipStream_t stream);
 /* Training backward of the same layer in ONE recompute pass (replaces modes 2 + 3): BatchNorm's
  * backward is linear in the two sums S1 = sum dz, S2 = sum dz * xhat, so
  *   dW = scale * (A1 - (S1/M) * S - (S2/M) * A3),  A1 = x^T dz, S and A3 from gram_compact (above).

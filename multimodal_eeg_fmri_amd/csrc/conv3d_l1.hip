@@ -63,6 +63,21 @@ __device__ __forceinline__ int tap_off(int tap) {          // halo offset of tap
     return kd * 10 * HP + kh * HP + kw;
 }
 
+// v_max3_f32 / v_min3_f32: the window extreme of 8 finite values in 4 instructions.  (fmaxf() in IEEE mode first
+// canonicalises every operand - one v_max_f32 v, v, v per member: 72 of mode 1's ~700 VALU instructions per tile.)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max8f(const float (&z)[8]) { return max3f(max3f(z[0], z[1], z[2]), max3f(z[3], z[4], z[5]), max3f(z[6], z[7], z[7])); }
+__device__ __forceinline__ float min8f(const float (&z)[8]) { return min3f(min3f(z[0], z[1], z[2]), min3f(z[3], z[4], z[5]), min3f(z[6], z[7], z[7])); }
+
 // ---- halo staging: the (2+2) x (8+2) x (32+2) input block of a tile, bf16, zero outside the volume -----------------
 // per-thread plan, computed once: element i = tid + 256 q -> offset relative to the tile's first voxel and a packed
 // descriptor (bits 0-11 LDS index, 12-13 depth row, 14-17 height row, 18-23 column; sign bit: no such element)
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
         // ---- pooled windows: (ip, ra, rb) -> regs {r0, r0+1, r0+4, r0+5} of tiles ip and ip+2
         // dy (mode 3) / dz (mode 4) fragments of the two conv tiles ip, ip + 2 that one pass of the ip loop completes;
         // their weight-gradient MFMAs run at the end of that pass, so only two tiles' fragments are ever live
-        bf16x8 dyf[2][2];
+        union DyFrag { bf16x8 v; uint32_t u[4]; } dyf[2][2];
         // flat index of this lane's first pooled output of the tile (32-bit: the host checks the tensor size)
         const uint32_t obase = ((((uint32_t)b * Do + (d0 >> 1)) * Ho + (h0 >> 1)) * Wo + (w0 >> 1) + 4 * wave + 2 * lh) * 32 + lr;
 #pragma unroll
@@ -229,13 +244,17 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
                     // for unit-normal pre-activations) needs the two evaluations - the backward modes then evaluate none
                     // to find the winner, the forward one.
                     // The winner is the FIRST member that equals the extreme value (as PyTorch's max-pool).
-                    float zsel = fmaxf(fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3])), fmaxf(fmaxf(z[4], z[5]), fmaxf(z[6], z[7])));
+                    // The all-negative case sits behind a WAVE-UNIFORM branch (no lane of the wave in ~78 % of the windows): as
+                    // a per-lane condition the compiler predicated it, i.e. ran the minimum tree and the second GELU always.
+                    float zsel = max8f(z);
                     float best = MODE == 1 ? gelu_erf(zsel) : 0.f;
-                    if (zsel < 0.f) {
-                        const float zmin = fminf(fminf(fminf(z[0], z[1]), fminf(z[2], z[3])), fminf(fminf(z[4], z[5]), fminf(z[6], z[7])));
-                        if (MODE != 1) best = gelu_erf(zsel);
-                        const float amin = gelu_erf(zmin);
-                        if (amin > best) { best = amin; zsel = zmin; }
+                    if (__builtin_amdgcn_ballot_w64(zsel < 0.f) != 0) {
+                        if (zsel < 0.f) {
+                            const float zmin = min8f(z);
+                            if (MODE != 1) best = gelu_erf(zsel);
+                            const float amin = gelu_erf(zmin);
+                            if (amin > best) { best = amin; zsel = zmin; }
+                        }
                     }
                     const uint32_t oidx = obase + ((uint32_t)(2 * ip + ra) * Wo + rb) * 32;
                     if (MODE == 1) {
@@ -259,27 +278,25 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
                     if (a.thresh) g *= dropout_scale(a.seed, oidx, a.thresh, a.inv_keep);
                     const float dzs = g * gelu_erf_grad(zsel);
                     if (MODE == 2 || MODE == 4) {
-                        // xhat of the winner: its accumulator value (+ bias) is at hand; going back from z would need a division
-                        float aw = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
-                            aw = js == j ? acc[ti][r] : aw;
-                        }
+                        // xhat of the winner: its accumulator value (+ bias) is at hand; going back from z would need a division.
+                        // Two-level select on (js >> 1, js & 1): the four pair masks are shared with the dz fragments below.
+                        const int jp = js >> 1;
+                        const int t1 = ip + 2;                                   // members j = 4..7 live in conv tile ip + 2
+                        const float lo = jp == 0 ? acc[ip][r0] : jp == 1 ? acc[ip][r0 + 4] : jp == 2 ? acc[t1][r0] : acc[t1][r0 + 4];
+                        const float hi = jp == 0 ? acc[ip][r0 + 1] : jp == 1 ? acc[ip][r0 + 5] : jp == 2 ? acc[t1][r0 + 1] : acc[t1][r0 + 5];
+                        const float aw = (js & 1) ? hi : lo;
                         acc1 += dzs;
                         acc2 += dzs * (aw + bias - mu) * rs;
                     }
                     if (MODE == 4) {
+                        // the window's 8 members are 4 packed bf16 pairs of the dz fragments - (dd, hh) -> register rb + 2 hh
+                        // of fragment [dd][ra], low / high half = ww - and exactly one member is non-zero (a window that
+                        // is not in the volume has g = 0): one converted value, shifted to its half, selected into its pair
+                        const bf16 db = (bf16)dzs;
+                        const uint32_t pairval = (uint32_t)(*reinterpret_cast<const unsigned short*>(&db)) << ((js & 1) << 4);
+                        const int jp = js >> 1;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
-                            bool in = true;
-                            if (!FULLT) {
-                                const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
-                                in = d < a.D && h < a.H && w < a.W;
-                            }
-                            dyf[ti >> 1][r >> 3][r & 7] = (bf16)((in && js == j) ? dzs : 0.f);
-                        }
+                        for (int k = 0; k < 4; ++k) dyf[k >> 1][ra].u[rb + 2 * (k & 1)] = jp == k ? pairval : 0u;
                     } else if (MODE == 3) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
                             const int d = d0 + (ti >> 1), h = h0 + 4 * (ti & 1) + (r >> 2), w = w0 + wbase + (r & 3) + 4 * lh;
                             if (!FULLT && !(d < a.D && h < a.H && w < a.W)) dy = 0.f;
                             acc1 += dy;
-                            dyf[ti >> 1][r >> 3][r & 7] = (bf16)dy;
+                            dyf[ti >> 1][r >> 3].v[r & 7] = (bf16)dy;
                         }
                     }
                 }
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
                             const int vb = ((m >> 6) * 10 + ((m >> 3) & 7)) * HP + (m & 7) + wbase;
                             fr.u[j] = hb[vb + my_tap_off];
                         }
-                        dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, dyf[tq][s], dwacc, 0, 0, 0);
+                        dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, dyf[tq][s].v, dwacc, 0, 0, 0);
                     }
             }
         }
@@ -374,7 +391,7 @@ __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
         const TileCoord c = tile_coord(tile, tw, th, td);
         halo_load(hv, tile_ptr(a.x, c, a.D, a.H, a.W), plan, c.d0, c.h0, c.w0, a.D, a.H, a.W);
     }
-    const unsigned short one = 0x3F80;                      // bf16(1.0)
+    const uint32_t keep = lr < 27 ? 0xFFFFFFFFu : 0u, orv = lr == 27 ? 0x3F803F80u : 0u;   // bf16(1.0) pairs for the ones row
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const TileCoord tc = tile_coord(tile, tw, th, td);
         unsigned short* hb = halo[buf];
@@ -390,16 +407,19 @@ __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
             // K-step s: voxels m = 16 s + 8 lh + j, j = 0..7: depth s >> 2, row (2 s + lh) & 7, columns wbase + j
             const int hrow = (2 * s + lh) & 7;
             const int vb = ((s >> 2) * 10 + hrow) * HP + wbase;
-            union { unsigned short u[8]; bf16x8 v; } fr;
+            union { uint32_t u[4]; bf16x8 v; } fr;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                unsigned short e = hb[vb + j + my_tap_off];     // (rows 27..31 read the voxel itself: replaced below)
-                e = lr < 27 ? e : (lr == 27 ? one : (unsigned short)0);
+            for (int jj = 0; jj < 4; ++jj) {
+                uint32_t lo = hb[vb + 2 * jj + my_tap_off], hi = hb[vb + 2 * jj + 1 + my_tap_off];   // (rows 27..31 read the voxel itself)
                 if (!FULLT) {                                   // an output voxel outside the volume contributes nothing
-                    const bool in = tc.h0 + hrow < a.H && tc.w0 + wbase + j < a.W;
-                    e = in ? e : (unsigned short)0;
+                    const bool inh = tc.h0 + hrow < a.H;
+                    lo = (inh && tc.w0 + wbase + 2 * jj < a.W) ? lo : 0u;
+                    hi = (inh && tc.w0 + wbase + 2 * jj + 1 < a.W) ? hi : 0u;
+                    fr.u[jj] = ((lo | (hi << 16)) & keep) | ((inh && tc.w0 + wbase + 2 * jj < a.W) ? (orv & 0xFFFFu) : 0u)
+                               | ((inh && tc.w0 + wbase + 2 * jj + 1 < a.W) ? (orv & 0xFFFF0000u) : 0u);
+                } else {
+                    fr.u[jj] = ((lo | (hi << 16)) & keep) | orv;    // rows 27..31: the column of ones / zero rows (v_and_or_b32)
                 }
-                fr.u[j] = e;
             }
             g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.v, fr.v, g, 0, 0, 0);
         }
@@ -412,9 +432,9 @@ __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
     }
     __syncthreads();
     mm_acc_t* gw = acc_rep(a.gram, blockIdx.x % MM_ACC_REPL, 32 * 32);
-    for (int i = tid; i < GN * 32; i += 256) {
+    for (int i = tid; i < GN * 32; i += 256) {                    // G is symmetric: the upper triangle only (half the atomics)
         const int m = i >> 5, n = i & 31;
-        if (n < GN)
+        if (n < GN && n >= m)
             acc_add<MM_ACC_STAT>(&gw[m * 32 + n], (gred[0][m][n] + gred[1][m][n]) + (gred[2][m][n] + gred[3][m][n]));
     }
 }
@@ -422,9 +442,14 @@ __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
 // BatchNorm statistics of y = conv + bias from the Gram matrix (one workgroup): stats[n] = sum_v y_n, stats[32 + n] =
 // sum_v y_n^2 as fixed-point accumulators (replica 0 of a zeroed workspace, the form mm_bn_finalize reads), and the
 // compact fp32 matrix gc[GN][32] (rows = taps + ones row, columns 0..27) the backward's combine step uses.
+// With `out4` the kernel also IS the BatchNorm finalize of the layer (mm_bn_finalize's train-mode arithmetic on the same
+// fixed-point sums: mean / rstd, scale, shift, running-statistic update with momentum and the unbiased variance,
+// num_batches_tracked) - one graph node and one dependent launch less per step.
+struct BnFin { const float* gamma; const float* beta; float* run_mean; float* run_var; float* out4; long long* tracked;
+               float count, momentum, eps; };
 __global__ __launch_bounds__(1024) void l1_gram_stats_kernel(const float* __restrict__ gram, const bf16* __restrict__ wimg,
                                                              const float* __restrict__ bias, float* __restrict__ stats,
-                                                             float* __restrict__ gc) {
+                                                             float* __restrict__ gc, BnFin fin) {
     __shared__ double G[GN][GN + 1];
     __shared__ float wsh[32][28];
     __shared__ int bad;
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(1024) void l1_gram_stats_kernel(const float* __rest
     if (tid < GN * 32) {
         const int m = tid >> 5, n = tid & 31;
         if (n < GN) {
-            const mm_acc_t s = acc_sum(gram, 32 * 32, (size_t)m * 32 + n);
+            const mm_acc_t s = acc_sum(gram, 32 * 32, (size_t)(m < n ? m : n) * 32 + (m < n ? n : m));   // upper triangle stored
             const float f = acc_val<MM_ACC_STAT>(s);          // NaN when a replica is poisoned / the sum out of range
             if (f != f) atomicOr(&bad, 1);
             G[m][n] = (double)s * (1.0 / (double)(1ull << MM_ACC_STAT));
@@ -464,8 +489,25 @@ __global__ __launch_bounds__(1024) void l1_gram_stats_kernel(const float* __rest
         const double s1 = ws + M * b, s2 = wgw + 2.0 * b * ws + M * b * b;
         mm_acc_t* out = reinterpret_cast<mm_acc_t*>(stats);     // replica 0 (whole values, one writer: the contract of acc_encode)
         const double f1 = s1 * (double)(1ull << MM_ACC_STAT), f2 = s2 * (double)(1ull << MM_ACC_STAT), lim = 2305843009213693952.0;   // 2^61
-        out[n] = (!bad && fabs(f1) < lim) ? (mm_acc_t)llrint(f1) : MM_ACC_POISON;
-        out[32 + n] = (!bad && fabs(f2) < lim) ? (mm_acc_t)llrint(f2) : MM_ACC_POISON;
+        const mm_acc_t i1 = (!bad && fabs(f1) < lim) ? (mm_acc_t)llrint(f1) : MM_ACC_POISON;
+        const mm_acc_t i2 = (!bad && fabs(f2) < lim) ? (mm_acc_t)llrint(f2) : MM_ACC_POISON;
+        if (stats) { out[n] = i1; out[32 + n] = i2; }
+        if (fin.out4) {                                         // = bn_finalize_kernel, mode 0, on {i1, i2}
+            if (n == 0 && fin.tracked) fin.tracked[0] += 1;
+            const float v1 = acc_val<MM_ACC_STAT>(i1), v2 = acc_val<MM_ACC_STAT>(i2), count = fin.count;
+            const float mean = v1 / count;
+            float var = v2 / count - mean * mean;
+            var = var < 0.f ? 0.f : var;                        // (not fmaxf: a NaN sum must stay NaN)
+            fin.run_mean[n] = (1.f - fin.momentum) * fin.run_mean[n] + fin.momentum * mean;
+            const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+            fin.run_var[n] = (1.f - fin.momentum) * fin.run_var[n] + fin.momentum * unb;
+            const float rstd = rsqrtf(var + fin.eps);
+            const float sc = fin.gamma[n] * rstd;
+            fin.out4[n] = sc;
+            fin.out4[32 + n] = fin.beta[n] - mean * sc;
+            fin.out4[64 + n] = mean;
+            fin.out4[96 + n] = rstd;
+        }
     }
 }
 
@@ -686,8 +728,18 @@ int mm_conv3d_l1_gram(const float* x, float* gram, int B, int D, int H, int W, h
 int mm_conv3d_l1_gram_stats(const float* gram, const void* wimg, const float* bias, float* stats, float* gram_compact,
                             hipStream_t st) {
     MM_REQUIRE(gram && wimg && stats, "conv3d_l1_gram_stats: null");
-    hipLaunchKernelGGL(l1_gram_stats_kernel, dim3(1), dim3(1024), 0, st, gram, (const bf16*)wimg, bias, stats, gram_compact);
+    BnFin fin{};
+    hipLaunchKernelGGL(l1_gram_stats_kernel, dim3(1), dim3(1024), 0, st, gram, (const bf16*)wimg, bias, stats, gram_compact, fin);
     return mm_check_launch("conv3d_l1_gram_stats");
+}
+
+int mm_conv3d_l1_gram_finalize(const float* gram, const void* wimg, const float* bias, const float* gamma, const float* beta,
+                               float* run_mean, float* run_var, float* out4, float* gram_compact, float count,
+                               float momentum, float eps, void* batches_tracked, hipStream_t st) {
+    MM_REQUIRE(gram && wimg && gamma && beta && run_mean && run_var && out4 && count >= 1.f, "conv3d_l1_gram_finalize: null/invalid");
+    BnFin fin{gamma, beta, run_mean, run_var, out4, (long long*)batches_tracked, count, momentum, eps};
+    hipLaunchKernelGGL(l1_gram_stats_kernel, dim3(1), dim3(1024), 0, st, gram, (const bf16*)wimg, bias, nullptr, gram_compact, fin);
+    return mm_check_launch("conv3d_l1_gram_finalize");
 }
 
 static int l1_tapsum_grid(int B, int D, int H, int W) {

@@ -587,6 +587,8 @@ def test_conv3d_l1_gram_matrix_and_the_statistics_derived_from_it(B, D, H, W):
     hip.call("mm_conv3d_l1_gram", x.cuda(), gram, B, D, H, W)
     G = _stat(gram).cpu().double()
     assert torch.equal(G[28:], torch.zeros_like(G[28:])) and torch.equal(G[:, 28:], torch.zeros_like(G[:, 28:]))
+    assert torch.equal(G.tril(-1), torch.zeros_like(G))                         # symmetric: only the upper triangle is accumulated
+    G = G + G.triu(1).t()
     torch.testing.assert_close(G[:28, :28], Gref, rtol=3e-5, atol=3e-5 * float(Gref.abs().max()))
     assert G[27, 27].item() == B * D * H * W
     w = _bf(torch.randn(32, 27, generator=g) * 0.25)
@@ -604,6 +606,22 @@ def test_conv3d_l1_gram_matrix_and_the_statistics_derived_from_it(B, D, H, W):
     torch.testing.assert_close(got, _stat(stats0).cpu().double(), rtol=2e-5, atol=2e-5 * float(want.abs().max()))
     torch.testing.assert_close(gc.cpu().double()[:, :28], G[:28, :28], rtol=1e-6, atol=1e-6 * float(Gref.abs().max()))
     assert torch.equal(gc[:, 28:].cpu(), torch.zeros(28, 4))
+    # the fused form (statistics + BatchNorm finalize in one launch) = mm_conv3d_l1_gram_stats followed by mm_bn_finalize, bit for bit
+    gam, bet = (0.5 + torch.rand(32, generator=g)).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
+    res = []
+    for fused in (False, True):
+        rm, rv = torch.full((32,), 0.25, device="cuda"), torch.full((32,), 1.5, device="cuda")
+        nb = torch.zeros((), dtype=torch.long, device="cuda")
+        out4 = torch.full((4, 32), float("nan"), device="cuda")
+        if fused:
+            hip.call("mm_conv3d_l1_gram_finalize", gram, wimg, bias.cuda(), gam, bet, rm, rv, out4, gc, float(B * D * H * W), 0.1, 1e-5, nb)
+        else:
+            hip.call("mm_bn_finalize", stats, gam, bet, rm, rv, None, out4, 32, float(B * D * H * W), 0.1, 1e-5, 0, nb)
+        res.append((out4.clone(), rm.clone(), rv.clone(), nb.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*res)) and res[1][3].item() == 1
+    mean, var = want[0] / (B * D * H * W), want[1] / (B * D * H * W) - (want[0] / (B * D * H * W)) ** 2
+    torch.testing.assert_close(res[1][0][2].cpu().double(), mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(res[1][0][3].cpu().double(), (var + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("R,S,p,p2", [(32, 512, 0.3, 0.1), (3, 37, 0.0, 0.0)])
