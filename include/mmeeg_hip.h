@@ -341,29 +341,22 @@ int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias
  * rounded, zero-padded volume - what the convolution sees), holds everything the layer needs from the input:
  *   sum_v y_n = w_n . S + M b_n,  sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2   (S[t] = G[t][27], M = G[27][27])
  * and, in the backward, A3[t][n] = sum_v xcol[v][t] xhat[v][n] = rstd_n ((G w_n)[t] + (b_n - mean_n) S[t]).
- * mm_conv3d_l1_gram: gram = ZEROED accumulator workspace [32][32][32] (activation-statistics scale); G is symmetric and
- * only its upper triangle (t <= t') is accumulated.
- * mm_conv3d_l1_gram_stats: -> stats (ZEROED accumulator workspace [32][2][32], replica 0 written: {sum y, sum y^2} of
- * conv + bias, the input of mm_bn_finalize) and gram_compact fp32 [28][32] (nullable; kept for mm_conv3d_l1_bwd). */
-int mm_conv3d_l1_gram(const float* x, float* gram, int B, int D, int H, int W, hipStream_t stream);
- * mm_conv3d_l1_gram_finalize: the same kernel carrying mm_bn_finalize's train-mode step for the layer (same fixed-point
- * sums, same arithmetic: out4 [4][32] = scale, shift (WITHOUT the conv bias: the apply pass adds it), mean, rstd; the
- * running-statistic update with momentum and the unbiased variance; batches_tracked += 1) - one launch instead of two. */
-int mm_conv3d_l1_gram_stats(const float* gram, const void* wimg, const float* bias, float* stats, float* gram_compact,
-                            hipStream_t stream);
-int mm_conv3d_l1_gram_finalize(const float* gram, const void* wimg, const float* bias, const float* gamma,
-                               const float* beta, float* run_mean, float* run_var, float* out4, float* gram_compact,
-                               float count, float momentum, float eps, void* batches_tracked, hipStream_t stream);
-/* Training backward of the same layer in ONE recompute pass (replaces modes 2 + 3): BatchNorm's
- * backward is linear in the two sums S1 = sum dz, S2 = sum dz * xhat, so
- *   dW = scale * (A1 - (S1/M) * S - (S2/M) * A3),  A1 = x^T dz, S and A3 from gram_compact (above).
- * Zeroed accumulator workspaces: sums_out [32][2][32] (also the BatchNorm parameter
- * gradients: dbeta = S1, dgamma = S2), a1 [32][27][32].  dw (PyTorch layout [32][1][3][3][3]) and dbias are ADDED to
- * (dbias only when train == 0; it is identically 0 otherwise).  gram_compact may be NULL when train == 0 (frozen
- * BatchNorm: the two correction terms vanish). */
+ * mm_conv3d_l1_gram: gram = ZEROED accumulator workspace [32][32][32] (activation-statistics scale; G is symmetric and
+ * only its upper triangle t <= t' is accumulated; kept for mm_conv3d_l1_bwd), stats = ZEROED accumulator workspace
+ * [32][2][32] receiving {sum y, sum y^2} of conv + bias - every workgroup adds the sums of its own voxels (they are
+ * linear in G) - i.e. the input of mm_bn_finalize, as after any other convolution.
+ * Training backward in ONE recompute pass (replaces modes 2 + 3): BatchNorm's backward is linear in the two sums
+ * S1 = sum dz, S2 = sum dz * xhat, so
+ *   dW = scale * (A1 - (S1/M) * S - (S2/M) * A3),  A1 = x^T dz, S and A3 from the Gram workspace.
+ * Zeroed accumulator workspaces: sums_out [32][2][32] (also the BatchNorm parameter gradients: dbeta = S1,
+ * dgamma = S2), a1 [32][27][32].  dw (PyTorch layout [32][1][3][3][3]) and dbias are ADDED to (dbias only when
+ * train == 0; it is identically 0 otherwise).  gram may be NULL when train == 0 (frozen BatchNorm: the two correction
+ * terms vanish).  mm_conv3d_l1_tapsum (S alone, by row sums) remains for callers that want it. */
+int mm_conv3d_l1_gram(const float* x, const void* wimg, const float* bias, float* gram, float* stats, int B, int D,
+                      int H, int W, hipStream_t stream);
 int mm_conv3d_l1_tapsum(const float* x, float* tapsum, int B, int D, int H, int W, hipStream_t stream);
 int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
-                     float* sums_out, float* a1, const float* gram_compact, float* dw, float* dbias, int B, int D,
+                     float* sums_out, float* a1, const float* gram, float* dw, float* dbias, int B, int D,
                      int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                      hipStream_t stream);
 /* dst[c][r] += fp32(sum over replicas of src[rep][r][c]); src = gradient accumulator workspace [32][R][C], nrep = 16 */

@@ -11,14 +11,14 @@
 //          32x32 MFMA accumulator per wave for the whole kernel, no epilogue.  Everything the layer needs to know
 //          about the input beyond the convolution itself is in G:
 //            sum_v y_n   = w_n . S + M b_n                       (S[t] = G[t][ones], M = G[ones][ones])
-//            sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2     -> BatchNorm statistics (l1_gram_stats_kernel)
+//            sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2     -> BatchNorm statistics (formed per workgroup: linear in G)
 //            A3[t][n] = sum_v xcol[v][t] xhat[v][n] = rstd_n ((G w_n)[t] + (b_n - mean_n) S[t])   (backward)
 //          It replaces the statistics pass (mode 0: a full recompute with a per-channel epilogue) AND the tap-sum
 //          kernel, and takes the second MFMA product out of the backward.
 //   mode 1 apply        : BN -> GELU -> 2x2x2 max -> dropout -> bf16
 // Training backward (one recompute pass, mode 4): BatchNorm's backward is linear in S1 = sum dz, S2 = sum dz xhat, so
 //   dW = sc (A1 - c0 S - c1 A3),  A1 = x^T dz,  c0 = S1 / M, c1 = S2 / M: the pass yields S1, S2 and A1 (one MFMA
-//   product with the sparse dz fragments), l1_combine_kernel finishes from the compact Gram matrix.
+//   product with the sparse dz fragments), l1_combine_kernel finishes from the Gram workspace.
 // Kept for callers of the C ABI / frozen-weight paths: mode 0 (statistics by recompute), mode 2 (S1, S2 only),
 // mode 3 (two-pass weight gradient), l1_tapsum_kernel.
 //
@@ -371,15 +371,22 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
 // the Gram matrix of the im2col matrix of the zero-padded, bf16-rounded volume.  A wave owns 2 x 8 x 8 voxels per tile
 // = 8 MFMA K-steps of 16 voxels; the A operand (row = tap lr, k = 8 consecutive voxels of one row) and the B operand
 // (k = voxel, column = tap lr) of G += Xcol^T Xcol are the SAME registers.  One accumulator for the whole kernel.
+// Every workgroup also turns ITS partial Gram matrix into partial BatchNorm sums (they are linear in G): 64 fixed-point
+// adds into the ordinary statistics workspace, so that mm_bn_finalize follows as after any other convolution and no
+// kernel has to wait for the whole of G.
 template <bool FULLT>
 __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
     __shared__ __attribute__((aligned(16))) unsigned short halo[2][HSZ];
     __shared__ float gred[4][GN][32];
+    __shared__ float wsh[32][28];
+    __shared__ double part[8][2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int tw = (a.W + 31) / 32, th = (a.H + 7) / 8, td = a.D / 2;
     const int ntiles = a.B * td * th * tw;
     const int my_tap_off = tap_off(lr);
+    for (int i = tid; i < 32 * 27; i += 256)                    // the bf16 weights the convolution multiplies with
+        wsh[i / 27][i % 27] = (float)a.wimg[(i / 27) * 32 + i % 27];
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = 0.f;
@@ -434,80 +441,34 @@ __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
     mm_acc_t* gw = acc_rep(a.gram, blockIdx.x % MM_ACC_REPL, 32 * 32);
     for (int i = tid; i < GN * 32; i += 256) {                    // G is symmetric: the upper triangle only (half the atomics)
         const int m = i >> 5, n = i & 31;
-        if (n < GN && n >= m)
-            acc_add<MM_ACC_STAT>(&gw[m * 32 + n], (gred[0][m][n] + gred[1][m][n]) + (gred[2][m][n] + gred[3][m][n]));
+        const float v = (gred[0][m][n] + gred[1][m][n]) + (gred[2][m][n] + gred[3][m][n]);
+        gred[0][m][n] = v;                                        // this workgroup's partial G, whole (same thread reads and writes)
+        if (n < GN && n >= m) acc_add<MM_ACC_STAT>(&gw[m * 32 + n], v);
     }
-}
-
-// BatchNorm statistics of y = conv + bias from the Gram matrix (one workgroup): stats[n] = sum_v y_n, stats[32 + n] =
-// sum_v y_n^2 as fixed-point accumulators (replica 0 of a zeroed workspace, the form mm_bn_finalize reads), and the
-// compact fp32 matrix gc[GN][32] (rows = taps + ones row, columns 0..27) the backward's combine step uses.
-// With `out4` the kernel also IS the BatchNorm finalize of the layer (mm_bn_finalize's train-mode arithmetic on the same
-// fixed-point sums: mean / rstd, scale, shift, running-statistic update with momentum and the unbiased variance,
-// num_batches_tracked) - one graph node and one dependent launch less per step.
-struct BnFin { const float* gamma; const float* beta; float* run_mean; float* run_var; float* out4; long long* tracked;
-               float count, momentum, eps; };
-__global__ __launch_bounds__(1024) void l1_gram_stats_kernel(const float* __restrict__ gram, const bf16* __restrict__ wimg,
-                                                             const float* __restrict__ bias, float* __restrict__ stats,
-                                                             float* __restrict__ gc, BnFin fin) {
-    __shared__ double G[GN][GN + 1];
-    __shared__ float wsh[32][28];
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
     __syncthreads();
-    if (tid < GN * 32) {
-        const int m = tid >> 5, n = tid & 31;
-        if (n < GN) {
-            const mm_acc_t s = acc_sum(gram, 32 * 32, (size_t)(m < n ? m : n) * 32 + (m < n ? n : m));   // upper triangle stored
-            const float f = acc_val<MM_ACC_STAT>(s);          // NaN when a replica is poisoned / the sum out of range
-            if (f != f) atomicOr(&bad, 1);
-            G[m][n] = (double)s * (1.0 / (double)(1ull << MM_ACC_STAT));
-            if (gc) gc[m * 32 + n] = f;
-        } else if (gc) gc[m * 32 + n] = 0.f;
-    }
-    if (tid < 32 * 27)                                          // the bf16 weights the convolution multiplies with
-        wsh[tid / 27][tid % 27] = (float)wimg[(tid / 27) * 32 + tid % 27];
-    __syncthreads();
-    // thread (n, t) forms row t of w_n^T G w_n in double; the 27 rows of a channel are then summed in a fixed order
-    __shared__ double rowsum[32][28];
-    if (tid < 32 * 27) {
-        const int n = tid / 27, t = tid % 27;
-        double row = 0.0;
-        for (int u = 0; u < 27; ++u) row += G[t][u] * (double)wsh[n][u];
-        rowsum[n][t] = (double)wsh[n][t] * row;
+    // partial sum_v y_n = w_n . S + M b_n and sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2 of this workgroup's voxels:
+    // thread (channel n, row group p) takes rows t = p, p + 8, ... in double
+    {
+        const int n = tid & 31, p = tid >> 5;
+        double q = 0.0, sd = 0.0;
+        for (int t = p; t < 27; t += 8) {
+            double row = 0.0;
+            for (int u = 0; u < 27; ++u) row += (double)gred[0][t][u] * (double)wsh[n][u];
+            q += (double)wsh[n][t] * row;
+            sd += (double)wsh[n][t] * (double)gred[0][t][27];
+        }
+        part[p][0][n] = q; part[p][1][n] = sd;
     }
     __syncthreads();
     if (tid < 32) {
         const int n = tid;
-        const double b = bias ? (double)bias[n] : 0.0, M = G[27][27];
-        double ws = 0.0, wgw = 0.0;
-        for (int t = 0; t < 27; ++t) {
-            ws += (double)wsh[n][t] * G[t][27];
-            wgw += rowsum[n][t];
-        }
-        const double s1 = ws + M * b, s2 = wgw + 2.0 * b * ws + M * b * b;
-        mm_acc_t* out = reinterpret_cast<mm_acc_t*>(stats);     // replica 0 (whole values, one writer: the contract of acc_encode)
-        const double f1 = s1 * (double)(1ull << MM_ACC_STAT), f2 = s2 * (double)(1ull << MM_ACC_STAT), lim = 2305843009213693952.0;   // 2^61
-        const mm_acc_t i1 = (!bad && fabs(f1) < lim) ? (mm_acc_t)llrint(f1) : MM_ACC_POISON;
-        const mm_acc_t i2 = (!bad && fabs(f2) < lim) ? (mm_acc_t)llrint(f2) : MM_ACC_POISON;
-        if (stats) { out[n] = i1; out[32 + n] = i2; }
-        if (fin.out4) {                                         // = bn_finalize_kernel, mode 0, on {i1, i2}
-            if (n == 0 && fin.tracked) fin.tracked[0] += 1;
-            const float v1 = acc_val<MM_ACC_STAT>(i1), v2 = acc_val<MM_ACC_STAT>(i2), count = fin.count;
-            const float mean = v1 / count;
-            float var = v2 / count - mean * mean;
-            var = var < 0.f ? 0.f : var;                        // (not fmaxf: a NaN sum must stay NaN)
-            fin.run_mean[n] = (1.f - fin.momentum) * fin.run_mean[n] + fin.momentum * mean;
-            const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-            fin.run_var[n] = (1.f - fin.momentum) * fin.run_var[n] + fin.momentum * unb;
-            const float rstd = rsqrtf(var + fin.eps);
-            const float sc = fin.gamma[n] * rstd;
-            fin.out4[n] = sc;
-            fin.out4[32 + n] = fin.beta[n] - mean * sc;
-            fin.out4[64 + n] = mean;
-            fin.out4[96 + n] = rstd;
-        }
+        double q = 0.0, sd = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { q += part[p][0][n]; sd += part[p][1][n]; }
+        const double b = a.bias ? (double)a.bias[n] : 0.0, M = (double)gred[0][27][27];
+        mm_acc_t* st = acc_rep(a.stats, blockIdx.x % MM_ACC_REPL, 64);
+        acc_add<MM_ACC_STAT>(st + n, (float)(sd + M * b));
+        acc_add<MM_ACC_STAT>(st + 32 + n, (float)(q + 2.0 * b * sd + M * b * b));
     }
 }
 
@@ -600,26 +561,37 @@ __global__ __launch_bounds__(256) void l1_tapsum_kernel(const float* __restrict_
     }
 }
 
-// dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1, with S[tap] = gc[tap][27] and
-// A3[tap][n] = rstd_n ((G w_n)[tap] + (b_n - mean_n) S[tap]) from the compact Gram matrix gc (l1_gram_stats_kernel);
-// a1 / sums: fixed-point accumulators x MM_ACC_REPL.  gc may be null when train == 0 (c0 = c1 = 0: frozen BatchNorm).
-__global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __restrict__ gc, const bf16* __restrict__ wimg,
+// dW[n][tap] += sc (A1 - c0 S - c1 A3);  dbias[n] += train ? 0 : sc S1, with S[tap] = G[tap][27] and
+// A3[tap][n] = rstd_n ((G w_n)[tap] + (b_n - mean_n) S[tap]) from the Gram accumulator workspace of the forward pass
+// (upper triangle, MM_ACC_REPL replicas); a1 / sums: fixed-point accumulators x MM_ACC_REPL.  One output per 16 lanes,
+// one REPLICA per lane: lane r forms its replica's share of (G w_n)[tap] and S[tap] in double (27 independent loads), the
+// 16 shares are summed by a fixed butterfly.  gram may be null when train == 0 (c0 = c1 = 0: frozen BatchNorm).
+__global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __restrict__ gram, const bf16* __restrict__ wimg,
                                   const float* __restrict__ bias, const float* __restrict__ sums, const float* __restrict__ out4,
                                   float* __restrict__ dw, float* __restrict__ dbias, float inv_count, int train) {
-    // one output per 16 lanes, one replica per lane: a single load round trip + (integer) shuffle sums
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, r = threadIdx.x & 15;
     if (i >= 32 * 27) return;
     const int n = i / 27, tap = i % 27;
     const mm_acc_t *q1 = reinterpret_cast<const mm_acc_t*>(a1), *qs = reinterpret_cast<const mm_acc_t*>(sums);
     mm_acc_t iA1 = q1[(size_t)r * 864 + tap * 32 + n], is0 = qs[r * 64 + n], is1 = qs[r * 64 + 32 + n];
-    // (G w_n)[tap]: 27 products, two per lane over the 16 lanes, summed in a fixed (butterfly) order
-    float gw = 0.f;
+    double gw = 0.0, St = 0.0;
+    unsigned bad = 0;
     if (train) {
-        const int u0 = r, u1 = r + 16;
-        gw = gc[tap * 32 + u0] * (float)wimg[n * 32 + u0];
-        if (u1 < 27) gw += gc[tap * 32 + u1] * (float)wimg[n * 32 + u1];
+        const mm_acc_t* gr = reinterpret_cast<const mm_acc_t*>(gram) + (size_t)r * 1024;
+        mm_acc_t v[28];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) gw += __shfl_xor(gw, o, 64);
+        for (int u = 0; u < 28; ++u) v[u] = gr[(u < tap ? u : tap) * 32 + (u < tap ? tap : u)];      // symmetric: upper triangle stored
+#pragma unroll
+        for (int u = 0; u < 28; ++u) bad |= (unsigned long long)(v[u] + (1ll << 61)) >= (1ull << 62) ? 1u : 0u;   // poisoned replica
+#pragma unroll
+        for (int u = 0; u < 27; ++u) gw += (double)v[u] * (double)(float)wimg[n * 32 + u];
+        St = (double)v[27];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            gw += __shfl_xor(gw, o, 64); St += __shfl_xor(St, o, 64); bad |= __shfl_xor(bad, o, 64);
+        }
+        const double k = 1.0 / (double)(1ull << MM_ACC_STAT);
+        gw *= k; St *= k;
     }
     iA1 = acc_sum_lanes16(iA1); is0 = acc_sum_lanes16(is0); is1 = acc_sum_lanes16(is1);
     if (r) return;
@@ -628,9 +600,10 @@ __global__ void l1_combine_kernel(const float* __restrict__ a1, const float* __r
     const float sc = out4[n], mu = out4[64 + n], rs = out4[96 + n];
     float corr = 0.f;
     if (train) {
-        const float St = gc[tap * 32 + 27], b = bias ? bias[n] : 0.f;
-        const float A3 = rs * (gw + (b - mu) * St);
-        corr = s0 * inv_count * St + s1 * inv_count * A3;
+        const float b = bias ? bias[n] : 0.f;
+        const float Stf = bad ? __builtin_nanf("") : (float)St;
+        const float A3 = rs * ((float)gw + (b - mu) * Stf);
+        corr = s0 * inv_count * Stf + s1 * inv_count * A3;
     }
     dw[i] += sc * (A1 - corr);
     if (tap == 0 && dbias && !train) dbias[n] += sc * s0;      // train: sum dy == 0 identically
@@ -713,33 +686,17 @@ int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias
     return mm_check_launch("conv3d_l1_fwd_winners");
 }
 
-int mm_conv3d_l1_gram(const float* x, float* gram, int B, int D, int H, int W, hipStream_t st) {
-    MM_REQUIRE(x && gram && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_gram: null/invalid");
+int mm_conv3d_l1_gram(const float* x, const void* wimg, const float* bias, float* gram, float* stats, int B, int D, int H,
+                      int W, hipStream_t st) {
+    MM_REQUIRE(x && wimg && gram && stats && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_gram: null/invalid");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_gram: D,H,W must be even (MaxPool3d(2))");
     L1Args a;
-    l1_fill(a, x, nullptr, nullptr, nullptr, B, D, H, W, 1, 0.f, 0, nullptr);
-    a.gram = gram;
+    l1_fill(a, x, wimg, bias, nullptr, B, D, H, W, 1, 0.f, 0, nullptr);
+    a.gram = gram; a.stats = stats;
     const int grid = l1_grid(l1_tiles(B, D, H, W), 3);
     if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((l1_gram_kernel<true>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((l1_gram_kernel<false>), dim3(grid), dim3(256), 0, st, a);
     return mm_check_launch("conv3d_l1_gram");
-}
-
-int mm_conv3d_l1_gram_stats(const float* gram, const void* wimg, const float* bias, float* stats, float* gram_compact,
-                            hipStream_t st) {
-    MM_REQUIRE(gram && wimg && stats, "conv3d_l1_gram_stats: null");
-    BnFin fin{};
-    hipLaunchKernelGGL(l1_gram_stats_kernel, dim3(1), dim3(1024), 0, st, gram, (const bf16*)wimg, bias, stats, gram_compact, fin);
-    return mm_check_launch("conv3d_l1_gram_stats");
-}
-
-int mm_conv3d_l1_gram_finalize(const float* gram, const void* wimg, const float* bias, const float* gamma, const float* beta,
-                               float* run_mean, float* run_var, float* out4, float* gram_compact, float count,
-                               float momentum, float eps, void* batches_tracked, hipStream_t st) {
-    MM_REQUIRE(gram && wimg && gamma && beta && run_mean && run_var && out4 && count >= 1.f, "conv3d_l1_gram_finalize: null/invalid");
-    BnFin fin{gamma, beta, run_mean, run_var, out4, (long long*)batches_tracked, count, momentum, eps};
-    hipLaunchKernelGGL(l1_gram_stats_kernel, dim3(1), dim3(1024), 0, st, gram, (const bf16*)wimg, bias, nullptr, gram_compact, fin);
-    return mm_check_launch("conv3d_l1_gram_finalize");
 }
 
 static int l1_tapsum_grid(int B, int D, int H, int W) {
@@ -756,11 +713,11 @@ int mm_conv3d_l1_tapsum(const float* x, float* tapsum, int B, int D, int H, int 
 }
 
 int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const float* out4, const void* dout,
-                     float* sums_out, float* a1, const float* gram_compact, float* dw, float* dbias, int B,
+                     float* sums_out, float* a1, const float* gram, float* dw, float* dbias, int B,
                      int D, int H, int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
                      hipStream_t st) {
     MM_REQUIRE(x && wimg && out4 && dout && sums_out && a1 && dw && B > 0, "conv3d_l1_bwd: null/invalid");
-    MM_REQUIRE(!train || gram_compact, "conv3d_l1_bwd: train-mode BatchNorm needs the compact Gram matrix of the forward pass");
+    MM_REQUIRE(!train || gram, "conv3d_l1_bwd: train-mode BatchNorm needs the Gram workspace of the forward pass");
     MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_bwd: D,H,W must be even (MaxPool3d(2))");
     MM_REQUIRE(l1_fits(B, D, H, W), "conv3d_l1_bwd: more than 2^31 pooled output elements");
     L1Args a;
@@ -769,7 +726,7 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
     const int grid = l1_grid(l1_tiles(B, D, H, W), 2);
     if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3d_l1_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 16, 256)), dim3(256), 0, st, a1, gram_compact,
+    hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 16, 256)), dim3(256), 0, st, a1, gram,
                        (const bf16*)wimg, bias, sums_out, out4, dw, dbias, a.inv_count, train);
     return mm_check_launch("conv3d_l1_bwd");
 }

@@ -754,14 +754,12 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     gramc = None
     if training:
         # BatchNorm statistics from the Gram matrix of the im2col matrix (no per-channel pass over the convolution):
-        # csrc/conv3d_l1.hip.  The compact matrix is kept: the backward's weight-gradient correction terms come from it.
+        # csrc/conv3d_l1.hip.  The workspace is kept: the backward's weight-gradient correction terms come from it.
         gram = _zeros((REPL, 32, 32), x)
-        _hip.call("mm_conv3d_l1_gram", x, gram, B, D, H, W)
-        gramc = _empty((28, 32), _F32, x)
-        out4 = _empty((4, 32), _F32, x)
-        mom = 0.1 if bn.momentum is None else float(bn.momentum)
-        _hip.call("mm_conv3d_l1_gram_finalize", gram, wimg, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                  out4, gramc, float(B * D * H * W), mom, float(bn.eps), bn.num_batches_tracked)
+        stats = _zeros((REPL, 2, 32), x)
+        _hip.call("mm_conv3d_l1_gram", x, wimg, conv.bias, gram, stats, B, D, H, W)
+        gramc = gram                                   # (the accumulator workspace itself: the backward's combine step reads it)
+        out4 = bn_finalize_train(bn, stats, B * D * H * W)
         bias = conv.bias
     elif save:
         out4 = bn_fold_eval(bn, None)                  # the backward recomputes conv + bias and needs mean / rstd apart

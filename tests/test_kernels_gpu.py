@@ -573,9 +573,9 @@ def test_conv3d_l1_tap_sums(B, D, H, W):
 def test_conv3d_l1_gram_matrix_and_the_statistics_derived_from_it(B, D, H, W):
     """csrc/conv3d_l1.hip, training forward of the first voxel layer: G = Xcol^T Xcol (27 taps + a column of ones) of the
     zero-padded, bf16-rounded volume against the same matrix formed in fp64 on the CPU (full tiles, ragged H and W tiles,
-    the C2 size); BatchNorm statistics derived from G (mm_conv3d_l1_gram_stats: sum y = w . S + M b, sum y^2 =
+    the C2 size); the BatchNorm sums every workgroup derives from its share of G (sum y = w . S + M b, sum y^2 =
     w^T G w + 2 b w . S + M b^2) against (a) the recompute pass of the same library (mm_conv3d_l1 mode 0) and (b)
-    F.conv3d in fp64; the compact matrix handed to the backward = G in fp32."""
+    F.conv3d in fp64."""
     hip = _hip()
     g = torch.Generator().manual_seed(B * 100 + W)
     x = torch.randn(B, D, H, W, generator=g) + 0.3
@@ -583,20 +583,18 @@ def test_conv3d_l1_gram_matrix_and_the_statistics_derived_from_it(B, D, H, W):
     cols = [xp[:, kd:kd + D, kh:kh + H, kw:kw + W].reshape(-1) for kd in range(3) for kh in range(3) for kw in range(3)]
     cols = torch.stack(cols + [torch.ones_like(cols[0])])                         # (28, M)
     Gref = cols @ cols.t()
+    w = _bf(torch.randn(32, 27, generator=g) * 0.25)
+    bias = torch.randn(32, generator=g) * 0.2
+    wimg, _ = _prep_w(hip, w.reshape(32, 27, 1), 32)
     gram = torch.zeros(32, 32, 32, device="cuda")
-    hip.call("mm_conv3d_l1_gram", x.cuda(), gram, B, D, H, W)
+    stats = torch.zeros(32, 2, 32, device="cuda")
+    hip.call("mm_conv3d_l1_gram", x.cuda(), wimg, bias.cuda(), gram, stats, B, D, H, W)
     G = _stat(gram).cpu().double()
     assert torch.equal(G[28:], torch.zeros_like(G[28:])) and torch.equal(G[:, 28:], torch.zeros_like(G[:, 28:]))
     assert torch.equal(G.tril(-1), torch.zeros_like(G))                         # symmetric: only the upper triangle is accumulated
     G = G + G.triu(1).t()
     torch.testing.assert_close(G[:28, :28], Gref, rtol=3e-5, atol=3e-5 * float(Gref.abs().max()))
     assert G[27, 27].item() == B * D * H * W
-    w = _bf(torch.randn(32, 27, generator=g) * 0.25)
-    bias = torch.randn(32, generator=g) * 0.2
-    wimg, _ = _prep_w(hip, w.reshape(32, 27, 1), 32)
-    stats = torch.zeros(32, 2, 32, device="cuda")
-    gc = torch.full((28, 32), float("nan"), device="cuda")
-    hip.call("mm_conv3d_l1_gram_stats", gram, wimg, bias.cuda(), stats, gc)
     got = _stat(stats).cpu().double()
     y = F.conv3d(_bf(x).double().unsqueeze(1), w.double().view(32, 1, 3, 3, 3), bias.double(), padding=1)
     want = torch.stack([y.sum(dim=(0, 2, 3, 4)), (y * y).sum(dim=(0, 2, 3, 4))])
@@ -604,24 +602,6 @@ def test_conv3d_l1_gram_matrix_and_the_statistics_derived_from_it(B, D, H, W):
     stats0 = torch.zeros(32, 2, 32, device="cuda")
     hip.call("mm_conv3d_l1", 0, x.cuda(), wimg, bias.cuda(), None, None, None, stats0, None, None, None, B, D, H, W, 1, 0.0, 0, None)
     torch.testing.assert_close(got, _stat(stats0).cpu().double(), rtol=2e-5, atol=2e-5 * float(want.abs().max()))
-    torch.testing.assert_close(gc.cpu().double()[:, :28], G[:28, :28], rtol=1e-6, atol=1e-6 * float(Gref.abs().max()))
-    assert torch.equal(gc[:, 28:].cpu(), torch.zeros(28, 4))
-    # the fused form (statistics + BatchNorm finalize in one launch) = mm_conv3d_l1_gram_stats followed by mm_bn_finalize, bit for bit
-    gam, bet = (0.5 + torch.rand(32, generator=g)).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
-    res = []
-    for fused in (False, True):
-        rm, rv = torch.full((32,), 0.25, device="cuda"), torch.full((32,), 1.5, device="cuda")
-        nb = torch.zeros((), dtype=torch.long, device="cuda")
-        out4 = torch.full((4, 32), float("nan"), device="cuda")
-        if fused:
-            hip.call("mm_conv3d_l1_gram_finalize", gram, wimg, bias.cuda(), gam, bet, rm, rv, out4, gc, float(B * D * H * W), 0.1, 1e-5, nb)
-        else:
-            hip.call("mm_bn_finalize", stats, gam, bet, rm, rv, None, out4, 32, float(B * D * H * W), 0.1, 1e-5, 0, nb)
-        res.append((out4.clone(), rm.clone(), rv.clone(), nb.clone()))
-    assert all(torch.equal(a, b) for a, b in zip(*res)) and res[1][3].item() == 1
-    mean, var = want[0] / (B * D * H * W), want[1] / (B * D * H * W) - (want[0] / (B * D * H * W)) ** 2
-    torch.testing.assert_close(res[1][0][2].cpu().double(), mean, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(res[1][0][3].cpu().double(), (var + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("R,S,p,p2", [(32, 512, 0.3, 0.1), (3, 37, 0.0, 0.0)])

@@ -308,12 +308,12 @@ def l1_case(B=32, D=32, H=32, W=32, p=0.3):
     stats = torch.zeros(32, 2, 32, device="cuda")
     dout = torch.randn(out.shape, device="cuda").to(BF)
     sums, a1 = torch.zeros(32, 2, 32, device="cuda"), torch.zeros(32, 27, 32, device="cuda")
-    gram, gramc = torch.zeros(32, 32, 32, device="cuda"), s["gramc"]
+    gram = torch.zeros(32, 32, 32, device="cuda")
+    gramc = s["gramc"].clone()
     tapsum = torch.zeros(32, 32, device="cuda")
     dw, db = torch.zeros(32, 1, 3, 3, 3, device="cuda"), torch.zeros(32, device="cuda")
     fl = 2.0 * 27 * 32 * B * D * H * W
-    tg = timeit(lambda: _hip.call("mm_conv3d_l1_gram", x, gram, B, D, H, W))
-    tgs = timeit(lambda: _hip.call("mm_conv3d_l1_gram_stats", gram, wimg, conv.bias, stats, gramc))
+    tg = timeit(lambda: _hip.call("mm_conv3d_l1_gram", x, wimg, conv.bias, gram, stats, B, D, H, W))
     t0 = timeit(lambda: _hip.call("mm_conv3d_l1", 0, x, wimg, conv.bias, None, None, None, stats, None, None, None,
                                   B, D, H, W, 1, 0.0, 0, None))
     t1 = timeit(lambda: _hip.call("mm_conv3d_l1", 1, x, wimg, conv.bias, out4, None, None, None, out, None, None,
@@ -322,7 +322,7 @@ def l1_case(B=32, D=32, H=32, W=32, p=0.3):
                                   B, D, H, W, 1, float(p), 123, None))
     tt = timeit(lambda: _hip.call("mm_conv3d_l1_tapsum", x, tapsum, B, D, H, W))
     inb, outb = x.numel() * 4, out.numel() * 2
-    for name, t, byts in (("Gram matrix (training stats)", tg, inb), ("stats from Gram (1 workgroup)", tgs, 0),
+    for name, t, byts in (("Gram matrix + BatchNorm sums", tg, inb),
                           ("stats by recompute (mode 0, ABI)", t0, inb), ("forward (mode 1)", t1, inb + outb),
                           ("backward (mode 4 + combine)", t4, inb + outb), ("tap sums (ABI)", tt, inb)):
         print(f"conv3d_l1 {name:34s} B={B} {D}x{H}x{W}: {t:7.1f} us  {fl / t / 1e6:6.1f} TF/s (of 157 fp32 / 2500 bf16)  "
