@@ -23,13 +23,22 @@
 // mode 3 (two-pass weight gradient), l1_tapsum_kernel.
 //
 // One wave owns a 2 x 8 x 8 block of conv outputs (= 1 x 4 x 4 pooled voxels) x 32 channels: all 8 members of
-// every pooling window sit in the same lane.  A workgroup (4 waves) walks tiles of 2 x 8 x 32 voxels persistently;
-// the halo of tile i + 1 is fetched into registers while tile i is computed and parked in the other half of a
-// double-buffered LDS halo (one barrier per tile); the per-thread halo addressing (6 elements) is computed once
-// per kernel, not per tile (it was ~250 of mode 1's ~860 VALU instructions per tile).
+// every pooling window sit in the same lane.  A workgroup (4 waves) walks tiles of 2 x 8 x 32 voxels persistently
+// through a double-buffered LDS halo (one barrier per tile); the per-thread halo addressing (6 elements) is computed
+// once per kernel, not per tile (it was ~250 of mode 1's ~860 VALU instructions per tile).  Fetching the halo of tile
+// i + 1 into registers during tile i was measured and is off: two other workgroups per CU already cover the load.
 // GELU is evaluated once per window when max(z) >= 0 (GELU is monotone on [-0.7518, inf) and negative left of 0,
 // so the window max is GELU(max z)); otherwise at the largest and the smallest member.  Both branches are exact.
 #include "common.h"
+
+// ablation builds (tools/abl_stream.sh with ABL_FILE=conv3d_l1 ABL_MACRO=L1_ABL; product = 0; profiles/r04_l1_ablation.txt):
+// 1 wave-uniform branch (ballot) in front of the all-negative-window path, 2 fmaxf / fminf trees instead of v_max3 / v_min3,
+// 4 dz fragments built member by member, 8 halo of tile i + 1 prefetched into registers during tile i.
+// Measured on one box, alternating: 1 and 8 make the backward 0.7 / 1.5 us SLOWER (and are off), 2 and 4 are what the
+// product does NOT do (they cost 0.3 / 1.3 us).
+#ifndef L1_ABL
+#define L1_ABL 0
+#endif
 
 namespace {
 
@@ -75,8 +84,14 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ float max8f(const float (&z)[8]) { return max3f(max3f(z[0], z[1], z[2]), max3f(z[3], z[4], z[5]), max3f(z[6], z[7], z[7])); }
-__device__ __forceinline__ float min8f(const float (&z)[8]) { return min3f(min3f(z[0], z[1], z[2]), min3f(z[3], z[4], z[5]), min3f(z[6], z[7], z[7])); }
+__device__ __forceinline__ float max8f(const float (&z)[8]) {
+    if (L1_ABL & 2) return fmaxf(fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3])), fmaxf(fmaxf(z[4], z[5]), fmaxf(z[6], z[7])));
+    return max3f(max3f(z[0], z[1], z[2]), max3f(z[3], z[4], z[5]), max3f(z[6], z[7], z[7]));
+}
+__device__ __forceinline__ float min8f(const float (&z)[8]) {
+    if (L1_ABL & 2) return fminf(fminf(fminf(z[0], z[1]), fminf(z[2], z[3])), fminf(fminf(z[4], z[5]), fminf(z[6], z[7])));
+    return min3f(min3f(z[0], z[1], z[2]), min3f(z[3], z[4], z[5]), min3f(z[6], z[7], z[7]));
+}
 
 // ---- halo staging: the (2+2) x (8+2) x (32+2) input block of a tile, bf16, zero outside the volume -----------------
 // per-thread plan, computed once: element i = tid + 256 q -> offset relative to the tile's first voxel and a packed
@@ -179,9 +194,10 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
         const TileCoord tc = tile_coord(tile, tw, th, td);
         const int b = tc.b, d0 = tc.d0, h0 = tc.h0, w0 = tc.w0;
         unsigned short* hb = halo[buf];
+        if (!(L1_ABL & 8) && tile != (int)blockIdx.x) halo_load(hv, tile_ptr(a.x, tc, a.D, a.H, a.W), plan, d0, h0, w0, a.D, a.H, a.W);
         halo_store(hb, plan, hv);
         __syncthreads();                                    // (the other buffer's readers passed the previous barrier)
-        if (tile + (int)gridDim.x < ntiles) {               // next tile's halo: in flight during this tile's compute
+        if ((L1_ABL & 8) && tile + (int)gridDim.x < ntiles) {    // ablation: next tile's halo in flight during this tile's compute
             const TileCoord c = tile_coord(tile + gridDim.x, tw, th, td);
             halo_load(hv, tile_ptr(a.x, c, a.D, a.H, a.W), plan, c.d0, c.h0, c.w0, a.D, a.H, a.W);
         }
@@ -244,11 +260,11 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
                     // for unit-normal pre-activations) needs the two evaluations - the backward modes then evaluate none
                     // to find the winner, the forward one.
                     // The winner is the FIRST member that equals the extreme value (as PyTorch's max-pool).
-                    // The all-negative case sits behind a WAVE-UNIFORM branch (no lane of the wave in ~78 % of the windows): as
-                    // a per-lane condition the compiler predicated it, i.e. ran the minimum tree and the second GELU always.
+                    // (A wave-uniform branch in front of the all-negative case - no lane of the wave in ~78 % of the windows -
+                    // measured 0.7 us slower than letting the compiler predicate it: L1_ABL bit 1.)
                     float zsel = max8f(z);
                     float best = MODE == 1 ? gelu_erf(zsel) : 0.f;
-                    if (__builtin_amdgcn_ballot_w64(zsel < 0.f) != 0) {
+                    if (!(L1_ABL & 1) || __builtin_amdgcn_ballot_w64(zsel < 0.f) != 0) {
                         if (zsel < 0.f) {
                             const float zmin = min8f(z);
                             if (MODE != 1) best = gelu_erf(zsel);
@@ -292,11 +308,19 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
                         // the window's 8 members are 4 packed bf16 pairs of the dz fragments - (dd, hh) -> register rb + 2 hh
                         // of fragment [dd][ra], low / high half = ww - and exactly one member is non-zero (a window that
                         // is not in the volume has g = 0): one converted value, shifted to its half, selected into its pair
-                        const bf16 db = (bf16)dzs;
-                        const uint32_t pairval = (uint32_t)(*reinterpret_cast<const unsigned short*>(&db)) << ((js & 1) << 4);
-                        const int jp = js >> 1;
+                        if (L1_ABL & 4) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) dyf[k >> 1][ra].u[rb + 2 * (k & 1)] = jp == k ? pairval : 0u;
+                            for (int j = 0; j < 8; ++j) {
+                                const int ti = ip + 2 * (j >> 2), r = r0 + 4 * ((j >> 1) & 1) + (j & 1);
+                                dyf[ti >> 1][r >> 3].v[r & 7] = (bf16)(js == j ? dzs : 0.f);
+                            }
+                        } else {
+                            const bf16 db = (bf16)dzs;
+                            const uint32_t pairval = (uint32_t)(*reinterpret_cast<const unsigned short*>(&db)) << ((js & 1) << 4);
+                            const int jp = js >> 1;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) dyf[k >> 1][ra].u[rb + 2 * (k & 1)] = jp == k ? pairval : 0u;
+                        }
                     } else if (MODE == 3) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -402,9 +426,10 @@ __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const TileCoord tc = tile_coord(tile, tw, th, td);
         unsigned short* hb = halo[buf];
+        if (!(L1_ABL & 8) && tile != (int)blockIdx.x) halo_load(hv, tile_ptr(a.x, tc, a.D, a.H, a.W), plan, tc.d0, tc.h0, tc.w0, a.D, a.H, a.W);
         halo_store(hb, plan, hv);
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) {
+        if ((L1_ABL & 8) && tile + (int)gridDim.x < ntiles) {
             const TileCoord c = tile_coord(tile + gridDim.x, tw, th, td);
             halo_load(hv, tile_ptr(a.x, c, a.D, a.H, a.W), plan, c.d0, c.h0, c.w0, a.D, a.H, a.W);
         }

@@ -12,7 +12,7 @@ mkdir -p "$here/build"
 for n in "$@"; do
   extra=""
   if [[ "$n" == s* ]]; then extra="-DSTREAM_STAMPS"; n="${n#s}"; fi
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -D$macro=$n $extra -I"$here" -I"$here/../../include" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize -D$macro=$n $extra -I"$here" -I"$here/../../include" \
       -c "$here/$file.hip" -o "$here/build/${file}_sabl$n$extra.o" 2>/dev/null
   objs=()
   for o in "$here"/build/*.o; do
