@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
 template <bool FULLT>
 __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
     __shared__ __attribute__((aligned(16))) unsigned short halo[2][HSZ];
-    __shared__ float gred[4][GN][32];
+    __shared__ __attribute__((aligned(16))) float gred[4][GN][32];
     __shared__ float wsh[32][28];
     __shared__ double part[8][2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -472,15 +472,28 @@ __global__ __launch_bounds__(256, 3) void l1_gram_kernel(L1Args a) {
     }
     __syncthreads();
     // partial sum_v y_n = w_n . S + M b_n and sum_v y_n^2 = w_n^T G w_n + 2 b_n w_n . S + M b_n^2 of this workgroup's voxels:
-    // thread (channel n, row group p) takes rows t = p, p + 8, ... in double
+    // thread (channel n, row group p) takes rows t = p, p + 8, ...; its channel's 27 weights sit in registers and a row of
+    // G is read as seven float4 (every lane of a row group reads the same addresses: LDS broadcasts).  fp32 products,
+    // summed per row in fp32 and across rows / groups / workgroups in double / fixed point.
     {
         const int n = tid & 31, p = tid >> 5;
+        float w[28];
+#pragma unroll
+        for (int u = 0; u < 27; ++u) w[u] = wsh[n][u];
+        w[27] = 0.f;
         double q = 0.0, sd = 0.0;
         for (int t = p; t < 27; t += 8) {
-            double row = 0.0;
-            for (int u = 0; u < 27; ++u) row += (double)gred[0][t][u] * (double)wsh[n][u];
-            q += (double)wsh[n][t] * row;
-            sd += (double)wsh[n][t] * (double)gred[0][t][27];
+            const float4* grow = reinterpret_cast<const float4*>(&gred[0][t][0]);
+            float row = 0.f;
+#pragma unroll
+            for (int u4 = 0; u4 < 7; ++u4) {
+                const float4 gv = grow[u4];
+                row = fmaf(gv.x, w[4 * u4], row); row = fmaf(gv.y, w[4 * u4 + 1], row);
+                row = fmaf(gv.z, w[4 * u4 + 2], row); row = fmaf(gv.w, w[4 * u4 + 3], row);      // (u = 27: w = 0)
+            }
+            const float wt = wsh[n][t];
+            q += (double)(wt * row);
+            sd += (double)(wt * gred[0][t][27]);
         }
         part[p][0][n] = q; part[p][1][n] = sd;
     }

@@ -401,6 +401,40 @@ def test_fused_launches_train_exactly_as_their_separate_forms(monkeypatch):
     assert ((p3 - p0).norm() / p0.norm()).item() < 2e-3
 
 
+def test_packed_host_batch_step_is_bit_identical_to_the_device_side_pack():
+    """the host-fed path: BridgeTrainer.pack_host_batch (CPU: EEG epochs into the first convolution's bf16 channels-last
+    operand, round-to-nearest-even, + fp32 volumes, ONE flat buffer) followed by train_step_packed (one D2D copy into the
+    step's static inputs + replay) trains BIT-identically to train_step on the fp32 device tensors (mm_stage_inputs packs on
+    the device), dropout on; a buffer of the wrong size is refused."""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    from multimodal_eeg_fmri_amd import ops
+    batches = [synthetic_pairs(8, 16, 256, (16, 16, 16), seed=700 + i) for i in range(3)]
+
+    def run(packed):
+        ops.set_seed_epoch(None)
+        ops.set_dropout_seed(77)
+        torch.manual_seed(0)
+        tr = BridgeTrainer(eeg_channels=16, dropout=0.2, lr=1e-3).train()
+        losses = [tr.train_step(*batches[0])["loss"].clone()]          # captures; fixes the shapes
+        for i in range(1, 6):
+            e, f = batches[i % 3]
+            if packed:
+                host = tr.pack_host_batch(e, f)
+                assert host.is_pinned() and host.dtype == torch.uint8 and host.numel() == 8 * 256 * 16 * 2 + 8 * 16 ** 3 * 4
+                losses.append(tr.train_step_packed(host.cuda(non_blocking=True))["loss"].clone())
+            else:
+                losses.append(tr.train_step(e, f)["loss"].clone())
+        torch.cuda.synchronize()
+        p = tr.bucket.p.detach().clone()
+        ops.set_seed_epoch(None)
+        return torch.stack(losses), p, tr
+    l0, p0, _ = run(False)
+    l1, p1, tr = run(True)
+    assert torch.isfinite(l0).all() and torch.equal(l0, l1) and torch.equal(p0, p1)
+    with pytest.raises(ValueError):
+        tr.train_step_packed(torch.zeros(100, dtype=torch.uint8, device="cuda"))
+
+
 def test_graph_mode_draws_new_dropout_masks_each_replay():
     from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
     from multimodal_eeg_fmri_amd import ops
