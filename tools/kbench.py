@@ -95,6 +95,34 @@ def conv3d_dims_case(B, D, H, W, Cin, Cout, dgrad=False):
           f"({fl / us / 1e6 / 2500:.3f} of 2.5 PF; graph-replayed)")
 
 
+def wres_sustained_case(B, D, H, W, launches=400):
+    """the roofline kernel (layer 2, 32 -> 64 channels) as `launches` back-to-back eager launches with no host
+    synchronisation in between - sustained clocks, the condition bench.py's roofline_c2_standalone / roofline_c4 time it
+    under; run under `rocprofv3 --kernel-trace --stats` for the per-launch mean the bench line must agree with"""
+    Cin, Cout = 32, 64
+    x = torch.randn(B, D, H, W, Cin, device="cuda").to(BF)
+    w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
+    wf = torch.empty(Cout, 27, Cin, dtype=BF, device="cuda")
+    _hip.call("mm_prep_conv_weight", w.contiguous(), wf, None, Cout, Cin, 27, Cin, 0)
+    of = torch.empty(B, D, H, W, Cout, device="cuda", dtype=BF)
+    stats = torch.zeros(32, 2, Cout, device="cuda")
+    b = torch.randn(Cout, device="cuda")
+    for _ in range(10):
+        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, b, stats, None, of)
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(4.0e6))
+    a.record()
+    for _ in range(launches):
+        _hip.call("mm_conv3d_fwd", x, wf, B, D, H, W, Cin, Cout, b, stats, None, of)
+    e.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(e) / launches * 1e3
+    fl = 2.0 * B * D * H * W * Cin * Cout * 27
+    print(f"conv3d_wres sustained B={B} {D}x{H}x{W}: {launches} launches, {us:8.2f} us each  {fl / us / 1e6:8.1f} TF/s "
+          f"({fl / us / 1e6 / 2500:.3f} of 2.5 PF; HIP events, gaps included)")
+
+
 def conv3d_case(B, S, Cin, Cout, wgrad=True, fwd=True):
     x = torch.randn(B, S, S, S, Cin, device="cuda").to(BF)
     w = torch.randn(Cout, Cin, 27, device="cuda") / math.sqrt(Cin * 27)
@@ -333,6 +361,12 @@ def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     if flt in ("l1", "pmcl1"):
         l1_case()
+        return
+    if flt == "sus4":
+        wres_sustained_case(32, 32, 32, 24)
+        return
+    if flt == "sus2":
+        wres_sustained_case(32, 16, 16, 16, launches=1200)
         return
     if "floor" in flt:
         floor_case()
