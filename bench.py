@@ -508,7 +508,9 @@ def main():
     if not args.profile:
         gc.collect()                                    # (before the warm-up: no host stall between warm-up and timed loop)
         gc.disable()
-        h2d = host_fed_loop(tr, dev_batches, args.steps, max(6, min(args.warmup, 20)), sync)
+        # its own conditioning: building the pinned buffers leaves the GPU idle for tens of milliseconds, and a chip that has
+        # idled runs its next steps slower (see above) - with --steps 20 that was the whole timed region
+        h2d = host_fed_loop(tr, dev_batches, args.steps, max(60, args.warmup), sync)
         gc.enable()
         h2d["seconds"] = max_over_ranks(h2d["seconds"])
     eeg, fmri = dev_batches[0]
@@ -616,6 +618,11 @@ def main():
                      "note": "measured inside the training step (other stream busy), uncorrected event bracket; stand-alone and "
                              "config-#4 figures: roofline_c2_standalone / roofline_c4"},
     }
+    prof1, prof1_src = profile_family_us(VOL)
+    if prof1:
+        # the same kernel's mean duration inside the replayed step under rocprofv3 --kernel-trace (committed table)
+        line["roofline"]["profile_in_step"] = {"source": prof1_src, "avg_launch_us": prof1["L2 fwd"],
+                                               "frac": flops / (prof1["L2 fwd"] * 1e-6) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
     if fam_ms and all(fam_ms.values()):
         tot_fl, tot_ms = sum(fam_fl.values()), sum(fam_ms.values())
         prof, prof_src = profile_family_us(VOL)
