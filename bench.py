@@ -84,8 +84,8 @@ CONFIGS = {
                         "EnhancedPowerEncoder + 32^3 fMRI (3-D conv encoder) + projection bridge + InfoNCE, fwd+bwd+clip+AdamW"),
 }
 
-PMC_SUMMARY = "profiles/r03_pmc_wres_c2.summary.txt"
-PMC_SUMMARY_C4 = "profiles/r03_pmc_wres_c4.summary.txt"
+PMC_SUMMARY = "profiles/r04_pmc_wres_c2.summary.txt"
+PMC_SUMMARY_C4 = "profiles/r04_pmc_wres_c4.summary.txt"
 # rocprofv3 --kernel-trace of this command (profiles/run_prof.sh): per-kernel mean durations inside the replayed step
 PROFILE_STEP_SUMMARIES = ("profiles/r04_step_kernel_summary.txt", "profiles/r03_step_kernel_summary.txt")
 
