@@ -141,6 +141,34 @@ int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t re
 int mm_bn_finalize(const float* stats, const float* gamma, const float* beta, float* run_mean,
                    float* run_var, const float* conv_bias, float* out4, int N, float count,
                    float momentum, float eps, int mode, void* batches_tracked, hipStream_t stream);
+/* The train-mode finalize as the PROLOGUE of its consumer (one launch and one graph node less per BatchNorm layer): the
+ * `*_fin` forms of the apply passes take, instead of scale / shift (or out4), a HOST pointer to this descriptor (read at
+ * call time, like the tables of mm_prep_many); every workgroup forms scale / shift of the N <= 256 channels from the
+ * statistics workspace with mm_bn_finalize's arithmetic (the same device function: same bits), workgroup 0 also writes
+ * out4 [4][N] = {scale, shift, mean, rstd} (the backward reads it) and updates the running statistics / batches_tracked.
+ * GELU only (the encoders' BatchNorm layers). */
+typedef struct {
+    const float* stats;      /* accumulator workspace [32][2][N] {sum, sumsq} */
+    const float* gamma; const float* beta;
+    float* run_mean; float* run_var;
+    float* out4;             /* [4][N], written */
+    void* batches_tracked;   /* int64 device scalar, nullable */
+    float count, momentum, eps;
+    int reserved;
+} mm_bn_fin_t;
+int mm_bn_act_fwd_fin(const float* y, const void* bn_fin_host, const float* pe, void* out_bf16, float* out_f32,
+                      int R, int S, int N, int act, int pool, int drop_first, float drop_p, uint32_t seed,
+                      float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, hipStream_t stream);
+int mm_bn_act_fwd_ln_fin(const float* y, const void* bn_fin_host, const float* pe, float* out_f32, int R, int S,
+                         int act, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
+                         const uint32_t* seed_epoch, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                         void* ln_out_bf16, float* ln_stat, hipStream_t stream);
+int mm_pool3d_bn_act_fwd_fin(const void* y, const void* bn_fin_host, void* out_bf16, void* ysel, void* arg, int B,
+                             int D, int H, int W, int N, int act, float drop_p, uint32_t seed,
+                             const uint32_t* seed_epoch, hipStream_t stream);
+int mm_conv3d_l1_fwd_fin(const float* x, const void* wimg, const float* bias, const void* bn_fin_host, void* out,
+                         int B, int D, int H, int W, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                         hipStream_t stream);
 /* y fp32 [R][S][N] -> act(y*scale+shift) [-> maxpool2 over S] [-> dropout] [+pe[s][n]]
  * (BN -> GELU -> MaxPool1d -> Dropout -> PositionalEncoding add,
  *  enhanced_models_v4.py:130-143, 49-54) */

@@ -258,6 +258,53 @@ __device__ __forceinline__ mm_acc_t acc_sum_lanes16(mm_acc_t v) {
 }
 #endif
 
+// ---- BatchNorm finalize (train mode), shared by mm_bn_finalize and by the consumers that carry it in their prologue
+// (mm_bn_act_fwd_fin, mm_pool3d_bn_act_fwd_fin, mm_conv3d_l1_fwd_fin): ONE function, so that both forms produce the
+// same bits.  Host side: mm_bn_fin_t (include/mmeeg_hip.h) has this layout.
+struct MmBnFin {
+    const float* stats;        // accumulator workspace [MM_REPL][2][N]: {sum, sumsq}
+    const float* gamma; const float* beta;
+    float* run_mean; float* run_var;
+    float* out4;               // [4][N]: scale, shift, mean, rstd (written by the launch's workgroup 0)
+    long long* tracked;        // num_batches_tracked (nullable)
+    float count, momentum, eps;
+    int N;
+};
+#ifdef __HIPCC__
+// channel n: {scale, shift, mean, rstd} from the fixed-point sums; `writer` (one thread per channel in the whole launch)
+// also updates the running statistics and stores the four values
+__device__ __forceinline__ void bn_fin_channel(const MmBnFin& f, int n, bool writer, float& sc, float& sh, float& mean, float& rstd) {
+    const float s1 = acc_val<MM_ACC_STAT>(acc_sum(f.stats, 2 * (size_t)f.N, n));
+    const float s2 = acc_val<MM_ACC_STAT>(acc_sum(f.stats, 2 * (size_t)f.N, (size_t)f.N + n));
+    mean = s1 / f.count;
+    float var = s2 / f.count - mean * mean;
+    var = var < 0.f ? 0.f : var;                         // (not fmaxf: a NaN sum - an accumulator out of range - must stay NaN)
+    rstd = rsqrtf(var + f.eps);
+    sc = f.gamma[n] * rstd;
+    sh = f.beta[n] + (0.f - mean) * sc;
+    if (writer) {
+        if (n == 0 && f.tracked) f.tracked[0] += 1;
+        f.run_mean[n] = (1.f - f.momentum) * f.run_mean[n] + f.momentum * mean;
+        const float unb = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+        f.run_var[n] = (1.f - f.momentum) * f.run_var[n] + f.momentum * unb;
+        f.out4[n] = sc; f.out4[f.N + n] = sh; f.out4[2 * f.N + n] = mean; f.out4[3 * f.N + n] = rstd;
+    }
+}
+#endif
+// host layout of the descriptor the *_fin entry points read (copied into the kernel's arguments at launch)
+struct MmBnFinHost {
+    const float* stats; const float* gamma; const float* beta; float* run_mean; float* run_var; float* out4;
+    void* batches_tracked; float count, momentum, eps; int reserved;
+};
+static inline bool bn_fin_from_host(MmBnFin& f, const void* host, int N) {
+    if (!host) return false;
+    const MmBnFinHost& h = *static_cast<const MmBnFinHost*>(host);
+    if (!h.stats || !h.gamma || !h.beta || !h.run_mean || !h.run_var || !h.out4 || !(h.count >= 1.f)) return false;
+    f.stats = h.stats; f.gamma = h.gamma; f.beta = h.beta; f.run_mean = h.run_mean; f.run_var = h.run_var; f.out4 = h.out4;
+    f.tracked = (long long*)h.batches_tracked; f.count = h.count; f.momentum = h.momentum; f.eps = h.eps; f.N = N;
+    return true;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- layout of a 3-D convolution weight image (k = 27).  Images are made by mm_prep_conv_weight / mm_prep_many and

@@ -272,13 +272,21 @@ struct Pool3Args {
     uint32_t thresh, seed; float inv_keep, inv_count;
     const uint32_t* epoch;
     int sums_nrep;                             // apply: 1 = compact fp32 sums, MM_REPL = the reduce pass's accumulator workspace
+    MmBnFin fin;                               // forward with FIN: the layer's BatchNorm finalize runs in the prologue (out4 is then written, not read)
 };
 
 // One thread = 8 channels of one pooled voxel: eight 16-byte loads of the bf16 pre-BatchNorm volume.
-template <int MODE, int ACT = -1>   // MODE 0 fwd, 2 bwd-apply; ACT >= 0: compiled for that activation (no per-element switch)
+// FIN (forward): the train-mode BatchNorm finalize as the kernel's prologue (csrc/common.h: bn_fin_channel; N <= 256)
+template <int MODE, int ACT = -1, bool FIN = false>   // MODE 0 fwd, 2 bwd-apply; ACT >= 0: compiled for that activation (no per-element switch)
 __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
     if (ACT >= 0) a.act = ACT;
     a.seed = mm_eff_seed(a.seed, a.epoch);
+    __shared__ float s_fin[FIN ? 4 : 1][FIN ? 256 : 1];
+    if (FIN) {
+        for (int n = threadIdx.x; n < a.N; n += 256)
+            bn_fin_channel(a.fin, n, blockIdx.x == 0, s_fin[0][n], s_fin[1][n], s_fin[2][n], s_fin[3][n]);
+        __syncthreads();
+    }
     const int nv = a.N / 8;
     const int Do = a.D / 2, Ho = a.H / 2, Wo = a.W / 2;
     const size_t nrows = (size_t)a.B * Do * Ho * Wo;
@@ -296,8 +304,12 @@ __global__ __launch_bounds__(256) void pool3_bn_act_kernel(Pool3Args a) {
     float sc[8], sh[8], mu[8], rs[8], c0[8], c1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        sc[q] = a.out4[n8 + q]; sh[q] = a.out4[a.N + n8 + q];
-        mu[q] = a.out4[2 * a.N + n8 + q]; rs[q] = a.out4[3 * a.N + n8 + q];
+        if (FIN) {
+            sc[q] = s_fin[0][n8 + q]; sh[q] = s_fin[1][n8 + q]; mu[q] = s_fin[2][n8 + q]; rs[q] = s_fin[3][n8 + q];
+        } else {
+            sc[q] = a.out4[n8 + q]; sh[q] = a.out4[a.N + n8 + q];
+            mu[q] = a.out4[2 * a.N + n8 + q]; rs[q] = a.out4[3 * a.N + n8 + q];
+        }
         c0[q] = (MODE == 2 && a.train) ? csum[n8 + q] * a.inv_count : 0.f;
         c1[q] = (MODE == 2 && a.train) ? csum[a.N + n8 + q] * a.inv_count : 0.f;
     }
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256) void pool3_bwd_reduce_kernel(Pool3Args a) {
 
 inline uint32_t thresh3(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
 
-int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
+int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st, bool with_fin = false) {
     MM_REQUIRE(a.out4 && a.B > 0 && a.D % 2 == 0 && a.H % 2 == 0 && a.W % 2 == 0, "pool3d_bn_act: dims must be even");
     MM_REQUIRE(a.N % 8 == 0 && a.N <= 1024, "pool3d_bn_act: N must be a multiple of 8");
     a.thresh = thresh3(drop_p); a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -446,7 +458,10 @@ int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st) {
     } else {
         if (grid > 4096) grid = 4096;
         const bool gelu = a.act == MM_ACT_GELU;
-        if (mode == 0 && gelu) hipLaunchKernelGGL((pool3_bn_act_kernel<0, MM_ACT_GELU>), dim3(grid), dim3(256), 0, st, a);
+        if (with_fin) {                                  // (mode 0, GELU, N <= 256: checked by the caller) few, longer workgroups:
+            if (grid > 512) grid = 512;                  // each re-reads the statistics workspace in its prologue
+            hipLaunchKernelGGL((pool3_bn_act_kernel<0, MM_ACT_GELU, true>), dim3(grid), dim3(256), 0, st, a);
+        } else if (mode == 0 && gelu) hipLaunchKernelGGL((pool3_bn_act_kernel<0, MM_ACT_GELU>), dim3(grid), dim3(256), 0, st, a);
         else if (mode == 0) hipLaunchKernelGGL((pool3_bn_act_kernel<0>), dim3(grid), dim3(256), 0, st, a);
         else if (gelu) hipLaunchKernelGGL((pool3_bn_act_kernel<2, MM_ACT_GELU>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((pool3_bn_act_kernel<2>), dim3(grid), dim3(256), 0, st, a);
@@ -510,6 +525,18 @@ int mm_pool3d_bn_act_fwd(const void* y, const float* out4, void* out_bf16, void*
     a.y = (const bf16*)y; a.out4 = out4; a.out = (bf16*)out_bf16; a.ysel = (bf16*)ysel; a.arg = (uint8_t*)arg;
     a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch;
     return pool3_launch(0, a, drop_p, st);
+}
+
+int mm_pool3d_bn_act_fwd_fin(const void* y, const void* bn_fin_host, void* out_bf16, void* ysel, void* arg, int B, int D,
+                             int H, int W, int N, int act, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
+                             hipStream_t st) {
+    MM_REQUIRE(y && out_bf16 && (!ysel == !arg), "pool3d_bn_act_fwd_fin: null out / ysel and arg go together");
+    MM_REQUIRE(N <= 256 && act == MM_ACT_GELU, "pool3d_bn_act_fwd_fin: N=%d (<= 256), GELU only", N);
+    Pool3Args a{};
+    MM_REQUIRE(bn_fin_from_host(a.fin, bn_fin_host, N), "pool3d_bn_act_fwd_fin: incomplete mm_bn_fin_t (null pointer or count < 1)");
+    a.y = (const bf16*)y; a.out4 = a.fin.out4; a.out = (bf16*)out_bf16; a.ysel = (bf16*)ysel; a.arg = (uint8_t*)arg;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.N = N; a.act = act; a.seed = seed; a.epoch = seed_epoch;
+    return pool3_launch(0, a, drop_p, st, true);
 }
 
 int mm_pool3d_bn_act_bwd_reduce(const void* ysel, const float* out4, const void* dout_bf16, float* sums_out, int B,

@@ -61,6 +61,7 @@ struct L1Args {
     float* dw;             // mode 3: [27][32] (tap-major, channel-contiguous); mode 4: A1
     float* dbias;          // mode 3
     float* gram;           // gram kernel: accumulator workspace [32][32] (tap, tap)
+    MmBnFin fin;           // mode 1 with FIN: the layer's BatchNorm finalize in the kernel's prologue (out4 written, not read)
     int B, D, H, W, train;
     uint32_t thresh, seed; float inv_keep, inv_count;
     const uint32_t* epoch;
@@ -145,7 +146,8 @@ __device__ __forceinline__ const float* tile_ptr(const float* x, const TileCoord
 // FULLT: H % 8 == 0 and W % 32 == 0, i.e. every 2 x 8 x 32 tile lies inside the volume: the per-voxel bounds tests
 // (three compares and the index arithmetic behind them, per voxel and channel) are compiled out.
 // ARG (mode 1): also write the window winners (inspection output of the parity tests, mm_conv3d_l1_fwd_winners).
-template <int MODE, bool FULLT = false, bool ARG = false>
+// FIN (mode 1): the train-mode BatchNorm finalize as the prologue (csrc/common.h: bn_fin_channel).
+template <int MODE, bool FULLT = false, bool ARG = false, bool FIN = false>
 __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Args a) {   // statistics / forward: three waves per SIMD (<= 168 registers), backward two
     a.seed = mm_eff_seed(a.seed, a.epoch);
     __shared__ __attribute__((aligned(16))) unsigned short halo[2][HSZ];
@@ -169,7 +171,15 @@ __global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Arg
         for (int j = 0; j < 8; ++j) foff[s][j] = tap_off(16 * s + 8 * lh + j);
     const float bias = a.bias ? a.bias[lr] : 0.f;
     float sc = 1.f, sh = 0.f, mu = 0.f, rs = 1.f, c0 = 0.f, c1 = 0.f;
-    if (MODE >= 1) {
+    if (FIN) {
+        __shared__ float s_fin[2][32];
+        if (tid < 32) {
+            float m_, r_;
+            bn_fin_channel(a.fin, tid, blockIdx.x == 0, s_fin[0][tid], s_fin[1][tid], m_, r_);
+        }
+        __syncthreads();
+        sc = s_fin[0][lr]; sh = s_fin[1][lr];
+    } else if (MODE >= 1) {
         sc = a.out4[lr]; sh = a.out4[32 + lr]; mu = a.out4[64 + lr]; rs = a.out4[96 + lr];
         if (MODE == 3 && a.train) { c0 = a.sums[lr] * a.inv_count; c1 = a.sums[32 + lr] * a.inv_count; }   // compact sums
     }
@@ -661,7 +671,7 @@ inline uint32_t thresh_l1(float p) { return p > 0.f ? (uint32_t)((double)p * 429
 inline void l1_fill(L1Args& a, const float* x, const void* wimg, const float* bias, const float* out4, int B, int D, int H,
                     int W, int train, float drop_p, uint32_t seed, const uint32_t* seed_epoch) {
     a.x = x; a.wimg = (const bf16*)wimg; a.bias = bias; a.out4 = out4; a.dout = nullptr; a.sums = nullptr;
-    a.stats = nullptr; a.out = nullptr; a.arg = nullptr; a.dw = nullptr; a.dbias = nullptr; a.gram = nullptr;
+    a.stats = nullptr; a.out = nullptr; a.arg = nullptr; a.dw = nullptr; a.dbias = nullptr; a.gram = nullptr; a.fin = MmBnFin{};
     a.B = B; a.D = D; a.H = H; a.W = W; a.train = train;
     a.thresh = thresh_l1(drop_p); a.seed = seed; a.inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     a.inv_count = 1.f / ((float)B * D * H * W);
@@ -722,6 +732,21 @@ int mm_conv3d_l1_fwd_winners(const float* x, const void* wimg, const float* bias
     if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<1, true, true>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3d_l1_kernel<1, false, true>), dim3(grid), dim3(256), 0, st, a);
     return mm_check_launch("conv3d_l1_fwd_winners");
+}
+
+int mm_conv3d_l1_fwd_fin(const float* x, const void* wimg, const float* bias, const void* bn_fin_host, void* out, int B, int D,
+                         int H, int W, float drop_p, uint32_t seed, const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(x && wimg && out && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_l1_fwd_fin: null/invalid");
+    MM_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "conv3d_l1_fwd_fin: D,H,W must be even (MaxPool3d(2))");
+    MM_REQUIRE(l1_fits(B, D, H, W), "conv3d_l1_fwd_fin: more than 2^31 pooled output elements");
+    L1Args a;
+    l1_fill(a, x, wimg, bias, nullptr, B, D, H, W, 1, drop_p, seed, seed_epoch);
+    MM_REQUIRE(bn_fin_from_host(a.fin, bn_fin_host, 32), "conv3d_l1_fwd_fin: incomplete mm_bn_fin_t (null pointer or count < 1)");
+    a.out4 = a.fin.out4; a.out = (bf16*)out;
+    const int grid = l1_grid(l1_tiles(B, D, H, W), 3);
+    if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<1, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3d_l1_kernel<1, false, false, true>), dim3(grid), dim3(256), 0, st, a);
+    return mm_check_launch("conv3d_l1_fwd_fin");
 }
 
 int mm_conv3d_l1_gram(const float* x, const void* wimg, const float* bias, float* gram, float* stats, int B, int D, int H,

@@ -17,21 +17,13 @@ __global__ void bn_finalize_kernel(const float* stats, const float* gamma, const
                                    float count, float momentum, float eps, int mode, long long* tracked) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    if (n == 0 && tracked && mode == 0) tracked[0] += 1;
-    float mean, var;
-    if (mode == 0) {
-        const float s1 = acc_val<MM_ACC_STAT>(acc_sum(stats, 2 * (size_t)N, n));
-        const float s2 = acc_val<MM_ACC_STAT>(acc_sum(stats, 2 * (size_t)N, (size_t)N + n));
-        mean = s1 / count;
-        var = s2 / count - mean * mean;
-        var = var < 0.f ? 0.f : var;                     // (not fmaxf: a NaN sum - an accumulator out of range - must stay NaN)
-        run_mean[n] = (1.f - momentum) * run_mean[n] + momentum * mean;
-        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-        run_var[n] = (1.f - momentum) * run_var[n] + momentum * unb;
-    } else {
-        mean = run_mean[n];
-        var = run_var[n];
+    if (mode == 0) {                                     // the shared train-mode finalize (csrc/common.h): same bits as the *_fin consumers
+        MmBnFin f{stats, gamma, beta, run_mean, run_var, out, tracked, count, momentum, eps, N};
+        float sc, sh, mean, rstd;
+        bn_fin_channel(f, n, true, sc, sh, mean, rstd);
+        return;
     }
+    const float mean = run_mean[n], var = run_var[n];
     const float rstd = rsqrtf(var + eps);
     const float sc = gamma[n] * rstd;
     const float cb = (mode == 1 && conv_bias) ? conv_bias[n] : 0.f;
@@ -57,6 +49,7 @@ struct BnActArgs {
     // 32 consecutive lanes hold one row
     const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 0.f;
     bf16* ln_out = nullptr; float* ln_stat = nullptr;
+    MmBnFin fin = {};            // FIN kernels: the BatchNorm finalize runs in the prologue (scale / shift are then unused)
 };
 
 template <int ACT>
@@ -67,11 +60,23 @@ __device__ __forceinline__ float bnact_one(const BnActArgs& a, float y, float sc
 }
 
 // ACT >= 0 / POOL > 0: compiled for that activation / pool size (GELU with pool 1 and 2: every BatchNorm of the encoders)
-template <int ACT = -1, int POOL = 0>
+// FIN: the train-mode BatchNorm finalize of the layer is this kernel's prologue (every workgroup forms scale / shift of all
+// N <= 256 channels in LDS from the statistics workspace; workgroup 0 also writes out4 and the running statistics): the
+// one-workgroup mm_bn_finalize launch between the convolution and this pass - ~5 us + a graph node on the chain - is gone.
+template <int ACT = -1, int POOL = 0, bool FIN = false>
 __global__ void bn_act_fwd_kernel(BnActArgs a) {
     a.seed = mm_eff_seed(a.seed, a.epoch);
     a.seed2 = mm_eff_seed(a.seed2, a.epoch);
     if (POOL > 0) a.pool = POOL;
+    __shared__ __attribute__((aligned(16))) float s_sc[FIN ? 256 : 4], s_sh[FIN ? 256 : 4];
+    if (FIN) {
+        for (int n = threadIdx.x; n < a.N; n += blockDim.x) {
+            float sc, sh, mean, rstd;
+            bn_fin_channel(a.fin, n, blockIdx.x == 0, sc, sh, mean, rstd);
+            s_sc[n] = sc; s_sh[n] = sh;
+        }
+        __syncthreads();
+    }
     const int So = a.S / a.pool;
     const unsigned nv = a.N / 4;
     const unsigned total = (unsigned)((size_t)a.R * So * nv);       // < 2^31 elements / 4: checked on the host
@@ -81,8 +86,8 @@ __global__ void bn_act_fwd_kernel(BnActArgs a) {
         const unsigned rs = i / nv;                                 // r * So + so
         const int n4 = (int)(i - rs * nv) * 4;
         const int so = a.pe ? (int)(rs % (unsigned)So) : 0;         // only the positional table needs the position itself
-        const float4 sc = *reinterpret_cast<const float4*>(a.scale + n4);
-        const float4 sh = *reinterpret_cast<const float4*>(a.shift + n4);
+        const float4 sc = FIN ? *reinterpret_cast<const float4*>(s_sc + n4) : *reinterpret_cast<const float4*>(a.scale + n4);
+        const float4 sh = FIN ? *reinterpret_cast<const float4*>(s_sh + n4) : *reinterpret_cast<const float4*>(a.shift + n4);
         float o[4];
         const size_t in0 = (size_t)rs * a.pool * a.N + n4;           // r * S + so * pool = (r * So + so) * pool
         const float4 y0 = *reinterpret_cast<const float4*>(a.y + in0);
@@ -589,16 +594,25 @@ static int bn_act_fwd_common(const float* y, const float* scale, const float* sh
                              float* out_f32, int R, int S, int N, int act, int pool, int drop_first, float drop_p,
                              uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch,
                              const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out, float* ln_stat,
-                             hipStream_t st) {
+                             hipStream_t st, const void* bn_fin_host = nullptr) {
+    MmBnFin fin{};
+    const bool with_fin = bn_fin_host != nullptr;
+    if (with_fin) {
+        MM_REQUIRE(bn_fin_from_host(fin, bn_fin_host, N), "bn_act_fwd_fin: incomplete mm_bn_fin_t (null pointer or count < 1)");
+        MM_REQUIRE(N <= 256 && act == MM_ACT_GELU, "bn_act_fwd_fin: N=%d (<= 256), GELU only", N);
+        scale = fin.out4; shift = fin.out4 + N;           // (what the non-fused form would read; unused by the FIN kernels)
+    }
     MM_REQUIRE(y && scale && shift && (out_bf16 || out_f32), "bn_act_fwd: null");
     MM_REQUIRE(N % 4 == 0 && (pool == 1 || (pool == 2 && S % 2 == 0)), "bn_act_fwd: N%%4, pool");
     BnActArgs a{y, scale, shift, pe, (bf16*)out_bf16, out_f32, R, S, N, act, pool, drop_first,
                 thresh_of(drop_p), seed, drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f,
                 thresh_of(drop2_p), seed2, drop2_p > 0.f ? 1.f / (1.f - drop2_p) : 1.f, seed_epoch};
     a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.ln_eps = ln_eps; a.ln_out = (bf16*)ln_out; a.ln_stat = ln_stat;
+    a.fin = fin;
     const size_t total = (size_t)R * (S / pool) * (N / 4);
     MM_REQUIRE(total < (1ull << 31), "bn_act_fwd: %zu vectors (32-bit indices)", total);
-    int grid = grid_for(total);
+    // FIN: every workgroup re-reads the statistics workspace (256 N bytes) in its prologue: few, longer workgroups
+    int grid = grid_for(total, 256, with_fin ? 512 : 4096);
     if (ln_out) {
         MM_REQUIRE(N == 128 && pool == 1 && ln_gamma && ln_beta, "bn_act_fwd_ln: N=%d (128) pool=%d (1)", N, pool);
         // every 32-lane group must walk its rows together (cross-lane sums): total is a multiple of 32; a grid that
@@ -606,7 +620,9 @@ static int bn_act_fwd_common(const float* y, const float* scale, const float* sh
         const size_t blocks = (total + 255) / 256;
         if ((size_t)grid > blocks) grid = (int)blocks;
     }
-    if (act == MM_ACT_GELU && pool == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 1>), dim3(grid), dim3(256), 0, st, a);
+    if (with_fin && pool == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 1, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (with_fin) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 2, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (act == MM_ACT_GELU && pool == 1) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (act == MM_ACT_GELU && pool == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MM_ACT_GELU, 2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<>), dim3(grid), dim3(256), 0, st, a);
     return mm_check_launch("bn_act_fwd");
@@ -617,6 +633,23 @@ int mm_bn_act_fwd(const float* y, const float* scale, const float* shift, const 
                   uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch, hipStream_t st) {
     return bn_act_fwd_common(y, scale, shift, pe, out_bf16, out_f32, R, S, N, act, pool, drop_first, drop_p, seed, drop2_p,
                              seed2, seed_epoch, nullptr, nullptr, 0.f, nullptr, nullptr, st);
+}
+
+int mm_bn_act_fwd_fin(const float* y, const void* bn_fin_host, const float* pe, void* out_bf16, float* out_f32, int R, int S,
+                      int N, int act, int pool, int drop_first, float drop_p, uint32_t seed, float drop2_p, uint32_t seed2,
+                      const uint32_t* seed_epoch, hipStream_t st) {
+    MM_REQUIRE(bn_fin_host, "bn_act_fwd_fin: null descriptor");
+    return bn_act_fwd_common(y, nullptr, nullptr, pe, out_bf16, out_f32, R, S, N, act, pool, drop_first, drop_p, seed, drop2_p,
+                             seed2, seed_epoch, nullptr, nullptr, 0.f, nullptr, nullptr, st, bn_fin_host);
+}
+
+int mm_bn_act_fwd_ln_fin(const float* y, const void* bn_fin_host, const float* pe, float* out_f32, int R, int S, int act,
+                         float drop_p, uint32_t seed, float drop2_p, uint32_t seed2, const uint32_t* seed_epoch,
+                         const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out_bf16, float* ln_stat,
+                         hipStream_t st) {
+    MM_REQUIRE(bn_fin_host && out_f32 && ln_out_bf16, "bn_act_fwd_ln_fin: null descriptor / output");
+    return bn_act_fwd_common(y, nullptr, nullptr, pe, nullptr, out_f32, R, S, 128, act, 1, 1, drop_p, seed, drop2_p, seed2,
+                             seed_epoch, ln_gamma, ln_beta, ln_eps, ln_out_bf16, ln_stat, st, bn_fin_host);
 }
 
 int mm_bn_act_fwd_ln(const float* y, const float* scale, const float* shift, const float* pe, float* out_f32, int R, int S,

@@ -344,6 +344,25 @@ def bn_finalize_train(bn, stats, count) -> torch.Tensor:
     return out4
 
 
+_NO_FIN_FOLD = bool(os.environ.get("MM_NO_FIN_FOLD"))      # A/B knob: BatchNorm finalize as its own launch (round 3)
+
+
+def bn_fin_desc(bn, stats, count):
+    """host-side mm_bn_fin_t for the `*_fin` apply passes (the train-mode finalize runs in their prologue) ->
+    (ctypes buffer to pass as ``bn_fin_host``, out4 tensor the launch will write, objects to keep alive)"""
+    import ctypes
+    import struct
+    n = bn.num_features
+    out4 = _empty((4, n), _F32, bn.weight)
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    nb = bn.num_batches_tracked
+    raw = struct.pack("<QQQQQQQfffi", stats.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), out4.data_ptr(), nb.data_ptr() if nb is not None else 0,
+                      float(count), mom, float(bn.eps), 0)
+    buf = ctypes.create_string_buffer(raw, len(raw))
+    return buf, out4
+
+
 def layernorm(x2d: torch.Tensor, ln, want_stat: bool):
     M, D = x2d.shape
     out = _empty((M, D), _BF, x2d)
@@ -404,7 +423,13 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
         return r, None
     stats = _zeros((REPL, 2, cout), xb) if training else None
     y = igemm(xb, wf, k, pad, cout, shift=conv.bias, stats=stats, out_f32=True, out_bf16=False)["f32"]
-    out4 = bn_finalize_train(bn, stats, B * T) if training else bn_fold_eval(bn, None)
+    # train mode, GELU, <= 256 channels: the finalize (mean / rstd / running statistics) runs in the apply pass's prologue
+    fold = training and act == "gelu" and cout <= 256 and not _NO_FIN_FOLD and isinstance(bn.running_mean, torch.Tensor)
+    fin = None
+    if fold:
+        fin, out4 = bn_fin_desc(bn, stats, B * T)
+    else:
+        out4 = bn_finalize_train(bn, stats, B * T) if training else bn_fold_eval(bn, None)
     if not training:
         drop_p = pe_drop_p = 0.0
     seed = _next_seed() if drop_p > 0 else 0
@@ -416,9 +441,18 @@ def conv_bn_act(xb: torch.Tensor, conv, bn, *, act="gelu", pool=1, training=Fals
             and tuple(next_norm.normalized_shape) == (128,):
         hn = _empty((B * T, cout), _BF, xb)
         stn = _empty((B * T, 2), _F32, xb)
-        _hip.call("mm_bn_act_fwd_ln", y, out4[0], out4[1], pe, of, B, T, ACT[act], float(drop_p), seed,
-                  float(pe_drop_p), seed2, EP(), next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn)
+        if fold:
+            import ctypes
+            _hip.call("mm_bn_act_fwd_ln_fin", y, ctypes.addressof(fin), pe, of, B, T, ACT[act], float(drop_p), seed,
+                      float(pe_drop_p), seed2, EP(), next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn)
+        else:
+            _hip.call("mm_bn_act_fwd_ln", y, out4[0], out4[1], pe, of, B, T, ACT[act], float(drop_p), seed,
+                      float(pe_drop_p), seed2, EP(), next_norm.weight, next_norm.bias, float(next_norm.eps), hn, stn)
         prenorm = (hn, stn)
+    elif fold:
+        import ctypes
+        _hip.call("mm_bn_act_fwd_fin", y, ctypes.addressof(fin), pe, ob, of, B, T, cout, ACT[act], pool,
+                  1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2, EP())
     else:
         _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, B, T, cout, ACT[act], pool,
                   1 if drop_first else 0, float(drop_p), seed, float(pe_drop_p), seed2, EP())
@@ -707,6 +741,7 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     assert cp == cinp, (cp, cinp)
     y = _empty((B, D, H, W, cout), _BF if pool else _F32, xv)
     yf, yb = (None, y) if pool else (y, None)
+    fin = None
     if training:
         stats = _zeros((REPL, 2, cout), xv)
         cal = kernel_timer.bracket(f"event_pair_c{cinp}")    # an EMPTY bracket on the same stream: what a pair of
@@ -716,7 +751,10 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
         _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, stats, yf, yb)
         if end is not None:
             end.record()
-        out4 = bn_finalize_train(bn, stats, B * D * H * W)
+        if cout <= 256 and not _NO_FIN_FOLD:           # the finalize runs in the prologue of the apply pass below
+            fin, out4 = bn_fin_desc(bn, stats, B * D * H * W)
+        else:
+            out4 = bn_finalize_train(bn, stats, B * D * H * W)
     elif save:
         _hip.call("mm_conv3d_fwd", xv, wf, B, D, H, W, cinp, cout, conv.bias, None, yf, yb)
         out4 = bn_fold_eval(bn, None)
@@ -726,16 +764,26 @@ def conv3d_bn_act(xv: torch.Tensor, conv, bn, *, pool: bool, training: bool, dro
     seed = _next_seed() if (training and drop_p > 0) else 0
     p = drop_p if training else 0.0
     ysel = arg = None
+    fold = training and fin is not None
     if pool:
         out = _empty((B, D // 2, H // 2, W // 2, cout), _BF, xv)
         if save:                                       # the window winners: all that BN-backward's reduction needs
             ysel = _empty(out.shape, _BF, xv)
             arg = _empty(out.shape, torch.uint8, xv)
-        _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, ysel, arg, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
+        if fold:
+            import ctypes
+            _hip.call("mm_pool3d_bn_act_fwd_fin", y, ctypes.addressof(fin), out, ysel, arg, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
+        else:
+            _hip.call("mm_pool3d_bn_act_fwd", y, out4, out, ysel, arg, B, D, H, W, cout, ACT["gelu"], float(p), seed, EP())
     else:
         out = _empty((B, D * H * W, cout), _F32, xv)
-        _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], None, None, out, B, D * H * W, cout,
-                  ACT["gelu"], 1, 1, float(p), seed, 0.0, 0, EP())
+        if fold:
+            import ctypes
+            _hip.call("mm_bn_act_fwd_fin", y, ctypes.addressof(fin), None, None, out, B, D * H * W, cout,
+                      ACT["gelu"], 1, 1, float(p), seed, 0.0, 0, EP())
+        else:
+            _hip.call("mm_bn_act_fwd", y, out4[0], out4[1], None, None, out, B, D * H * W, cout,
+                      ACT["gelu"], 1, 1, float(p), seed, 0.0, 0, EP())
     saved = dict(xv=xv, y=y, out4=out4, pool=pool, drop_p=p, seed=seed, conv=conv, bn=bn,
                  ysel=ysel, arg=arg, train=training) if save else None
     return out, saved
@@ -751,7 +799,7 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     out = _empty((B, D // 2, H // 2, W // 2, 32), _BF, x)
     p = drop_p if training else 0.0
     seed = _next_seed() if p > 0 else 0
-    gramc = None
+    gramc = fin = None
     if training:
         # BatchNorm statistics from the Gram matrix of the im2col matrix (no per-channel pass over the convolution):
         # csrc/conv3d_l1.hip.  The workspace is kept: the backward's weight-gradient correction terms come from it.
@@ -759,7 +807,10 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
         stats = _zeros((REPL, 2, 32), x)
         _hip.call("mm_conv3d_l1_gram", x, wimg, conv.bias, gram, stats, B, D, H, W)
         gramc = gram                                   # (the accumulator workspace itself: the backward's combine step reads it)
-        out4 = bn_finalize_train(bn, stats, B * D * H * W)
+        if not _NO_FIN_FOLD and winners is None:       # the finalize runs in the forward kernel's prologue
+            fin, out4 = bn_fin_desc(bn, stats, B * D * H * W)
+        else:
+            out4 = bn_finalize_train(bn, stats, B * D * H * W)
         bias = conv.bias
     elif save:
         out4 = bn_fold_eval(bn, None)                  # the backward recomputes conv + bias and needs mean / rstd apart
@@ -767,7 +818,10 @@ def conv3d_l1_bn_act(x: torch.Tensor, conv, bn, *, training: bool, drop_p: float
     else:
         out4 = bn_fold_eval(bn, conv.bias)
         bias = None
-    if winners is not None:
+    if training and fin is not None:
+        import ctypes
+        _hip.call("mm_conv3d_l1_fwd_fin", x, wimg, bias, ctypes.addressof(fin), out, B, D, H, W, float(p), seed, EP())
+    elif winners is not None:
         arg = _empty(tuple(out.shape), torch.uint8, x)
         _hip.call("mm_conv3d_l1_fwd_winners", x, wimg, bias, out4, out, arg, B, D, H, W, 1 if training else 0, float(p), seed, EP())
         winners.append(arg)

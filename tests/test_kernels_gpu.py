@@ -604,6 +604,118 @@ def test_conv3d_l1_gram_matrix_and_the_statistics_derived_from_it(B, D, H, W):
     torch.testing.assert_close(got, _stat(stats0).cpu().double(), rtol=2e-5, atol=2e-5 * float(want.abs().max()))
 
 
+def _bn_fin(stats, gam, bet, rm, rv, out4, nb, count, mom=0.1, eps=1e-5):
+    """host-side mm_bn_fin_t (include/mmeeg_hip.h) -> (address, keep-alive)"""
+    import ctypes
+    import struct
+    raw = struct.pack("<QQQQQQQfffi", stats.data_ptr(), gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                      out4.data_ptr(), nb.data_ptr() if nb is not None else 0, float(count), mom, eps, 0)
+    buf = ctypes.create_string_buffer(raw, len(raw))
+    return ctypes.addressof(buf), buf
+
+
+@pytest.mark.parametrize("R,S,N,pool,ln", [(32, 512, 128, 1, True), (32, 1024, 128, 2, False), (32, 1024, 64, 1, False), (3, 38, 64, 2, False),
+                                           (2, 100, 256, 1, False)])
+def test_batchnorm_finalize_folded_into_the_apply_pass_is_bit_identical(R, S, N, pool, ln):
+    """mm_bn_act_fwd_fin / mm_bn_act_fwd_ln_fin = mm_bn_finalize (train mode) + mm_bn_act_fwd[_ln]: the finalize runs in the
+    apply pass's prologue (one launch, one graph node less per BatchNorm layer) with the SAME device function - outputs,
+    out4, running statistics and num_batches_tracked equal bit for bit; an incomplete descriptor is refused."""
+    hip = _hip()
+    from multimodal_eeg_fmri_amd.ops import ACC_STAT, acc_encode
+    g = torch.Generator().manual_seed(R * S + N)
+    y = (torch.randn(R, S, N, generator=g) * 1.3 + 0.2).cuda()
+    cnt = R * S
+    stats = acc_encode(torch.stack([y.sum(dim=(0, 1)), (y * y).sum(dim=(0, 1))]), ACC_STAT).contiguous()
+    gam, bet = (0.5 + torch.rand(N, generator=g)).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    pe = torch.randn(S // pool, N, generator=g).cuda()
+    lg, lb = (0.5 + torch.rand(N, generator=g)).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    res = []
+    for fused in (False, True):
+        rm, rv = torch.full((N,), 0.25, device="cuda"), torch.full((N,), 1.5, device="cuda")
+        nb = torch.zeros((), dtype=torch.long, device="cuda")
+        out4 = torch.full((4, N), float("nan"), device="cuda")
+        of = torch.full((R, S // pool, N), float("nan"), device="cuda")
+        ob = None if ln else torch.full((R, S // pool, N), float("nan"), device="cuda").to(torch.bfloat16)
+        hn = torch.full((R * S, N), float("nan"), device="cuda").to(torch.bfloat16) if ln else None
+        st = torch.full((R * S, 2), float("nan"), device="cuda") if ln else None
+        if fused:
+            addr, keep = _bn_fin(stats, gam, bet, rm, rv, out4, nb, cnt)
+            if ln:
+                hip.call("mm_bn_act_fwd_ln_fin", y, addr, pe, of, R, S, 1, 0.3, 11, 0.1, 22, None, lg, lb, 1e-5, hn, st)
+            else:
+                hip.call("mm_bn_act_fwd_fin", y, addr, pe, ob, of, R, S, N, 1, pool, 0, 0.3, 11, 0.1, 22, None)
+        else:
+            hip.call("mm_bn_finalize", stats, gam, bet, rm, rv, None, out4, N, float(cnt), 0.1, 1e-5, 0, nb)
+            if ln:
+                hip.call("mm_bn_act_fwd_ln", y, out4[0], out4[1], pe, of, R, S, 1, 0.3, 11, 0.1, 22, None, lg, lb, 1e-5, hn, st)
+            else:
+                hip.call("mm_bn_act_fwd", y, out4[0], out4[1], pe, ob, of, R, S, N, 1, pool, 0, 0.3, 11, 0.1, 22, None)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (of, out4, rm, rv, nb) + ((hn, st) if ln else (ob,))])
+    for a, b in zip(*res):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    assert res[1][4].item() == 1
+    mean = y.double().mean(dim=(0, 1)).cpu()
+    torch.testing.assert_close(res[1][1][2].cpu().double(), mean, rtol=1e-4, atol=1e-5)
+    bad = _bn_fin(stats, gam, bet, rm, rv, out4, nb, 0.0)
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_bn_act_fwd_fin", y, bad[0], pe, ob, of, R, S, N, 1, pool, 0, 0.0, 0, 0.0, 0, None)
+
+
+def test_batchnorm_finalize_folded_into_the_voxel_apply_passes_is_bit_identical():
+    """the same for the two voxel-encoder consumers: mm_pool3d_bn_act_fwd_fin (layer 2: bf16 pre-BatchNorm volume, pooled)
+    and mm_conv3d_l1_fwd_fin (the fused first layer's forward kernel)."""
+    hip = _hip()
+    from multimodal_eeg_fmri_amd.ops import ACC_STAT, acc_encode
+    g = torch.Generator().manual_seed(77)
+    B, D, H, W, N = 4, 8, 8, 8, 64
+    y = (torch.randn(B, D, H, W, N, generator=g) * 1.2 + 0.1).cuda().to(torch.bfloat16)
+    yf = y.float()
+    cnt = B * D * H * W
+    stats = acc_encode(torch.stack([yf.sum(dim=(0, 1, 2, 3)), (yf * yf).sum(dim=(0, 1, 2, 3))]), ACC_STAT).contiguous()
+    gam, bet = (0.5 + torch.rand(N, generator=g)).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    res = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        nb = torch.zeros((), dtype=torch.long, device="cuda")
+        out4 = torch.full((4, N), float("nan"), device="cuda")
+        out = torch.full((B, D // 2, H // 2, W // 2, N), float("nan"), device="cuda").to(torch.bfloat16)
+        ysel, arg = torch.zeros_like(out), torch.zeros(out.shape, dtype=torch.uint8, device="cuda")
+        if fused:
+            addr, keep = _bn_fin(stats, gam, bet, rm, rv, out4, nb, cnt)
+            hip.call("mm_pool3d_bn_act_fwd_fin", y, addr, out, ysel, arg, B, D, H, W, N, 1, 0.3, 5, None)
+        else:
+            hip.call("mm_bn_finalize", stats, gam, bet, rm, rv, None, out4, N, float(cnt), 0.1, 1e-5, 0, nb)
+            hip.call("mm_pool3d_bn_act_fwd", y, out4, out, ysel, arg, B, D, H, W, N, 1, 0.3, 5, None)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (out, ysel, arg, out4, rm, rv, nb)])
+    assert all(torch.equal(a, b) for a, b in zip(*res)) and torch.isfinite(res[1][0].float()).all()
+    # layer 1: Gram statistics -> [finalize ->] forward
+    B, D, H, W = 3, 6, 8, 32
+    x = (torch.randn(B, D, H, W, generator=g) + 0.2).cuda()
+    w = _bf(torch.randn(32, 27, generator=g) * 0.25)
+    bias = (torch.randn(32, generator=g) * 0.2).cuda()
+    wimg, _ = _prep_w(hip, w.reshape(32, 27, 1), 32)
+    gam, bet = (0.5 + torch.rand(32, generator=g)).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
+    res = []
+    for fused in (False, True):
+        gram, stats = torch.zeros(32, 32, 32, device="cuda"), torch.zeros(32, 2, 32, device="cuda")
+        hip.call("mm_conv3d_l1_gram", x, wimg, bias, gram, stats, B, D, H, W)
+        rm, rv = torch.zeros(32, device="cuda"), torch.ones(32, device="cuda")
+        nb = torch.zeros((), dtype=torch.long, device="cuda")
+        out4 = torch.full((4, 32), float("nan"), device="cuda")
+        out = torch.full((B, D // 2, H // 2, W // 2, 32), float("nan"), device="cuda").to(torch.bfloat16)
+        if fused:
+            addr, keep = _bn_fin(stats, gam, bet, rm, rv, out4, nb, B * D * H * W)
+            hip.call("mm_conv3d_l1_fwd_fin", x, wimg, bias, addr, out, B, D, H, W, 0.2, 9, None)
+        else:
+            hip.call("mm_bn_finalize", stats, gam, bet, rm, rv, None, out4, 32, float(B * D * H * W), 0.1, 1e-5, 0, nb)
+            hip.call("mm_conv3d_l1", 1, x, wimg, bias, out4, None, None, None, out, None, None, B, D, H, W, 1, 0.2, 9, None)
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (out, out4, rm, rv, nb)])
+    assert all(torch.equal(a, b) for a, b in zip(*res)) and torch.isfinite(res[1][0].float()).all()
+
+
 @pytest.mark.parametrize("R,S,p,p2", [(32, 512, 0.3, 0.1), (3, 37, 0.0, 0.0)])
 def test_bn_act_with_fused_first_layernorm(R, S, p, p2):
     """mm_bn_act_fwd_ln = mm_bn_act_fwd (fp32 out, positional add, both dropouts) + mm_layernorm_fwd of its rows"""
