@@ -371,7 +371,18 @@ def layernorm(x2d: torch.Tensor, ln, want_stat: bool):
     return out, stat
 
 
+def attn_effective_dropout(p: float) -> float:
+    """the attention-probability dropout rate the kernels apply for a requested ``p``: csrc/attention.hip decides a 2 x 2 block
+    of scores with one 32-bit hash and 8-bit fields, so the rate is quantised to round(256 p) / 256 (p = 0.1 -> 0.1016,
+    the keep scale is that of the quantised rate: the mask stays unbiased); 0 < p < 1/512 rounds to NO dropout"""
+    return round(256.0 * float(p)) / 256.0
+
+
 def attention(qkv: torch.Tensor, nhead: int, want_lse: bool, drop_p: float = 0.0, seed: int = 0, mask=None):
+    if 0.0 < float(drop_p) < 1.0 / 512.0:
+        import warnings
+        warnings.warn(f"attention dropout p = {drop_p} is below the kernels' resolution (1/256): no attention-probability dropout "
+                      "is applied (nn.MultiheadAttention(dropout=p) would drop with probability p)")
     B, L, E3 = qkv.shape
     E = E3 // 3
     dh = E // nhead

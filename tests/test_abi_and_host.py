@@ -157,7 +157,10 @@ def test_f3_csv_and_mat_loaders_match_reference_golden(golden, tmp_path):
     """the fMRI CSV loaders and the EEG .mat/CSV loaders return exactly (bit-equal, same
     keys in the same order) what the reference's loaders returned for the same synthetic tree
     (oracle/make_goldens.py wrote the tree and ran both).  The tree holds NaNs, a 'Subject' column in
-    some files, a missing activation type, a subject without a directory, the band-key fallback name."""
+    some files, a missing activation type, a subject without a directory, the band-key fallback name.
+    UNPINNED: the HDF5 (MATLAB v7.3) branch of load_eeg_erp_features (reference eeg_data_utils.py:140-165) - h5py is not in
+    the image, so neither the reference (imported with an empty `h5py` module object) nor this test can take it; the
+    MATLAB-v5 files here go through both sides' scipy.io.loadmat fallback."""
     import multimodal_eeg_fmri_amd.eeg_data_utils as Ed
     fx = golden("f3_loaders.npz")
     _rebuild_tree(fx, str(tmp_path))
@@ -375,6 +378,17 @@ def test_built_library_has_no_half_selecting_packed_fp32():
     assert kernels > 100, kernels                     # the disassembly really covered the library
     assert packed >= 100, packed                      # ... down to the instruction level (conv3d_wres's hand-written pairs)
     assert not bad, bad[:5]
+
+
+def test_attention_dropout_rate_is_quantised_and_small_rates_warn():
+    """csrc/attention.hip quantises the attention-probability dropout rate to 1/256; ops documents the effective
+    rate and warns when a requested rate rounds to none (host logic: the warning fires before any kernel is called)"""
+    from multimodal_eeg_fmri_amd import ops
+    assert ops.attn_effective_dropout(0.1) == 26 / 256 and ops.attn_effective_dropout(0.3) == 77 / 256
+    assert ops.attn_effective_dropout(0.001) == 0.0 and ops.attn_effective_dropout(0.0) == 0.0
+    with pytest.warns(UserWarning, match="below the kernels' resolution"):
+        with pytest.raises(Exception):                       # (a CPU tensor: the HIP path refuses it right after the warning)
+            ops.attention(torch.zeros(1, 4, 96), 4, False, drop_p=0.001)
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
