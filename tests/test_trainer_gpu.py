@@ -156,6 +156,87 @@ def test_c2_graph_step_at_the_benchmarked_batch_vs_oracle():
     torch.testing.assert_close(tr.bucket.p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("kind", ["stft", "power"])
+def test_bridge_step_with_the_config5_eeg_branch_vs_oracle(kind):
+    """BASELINE config #5 in the trainer: BridgeTrainer(eeg_encoder=MultiScaleSTFTPowerEncoder(...)) - raw EEG -> multi-scale
+    STFT power (z-scored) -> EnhancedPowerEncoder - and a bare EnhancedPowerEncoder as the EEG branch, on the tape and in the
+    hipGraph (dropout 0): one step against the CPU oracle (loss 2e-3; embeddings cos >= 1 - 1e-4 vs fp32; every parameter
+    gradient of the flat bucket <= 7e-2 rel-L2 vs the oracle with bf16-rounded GEMM operands), and graph replay == eager
+    tape bit for bit over four steps."""
+    import torch.nn.functional as F
+    from multimodal_eeg_fmri_amd import ops
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    from multimodal_eeg_fmri_amd.crossmodal_v4_enhancements import MultiScaleSTFTPowerEncoder
+    from multimodal_eeg_fmri_amd.enhanced_models_v4 import EnhancedPowerEncoder
+    from oracle.bf16_emulation import bf16_operands
+    import contextlib
+    C, T, vol, Bsz = 8, 256, (16, 16, 16), 8
+    nffts, hop = (16, 32), 8
+
+    def make(mode):
+        ops.set_seed_epoch(None)
+        torch.manual_seed(0)
+        enc = MultiScaleSTFTPowerEncoder(C, nffts, hop, 128, 2, 4, 0.0) if kind == "stft" else EnhancedPowerEncoder(C, 128, 2, 4, 0.0)
+        return BridgeTrainer(eeg_channels=C, dropout=0.0, lr=1e-3, mode=mode, eeg_encoder=enc).train()
+
+    eeg, fmri = synthetic_pairs(Bsz, C, T, vol, seed=4400)
+    tr = make("manual")
+    assert tr._eeg_kind == kind
+
+    def oracle(emulate):
+        sd = {}
+        for pre, m in (("e.", tr.eeg_encoder), ("f.", tr.fmri_encoder), ("h.", tr.head)):
+            for k, v in m.state_dict().items():
+                sd[pre + k] = v.detach().cpu().clone().requires_grad_(v.is_floating_point())
+        with (bf16_operands() if emulate else contextlib.nullcontext()):
+            if kind == "stft":
+                fe = RF.stft_power_encoder(sd, eeg.cpu(), nffts, hop, "e.encoder.", train=True)
+            else:
+                fe = RF.power_encoder(sd, eeg.cpu(), "e.", train=True)
+            ff = RF.volume_encoder3d(sd, fmri.cpu(), "f.", train=True)
+            ze, zf = RF.contrastive_head(sd, fe, ff, "h.bridge.")
+            loss = RF.clip_loss(ze, zf, ze, zf, sd["h.logit_scale"].exp())[0]
+            loss.backward()
+        return loss.item(), ze.detach(), zf.detach(), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    l32, ze32, zf32, _ = oracle(False)
+    _, _, _, g16 = oracle(True)
+    with torch.no_grad():
+        z, saved = tr._seg_forward(eeg, fmri)
+        dz = torch.empty_like(z)
+        tr._seg_loss(z, tr._scal, dz)
+        tr._seg_backward(saved, dz, tr._scal)
+        ops.arena.end()
+    torch.cuda.synchronize()
+    N = tr.head.bridge.bridge_dim
+    cos_e = F.cosine_similarity(z[:, :N].cpu().double(), ze32.double(), dim=1).min().item()
+    cos_f = F.cosine_similarity(z[:, N:].cpu().double(), zf32.double(), dim=1).min().item()
+    assert cos_e >= 1 - 1e-4 and cos_f >= 1 - 1e-4, (cos_e, cos_f)
+    assert abs(tr._scal[0].item() - l32) <= 2e-3 * max(1.0, abs(l32)), (tr._scal[0].item(), l32)
+    named = {}
+    for pre, m in (("e.", tr.eeg_encoder), ("f.", tr.fmri_encoder), ("h.", tr.head)):
+        named.update({pre + k: v for k, v in m.named_parameters()})
+    worst, checked = ("", 0.0), 0
+    for n, p in named.items():
+        sink = getattr(p, "_mm_grad", None)
+        if sink is None or n not in g16 or g16[n].norm() < 1e-5:
+            continue
+        got = sink.detach().cpu().view(g16[n].shape).double()
+        worst = max(worst, (n, ((got - g16[n].double()).norm() / g16[n].double().norm()).item()), key=lambda t: t[1])
+        checked += 1
+    assert checked >= 45, checked
+    assert worst[1] <= 7e-2, ("vs the bf16-operand oracle", worst)
+    # graph replay == eager tape, bit for bit
+    res = []
+    for mode in ("manual", "graph"):
+        t2 = make(mode)
+        losses = [t2.train_step(eeg, fmri)["loss"].clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses), t2.bucket.p.detach().clone()))
+        ops.set_seed_epoch(None)
+    assert torch.isfinite(res[0][0]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_projection_heads_with_dropout_match_masked_oracle():
     """both projection heads' nn.Dropout (bridge_utils.py:34-45) at p = 0.3 in ONE launch each way
     (mm_proj_heads_fwd / _bwd): embeddings, loss and every gradient against the CPU oracle evaluated with the same
