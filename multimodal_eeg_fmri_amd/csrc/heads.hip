@@ -1025,44 +1025,115 @@ __global__ void stft_power_kernel(const float* __restrict__ x, bf16* __restrict_
     extern __shared__ float sm[];
     float* tw_c = sm;                  // [nfft]
     float* tw_s = tw_c + nfft;         // [nfft]
-    float* fr = tw_s + nfft;           // [8][nfft] windowed frames
-    const int b = blockIdx.z, c = blockIdx.y, f0 = blockIdx.x * 8;
+    float* win = tw_s + nfft;          // [nfft] periodic Hann window
+    float* fr = win + nfft;            // [8][nfft] windowed frames
+    const int b = blockIdx.z, c = blockIdx.y;
     const int F = nfft / 2 + 1;
     for (int n = threadIdx.x; n < nfft; n += blockDim.x) {
         float s, co;
         __sincosf(6.283185307179586f * (float)n / (float)nfft, &s, &co);
         tw_c[n] = co; tw_s[n] = s;
+        win[n] = 0.5f - 0.5f * __cosf(6.283185307179586f * (float)n / (float)nfft);
     }
     const float* xr = x + ((size_t)b * C + c) * T;
-    for (int i = threadIdx.x; i < 8 * nfft; i += blockDim.x) {
-        const int fi = i / nfft, n = i % nfft;
-        const int frame = f0 + fi;
-        float v = 0.f;
-        if (frame < frames) {
-            int t = frame * hop + n - nfft / 2;
-            if (t < 0) t = -t;                              // reflect padding
-            if (t >= T) t = 2 * (T - 1) - t;
-            const float win = 0.5f - 0.5f * __cosf(6.283185307179586f * (float)n / (float)nfft);
-            v = xr[t] * win;
+    // the workgroup walks its share of the frame blocks (gridDim.x = 1 for short sequences: 10 240 tiny workgroups - twiddles,
+    // window and launch overhead per 8 frames - were 133 us per scale at config #5; one workgroup per (b, c) now)
+    for (int f0 = blockIdx.x * 8; f0 < frames; f0 += gridDim.x * 8) {
+        __syncthreads();                                    // twiddles ready / the previous block's frames consumed
+        for (int i = threadIdx.x; i < 8 * nfft; i += blockDim.x) {
+            const int fi = i / nfft, n = i % nfft;
+            const int frame = f0 + fi;
+            float v = 0.f;
+            if (frame < frames) {
+                int t = frame * hop + n - nfft / 2;
+                if (t < 0) t = -t;                              // reflect padding
+                if (t >= T) t = 2 * (T - 1) - t;
+                v = xr[t] * win[n];
+            }
+            fr[i] = v;
         }
-        fr[i] = v;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * F; i += blockDim.x) {
+            const int fi = i / F, f = i % F;
+            const int frame = f0 + fi;
+            if (frame >= frames) continue;
+            float re = 0.f, im = 0.f;
+            const float* fv = fr + fi * nfft;
+            for (int n = 0; n < nfft; ++n) {
+                const int k = (f * n) & (nfft - 1);             // nfft is a power of two
+                re += fv[n] * tw_c[k];
+                im -= fv[n] * tw_s[k];
+            }
+            const float p = re * re + im * im;
+            const size_t o = ((size_t)b * frames + frame) * ch_total + ch_off + (size_t)c * F + f;
+            if (out) out[o] = (bf16)p;
+            if (out_f32) out_f32[o] = p;
+        }
+    }
+}
+
+// The same spectra by a radix-2 FFT (nfft <= 256): one workgroup per (b, c), each of its four waves transforms one frame at
+// a time in its own LDS scratch (decimation in time on the bit-reversed, windowed frame; log2(nfft) butterfly stages of
+// nfft / 2 butterflies, lanes = butterflies).  The direct DFT above costs nfft MACs per (frame, bin) - 705 M MAC pairs at
+// config #5 (64 ch x 1024 samples, nfft 64 + 128, hop 32): 145 us per scale; the FFT needs nfft / 2 * log2(nfft) butterflies
+// per frame.  fp32 throughout; twiddles from __sincosf (as the DFT's).
+template <int LOG2N>
+__global__ __launch_bounds__(256) void stft_power_fft_kernel(const float* __restrict__ x, bf16* __restrict__ out,
+                                                             float* __restrict__ out_f32, int C, int T, int hop, int frames,
+                                                             int ch_off, int ch_total) {
+    constexpr int N = 1 << LOG2N, H = N / 2, F = H + 1;
+    __shared__ float tw_c[H], tw_s[H], win[N];
+    __shared__ float re[4][N], im[4][N];
+    const int b = blockIdx.z, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int n = tid; n < N; n += 256) {
+        float sn, cs;
+        __sincosf(6.283185307179586f * (float)n / (float)N, &sn, &cs);
+        if (n < H) { tw_c[n] = cs; tw_s[n] = sn; }             // e^{-2 pi i n / N} = tw_c - i tw_s
+        win[n] = 0.5f - 0.5f * cs;                              // periodic Hann
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 8 * F; i += blockDim.x) {
-        const int fi = i / F, f = i % F;
-        const int frame = f0 + fi;
-        if (frame >= frames) continue;
-        float re = 0.f, im = 0.f;
-        const float* fv = fr + fi * nfft;
-        for (int n = 0; n < nfft; ++n) {
-            const int k = (f * n) & (nfft - 1);             // nfft is a power of two
-            re += fv[n] * tw_c[k];
-            im -= fv[n] * tw_s[k];
+    const float* xr = x + ((size_t)b * C + c) * T;
+    float* r = re[wave];
+    float* q = im[wave];
+    const int rounds = (frames + 3) / 4;                        // the four waves step together (block barriers below)
+    for (int it = 0; it < rounds; ++it) {
+        const int frame = it * 4 + wave;
+        const bool live = frame < frames;
+        // bit-reversed load of the windowed frame
+        for (int n = lane; n < N; n += 64) {
+            int t = frame * hop + n - H;
+            if (t < 0) t = -t;                                  // reflect padding (torch.stft center = True)
+            if (t >= T) t = 2 * (T - 1) - t;
+            const int rv = (int)(__brev((unsigned)n) >> (32 - LOG2N));
+            r[rv] = live ? xr[t] * win[n] : 0.f;
+            q[rv] = 0.f;
         }
-        const float p = re * re + im * im;
-        const size_t o = ((size_t)b * frames + frame) * ch_total + ch_off + (size_t)c * F + f;
-        if (out) out[o] = (bf16)p;
-        if (out_f32) out_f32[o] = p;
+        __syncthreads();
+#pragma unroll
+        for (int sgm = 0; sgm < LOG2N; ++sgm) {
+            const int m = 1 << sgm;                             // half size of this stage's butterflies
+            for (int j = lane; j < H; j += 64) {
+                const int k = j & (m - 1);
+                const int i0 = ((j >> sgm) << (sgm + 1)) + k, i1 = i0 + m;
+                const int tk = k << (LOG2N - 1 - sgm);          // twiddle index k * N / (2 m)
+                const float wc = tw_c[tk], ws = tw_s[tk];
+                const float ar = r[i1], ai = q[i1];
+                const float tr = ar * wc + ai * ws, ti = ai * wc - ar * ws;     // (ar + i ai) (wc - i ws)
+                const float br = r[i0], bi = q[i0];
+                r[i0] = br + tr; q[i0] = bi + ti;
+                r[i1] = br - tr; q[i1] = bi - ti;
+            }
+            __syncthreads();
+        }
+        if (live) {
+            const size_t o = ((size_t)b * frames + frame) * ch_total + ch_off + (size_t)c * F;
+            for (int f = lane; f < F; f += 64) {
+                const float p = r[f] * r[f] + q[f] * q[f];
+                if (out) out[o + f] = (bf16)p;
+                if (out_f32) out_f32[o + f] = p;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1091,6 +1162,28 @@ __global__ __launch_bounds__(1024) void sample_zscore_kernel(const float* __rest
         for (int w = 0; w < 16; ++w) t += red[w];
         return t;
     };
+    if (ch_valid == ch_total && (ch_total & 3) == 0 && n < (1ull << 31)) {
+        // no padding channels (config #5: 6 272 of 6 272): three float4 sweeps with 32-bit indices.  (The general path's 64-bit
+        // modulo per ELEMENT and scalar loads made this one-workgroup-per-sample kernel 200 us at config #5.)
+        const unsigned n4 = (unsigned)(n >> 2);
+        const float4* x4 = reinterpret_cast<const float4*>(xs);
+        float s = 0.f;
+        for (unsigned i = tid; i < n4; i += 1024) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
+        const float mean = block_sum(s) / cnt;
+        float q = 0.f;
+        for (unsigned i = tid; i < n4; i += 1024) {
+            const float4 v = x4[i];
+            const float a = v.x - mean, c = v.y - mean, d = v.z - mean, e = v.w - mean;
+            q += (a * a + c * c) + (d * d + e * e);
+        }
+        const float inv = 1.f / (sqrtf(block_sum(q) / cnt) + eps);   // population std: the reference z-scores numpy arrays (ddof = 0)
+        for (unsigned i = tid; i < n4; i += 1024) {
+            const float4 v = x4[i];
+            bf16x4 o = {(bf16)((v.x - mean) * inv), (bf16)((v.y - mean) * inv), (bf16)((v.z - mean) * inv), (bf16)((v.w - mean) * inv)};
+            *reinterpret_cast<bf16x4*>(os + 4 * (size_t)i) = o;
+        }
+        return;
+    }
     float s = 0.f;
     for (size_t i = tid; i < n; i += 1024) s += ((int)(i % ch_total) < ch_valid) ? xs[i] : 0.f;
     const float mean = block_sum(s) / cnt;
@@ -1595,8 +1688,24 @@ int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, 
     const int frames = T / hop + 1;
     const int F = nfft / 2 + 1;
     MM_REQUIRE(ch_off >= 0 && ch_off + C * F <= ch_total, "stft_power: channel window");
-    const size_t lds = (size_t)(2 * nfft + 8 * nfft) * sizeof(float);
-    hipLaunchKernelGGL(stft_power_kernel, dim3(ceil_div(frames, 8), C, B), dim3(256), lds, st, x, (bf16*)out_bf16, out_f32,
+    if (nfft <= 256 && !getenv("MM_STFT_DFT")) {                // the FFT form (MM_STFT_DFT=1: the direct DFT, for A/B)
+        const dim3 grid(1, C, B);
+        switch (nfft) {
+            case 8: hipLaunchKernelGGL((stft_power_fft_kernel<3>), grid, dim3(256), 0, st, x, (bf16*)out_bf16, out_f32, C, T, hop, frames, ch_off, ch_total); break;
+            case 16: hipLaunchKernelGGL((stft_power_fft_kernel<4>), grid, dim3(256), 0, st, x, (bf16*)out_bf16, out_f32, C, T, hop, frames, ch_off, ch_total); break;
+            case 32: hipLaunchKernelGGL((stft_power_fft_kernel<5>), grid, dim3(256), 0, st, x, (bf16*)out_bf16, out_f32, C, T, hop, frames, ch_off, ch_total); break;
+            case 64: hipLaunchKernelGGL((stft_power_fft_kernel<6>), grid, dim3(256), 0, st, x, (bf16*)out_bf16, out_f32, C, T, hop, frames, ch_off, ch_total); break;
+            case 128: hipLaunchKernelGGL((stft_power_fft_kernel<7>), grid, dim3(256), 0, st, x, (bf16*)out_bf16, out_f32, C, T, hop, frames, ch_off, ch_total); break;
+            default: hipLaunchKernelGGL((stft_power_fft_kernel<8>), grid, dim3(256), 0, st, x, (bf16*)out_bf16, out_f32, C, T, hop, frames, ch_off, ch_total); break;
+        }
+        return mm_check_launch("stft_power");
+    }
+    const size_t lds = (size_t)(3 * nfft + 8 * nfft) * sizeof(float);
+    // (b, c) pairs fill the chip by themselves at the encoder's sizes: one workgroup each walks all its frame blocks; only a
+    // small problem is also split over the frame blocks
+    const int fblocks = ceil_div(frames, 8);
+    const int gx = (long)B * C >= 1024 ? 1 : (fblocks < 8 ? fblocks : 8);
+    hipLaunchKernelGGL(stft_power_kernel, dim3(gx, C, B), dim3(256), lds, st, x, (bf16*)out_bf16, out_f32,
                        C, T, nfft, hop, frames, ch_off, ch_total);
     return mm_check_launch("stft_power");
 }

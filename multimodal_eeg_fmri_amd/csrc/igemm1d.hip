@@ -870,6 +870,7 @@ struct WgradArgs {
     int B, T, Cin, Cout, pad, Cin_real, rows_per_wg, nrep;
     long sn, sc, stap, rep_stride;
     int slot_mode;            // 1: workgroup x stores its partial tile into slot blockIdx.x (no atomics)
+    int bgroup;               // samples one workgroup accumulates over (> 1 only when a sample is a single row chunk)
 };
 
 template <int TAPS>
@@ -879,12 +880,13 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
     const int chunksT = (a.T + a.rows_per_wg - 1) / a.rows_per_wg;
-    const int b = bx / chunksT;
+    // samples [b0, b1) of this workgroup: one, or - short sequences with many output tiles (config #5: 33 frames x 6 272
+    // channels) - a group of them, so that the number of SLOTS (each a full weight-shaped fp32 image that the flush has to
+    // sum: 33.7 MB there) does not grow with the batch
+    const int b0 = (bx / chunksT) * a.bgroup, b1 = min(a.B, b0 + a.bgroup);
     const int tbeg = (bx % chunksT) * a.rows_per_wg;
     const int tend = min(a.T, tbeg + a.rows_per_wg);
     const int n0 = by * 64, c0 = bz * 64;
-    const bf16* dyb = a.dy + (size_t)b * a.T * a.Cout;
-    const bf16* xb = a.x + (size_t)b * a.T * a.Cin;
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -893,12 +895,14 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
         for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
     float bsum = 0.f;
 
-    // tiles are fetched into registers one iteration ahead (all loads in flight
+    // tiles are fetched into registers one work item (sample, row tile) ahead (all loads in flight
     // before any LDS write, and in flight during the previous tile's MFMAs)
     constexpr int YREG = WG_MK * 8 / 256;                           // 2
     constexpr int XREG = ((WG_MK + TAPS - 1) * 8 + 255) / 256;      // 3
     uint4 yv[YREG], xv[XREG];
-    auto fetch = [&](int t0) {
+    auto fetch = [&](int b, int t0) {
+        const bf16* dyb = a.dy + (size_t)b * a.T * a.Cout;
+        const bf16* xb = a.x + (size_t)b * a.T * a.Cin;
 #pragma unroll
         for (int i = 0; i < YREG; ++i) {
             const int s = tid + i * 256, r = s >> 3, sg = s & 7;
@@ -913,8 +917,9 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
                         ? *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c) : make_uint4(0, 0, 0, 0);
         }
     };
-    if (tbeg < tend) fetch(tbeg);
-    for (int t0 = tbeg; t0 < tend; t0 += WG_MK) {
+    int b = b0, t0 = tbeg;
+    if (b < b1 && tbeg < tend) fetch(b, t0);
+    while (b < b1 && tbeg < tend) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < YREG; ++i) {
@@ -927,7 +932,9 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
             if (s < (WG_MK + TAPS - 1) * 8) *reinterpret_cast<uint4*>(Xs + (s >> 3) * WG_LD + (s & 7) * 8) = xv[i];
         }
         __syncthreads();
-        if (t0 + WG_MK < tend) fetch(t0 + WG_MK);
+        int nb = b, nt = t0 + WG_MK;                                // next work item
+        if (nt >= tend) { ++nb; nt = tbeg; }
+        if (nb < b1) fetch(nb, nt);
 #pragma unroll
         for (int kk = 0; kk < WG_MK; kk += 16) {
             const bf16x8 af = tr_frag(Ys, kk, wn * 32, lane);
@@ -940,6 +947,7 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
                 acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tp], 0, 0, 0);
             }
         }
+        b = nb; t0 = nt;
     }
     // D[i = n][j = c]: lane owns column c, rows n = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int c = c0 + wc * 32 + (lane & 31);
@@ -1152,7 +1160,7 @@ __global__ void acc_reduce_kernel(const mm_acc_t* __restrict__ src, float* __res
 template <int TAPS>
 int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int chunksT = ceil_div(a.T, a.rows_per_wg);
-    dim3 grid(a.B * chunksT, ceil_div(a.Cout, 64), ceil_div(a.Cin, 64));
+    dim3 grid(ceil_div(a.B, a.bgroup) * chunksT, ceil_div(a.Cout, 64), ceil_div(a.Cin, 64));
     hipLaunchKernelGGL(conv1d_wgrad_kernel<TAPS>, grid, dim3(256), 0, st, a);
     return mm_check_launch("conv1d_wgrad");
 }
@@ -1499,6 +1507,17 @@ static int wgrad_rows_per_wg(int B, int T, int Cin, int Cout, int taps, int slot
     return ceil_div(tilesT, want_chunks) * WG_MK;
 }
 
+// samples per workgroup (conv1d_wgrad_body): 1 unless a sample is a single row chunk AND the output tiles alone fill the chip
+static int wgrad_bgroup(int B, int T, int Cin, int Cout, int taps, int slot_mode) {
+    const int rows = wgrad_rows_per_wg(B, T, Cin, Cout, taps, slot_mode);
+    if (ceil_div(T, rows) != 1) return 1;
+    const int tiles = ceil_div(Cout, 64) * ceil_div(Cin, 64);
+    int nsl = 384 / tiles;                                          // slots wanted: ~384 workgroups in all
+    if (nsl < 1) nsl = 1;
+    if (nsl > B) nsl = B;
+    return ceil_div(B, nsl);
+}
+
 // grouped launches (mm_conv1d_wgrad_many) get their parallelism from the number of problems, so each
 // problem is cut into far fewer row chunks: ~32 workgroups per problem instead of 384 (round-1 sweep: 384 1.127, 128 1.124,
 // 64 1.120, 32 1.158 ms/step; end of round 2, with the launch on the side stream beside the chain: 128 0.880, 96 0.873,
@@ -1525,7 +1544,7 @@ int mm_conv1d_wgrad_many_slots(int B, int T, int Cin, int Cout, int* slots_host,
 
 int mm_conv1d_wgrad_slots(int B, int T, int Cin, int Cout, int taps, int* slots_host, hipStream_t) {
     MM_REQUIRE(slots_host && B > 0 && T > 0 && Cin > 0 && Cout > 0, "conv1d_wgrad_slots: bad args");
-    *slots_host = B * ceil_div(T, wgrad_rows_per_wg(B, T, Cin, Cout, taps, 1));
+    *slots_host = ceil_div(B, wgrad_bgroup(B, T, Cin, Cout, taps, 1)) * ceil_div(T, wgrad_rows_per_wg(B, T, Cin, Cout, taps, 1));
     return 0;
 }
 
@@ -1541,8 +1560,9 @@ int mm_conv1d_wgrad(const void* dy, const void* x, float* dw, float* dbias, int 
     a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.pad = pad; a.Cin_real = Cin_real;
     a.sn = sn; a.sc = sc; a.stap = stap; a.nrep = nrep; a.rep_stride = rep_stride; a.slot_mode = slot_mode;
     a.rows_per_wg = wgrad_rows_per_wg(B, T, Cin, Cout, taps, slot_mode);
-    MM_REQUIRE(!slot_mode || nrep >= B * ceil_div(T, a.rows_per_wg),
-               "conv1d_wgrad: slot mode needs %d slots (mm_conv1d_wgrad_slots), got %d", B * ceil_div(T, a.rows_per_wg), nrep);
+    a.bgroup = wgrad_bgroup(B, T, Cin, Cout, taps, slot_mode);
+    MM_REQUIRE(!slot_mode || nrep >= ceil_div(B, a.bgroup) * ceil_div(T, a.rows_per_wg),
+               "conv1d_wgrad: slot mode needs %d slots (mm_conv1d_wgrad_slots), got %d", ceil_div(B, a.bgroup) * ceil_div(T, a.rows_per_wg), nrep);
     switch (taps) {
         case 1: return launch_wgrad<1>(a, st);
         case 3: return launch_wgrad<3>(a, st);
@@ -1572,6 +1592,7 @@ int mm_conv1d_wgrad_many(const void* desc_host, int n, hipStream_t st) {
             a.B = q.B; a.T = q.T; a.Cin = q.Cin; a.Cout = q.Cout; a.pad = 0; a.Cin_real = q.Cin_real;
             a.sn = q.Cin; a.sc = 1; a.stap = q.Cin; a.nrep = q.nslots; a.rep_stride = (long)q.Cout * q.Cin; a.slot_mode = 1;
             a.rows_per_wg = wgrad_many_rows_per_wg(q.T, q.Cin, q.Cout);
+            a.bgroup = 1;
             const int chunks = q.B * ceil_div(q.T, a.rows_per_wg);
             MM_REQUIRE(q.nslots == chunks, "conv1d_wgrad_many: needs exactly %d slots (mm_conv1d_wgrad_many_slots), got %d",
                        chunks, q.nslots);

@@ -131,8 +131,11 @@ def test_attention_fwd_bwd(B, L, H):
 
 
 @pytest.mark.parametrize("B,C,T,Cout,k", [(2, 64, 256, 64, 7), (3, 64, 200, 128, 5), (2, 128, 128, 128, 3),
-                                          (4, 8, 256, 64, 7), (1, 128, 1000, 384, 1), (2, 512, 64, 128, 1)])
+                                          (4, 8, 256, 64, 7), (1, 128, 1000, 384, 1), (2, 512, 64, 128, 1),
+                                          (6, 1024, 20, 768, 3), (5, 2048, 33, 192, 7)])
 def test_conv1d_wgrad_matches_autograd(B, C, T, Cout, k):
+    """(the last two shapes: short sequences with 192 / 96 output tiles - the config-#5 kind - where a workgroup accumulates
+    over a GROUP of samples, so that the slot count does not grow with the batch: 2 and 3 slots instead of 6 and 5)"""
     hip = _hip()
     g = torch.Generator().manual_seed(C + T + k)
     x = _bf(torch.randn(B, C, T, generator=g))
@@ -150,6 +153,8 @@ def test_conv1d_wgrad_matches_autograd(B, C, T, Cout, k):
     hip.call("mm_conv1d_wgrad_slots", B, T, cp, Cout, k, ctypes.addressof(n))
     slots = n.value
     assert slots >= 1
+    if T <= 64 and C >= 1024:
+        assert slots == {1024: 2, 2048: 3}[C], slots
     dw = torch.full((slots, Cout, C, k), float("nan"), device="cuda")
     db = torch.zeros(32, Cout, device="cuda")
     hip.call("mm_conv1d_wgrad", dyg, xg, dw, db, B, T, cp, Cout, k, k // 2, C, C * k, k, 1, slots, Cout * C * k, 1)
