@@ -129,6 +129,44 @@ def loops(steps):
             tr.train_step_packed(ring[i % depth])
             con[i % depth].record()
 
+    # the same packed loop with events that release to DEVICE scope only (hipEventReleaseToDevice; torch.cuda.Event has no
+    # such flag: raw HIP events through ctypes).  A default event record is a system-scope release (cache write-back).
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hipEventDisableTiming, hipEventReleaseToDevice = 0x2, 0x40000000
+
+    class RawEvent:
+        def __init__(self, flags):
+            self.h = ctypes.c_void_p()
+            assert hip.hipEventCreateWithFlags(ctypes.byref(self.h), ctypes.c_uint(flags)) == 0
+
+        def record(self, stream):
+            assert hip.hipEventRecord(self.h, ctypes.c_void_p(stream.cuda_stream)) == 0
+
+        def wait(self, stream):
+            assert hip.hipStreamWaitEvent(ctypes.c_void_p(stream.cuda_stream), self.h, ctypes.c_uint(0)) == 0
+
+    def loop_raw(n, flags):
+        rdy = [RawEvent(flags) for _ in range(2)]
+        con = [RawEvent(flags) for _ in range(2)]
+        main = torch.cuda.current_stream()
+        for e in con:
+            e.record(main)
+
+        def up(i):
+            b = i % 2
+            con[b].wait(copy_s)
+            with torch.cuda.stream(copy_s):
+                stage1[b].copy_(packed[i % NB], non_blocking=True)
+            rdy[b].record(copy_s)
+        up(0)
+        for i in range(n):
+            if i + 1 < n:
+                up(i + 1)
+            rdy[i % 2].wait(main)
+            tr.train_step_packed(stage1[i % 2])
+            con[i % 2].record(main)
+
     timed("round 3: two fp32 H2D copies (12.6 MB) + stage kernel + replay", loop_two)
     timed("   the same event / copy structure without the training step", lambda n: loop_two(n, False))
     timed("ONE packed H2D copy (bf16 EEG operand + fp32 volumes, 8.4 MB) + one D2D + replay", loop_one)
@@ -138,6 +176,8 @@ def loops(steps):
           lambda n: [tr.train_step_packed(stage1[i % 2]) for i in range(n)])
     timed("ONE packed copy, ring of 4 staging buffers, copies issued 3 steps ahead", loop_deep)
     timed("ONE packed copy, ring of 3 staging buffers, copies issued 2 steps ahead", lambda n: loop_deep(n, 3))
+    timed("ONE packed copy, raw HIP events, default flags (disable timing)", lambda n: loop_raw(n, hipEventDisableTiming))
+    timed("ONE packed copy, raw HIP events with hipEventReleaseToDevice", lambda n: loop_raw(n, hipEventDisableTiming | hipEventReleaseToDevice))
     timed("resident batches again", lambda n: [tr.train_step(*dev[i % NB]) for i in range(n)])
     # same packed loop, H2D on the MAIN stream (no second stream, no events): copy and step serialised
     def serial(n):
