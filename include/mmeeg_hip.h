@@ -287,14 +287,16 @@ int mm_pooled_head_bwd_rows(const float* dout, const void* z_pre_bf16, const flo
  * head-averaged weights the reference computes and discards (:99) are not produced.
  * attn_mask (nullable): the `mask` of TemporalTransformerBlock.forward(x, mask)
  * (enhanced_models_v4.py:88-98 -> self_attn(..., attn_mask=mask)) as an ADDITIVE fp32 (L, L)
- * matrix shared by every batch element and head (a boolean mask = 0 / -inf; the (B*H, L, L)
- * form is not supported).  A fully masked row yields NaN, as in PyTorch. */
+ * matrix shared by every batch element and head (a boolean mask = 0 / -inf), or - attn_mask_per_head != 0 -
+ * nn.MultiheadAttention's 3-D form: (B*H, L, L), matrix b*H + h for head h of batch element b.
+ * A fully masked row yields NaN, as in PyTorch. */
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim,
                 float scale, float drop_p, uint32_t seed, const uint32_t* seed_epoch,
-                const float* attn_mask, hipStream_t stream);
+                const float* attn_mask, int attn_mask_per_head, hipStream_t stream);
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                 float* delta_ws, int B, int L, int H, int head_dim, float scale, float drop_p,
-                uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, hipStream_t stream);
+                uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, int attn_mask_per_head,
+                hipStream_t stream);
 
 /* ---- small reductions / elementwise --------------------------------------- */
 int mm_colsum(const void* a_bf16, const float* a_f32, float* out, int M, int N, hipStream_t stream);

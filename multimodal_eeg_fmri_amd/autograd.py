@@ -390,7 +390,7 @@ def transformer_block_bwd(bag: GradBag, s: dict, dx2: torch.Tensor, dy2=None, em
     dh = D // blk.nhead
     pa, sa = s.get("attn_drop", (0.0, 0))
     _hip.call("mm_attn_bwd", s["qkv"], s["o"], do, s["lse"], dqkv, delta, B, L, blk.nhead, dh, float(dh) ** -0.5,
-              float(pa), int(sa), ops.EP(), s.get("mask"))
+              float(pa), int(sa), ops.EP(), s.get("mask"), ops.attn_mask_per_head(s.get("mask"), B, blk.nhead, L))
     dx0 = _empty((M, D), _F32, dx2)
     emit = _empty((M, D), _BF, dx2) if emit_for is not None else None
     ep, es = emit_for if emit_for is not None else (0.0, 0)

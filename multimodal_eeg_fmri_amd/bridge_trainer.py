@@ -415,7 +415,7 @@ class BridgeTrainer(nn.Module):
                 self._seg_adamw()
             record(whole)
             self.capture_mode = "one graph"
-        elif dp.CAPTURABLE and os.environ.get("MM_DP_CAPTURE", "1") != "0" and self._capture_with_collectives(c, record, B, N2, world, dev):
+        elif dp.CAPTURABLE and os.environ.get("MM_DP_CAPTURE", "1") != "0" and self._capture_with_collectives(c, record, graphs, B, N2, world, dev):
             self.capture_mode = "one graph + captured RCCL collectives"
         else:
             self.capture_mode = "3 segments + 2 eager collectives"
@@ -445,12 +445,13 @@ class BridgeTrainer(nn.Module):
         if probe is not None:
             probe.copy_(self.bucket.g)
 
-    def _capture_with_collectives(self, c, record, B, N2, world, dev) -> bool:
+    def _capture_with_collectives(self, c, record, graphs, B, N2, world, dev) -> bool:
         """the N > 1 step as ONE hipGraph: the all-gather of the embeddings and the all-reduce of every layer group of the
         gradient bucket (side branch / chain, `_seg_backward`) are graph nodes (no replay gaps, no host in the step).
-        Every rank then reports its outcome and ALL take the same form (`dp.agree_on_capture`): the graph, or - only when
-        every rank was refused before a collective had been enqueued - the three segments (returns False, nothing
-        recorded); a mixed outcome raises on every rank, so the job exits non-zero instead of hanging."""
+        Every rank then reports its outcome and ALL take the same form (`dp.agree_on_capture`): the graph when every rank
+        captured it, else the three segments on every rank (returns False, nothing recorded).  A recorded collective has
+        not run, so dropping the graphs leaves the ranks in step; when the abort came after collectives had been recorded,
+        or only on some ranks, the communicator must first pass `dp.check_communicator`."""
         c["z_all"] = torch.empty(world * B, N2, device=dev)
         # the communicator must exist before the capture starts (its lazy initialisation is not capturable)
         dp.all_gather_into(c["z_all"], torch.zeros(B, N2, device=dev), self.group)
@@ -476,14 +477,19 @@ class BridgeTrainer(nn.Module):
             record(whole_dp, mode="thread_local")
         except Exception as e:  # noqa: BLE001 - any refusal (RCCL, the caching allocator, a host sync)
             err = e
-        verdict = dp.agree_on_capture(err is None, dp.issued - issued0, self.group)      # raises on a mixed outcome
+        verdict = dp.agree_on_capture(err is None, dp.issued - issued0, self.group)
         if verdict == "captured":
             return True
         import warnings
-        warnings.warn(f"collectives not captured into the step's hipGraph on any rank ({type(err).__name__}: {err}); "
+        warnings.warn(f"collectives not captured into the step's hipGraph on every rank (this rank: "
+                      f"{'captured' if err is None else type(err).__name__ + ': ' + str(err)}; group verdict {verdict}); "
                       "all ranks use three graph segments around two eager collectives")
+        if err is None:
+            graphs.pop()                                          # this rank's graph is dropped with the others'
         torch.cuda.synchronize()
         self._works = []
+        if verdict == "segments-after-abort":
+            dp.check_communicator(self.group, dev)
         ops.arena.end()
         ops.weights_changed()
         return False

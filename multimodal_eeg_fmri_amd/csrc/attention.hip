@@ -109,8 +109,9 @@ template <bool DROP, bool FULL, bool MASK = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int L, int H, float scale_log2,
                                                        uint32_t dthresh, uint32_t dseed, float dinv,
-                                                       const uint32_t* epoch, const float* __restrict__ amask) {
+                                                       const uint32_t* epoch, const float* __restrict__ amask, size_t amask_bh) {
     dseed = mm_eff_seed(dseed, epoch);
+    if (MASK) amask += (size_t)(blockIdx.z * H + blockIdx.y) * amask_bh;      // (B*H, L, L) form: one matrix per (batch, head); 0 = shared
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * VR];      // V row-major, row = vperm(key): read transposed by tr_frag32
     const int E = H * DH, E3 = 3 * E;
@@ -269,8 +270,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           bf16* __restrict__ dqkv, float* __restrict__ delta,
                                                           int L, int H, float scale, uint32_t dthresh,
                                                           uint32_t dseed, float dinv, const uint32_t* epoch,
-                                                          const float* __restrict__ amask) {
+                                                          const float* __restrict__ amask, size_t amask_bh) {
     dseed = mm_eff_seed(dseed, epoch);
+    if (MASK) amask += (size_t)(blockIdx.z * H + blockIdx.y) * amask_bh;
     __shared__ __attribute__((aligned(16))) bf16 Ks[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[KCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Kr[KCH * VR];      // K again, row = vperm(key), for the transposed product (tr_frag32)
@@ -409,8 +411,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16* __restrict__ dqkv, int L, int H, float scale,
                                                            uint32_t dthresh, uint32_t dseed, float dinv,
-                                                           const uint32_t* epoch, const float* __restrict__ amask) {
+                                                           const uint32_t* epoch, const float* __restrict__ amask, size_t amask_bh) {
     dseed = mm_eff_seed(dseed, epoch);
+    if (MASK) amask += (size_t)(blockIdx.z * H + blockIdx.y) * amask_bh;
     __shared__ __attribute__((aligned(16))) bf16 Qs[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Ds[QCH * KS];
     __shared__ __attribute__((aligned(16))) bf16 Qr[QCH * VR];      // Q and dO again, row = vperm(query), for the transposed
@@ -562,8 +565,10 @@ static inline uint32_t attn_thresh(float p) { return p > 0.f ? (uint32_t)((doubl
 static inline float attn_keep_scale(uint32_t t) { return t ? 256.f / (256.f - (float)t) : 1.f; }
 
 int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int head_dim, float scale,
-                float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
+                float drop_p, uint32_t seed, const uint32_t* seed_epoch, const float* attn_mask, int attn_mask_per_head,
+                hipStream_t st) {
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_fwd: drop_p");
+    const size_t mask_bh = attn_mask && attn_mask_per_head ? (size_t)L * L : 0;
     MM_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0, "attn_fwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_fwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
@@ -573,15 +578,16 @@ int mm_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int
                     : (full ? attn_fwd_kernel<false, true> : attn_fwd_kernel<false, false>);
     if (attn_mask) kern = dth ? attn_fwd_kernel<true, false, true> : attn_fwd_kernel<false, false, true>;
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, L, H,
-                       scale * 1.4426950408889634f, dth, seed, attn_keep_scale(dth), seed_epoch, attn_mask);
+                       scale * 1.4426950408889634f, dth, seed, attn_keep_scale(dth), seed_epoch, attn_mask, mask_bh);
     return mm_check_launch("attn_fwd");
 }
 
 int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta_ws,
                 int B, int L, int H, int head_dim, float scale, float drop_p, uint32_t seed,
-                const uint32_t* seed_epoch, const float* attn_mask, hipStream_t st) {
+                const uint32_t* seed_epoch, const float* attn_mask, int attn_mask_per_head, hipStream_t st) {
     const uint32_t dth = attn_thresh(drop_p);
     const float dinv = attn_keep_scale(dth);
+    const size_t mask_bh = attn_mask && attn_mask_per_head ? (size_t)L * L : 0;
     MM_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws && B > 0 && L > 0 && H > 0, "attn_bwd: null/invalid");
     MM_REQUIRE(head_dim == DH, "attn_bwd: head_dim=%d (kernel is specialised for 32)", head_dim);
     dim3 grid(ceil_div(L, 128), H, B);
@@ -595,11 +601,11 @@ int mm_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
         kdkv = dth ? attn_bwd_dkv_kernel<true, false, true> : attn_bwd_dkv_kernel<false, false, true>;
     }
     hipLaunchKernelGGL(kdq, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)out,
-                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv, seed_epoch, attn_mask);
+                       (const bf16*)dout, lse, (bf16*)dqkv, delta_ws, L, H, scale, dth, seed, dinv, seed_epoch, attn_mask, mask_bh);
     int rc = mm_check_launch("attn_bwd_dq");
     if (rc) return rc;
     hipLaunchKernelGGL(kdkv, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse,
-                       delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv, seed_epoch, attn_mask);
+                       delta_ws, (bf16*)dqkv, L, H, scale, dth, seed, dinv, seed_epoch, attn_mask, mask_bh);
     return mm_check_launch("attn_bwd_dkv");
 }
 

@@ -98,28 +98,36 @@ def _control_group(group):
 
 
 def agree_on_capture(ok: bool, issued_in_attempt: int, group) -> str:
-    """every rank reports whether its capture of the step succeeded -> ONE verdict for the whole group:
+    """every rank reports whether its capture of the step succeeded -> ONE verdict for the whole group, so that no two
+    ranks ever replay different collective sequences:
 
     * ``"captured"``  every rank holds the one-graph step;
     * ``"segments"``  every rank was refused before any collective had been handed to the backend: all fall back to
       the segmented form together;
-    * otherwise a RuntimeError on EVERY rank (some rank failed after a collective was enqueued somewhere: ranks would
-      issue different collective sequences, and an aborted capture leaves the communicator undefined) - the job
-      exits non-zero instead of hanging."""
+    * ``"segments-after-abort"``  some rank failed while another captured, or a capture was aborted after collectives
+      had been recorded.  Recorded collectives never ran (a capture executes nothing), so all ranks drop their graphs
+      and fall back together - but the communicator has seen an aborted capture, and the caller must prove it still
+      works (``check_communicator``) before the first step."""
     if group is None or world_size(group) == 1:
-        return "captured" if ok else ("segments" if issued_in_attempt == 0 else _raise_mixed(0 if ok else 1, issued_in_attempt, 1))
-    t = torch.tensor([0 if ok else 1, int(issued_in_attempt)], dtype=torch.int64)
+        return "captured" if ok else ("segments" if issued_in_attempt == 0 else "segments-after-abort")
+    t = torch.tensor([0 if ok else 1, 0 if ok else int(issued_in_attempt)], dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_control_group(group))
     failed, enq = int(t[0]), int(t[1])
-    w = world_size(group)
     if failed == 0:
         return "captured"
-    if failed == w and enq == 0:
+    if failed == world_size(group) and enq == 0:
         return "segments"
-    return _raise_mixed(failed, enq, w)
+    return "segments-after-abort"
 
 
-def _raise_mixed(failed, enq, w):
-    raise RuntimeError(f"hipGraph capture of the data-parallel step failed on {failed} of {w} rank(s) after {enq} collective(s) "
-                       "had been enqueued: the ranks no longer agree on the collective sequence; aborting the job "
-                       "(set MM_DP_CAPTURE=0 for the segmented form)")
+def check_communicator(group, device) -> None:
+    """one eager all-reduce over the data group whose answer is known (ones -> world size).  After an aborted capture
+    this is what tells a working communicator from a broken one: a wrong sum raises here on every rank; a collective
+    that never completes is ended by the process group's own timeout (the job exits non-zero, it does not hang)."""
+    w = world_size(group)
+    t = torch.ones(64, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    got = t.cpu()
+    if not bool((got == float(w)).all()):
+        raise RuntimeError(f"the data-parallel communicator returns {got[:4].tolist()} for a sum of ones over {w} rank(s) after an "
+                           "aborted hipGraph capture; aborting the job (set MM_DP_CAPTURE=0 for the segmented form)")

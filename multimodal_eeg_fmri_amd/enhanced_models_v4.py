@@ -71,8 +71,8 @@ class TemporalTransformerBlock(nn.Module):
         self.nhead = nhead
 
     def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        # ``mask`` = nn.MultiheadAttention's attn_mask (reference :98): 2-D (L, L), boolean (True = not
-        # allowed) or additive float; the encoders themselves never pass one (reference :169-193)
+        # ``mask`` = nn.MultiheadAttention's attn_mask (reference :98): (L, L) or (batch * heads, L, L), boolean
+        # (True = not allowed) or additive float; the encoders themselves never pass one (reference :169-193)
         return ops.transformer_block(x, self, self.training, mask)
 
 

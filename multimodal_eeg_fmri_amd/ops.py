@@ -388,19 +388,31 @@ def attention(qkv: torch.Tensor, nhead: int, want_lse: bool, drop_p: float = 0.0
     dh = E // nhead
     out = _empty((B, L, E), _BF, qkv)
     lse = _empty((B, nhead, L), _F32, qkv) if want_lse else None
-    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), int(seed), EP(), mask)
+    _hip.call("mm_attn_fwd", qkv, out, lse, B, L, nhead, dh, 1.0 / math.sqrt(dh), float(drop_p), int(seed), EP(), mask,
+              attn_mask_per_head(mask, B, nhead, L))
     return out, lse
 
 
+def attn_mask_per_head(mask, B: int, nhead: int, L: int) -> int:
+    """0: ``mask`` is None or the shared (L, L) matrix; 1: the (B * nhead, L, L) form - its leading size is checked
+    here, where the batch is known"""
+    if mask is None or mask.dim() == 2:
+        return 0
+    if tuple(mask.shape) != (B * nhead, L, L):
+        raise ValueError(f"attn_mask: the 3-D form must be (batch * heads, L, L) = ({B * nhead}, {L}, {L}), got {tuple(mask.shape)}")
+    return 1
+
+
 def additive_attn_mask(mask, L: int, like: torch.Tensor):
-    """nn.MultiheadAttention's ``attn_mask`` (enhanced_models_v4.py:98) as the additive fp32 (L, L)
-    matrix the kernels take: a boolean mask marks NOT-allowed positions with True (-> -inf)."""
+    """nn.MultiheadAttention's ``attn_mask`` (enhanced_models_v4.py:98) as the additive fp32 matrix the kernels take -
+    (L, L) shared by all heads (the only form the reference passes) or (batch * heads, L, L): a boolean mask marks
+    NOT-allowed positions with True (-> -inf)."""
     if mask is None:
         return None
-    if mask.dim() != 2 or tuple(mask.shape) != (L, L):
-        raise NotImplementedError(f"attn_mask: only the 2-D (L, L) = ({L}, {L}) form is supported, got {tuple(mask.shape)}")
+    if mask.dim() not in (2, 3) or tuple(mask.shape[-2:]) != (L, L):
+        raise ValueError(f"attn_mask: expected (L, L) or (batch * heads, L, L) with L = {L}, got {tuple(mask.shape)}")
     if mask.dtype == torch.bool:
-        m = torch.zeros((L, L), dtype=_F32, device=like.device)
+        m = torch.zeros(tuple(mask.shape), dtype=_F32, device=like.device)
         m.masked_fill_(mask.to(like.device), float("-inf"))
         return m
     return mask.to(device=like.device, dtype=_F32).contiguous()

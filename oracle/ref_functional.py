@@ -77,7 +77,9 @@ def positional_encoding(sd: SD, p: str, x):
 # --------------------------------------------------------------------------
 def multihead_attention(sd: SD, p: str, q_in, kv_in, nhead: int, attn_mask=None):
     """returns (out (B,Lq,E), head-averaged weights (B,Lq,Lk)).  ``attn_mask`` (Lq, Lk): boolean
-    (True = not allowed) or additive float, as nn.MultiheadAttention takes it (enhanced_models_v4.py:98)."""
+    (True = not allowed) or additive float, as nn.MultiheadAttention takes it (enhanced_models_v4.py:98); its 3-D form
+    (B * nhead, Lq, Lk) - matrix b * nhead + h for head h of sample b - is accepted too (the reference never passes it:
+    tests/test_oracle_golden.py pins that branch against torch.nn.MultiheadAttention itself)."""
     E = q_in.shape[-1]
     W, b = sd[p + "in_proj_weight"], sd[p + "in_proj_bias"]
     q = F.linear(q_in, W[:E], b[:E])
@@ -91,6 +93,8 @@ def multihead_attention(sd: SD, p: str, q_in, kv_in, nhead: int, attn_mask=None)
     v = v.view(B, Lk, nhead, dh).transpose(1, 2)
     s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
     if attn_mask is not None:
+        if attn_mask.dim() == 3:
+            attn_mask = attn_mask.view(B, nhead, Lq, Lk)
         if attn_mask.dtype == torch.bool:
             s = s.masked_fill(attn_mask, float("-inf"))
         else:

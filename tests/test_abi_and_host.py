@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in list(sigs) + ["mm_last_error", "mm_abi_version"] if not hasattr(lib, n)]
     assert not missing, missing
     lib.mm_abi_version.restype = ctypes.c_int
-    assert lib.mm_abi_version() == 3
+    assert lib.mm_abi_version() == 4
 
 
 def test_argument_errors_are_reported_not_crashed():
@@ -39,7 +39,7 @@ def test_argument_errors_are_reported_not_crashed():
     rc = lib.mm_pack_nct_bf16(None, None, 0, 0, 0, 0, None)
     assert rc == -1 and b"pack_nct" in lib.mm_last_error()
     rc = lib.mm_attn_fwd(ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 16, 4, 64, ctypes.c_float(0.1),
-                         ctypes.c_float(0.0), 0, None, None, None)
+                         ctypes.c_float(0.0), 0, None, None, 0, None)
     assert rc == -1 and b"head_dim" in lib.mm_last_error()
 
 

@@ -173,11 +173,21 @@ def _agree_worker(rank, world, port, q):
         out.append(dp.agree_on_capture(False, 0, g))                      # every rank refused before any collective
         for ok, enq in (((rank == 0), 5 if rank == 0 else 0),             # one rank failed, cleanly - but its peer captured
                         (False, 1 if rank == 1 else 0)):                  # all failed, one of them after a collective
-            try:
-                dp.agree_on_capture(ok, enq, g)
-                out.append("no error")
-            except RuntimeError as e:
-                out.append("raised" if "aborting the job" in str(e) else str(e))
+            out.append(dp.agree_on_capture(ok, enq, g))
+        dp.check_communicator(g, "cpu")                                   # a working group passes
+        real = dist.all_reduce
+
+        def short_sum(t, *a, **k):                                        # a communicator that lost a rank's contribution
+            real(t, *a, **k)
+            t.sub_(1.0)
+        dist.all_reduce = short_sum
+        try:
+            dp.check_communicator(g, "cpu")
+            out.append("no error")
+        except RuntimeError as e:
+            out.append("raised" if "aborting the job" in str(e) else str(e))
+        finally:
+            dist.all_reduce = real
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -185,9 +195,10 @@ def _agree_worker(rank, world, port, q):
 
 def test_ranks_agree_on_the_capture_form():
     """the fallback from the one-graph step to the segmented form must be a GROUP decision.  All captured ->
-    "captured"; all refused before a collective was enqueued -> "segments" on every rank; anything mixed (a rank failed
-    while another captured, or a failure after a collective had been handed to the backend) -> RuntimeError on EVERY
-    rank, so the job exits non-zero instead of issuing different collective sequences."""
+    "captured"; all refused before a collective was recorded -> "segments" on every rank; anything mixed (a rank failed
+    while another captured, or a failure after a collective had been recorded) -> "segments-after-abort" on EVERY rank
+    (recorded collectives never ran: all drop their graphs together), after which the communicator has to pass a
+    known-answer all-reduce - a wrong sum raises on every rank, so the job exits non-zero."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -200,8 +211,7 @@ def test_ranks_agree_on_the_capture_form():
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in range(world):
-        assert got[r] == ["captured", "segments", "raised", "raised"], got
+        assert got[r] == ["captured", "segments", "segments-after-abort", "segments-after-abort", "raised"], got
     from multimodal_eeg_fmri_amd import dp
     assert dp.agree_on_capture(True, 3, None) == "captured" and dp.agree_on_capture(False, 0, None) == "segments"
-    with pytest.raises(RuntimeError):
-        dp.agree_on_capture(False, 2, None)
+    assert dp.agree_on_capture(False, 2, None) == "segments-after-abort"

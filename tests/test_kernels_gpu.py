@@ -116,7 +116,7 @@ def test_attention_fwd_bwd(B, L, H):
     qg = qkv.cuda().to(torch.bfloat16)
     out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None, 0)
     qr = qkv.clone().requires_grad_(True)
     o_ref, lse_ref = _attn_ref(qr, H)
     torch.testing.assert_close(out.float().cpu(), o_ref.detach(), rtol=2e-2, atol=2e-2)
@@ -124,7 +124,7 @@ def test_attention_fwd_bwd(B, L, H):
     o_ref.backward(do)
     dqkv = torch.empty_like(qg)
     delta = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None, 0)
     got, want = dqkv.float().cpu(), qr.grad
     assert ((got - want).norm() / want.norm()).item() < 2e-2
     torch.testing.assert_close(got, want, rtol=5e-2, atol=3e-2)
@@ -1247,9 +1247,9 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     qg = qkv.cuda().to(torch.bfloat16)
     out = torch.empty(B, L, E, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None)
+    hip.call("mm_attn_fwd", qg, out, lse, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None, 0)
     out0 = torch.empty_like(out)
-    hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None)
+    hip.call("mm_attn_fwd", qg, out0, lse, B, L, H, 32, 1 / math.sqrt(32), 0.0, 0, None, None, 0)
     # recover the mask from V = identity-like probe: compare row sums of kept probabilities
     # host replica of the attention kernels' block hash (attention.hip: attn_block_hash / attn_keep2)
     from oracle.dropout_replica import attn_keep_scale
@@ -1264,7 +1264,7 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd(L):
     o_ref.backward(do.double())
     dqkv = torch.empty_like(qg)
     delta = torch.empty(B, H, L, device="cuda")
-    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None)
+    hip.call("mm_attn_bwd", qg, out, do.cuda().to(torch.bfloat16), lse, dqkv, delta, B, L, H, 32, 1 / math.sqrt(32), p, seed, None, None, 0)
     dq_got = dqkv.float().cpu()[:, :, :E].view(B, L, H, 32).transpose(1, 2)
     assert ((dq_got - q.grad.float()).norm() / q.grad.float().norm()).item() < 3e-2
     # the dkv kernel's registers run along the queries: it reads the other two bytes of each 2 x 2 block hash

@@ -824,6 +824,40 @@ def test_a2_transformer_block_standalone_and_masked_vs_reference_golden(golden, 
         assert abs(g.double().norm().item() - gn) <= 5e-2 * gn + 1e-6, (n, g.double().norm().item(), gn)
 
 
+@pytest.mark.parametrize("kind", ["float", "bool"])
+def test_a2_transformer_block_with_a_per_head_mask_vs_oracle(kind):
+    """nn.MultiheadAttention's 3-D attn_mask, (batch * heads, L, L) - one matrix per head of each sample (the reference
+    itself only passes the 2-D form, enhanced_models_v4.py:98; this is the other form its MultiheadAttention accepts).
+    L = 160: two key chunks with a ragged second one, queries over two workgroups.  Eval output cos >= 1 - 1e-4 and
+    rel-L2 <= 2e-2; train-mode (dropout 0) input and parameter gradients 5e-2, against the CPU oracle (whose 3-D branch
+    is pinned to torch.nn.MultiheadAttention by tests/test_oracle_golden.py).  A wrong leading size is refused."""
+    B, L, H = 3, 160, 4
+    g = torch.Generator().manual_seed(5)
+    if kind == "float":
+        msk = torch.randn(B * H, L, L, generator=g)
+    else:
+        msk = torch.rand(B * H, L, L, generator=g) < 0.3
+        msk[:, torch.arange(L), torch.arange(L)] = False
+    m = build(E.TemporalTransformerBlock, 21, 128, H, 512, 0.0).train().cuda()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = seeded_randn(22, B, L, 128)
+    gy = seeded_randn(23, B, L, 128)
+    xo = x.clone().requires_grad_(True)
+    want = RF.transformer_block(sd, "", xo, H, mask=msk)
+    want.backward(gy)
+    with torch.no_grad():
+        y = m.eval()(x.cuda(), msk.cuda()).cpu()
+    assert cos_min(y, want.detach()) >= 1 - COS_TOL, cos_min(y, want.detach())
+    assert rel_err(y, want.detach()) < 2e-2
+    xg = x.cuda().requires_grad_(True)
+    m.train()(xg, msk.cuda()).backward(gy.cuda())
+    _grad_check("dx", xg.grad.cpu(), xo.grad, 5e-2)
+    for n, p in m.named_parameters():
+        _grad_check(n, p.grad.cpu(), sd[n].grad, 5e-2)
+    with pytest.raises(ValueError, match="batch \\* heads"):
+        m(x.cuda(), msk[:H].cuda())
+
+
 def test_a3_erp_encoder_train_grads_at_c2_shape_vs_reference_golden(golden):
     """the train-mode forward + backward at the shape bench.py times (64 ch x 1024 samples: L = 512 full-tile
     attention specialisation, the size-dependent slot counts of the weight-gradient kernels), against the

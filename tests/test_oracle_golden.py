@@ -243,3 +243,23 @@ def test_a3_train_grads_at_c2_shape_vs_reference_golden(golden):
         if gn < 1e-4:
             continue
         assert abs(sd[n].grad.double().norm().item() - gn) <= 1e-3 * gn, n
+
+
+def test_oracle_attention_with_a_per_head_mask_equals_torch_multihead_attention():
+    """the (B * heads, L, L) attn_mask branch of the oracle's attention (not a form the reference uses, so no golden
+    holds it): pinned against torch.nn.MultiheadAttention on the same weights, float and boolean masks, 1e-5."""
+    import torch.nn as nn
+    from oracle import ref_functional as RF
+    torch.manual_seed(3)
+    B, L, E, H = 3, 20, 32, 4
+    mha = nn.MultiheadAttention(E, H, batch_first=True).eval()
+    sd = {"a." + k: v for k, v in mha.state_dict().items()}
+    x = torch.randn(B, L, E)
+    fm = torch.randn(B * H, L, L)
+    bm = torch.rand(B * H, L, L) < 0.3
+    bm[:, torch.arange(L), torch.arange(L)] = False                 # no fully masked row
+    for m in (fm, bm):
+        with torch.no_grad():
+            want, _ = mha(x, x, x, attn_mask=m, need_weights=False)
+            got, _ = RF.multihead_attention(sd, "a.", x, x, H, attn_mask=m)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), (got - want).abs().max()

@@ -81,11 +81,23 @@ def run_rccl_world1():
         res = {}
         issued = {}
         for tag, group, force, cap in (("one graph", None, False, "1"), ("captured RCCL", dist.group.WORLD, True, "1"),
-                                       ("segments + RCCL", dist.group.WORLD, True, "0")):
+                                       ("segments + RCCL", dist.group.WORLD, True, "0"),
+                                       ("aborted capture", dist.group.WORLD, True, "1")):
             os.environ["MM_DP_CAPTURE"] = cap
             torch.manual_seed(0)
             tr = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-3, group=group).train()
             tr.force_segments = force
+            if tag == "aborted capture":
+                # the capture dies AFTER all five collectives were recorded (once): every rank must drop to the segmented
+                # form, the communicator must pass its known-answer all-reduce, and training must go on unchanged
+                probe, fired = tr._grad_probe, []
+
+                def dying_probe():
+                    if torch.cuda.is_current_stream_capturing() and not fired:
+                        fired.append(1)
+                        raise RuntimeError("injected: capture aborted after its collectives were recorded")
+                    probe()
+                tr._grad_probe = dying_probe
             n0 = dp.issued
             ls = [tr.train_step(eeg, fmri)["loss"].item() for _ in range(6)]
             torch.cuda.synchronize()
@@ -96,10 +108,12 @@ def run_rccl_world1():
                 tr.train_step(eeg, fmri)
                 ev = tr.evaluate(eeg, fmri)
                 assert ev["loss"].item() == ev["loss"].item()
-        a, b, cg = res["one graph"], res["segments + RCCL"], res["captured RCCL"]
+        a, b, cg, ab = res["one graph"], res["segments + RCCL"], res["captured RCCL"], res["aborted capture"]
         rel = ((a[1] - b[1]).norm() / a[1].norm()).item()
         return {"graphs": (a[2], b[2]), "losses": (a[0], b[0]), "param_rel": rel, "collectives_issued": issued,
                 "groups": [g[0] for g in tr.groups],
+                "aborted_capture": {"mode": ab[3], "graphs": ab[2], "bit_identical_to_segments": bool(torch.equal(b[1], ab[1])),
+                                    "losses_equal": ab[0] == b[0]},
                 # the N > 1 step with its collectives recorded into the graph (falls back to segments if RCCL refuses):
                 "captured": {"mode": cg[3], "graphs": cg[2], "losses": cg[0],
                              "param_rel_vs_one_graph": ((a[1] - cg[1]).norm() / a[1].norm()).item(),
@@ -157,6 +171,8 @@ if __name__ == "__main__":
         assert r["captured"]["mode"] == "one graph + captured RCCL collectives", r
         assert r["collectives_issued"]["captured RCCL"] == 2 + 3 * (1 + ngroups), r
         assert r["captured"]["bit_identical_to_segments"], r
+        assert r["aborted_capture"] == {"mode": "3 segments + 2 eager collectives", "graphs": 3, "bit_identical_to_segments": True,
+                                        "losses_equal": True}, r
         assert r["captured"]["param_rel_vs_one_graph"] < 1e-2, r
         assert r["param_rel"] < 1e-2, r
         for i, (x, y) in enumerate(zip(*r["losses"])):      # (tolerances from before the step became bit-reproducible; kept loose: RCCL owns the reduction order)

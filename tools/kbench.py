@@ -219,8 +219,8 @@ def attn_case(B=32, L=512, H=4, p=0.1):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, L, device="cuda")
     sc = 1 / math.sqrt(32)
-    f = timeit(lambda: _hip.call("mm_attn_fwd", qkv, out, lse, B, L, H, 32, sc, p, 77, None, None))
-    b = timeit(lambda: _hip.call("mm_attn_bwd", qkv, out, dout, lse, dqkv, delta, B, L, H, 32, sc, p, 77, None, None))
+    f = timeit(lambda: _hip.call("mm_attn_fwd", qkv, out, lse, B, L, H, 32, sc, p, 77, None, None, 0))
+    b = timeit(lambda: _hip.call("mm_attn_bwd", qkv, out, dout, lse, dqkv, delta, B, L, H, 32, sc, p, 77, None, None, 0))
     fl = 4.0 * B * H * L * L * 32
     print(f"attention B={B} L={L} H={H} p={p}: fwd {f:6.1f} us ({fl / f / 1e6:6.1f} TF/s)   bwd (dq + dkv) {b:6.1f} us")
 
@@ -298,7 +298,7 @@ def split_case():
         def chain():
             for _ in range(4):
                 _hip.call("mm_conv1d_fwd", x, wf, 1, M, 128, 384, 1, 0, None, None, 0, None, None, 1, None, None, qkv, None, 0.0, 0, None, None, 0)
-                _hip.call("mm_attn_fwd", qkv, o, lse, B, 512, 4, 32, 1.0 / _m.sqrt(32), 0.1, 5, None, None)
+                _hip.call("mm_attn_fwd", qkv, o, lse, B, 512, 4, 32, 1.0 / _m.sqrt(32), 0.1, 5, None, None, 0)
                 _hip.call("mm_conv1d_fwd", o, wf2, 1, M, 128, 128, 1, 0, None, None, 0, res, None, 1, None, out, None, None, 0.1, 7, None, None, 0)
         return chain
     full = mk(16384)
