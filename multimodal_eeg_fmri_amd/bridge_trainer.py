@@ -390,12 +390,12 @@ class BridgeTrainer(nn.Module):
             for t, sv in zip(bufs, snap_bufs):
                 t.copy_(sv)
         ops.weights_changed()                                     # weight-image kernels must be recorded
-        pool = torch.cuda.graph_pool_handle()
+        c["pool"] = torch.cuda.graph_pool_handle()
         graphs = []
 
         def record(fn, mode="global"):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode), torch.no_grad():
+            with torch.cuda.graph(g, pool=c["pool"], capture_error_mode=mode), torch.no_grad():
                 fn()
             graphs.append(g)
 
@@ -476,17 +476,26 @@ class BridgeTrainer(nn.Module):
             # thread-local capture mode: the process group's watchdog thread polls its events while this thread captures
             record(whole_dp, mode="thread_local")
         except Exception as e:  # noqa: BLE001 - any refusal (RCCL, the caching allocator, a host sync)
-            err = e
+            # keep the text only: the traceback holds `record`'s frame and with it the half-built graph object, and a
+            # graph destroyed by the cyclic collector DURING the next capture ends the process (~CUDAGraph: "operation
+            # not permitted when stream is capturing")
+            err = f"{type(e).__name__}: {e}"
+            e.__traceback__ = None
+            del e
         verdict = dp.agree_on_capture(err is None, dp.issued - issued0, self.group)
         if verdict == "captured":
             return True
+        import gc
         import warnings
         warnings.warn(f"collectives not captured into the step's hipGraph on every rank (this rank: "
-                      f"{'captured' if err is None else type(err).__name__ + ': ' + str(err)}; group verdict {verdict}); "
+                      f"{'captured' if err is None else err}; group verdict {verdict}); "
                       "all ranks use three graph segments around two eager collectives")
         if err is None:
             graphs.pop()                                          # this rank's graph is dropped with the others'
+        c.pop("z", None), c.pop("dz", None)
+        gc.collect()                                              # every graph of the attempt is gone before the segments are recorded
         torch.cuda.synchronize()
+        c["pool"] = torch.cuda.graph_pool_handle()                # (the attempt's memory pool went with its last graph)
         self._works = []
         if verdict == "segments-after-abort":
             dp.check_communicator(self.group, dev)
