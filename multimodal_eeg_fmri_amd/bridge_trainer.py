@@ -200,19 +200,37 @@ class BridgeTrainer(nn.Module):
         self._stamp(1)
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)                 # fork point: recorded before any encoder kernel
-        # The EEG branch is the longer chain, so it is issued FIRST: a hipGraph replay writes its
-        # kernel packets in capture order at ~4.6 us per node, and the branch captured second
-        # cannot start before the host has written every packet of the first (profiles/README.md).
+        # The longer branch is issued FIRST: a hipGraph replay writes its kernel packets in capture order at
+        # ~4.6 us per node, and the branch captured second cannot start before the host has written every packet
+        # of the first (profiles/README.md).  That is the EEG chain at 32^3 voxels, the fMRI branch at config #4's
+        # 64 x 64 x 48 (`_fmri_is_longer`).
+        self._fmri_longer = self._fmri_is_longer(fmri)
+
+        def fmri_branch():
+            with torch.cuda.stream(self._side):
+                self._stamp(3)
+                out = ops._vol_forward_impl(self.fmri_encoder, fmri, True, True)
+                self._stamp(4)
+            return out
+        if self._fmri_longer:
+            ff, sv_f = fmri_branch()
         fe, sv_e = self._eeg_forward(eeg, xb)
         self._stamp(2)
-        with torch.cuda.stream(self._side):
-            self._stamp(3)
-            ff, sv_f = ops._vol_forward_impl(self.fmri_encoder, fmri, True, True)
-            self._stamp(4)
+        if not self._fmri_longer:
+            ff, sv_f = fmri_branch()
         main.wait_stream(self._side)
         z, sv_h = ops.contrastive_embed_impl(self.head.bridge, fe, ff, True)
         self._stamp(5)
         return z, (sv_e, sv_f, sv_h)
+
+    @staticmethod
+    def _fmri_is_longer(fmri) -> bool:
+        """the voxel branch outlasts the EEG chain (config #4: 64 x 64 x 48 = 6 x the voxels of 32^3, 1.4 ms of kernels
+        against 1.1 ms): its stream then takes no work from the chain and is issued first.  MM_FMRI_LONGER=0/1 overrides."""
+        env = os.environ.get("MM_FMRI_LONGER")
+        if env is not None:
+            return env == "1"
+        return fmri[0].numel() >= 4 * 32 ** 3
 
     def _eeg_forward(self, eeg, xb):
         enc = self.eeg_encoder
@@ -258,10 +276,14 @@ class BridgeTrainer(nn.Module):
             self._side.wait_stream(main)
             # the transformer stack's weight-gradient slot sums and parameter reductions (~50 MB of
             # reads) do not wait for the end of the chain: they are handed to the side stream, which
-            # is idle once the fMRI branch is done
+            # is idle once the fMRI branch is done - unless that branch is the longer one (`_fmri_is_longer`): then
+            # nothing is handed over, the chain flushes its own sums, and the fMRI backward is issued first
+            hand = not getattr(self, "_fmri_longer", False)
             handed = []
 
             def split():
+                if not hand:
+                    return
                 ev = torch.cuda.Event()
                 handed.append((bag.hand_over(), ev))
                 ev.record()
@@ -274,11 +296,30 @@ class BridgeTrainer(nn.Module):
             # MM_CONV_WGRADS_HANDED: 1 = block 2's only (default: block 3's weight gradient stays on the chain), 2 = blocks 3
             # and 2 (round 2 / early round 3, when the chain was the later stream), 0 = none.  Which stream ends later
             # decides: 0.773-0.776 / 0.782-0.799 / 0.789-0.793 ms per step for 1 / 2 / 0 (profiles/r03_second_half_ab.txt)
-            handed_convs = int(os.environ.get("MM_CONV_WGRADS_HANDED", "1"))
+            handed_convs = int(os.environ.get("MM_CONV_WGRADS_HANDED", "1")) if hand else 0
             bag.defer_conv_wgrads = handed_convs >= 2
 
             def conv3_done():
                 bag.defer_conv_wgrads = handed_convs >= 1
+
+            def fmri_branch():
+                with torch.cuda.stream(self._side):
+                    self._stamp(9)
+                    bag_f = GradBag()                    # the fMRI branch flushes its own reductions on ITS stream,
+                    with deferred(bag_f, dz.device):     # hidden beside the rest of the EEG backward
+                        volume_encoder_bwd(bag_f, sv_f, dff)
+                    self._stamp(10)
+                    if reduce and hand:
+                        self._reduce_group("fmri")
+                    for i, (hb, ev) in enumerate(handed):
+                        self._side.wait_event(ev)
+                        hb.flush(dz.device)
+                        if reduce:
+                            self._reduce_group(f"handed{i}")
+                    self._stamp(13)
+                return bag_f
+            if not hand:
+                bag_f = fmri_branch()
             finish = None
             if self._eeg_kind == "erp":
                 erp_encoder_bwd(bag, sv_e, dfe, after_blocks=split, after_conv2=split_convs, after_conv3=conv3_done)   # longer chain first (see _seg_forward)
@@ -288,22 +329,16 @@ class BridgeTrainer(nn.Module):
             if finish is not None:
                 finish()                         # the merged 192-channel conv / BatchNorm gradients back into the six real parameters
             self._stamp(8)
-            with torch.cuda.stream(self._side):
-                self._stamp(9)
-                bag_f = GradBag()                    # the fMRI branch flushes its own reductions on ITS stream,
-                with deferred(bag_f, dz.device):     # hidden beside the rest of the EEG backward
-                    volume_encoder_bwd(bag_f, sv_f, dff)
-                self._stamp(10)
-                if reduce:
-                    self._reduce_group("fmri")
-                for i, (hb, ev) in enumerate(handed):
-                    self._side.wait_event(ev)
-                    hb.flush(dz.device)
-                    if reduce:
-                        self._reduce_group(f"handed{i}")
-                self._stamp(13)
+            if hand:
+                bag_f = fmri_branch()
             if reduce:
+                if not hand:                     # the chain's groups are final first; the fMRI encoder's goes out last
+                    self._reduce_group("handed0")
+                    self._reduce_group("handed1")
                 self._reduce_group("main")       # issued last on the host: the collectives run in issue order
+                if not hand:
+                    with torch.cuda.stream(self._side):
+                        self._reduce_group("fmri")
             main.wait_stream(self._side)
         self._stamp(11)
         self._bags = getattr(self, "_bags", [])[-12:] + [bag, bag_f] + [hb for hb, _ in handed]   # keep descriptor tables alive

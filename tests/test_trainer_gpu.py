@@ -482,6 +482,36 @@ def test_fused_launches_train_exactly_as_their_separate_forms(monkeypatch):
     assert ((p3 - p0).norm() / p0.norm()).item() < 2e-3
 
 
+def test_config4_volume_step_takes_the_fmri_first_schedule_and_matches_the_other(monkeypatch):
+    """config #4's 64 x 64 x 48 volumes make the voxel branch the longer stream: the trainer picks the fMRI-first
+    schedule by itself (`_fmri_is_longer`), and four graph steps end bit-identical to the EEG-first / hand-over schedule
+    forced by MM_FMRI_LONGER=0 (what config #2 runs, which the oracle tests pin).  Dropout off: the masks' seeds are
+    drawn in issue order, so the two schedules would draw different (equally valid) masks."""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    from multimodal_eeg_fmri_amd import ops
+    batches = [synthetic_pairs(4, 16, 256, (64, 64, 48), seed=500 + i) for i in range(2)]
+
+    def run(env):
+        if env is not None:
+            monkeypatch.setenv("MM_FMRI_LONGER", env)
+        ops.set_seed_epoch(None)
+        ops.set_dropout_seed(99)
+        torch.manual_seed(0)
+        tr = BridgeTrainer(eeg_channels=16, dropout=0.0, lr=1e-3).train()
+        losses = [tr.train_step(*batches[i % 2])["loss"].clone() for i in range(4)]
+        torch.cuda.synchronize()
+        params = tr.bucket.p.detach().clone()
+        ops.set_seed_epoch(None)
+        monkeypatch.undo()
+        return torch.stack(losses), params, tr._fmri_longer
+    la, pa, longer = run(None)
+    assert longer and torch.isfinite(la).all()
+    lb, pb, longer_b = run("0")
+    assert not longer_b
+    assert torch.equal(la, lb) and torch.equal(pa, pb)
+    assert not BridgeTrainer._fmri_is_longer(torch.empty(2, 1, 32, 32, 32))
+
+
 def test_packed_host_batch_step_is_bit_identical_to_the_device_side_pack():
     """the host-fed path: BridgeTrainer.pack_host_batch (CPU: EEG epochs into the first convolution's bf16 channels-last
     operand, round-to-nearest-even, + fp32 volumes, ONE flat buffer) followed by train_step_packed (one D2D copy into the
