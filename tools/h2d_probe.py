@@ -60,6 +60,23 @@ def loops(steps):
 
     print(f"== C2 training loop, {steps} steps each")
     base = timed("resident batches (mm_stage_inputs + replay)", lambda n: [tr.train_step(*dev[i % NB]) for i in range(n)])
+    # the same steps with the host given a head start: K steps are enqueued while the GPU spins, then timed by device
+    # events - the step's pure GPU time, with every packet written before it is needed
+    if os.environ.get("MM_PROBE_HEADSTART", "1") == "1":
+        for K, spin_ms in ((8, 10), (40, 40), (40, 40)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            torch.cuda._sleep(int(spin_ms * 2.1e6))            # ~spin_ms at ~2.1 GHz
+            e0.record()
+            for i in range(K):
+                tr.train_step(*dev[i % NB])
+            e1.record()
+            t_issue = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            print(f"  {K} steps enqueued behind a {spin_ms} ms spin kernel: {e0.elapsed_time(e1) / K:7.4f} ms/step by device events "
+                  f"(host needed {t_issue * 1e3:.2f} ms to enqueue them, everything done after {t_all * 1e3:.2f} ms)", flush=True)
     host = [(e.cpu().pin_memory(), f.cpu().pin_memory()) for e, f in dev]
     packed = [tr.pack_host_batch(e, f) for e, f in dev]
     copy_s = torch.cuda.Stream()
