@@ -662,34 +662,20 @@ def main():
 def host_fed_loop(tr, dev_batches, steps, warm, sync):
     """every step's batch comes from pinned host memory, the way a training loop feeds the step: the loader hands over ONE
     packed pinned buffer per batch (BridgeTrainer.pack_host_batch: the EEG epochs already in the first convolution's bf16
-    operand layout + the fp32 volumes - 8.4 MB instead of 12.6 MB at C2), ONE H2D copy on a copy stream into a staging
-    pair, overlapped with the previous step, one device-to-device copy into the step's static inputs.  Round 3's form
-    (two fp32 copies + events per step) was HOST-bound: 1.09 ms of issue time per step (profiles/r04_h2d_probe.txt).
+    operand layout + the fp32 volumes - 8.4 MB instead of 12.6 MB at C2), `HostFeeder` copies it on a copy stream into a
+    ring of three staging buffers, overlapped with the previous step, and orders copies and steps from the HOST (no
+    cross-queue waits: they cost 8 %, profiles/r04_h2d_probe.txt); one device-to-device copy into the step's static inputs.
     -> {seconds, description}"""
     NB = len(dev_batches)
     packed = [tr.pack_host_batch(e, f) for e, f in dev_batches]        # (a loader's work, done off the timed loop)
-    stage = [torch.empty(packed[0].numel(), dtype=torch.uint8, device="cuda") for _ in range(2)]
-    copy_s = torch.cuda.Stream()
-    ready = [torch.cuda.Event(), torch.cuda.Event()]
-    consumed = [torch.cuda.Event(), torch.cuda.Event()]
-
-    def upload(i):
-        b = i % 2
-        with torch.cuda.stream(copy_s):
-            copy_s.wait_event(consumed[b])               # the step that read this staging buffer is done with it
-            stage[b].copy_(packed[i % NB], non_blocking=True)
-            ready[b].record(copy_s)
-    for b in range(2):
-        consumed[b].record()
+    feeder = tr.host_feeder()
 
     def loop(n):
-        upload(0)
+        feeder.upload(packed[0])
         for i in range(n):
             if i + 1 < n:
-                upload(i + 1)
-            torch.cuda.current_stream().wait_event(ready[i % 2])
-            tr.train_step_packed(stage[i % 2])
-            consumed[i % 2].record()
+                feeder.upload(packed[(i + 1) % NB])
+            feeder.step()
     loop(warm)            # its own warm-up: copy stream, pinned copies, event pool (first use of each costs milliseconds)
     sync()
     t0 = time.perf_counter()
@@ -697,8 +683,9 @@ def host_fed_loop(tr, dev_batches, steps, warm, sync):
     sync()
     return {"seconds": time.perf_counter() - t0, "bytes_per_step": packed[0].numel(),
             "how": "every step's batch as ONE packed pinned buffer (EEG epochs in the first convolution's bf16 operand layout + fp32 "
-                   "volumes), one H2D copy on a copy stream into a staging pair overlapped with the previous step, one D2D copy "
-                   "into the step's static inputs; `value` keeps the batches resident in HBM"}
+                   "volumes), one H2D copy on a copy stream into a ring of three staging buffers overlapped with the previous step "
+                   "(copies and steps ordered by host-side event waits: BridgeTrainer.host_feeder), one D2D copy into the step's "
+                   "static inputs; `value` keeps the batches resident in HBM"}
 
 
 if __name__ == "__main__":

@@ -609,6 +609,10 @@ class BridgeTrainer(nn.Module):
         c["in"].copy_(flat, non_blocking=True)
         return self._replay()
 
+    def host_feeder(self, depth: int = 3) -> "HostFeeder":
+        """the loop that feeds `train_step_packed` from pinned host buffers (see `HostFeeder`)"""
+        return HostFeeder(self, depth)
+
     def time_collectives(self, batch: int, iters: int = 50) -> Dict[str, float]:
         """microseconds per call of every collective one step issues, each alone at its message size (HIP events on the
         current stream around ``iters`` back-to-back calls; collective: every rank of the group must call it).  What the
@@ -653,6 +657,68 @@ class BridgeTrainer(nn.Module):
         finally:
             self.train(was)
         return {"loss": loss, "top1_e2f": acc_e, "top1_f2e": acc_f}
+
+
+class HostFeeder:
+    """Feeds `BridgeTrainer.train_step_packed` from packed pinned host buffers (`pack_host_batch`), one H2D copy per
+    batch on a copy stream into a ring of ``depth`` staging buffers, overlapped with the steps before it.
+
+    The ordering between the copy stream and the step's stream is kept by the HOST: `step()` blocks on the event its
+    batch's copy recorded (issued a whole step earlier), `upload()` on the event recorded after the step that last read
+    the staging buffer (``depth - 1`` steps earlier).  Neither queue ever holds a barrier for the other: with
+    hipStreamWaitEvent in both directions the same loop lost 8 % to the two cross-queue waits per step, ordered from the
+    host it loses 1 % (0.786 vs 0.779 ms, profiles/r04_h2d_probe.txt) - the host has the time, a step costs it 0.25 ms.
+
+        feeder = trainer.host_feeder()
+        feeder.upload(packed[0])
+        for i in range(n):
+            if i + 1 < n:
+                feeder.upload(packed[i + 1])      # returns at once; the pinned buffer is free again when the event it returns is done
+            out = feeder.step()
+
+    Reference counterpart: the per-batch ``.to(device)`` + step of run_training_lite.py:474-489."""
+
+    def __init__(self, trainer: BridgeTrainer, depth: int = 3):
+        if trainer._cap is None:
+            raise RuntimeError("HostFeeder: run one train_step(eeg, fmri) first (it captures the step and fixes the shapes)")
+        if depth < 2:
+            raise ValueError("HostFeeder: at least two staging buffers")
+        n = trainer._cap["in"].numel()
+        dev = trainer._cap["in"].device
+        self.trainer, self.depth, self.nbytes = trainer, depth, n
+        self.ring = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(depth)]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.ready = [torch.cuda.Event() for _ in range(depth)]
+        self.done = [torch.cuda.Event() for _ in range(depth)]
+        self.uploaded = 0
+        self.stepped = 0
+
+    def upload(self, packed: torch.Tensor) -> "torch.cuda.Event":
+        """start the H2D copy of the next batch; ``packed``: a pinned uint8 buffer from `pack_host_batch`.  Returns the
+        event that marks the copy's end (until then the pinned buffer must not be rewritten)."""
+        if packed.dtype != torch.uint8 or packed.numel() != self.nbytes or packed.is_cuda:
+            raise ValueError(f"HostFeeder.upload: expected a host uint8 buffer of {self.nbytes} bytes")
+        if self.uploaded - self.stepped >= self.depth:
+            raise RuntimeError(f"HostFeeder.upload: {self.depth} batches are already waiting for their step")
+        b = self.uploaded % self.depth
+        if self.uploaded >= self.depth:
+            self.done[b].synchronize()                    # the step that read this staging buffer has finished with it
+        with torch.cuda.stream(self.copy_stream):
+            self.ring[b].copy_(packed, non_blocking=True)
+            self.ready[b].record(self.copy_stream)
+        self.uploaded += 1
+        return self.ready[b]
+
+    def step(self) -> Dict[str, torch.Tensor]:
+        """one training step on the oldest uploaded batch"""
+        if self.stepped >= self.uploaded:
+            raise RuntimeError("HostFeeder.step: nothing uploaded")
+        b = self.stepped % self.depth
+        self.ready[b].synchronize()                       # host-side: no barrier packet on the step's queue
+        out = self.trainer.train_step_packed(self.ring[b])
+        self.done[b].record()
+        self.stepped += 1
+        return out
 
 
 def synthetic_pairs(batch: int, eeg_channels: int = 64, samples: int = 1024, vol=(32, 32, 32),

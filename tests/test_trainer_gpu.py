@@ -516,7 +516,8 @@ def test_packed_host_batch_step_is_bit_identical_to_the_device_side_pack():
     """the host-fed path: BridgeTrainer.pack_host_batch (CPU: EEG epochs into the first convolution's bf16 channels-last
     operand, round-to-nearest-even, + fp32 volumes, ONE flat buffer) followed by train_step_packed (one D2D copy into the
     step's static inputs + replay) trains BIT-identically to train_step on the fp32 device tensors (mm_stage_inputs packs on
-    the device), dropout on; a buffer of the wrong size is refused."""
+    the device), dropout on; a buffer of the wrong size is refused.  So does the loop a loader drives (`HostFeeder`: H2D
+    copies one step ahead on a copy stream, ordered from the host)."""
     from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
     from multimodal_eeg_fmri_amd import ops
     batches = [synthetic_pairs(8, 16, 256, (16, 16, 16), seed=700 + i) for i in range(3)]
@@ -527,7 +528,19 @@ def test_packed_host_batch_step_is_bit_identical_to_the_device_side_pack():
         torch.manual_seed(0)
         tr = BridgeTrainer(eeg_channels=16, dropout=0.2, lr=1e-3).train()
         losses = [tr.train_step(*batches[0])["loss"].clone()]          # captures; fixes the shapes
-        for i in range(1, 6):
+        if packed == "feeder":                                          # the loop a loader drives: copies one step ahead
+            feeder = tr.host_feeder()
+            hosts = [tr.pack_host_batch(*batches[i % 3]) for i in range(1, 6)]
+            feeder.upload(hosts[0])
+            for i in range(5):
+                if i + 1 < 5:
+                    feeder.upload(hosts[i + 1])
+                losses.append(feeder.step()["loss"].clone())
+            with pytest.raises(RuntimeError, match="nothing uploaded"):
+                feeder.step()
+            with pytest.raises(ValueError):
+                feeder.upload(torch.zeros(10, dtype=torch.uint8))
+        for i in range(1, 6 if packed != "feeder" else 1):
             e, f = batches[i % 3]
             if packed:
                 host = tr.pack_host_batch(e, f)
@@ -542,6 +555,8 @@ def test_packed_host_batch_step_is_bit_identical_to_the_device_side_pack():
     l0, p0, _ = run(False)
     l1, p1, tr = run(True)
     assert torch.isfinite(l0).all() and torch.equal(l0, l1) and torch.equal(p0, p1)
+    l2, p2, _ = run("feeder")
+    assert torch.equal(l0, l2) and torch.equal(p0, p2)
     with pytest.raises(ValueError):
         tr.train_step_packed(torch.zeros(100, dtype=torch.uint8, device="cuda"))
 

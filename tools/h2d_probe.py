@@ -63,7 +63,7 @@ def loops(steps):
     # the same steps with the host given a head start: K steps are enqueued while the GPU spins, then timed by device
     # events - the step's pure GPU time, with every packet written before it is needed
     if os.environ.get("MM_PROBE_HEADSTART", "1") == "1":
-        for K, spin_ms in ((8, 10), (40, 40), (40, 40)):
+        for K, spin_ms in ((40, 40),):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -121,6 +121,33 @@ def loops(steps):
             if train:
                 tr.train_step_packed(stage1[i % 2])
             consumed[i % 2].record()
+
+    def loop_hostsync(n, depth=3, record_main=True):
+        """the same copies ordered from the HOST: the loop blocks on `ready` (an event on the copy stream, recorded a whole step
+        ago) before it launches the step, and on `consumed` (recorded on the step's stream two steps ago) before it reuses a
+        staging buffer - no hipStreamWaitEvent anywhere, so neither queue ever holds a barrier for the other.  The host has
+        the time (0.25 ms of work per 0.77 ms step)."""
+        ring = [torch.empty(packed[0].numel(), dtype=torch.uint8, device="cuda") for _ in range(depth)]
+        rdy = [torch.cuda.Event() for _ in range(depth)]
+        con = [torch.cuda.Event() for _ in range(depth)]
+        for e in con:
+            e.record()
+
+        def up(i):
+            b = i % depth
+            if record_main:
+                con[b].synchronize()
+            with torch.cuda.stream(copy_s):
+                ring[b].copy_(packed[i % NB], non_blocking=True)
+                rdy[b].record(copy_s)
+        up(0)
+        for i in range(n):
+            if i + 1 < n:
+                up(i + 1)
+            rdy[i % depth].synchronize()
+            tr.train_step_packed(ring[i % depth])
+            if record_main:
+                con[i % depth].record()
 
     def loop_deep(n, depth=4):
         """packed copies into a ring of `depth` staging buffers, issued depth - 1 steps ahead: the buffer-reuse guard is then
@@ -195,6 +222,8 @@ def loops(steps):
     timed("ONE packed copy, ring of 3 staging buffers, copies issued 2 steps ahead", lambda n: loop_deep(n, 3))
     timed("ONE packed copy, raw HIP events, default flags (disable timing)", lambda n: loop_raw(n, hipEventDisableTiming))
     timed("ONE packed copy, raw HIP events with hipEventReleaseToDevice", lambda n: loop_raw(n, hipEventDisableTiming | hipEventReleaseToDevice))
+    timed("ONE packed copy, ordered by HOST-side event waits only (3 staging buffers)", lambda n: loop_hostsync(n))
+    timed("   the same without the per-step event record on the step's stream (reuse guard dropped: diagnostic)", lambda n: loop_hostsync(n, record_main=False))
     timed("resident batches again", lambda n: [tr.train_step(*dev[i % NB]) for i in range(n)])
     # same packed loop, H2D on the MAIN stream (no second stream, no events): copy and step serialised
     def serial(n):
