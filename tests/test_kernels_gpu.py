@@ -1396,3 +1396,38 @@ def test_stft_power_backward_vs_torch_autograd(B, C, T, nfft, hop):
     ds = torch.full((B, rows, cht), float("nan"), device="cuda")
     hip.call("mm_sample_zscore_bwd", s.cuda(), gz.cuda().to(torch.bfloat16), ds, B, rows, chv, cht, 1e-8)
     torch.testing.assert_close(ds.cpu(), sr.grad, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1000, 2_600_000])
+def test_adamw_clip_kernel_vs_torch_and_its_bookkeeping(n):
+    """mm_sumsq + mm_adamw_clip (run_training_lite.py:487-488: clip_grad_norm_ + AdamW.step) against torch.optim.AdamW on
+    the same flat tensor for three steps (1e-6), and the step's bookkeeping, done by the update kernel's last workgroup:
+    step count, squared norm, clip coefficient, norm, the dropout-epoch word incremented once per step, the arrival
+    counter back at zero (n = 2.6 M: the bucket size of the bridge step, many workgroups; n = 1000: one)."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * (0.5 + i) for i in range(3)]
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=3e-3, weight_decay=0.02, betas=(0.9, 0.98), eps=1e-8)
+    p, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    state = torch.zeros(8 + 1024, device="cuda")
+    state[2] = 3e-3
+    epoch = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for i, gr in enumerate(grads):
+        ref.grad = gr.clone()
+        norm = torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gd = gr.cuda()
+        hip.call("mm_sumsq", gd, state, n)
+        hip.call("mm_adamw_clip", p, gd, m, v, state, n, 0.9, 0.98, 1e-8, 0.02, 1.0, 1.0, 1, epoch)
+        torch.cuda.synchronize()
+        st = state[:8].cpu()
+        assert st[0].item() == i + 1 and int(epoch.item()) == i + 1
+        assert abs(st[4].item() - norm.item()) <= 2e-4 * norm.item()          # (fp32 sums of 2.6 M squares, two summation orders)
+        assert abs(st[1].item() - norm.item() ** 2) <= 4e-4 * norm.item() ** 2
+        assert abs(st[3].item() - min(1.0, 1.0 / (norm.item() + 1e-6))) <= 2e-4 * st[3].item()
+        assert st[7].view(torch.int32).item() == 0                      # every workgroup arrived, the counter is at rest
+        assert torch.count_nonzero(gd).item() == 0                       # zero_grad
+        torch.testing.assert_close(p.cpu(), ref.detach(), rtol=2e-6, atol=2e-6)
