@@ -444,6 +444,22 @@ int mm_clip_loss_own_rows(const float* z_all, const float* logit_scale, float* s
                           int B, int Bg, int N, int row0, hipStream_t stream);
 int mm_clip_loss_ws_floats(int B, int Bg, int* floats_host, hipStream_t stream);
 
+/* ---- EnhancedPowerEncoder: its three Conv1d(C -> 64, k = 3 | 5 | 7) + BatchNorm1d(64) branches
+ * (enhanced_models_v4.py:210-234, forward :258-266: torch.cat of the three) as ONE Conv1d(C -> 192, k = 7, p = 3) +
+ * BatchNorm1d(192).  desc_host = HOST pointer to this descriptor (read at call time, like the tables of mm_prep_many):
+ *   mode 0  parts -> merged: W[o][c][t] = w_i[o % 64][c][t - (7 - k_i) / 2] inside branch i = o / 64's taps, else 0;
+ *           bias / gamma / beta / running mean / running var concatenated
+ *   mode 1  merged running mean / var -> the parts' (after a train-mode forward); batches_tracked[i] += 1 (nullable)
+ *   mode 2  gradients: the parts' sinks (w, b, gamma, beta; null = frozen) += their slices of the merged gradients
+ *           (W, B, Gamma, Beta; null = absent) */
+typedef struct {
+    float* w[3]; float* b[3]; float* gamma[3]; float* beta[3]; float* run_mean[3]; float* run_var[3];
+    void* batches_tracked[3];            /* int64 device scalars */
+    float* W; float* B; float* Gamma; float* Beta; float* Run_mean; float* Run_var;
+    int cin; int k[3];
+} mm_power_merge_t;
+int mm_power_merge(const void* desc_host, int mode, hipStream_t stream);
+
 /* ---- fused tails of the small models (forward) ------------------------------ */
 /* fMRIFusionNet weighted concat (fmri_utils.py:93-96) */
 int mm_softmax2_concat(const float* a, const float* c, const float* pa, const float* pc, float* out, int B,

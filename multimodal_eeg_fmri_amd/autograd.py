@@ -545,16 +545,13 @@ def power_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool 
     conv, bn, seqs = sv["merged"]
 
     def finish():
-        for i, sq in enumerate(seqs):
-            k = sq[0].kernel_size[0]
-            lo = (7 - k) // 2
-            for real, merged, cut in ((sq[0].weight, conv.weight, lambda t: t[64 * i:64 * i + 64, :, lo:lo + k]),
-                                      (sq[0].bias, conv.bias, lambda t: t[64 * i:64 * i + 64]),
-                                      (sq[1].weight, bn.weight, lambda t: t[64 * i:64 * i + 64]),
-                                      (sq[1].bias, bn.bias, lambda t: t[64 * i:64 * i + 64])):
-                dst, src = bag.target(real), bag.result(merged)
-                if dst is not None and src is not None:
-                    dst.add_(cut(src))
+        # ONE launch adds the merged gradients' slices into the six real parameters' sinks (it was twelve sliced add_)
+        tg = lambda ps: [bag.target(p) for p in ps]       # noqa: E731
+        none3 = [None] * 3
+        ops.power_merge_call(2, (tg([sq[0].weight for sq in seqs]), tg([sq[0].bias for sq in seqs]), tg([sq[1].weight for sq in seqs]),
+                                 tg([sq[1].bias for sq in seqs]), none3, none3),
+                             [bag.result(conv.weight), bag.result(conv.bias), bag.result(bn.weight), bag.result(bn.bias), None, None],
+                             cin=conv.in_channels, ks=[sq[0].kernel_size[0] for sq in seqs])
     return g, finish
 
 

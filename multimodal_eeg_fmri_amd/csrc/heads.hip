@@ -565,6 +565,54 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
 
 
 // ---------------------------------------------------------------------------
+// EnhancedPowerEncoder's three parallel Conv1d(C -> 64, k = 3 | 5 | 7) + BatchNorm1d(64) branches
+// (enhanced_models_v4.py:210-234) run as ONE Conv1d(C -> 192, k = 7) + BatchNorm1d(192).  The merged tensors are built
+// from the parts, their running statistics handed back, and their gradients added back into the parts' - each in one
+// launch (the host glue was ~55 tiny torch launches per training step: pads, cats, slice copies, slice adds).
+//   mode 0: parts -> merged      W[o][c][t] = w_i[o % 64][c][t - lo_i] inside the branch's taps, else 0  (i = o / 64,
+//                                 lo_i = (7 - k_i) / 2: the shorter kernels sit around the centre tap);  vectors concatenated
+//   mode 1: merged running mean / var -> the parts';  batches_tracked += 1
+//   mode 2: parts' gradient sinks += their slices of the merged gradients (null part = frozen parameter: skipped)
+// ---------------------------------------------------------------------------
+struct PowerMergeArgs {
+    float* w[3]; float* b[3]; float* gamma[3]; float* beta[3]; float* run_mean[3]; float* run_var[3];
+    long long* tracked[3];
+    float* W; float* B; float* Gamma; float* Beta; float* Run_mean; float* Run_var;
+    int cin, k[3];
+};
+
+template <int MODE>
+__global__ void power_merge_kernel(PowerMergeArgs a) {
+    const size_t per_o = (size_t)a.cin * 7, total = 192 * per_o;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < 192) {                                          // the per-channel vectors
+        const int i = (int)gid / 64, j = (int)gid % 64;
+        if (MODE == 0) {
+            a.B[gid] = a.b[i][j]; a.Gamma[gid] = a.gamma[i][j]; a.Beta[gid] = a.beta[i][j];
+            a.Run_mean[gid] = a.run_mean[i][j]; a.Run_var[gid] = a.run_var[i][j];
+        } else if (MODE == 1) {
+            a.run_mean[i][j] = a.Run_mean[gid]; a.run_var[i][j] = a.Run_var[gid];
+            if (j == 0 && a.tracked[i]) a.tracked[i][0] += 1;
+        } else {
+            if (a.b[i] && a.B) a.b[i][j] += a.B[gid];
+            if (a.gamma[i] && a.Gamma) a.gamma[i][j] += a.Gamma[gid];
+            if (a.beta[i] && a.Beta) a.beta[i][j] += a.Beta[gid];
+        }
+    }
+    if (MODE == 1 || (MODE == 2 && !a.W)) return;
+    for (size_t e = gid; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(e / per_o);
+        const int r = (int)(e - (size_t)o * per_o);
+        const int c = r / 7, t = r - 7 * c;
+        const int i = o / 64, k = a.k[i], lo = (7 - k) >> 1;
+        const bool in = t >= lo && t < lo + k;
+        const size_t pe = ((size_t)(o - 64 * i) * a.cin + c) * k + (t - lo);
+        if (MODE == 0) a.W[e] = in ? a.w[i][pe] : 0.f;
+        else if (in && a.w[i]) a.w[i][pe] += a.W[e];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // tiny fused tails of the tabular / bridge models (forward)
 // ---------------------------------------------------------------------------
 // out[b] = [ w0 * a[b][:Ha] | w1 * c[b][:Hc] ],  (w0, w1) = softmax(pa[0], pc[0])   (fmri_utils.py:93-96)
@@ -1595,6 +1643,27 @@ int mm_adamw_clip(float* p, float* g, float* m, float* v, float* state, int64_t 
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, p, g, m, v, state, (size_t)n, beta1,
                        beta2, eps, weight_decay, max_norm, grad_scale, zero_grad, seed_epoch);
     return mm_check_launch("adamw_clip");
+}
+
+int mm_power_merge(const void* desc_host, int mode, hipStream_t st) {
+    MM_REQUIRE(desc_host && mode >= 0 && mode <= 2, "power_merge: null / mode");
+    const PowerMergeArgs a = *static_cast<const PowerMergeArgs*>(desc_host);
+    MM_REQUIRE(a.cin > 0, "power_merge: cin");
+    for (int i = 0; i < 3; ++i) MM_REQUIRE(a.k[i] == 3 || a.k[i] == 5 || a.k[i] == 7, "power_merge: kernel sizes must be 3, 5 or 7");
+    if (mode == 0) {
+        for (int i = 0; i < 3; ++i)
+            MM_REQUIRE(a.w[i] && a.b[i] && a.gamma[i] && a.beta[i] && a.run_mean[i] && a.run_var[i], "power_merge(0): null part");
+        MM_REQUIRE(a.W && a.B && a.Gamma && a.Beta && a.Run_mean && a.Run_var, "power_merge(0): null merged tensor");
+    } else if (mode == 1) {
+        for (int i = 0; i < 3; ++i) MM_REQUIRE(a.run_mean[i] && a.run_var[i], "power_merge(1): null part");
+        MM_REQUIRE(a.Run_mean && a.Run_var, "power_merge(1): null merged statistics");
+    }
+    const size_t total = (size_t)192 * a.cin * 7;
+    const int grid = mode == 1 ? 1 : grid_h(total, 2048);
+    if (mode == 0) hipLaunchKernelGGL(power_merge_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL(power_merge_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(power_merge_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+    return mm_check_launch("power_merge");
 }
 
 int mm_softmax2_concat(const float* a, const float* c, const float* pa, const float* pc, float* out, int B, int Ha,

@@ -1311,21 +1311,40 @@ class _Merged:
         self.__dict__.update(kw)
 
 
+def power_merge_call(mode: int, parts, merged, tracked=(None, None, None), cin: int = 0, ks=(3, 5, 7)):
+    """mm_power_merge: ``parts`` = six triples (conv weight, conv bias, BN weight, BN bias, running mean, running var) of
+    fp32 tensors or None, ``merged`` = the six merged tensors or None (include/mmeeg_hip.h: mm_power_merge_t)"""
+    import ctypes
+    import struct
+    ptr = lambda t: 0 if t is None else t.data_ptr()      # noqa: E731
+    flat = [ptr(t) for trip in parts for t in trip] + [ptr(t) for t in tracked] + [ptr(t) for t in merged]
+    buf = struct.pack("<27Q4i", *flat, int(cin), *[int(k) for k in ks])
+    host = ctypes.create_string_buffer(buf, len(buf))
+    _hip.call("mm_power_merge", ctypes.addressof(host), int(mode))
+
+
 def _power_merged_train(m):
     """the three conv scales as ONE Conv1d(C -> 192, k=7, p=3) + BatchNorm1d(192) whose tensors are
     fresh leaves (requires_grad as the parts'), so the generic conv/BN forward+backward applies;
-    autograd.power_encoder_bwd slices their gradients back into the six real parameters."""
+    autograd.power_encoder_bwd adds their gradients back into the six real parameters.  Built by ONE launch
+    (mm_power_merge mode 0: the pads / cats of the three branches were ~20 tiny torch launches per step)."""
     seqs = (m.conv_scale1, m.conv_scale2, m.conv_scale3)
-    F = torch.nn.functional
-    cat = lambda ts: torch.cat([t.detach() for t in ts], dim=0).contiguous()    # noqa: E731
-    w = cat([F.pad(s[0].weight.detach(), ((7 - s[0].kernel_size[0]) // 2,) * 2) for s in seqs])
+    ref = seqs[0][0].weight
+    cin = seqs[0][0].in_channels
+    ks = tuple(s[0].kernel_size[0] for s in seqs)
+    assert all(s[0].out_channels == 64 and s[0].in_channels == cin and s[0].weight.dtype == _F32 for s in seqs), "three 64-channel branches"
+    w = _empty((192, cin, 7), _F32, ref)
+    vec = [_empty((192,), _F32, ref) for _ in range(5)]
+    parts = ([s[0].weight.detach() for s in seqs], [s[0].bias.detach() for s in seqs], [s[1].weight.detach() for s in seqs],
+             [s[1].bias.detach() for s in seqs], [s[1].running_mean for s in seqs], [s[1].running_var for s in seqs])
+    power_merge_call(0, parts, [w] + vec, cin=cin, ks=ks)
     w._mm_transient = True        # rebuilt every step: a trainer's recorded weight list must not hold on to this one
     conv = _Merged(weight=w.requires_grad_(any(s[0].weight.requires_grad for s in seqs)),
-                   bias=cat([s[0].bias for s in seqs]).requires_grad_(any(s[0].bias.requires_grad for s in seqs)),
-                   kernel_size=(7,), padding=(3,), in_channels=seqs[0][0].in_channels, out_channels=192)
-    bn = _Merged(weight=cat([s[1].weight for s in seqs]).requires_grad_(any(s[1].weight.requires_grad for s in seqs)),
-                 bias=cat([s[1].bias for s in seqs]).requires_grad_(any(s[1].bias.requires_grad for s in seqs)),
-                 running_mean=cat([s[1].running_mean for s in seqs]), running_var=cat([s[1].running_var for s in seqs]),
+                   bias=vec[0].requires_grad_(any(s[0].bias.requires_grad for s in seqs)),
+                   kernel_size=(7,), padding=(3,), in_channels=cin, out_channels=192)
+    bn = _Merged(weight=vec[1].requires_grad_(any(s[1].weight.requires_grad for s in seqs)),
+                 bias=vec[2].requires_grad_(any(s[1].bias.requires_grad for s in seqs)),
+                 running_mean=vec[3], running_var=vec[4],
                  num_batches_tracked=None, num_features=192, eps=seqs[0][1].eps, momentum=seqs[0][1].momentum)
     assert all(s[1].eps == bn.eps and s[1].momentum == bn.momentum for s in seqs)
     return conv, bn, seqs
@@ -1336,13 +1355,12 @@ def _power_forward_impl(m, xb: torch.Tensor, training: bool, need_dgrad: bool, s
     save = training if save is None else save
     conv, bn, seqs = _power_merged_train(m)
     r, s0 = conv_bn_act(xb, conv, bn, training=training, need_dgrad=need_dgrad, save=save)
-    if training:                                  # running statistics live in the three real modules
-        with torch.no_grad():
-            for i, sq in enumerate(seqs):
-                sq[1].running_mean.copy_(bn.running_mean[64 * i:64 * i + 64])
-                sq[1].running_var.copy_(bn.running_var[64 * i:64 * i + 64])
-                if sq[1].num_batches_tracked is not None:
-                    sq[1].num_batches_tracked.add_(1)
+    if training:                                  # running statistics live in the three real modules: handed back in one launch
+        none3 = [None] * 3
+        power_merge_call(1, (none3, none3, none3, none3, [sq[1].running_mean for sq in seqs], [sq[1].running_var for sq in seqs]),
+                         [None, None, None, None, bn.running_mean, bn.running_var],
+                         tracked=[sq[1].num_batches_tracked for sq in seqs], cin=conv.in_channels,
+                         ks=[sq[0].kernel_size[0] for sq in seqs])
     T = xb.shape[1]
     p = m.drop_p if training else 0.0
     r, s1 = conv_bn_act(r["bf16"], m.fusion[0], m.fusion[1], training=training, drop_p=p,
