@@ -73,6 +73,18 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
                   const float* pe, int pool, float* stats, float* out_f32, void* out_bf16,
                   void* out_pre, float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch,
                   const void* gradz, int gradz_act, hipStream_t stream);
+/* mm_conv1d_fwd with the reduction split over input-channel slices (few output tiles, long reduction: the merged
+ * 192-channel k = 7 convolution of EnhancedPowerEncoder over the ~6 000 STFT channels of config #5 is 96 tiles of 98
+ * chunks on 256 CUs): nsplit x the workgroups, each slice's raw fp32 tile to ws, a second launch adds the slices in order
+ * (same bits every run) and runs the epilogue.  mm_conv1d_fwd_splitk_plan says when it pays (nsplit_host = 1: call
+ * mm_conv1d_fwd) and how many floats ws needs; k > 1 convolutions with Cin % 64 == 0 only. */
+int mm_conv1d_fwd_splitk_plan(int B, int T, int Cin, int Cout, int taps, int* nsplit_host, int64_t* ws_floats_host,
+                              hipStream_t stream);
+int mm_conv1d_fwd_splitk(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
+                  const float* scale, const float* shift, int act, const float* residual,
+                  const float* pe, int pool, float* stats, float* out_f32, void* out_bf16,
+                  void* out_pre, float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch,
+                  const void* gradz, int gradz_act, float* ws, int nsplit, hipStream_t stream);
 /* dW[n][c][tap] (fp32, strides sn/sc/stap in elements) += sum_{b,t} dY[b,t,n]*X[b,t+tap-pad,c];
  * optional dbias[n] += sum dY.  Replaces the weight/bias gradients autograd
  * derives for the layers above (loss.backward(), run_training_lite.py:486).

@@ -92,6 +92,11 @@ struct ConvArgs {
     const bf16* w;
     int B, T, Cin, Cout, taps, pad;
     EpiArgs e;
+    // split-K (few output tiles, long reduction: config #5's 192-channel k = 7 convolution over ~6 000 input channels is
+    // 96 tiles of 98 chunks): workgroup z reduces input channels [z * csplit, (z + 1) * csplit) and stores its raw fp32
+    // tile to partial[z][b][t][n]; conv1d_splitk_epilogue_kernel adds the slices in order and runs the epilogue
+    float* partial = nullptr;
+    int csplit = 0;
 };
 
 // Epilogue feature mask of a launch: which of epilogue_rows' optional steps it needs, the activation in bits 16-19 and
@@ -541,8 +546,10 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
         return (s < nW && r < wvalid) ? *reinterpret_cast<const uint4*>(wb + (size_t)r * a.Cin + c0 + sg * 8)
                                       : make_uint4(0, 0, 0, 0);
     };
-    for (int c0 = 0; c0 < a.Cin; c0 += KCT) {
-        if (c0) __syncthreads();
+    const int c_lo = a.partial ? (int)blockIdx.z * a.csplit : 0;
+    const int c_hi = a.partial ? min(a.Cin, c_lo + a.csplit) : a.Cin;
+    for (int c0 = c_lo; c0 < c_hi; c0 += KCT) {
+        if (c0 != c_lo) __syncthreads();
         if constexpr (MERGE) {
             uint4 va[NA], vw[NB];
 #pragma unroll
@@ -616,6 +623,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
                 const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 Cs[row * LDC + (wn * TN + j) * 32 + lr] = acc[i][j][r];
             }
+    if (a.partial) {                               // split-K: the raw tile of this channel range, no epilogue
+        __syncthreads();
+        float* dst = a.partial + ((size_t)blockIdx.z * a.B + b) * a.T * a.Cout;
+        for (int i = tid; i < BM * (BN / 4); i += 256) {
+            const int row = i / (BN / 4), n = n0 + (i % (BN / 4)) * 4;
+            if (t0 + row < a.T && n < a.Cout)
+                *reinterpret_cast<float4*>(dst + (size_t)(t0 + row) * a.Cout + n) = *reinterpret_cast<const float4*>(Cs + row * LDC + (n - n0));
+        }
+        return;
+    }
     if (a.e.stats || a.e.ln_dgb)
         for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
     __syncthreads();
@@ -651,6 +668,38 @@ __global__ __launch_bounds__(256, 2) void conv1d_fwd_kernel(ConvArgs a) {
     epilogue_rows<BM, BN, FEAT>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
 }
 
+// second half of a split-K launch: the slices are added in slice order (same bits every run) into the C tile, then the
+// ordinary epilogue runs on it (generic form: every step behind its run-time test, bit-equal to the compiled-in forms)
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv1d_splitk_epilogue_kernel(ConvArgs a, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);
+    float* sstat = Cs + BM * LDC;
+    const int tid = threadIdx.x;
+    const int tilesT = (a.T + BM - 1) / BM;
+    const int b = blockIdx.x / tilesT, t0 = (blockIdx.x % tilesT) * BM, n0 = blockIdx.y * BN;
+    const size_t slice = (size_t)a.B * a.T * a.Cout;
+    const float* src = a.partial + (size_t)b * a.T * a.Cout;
+    for (int i = tid; i < BM * (BN / 4); i += 256) {
+        const int row = i / (BN / 4), n = n0 + (i % (BN / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 + row < a.T && n < a.Cout) {
+            const float* p = src + (size_t)(t0 + row) * a.Cout + n;
+            v = *reinterpret_cast<const float4*>(p);
+            for (int z = 1; z < nsplit; ++z) {
+                const float4 u = *reinterpret_cast<const float4*>(p + z * slice);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+        }
+        *reinterpret_cast<float4*>(Cs + row * LDC + (n - n0)) = v;
+    }
+    if (a.e.stats || a.e.ln_dgb)
+        for (int i = tid; i < 2 * BN; i += 256) sstat[i] = 0.f;
+    __syncthreads();
+    epilogue_rows<BM, BN, EF_ANY>(Cs, a.e, tid, b, t0, a.T, n0, a.Cout, sstat);
+}
+
 template <int BM, int BN, int WM, int WN, int KCT, unsigned FEAT, int TAPS = 0>
 int launch_fwd_feat(const ConvArgs& a, hipStream_t st) {
     const size_t stage = (size_t)(BM + a.taps - 1 + BN * a.taps) * (KCT + KPAD) * sizeof(bf16);
@@ -662,6 +711,16 @@ int launch_fwd_feat(const ConvArgs& a, hipStream_t st) {
     if (need > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
     dim3 grid(a.B * ceil_div(a.T, BM), ceil_div(a.Cout, BN));
+    if (a.partial) {
+        const int nsplit = ceil_div(a.Cin, a.csplit);
+        grid.z = nsplit;
+        hipLaunchKernelGGL(kern, grid, dim3(256), need, st, a);
+        int rc = mm_check_launch("conv1d_fwd(split-K)");
+        if (rc) return rc;
+        grid.z = 1;
+        hipLaunchKernelGGL((conv1d_splitk_epilogue_kernel<BM, BN>), grid, dim3(256), ctile, st, a, nsplit);
+        return mm_check_launch("conv1d_fwd(split-K epilogue)");
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), need, st, a);
     return mm_check_launch("conv1d_fwd");
 }
@@ -672,7 +731,7 @@ template <int BM, int BN, int WM, int WN, int KCT>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     const unsigned m = epi_mask(a.e);
     if (getenv("MM_EPI_LOG")) fprintf(stderr, "EPI %d %d %d mask %06x K=%d N=%d taps=%d\n", BM, BN, KCT, m, a.Cin, a.Cout, a.taps);
-    if (getenv("MM_EPI_GENERIC")) return launch_fwd_feat<BM, BN, WM, WN, KCT, EF_ANY>(a, st);      // tests: generic vs compiled-in epilogues
+    if (getenv("MM_EPI_GENERIC") || a.partial) return launch_fwd_feat<BM, BN, WM, WN, KCT, EF_ANY>(a, st);      // tests: generic vs compiled-in epilogues; split-K
 #define EPI_CASE(mask) case mask: return launch_fwd_feat<BM, BN, WM, WN, KCT, mask, LT>(a, st);
     if constexpr (BM == 64 && BN == 128 && KCT == 128) {
         constexpr int LT = 1;                 // the Linear layers: one tap
@@ -1263,12 +1322,66 @@ static int conv1d_dispatch(const ConvArgs& a, hipStream_t st) {
 #undef MM_FWD
 }
 
+// split-K plan of a forward launch: only the k > 1 convolutions on the 64 x 64 x 64 tile, when the output tiles do not
+// fill the chip and the reduction is long.  -> number of channel slices (1 = run it whole)
+static int conv1d_splitk_slices(int B, int T, int Cin, int Cout, int taps) {
+    if (taps == 1 || Cin % 64) return 1;
+    const long tiles = (long)B * ceil_div(T, 64) * ceil_div(Cout, 64);
+    const int chunks = Cin / 64;
+    if (tiles >= 192 || chunks < 16) return 1;
+    long n = 512 / tiles;                       // ~2 workgroups per CU
+    if (n > chunks / 8) n = chunks / 8;         // >= 8 chunks per slice
+    if (n > 8) n = 8;
+    return n < 2 ? 1 : (int)n;
+}
+
+int mm_conv1d_fwd_splitk_plan(int B, int T, int Cin, int Cout, int taps, int* nsplit_host, int64_t* ws_floats_host, hipStream_t) {
+    MM_REQUIRE(nsplit_host && ws_floats_host && B > 0 && T > 0 && Cin > 0 && Cout > 0 && taps >= 1, "conv1d_fwd_splitk_plan: bad args");
+    const int n = conv1d_splitk_slices(B, T, Cin, Cout, taps);
+    *nsplit_host = n;
+    *ws_floats_host = n > 1 ? (int64_t)n * B * T * Cout : 0;
+    return 0;
+}
+
+static int conv1d_fwd_args(ConvArgs& a, const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
+                           const float* scale, const float* shift, int act, const float* residual, const float* pe,
+                           int pool, float* stats, float* out_f32, void* out_bf16, void* out_pre,
+                           float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, const void* gradz, int gradz_act);
+
+int mm_conv1d_fwd_splitk(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
+                         const float* scale, const float* shift, int act, const float* residual, const float* pe,
+                         int pool, float* stats, float* out_f32, void* out_bf16, void* out_pre,
+                         float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, const void* gradz, int gradz_act,
+                         float* ws, int nsplit, hipStream_t st) {
+    ConvArgs a;
+    int rc = conv1d_fwd_args(a, x, w, B, T, Cin, Cout, taps, pad, scale, shift, act, residual, pe, pool, stats, out_f32, out_bf16,
+                             out_pre, drop_p, drop_seed, seed_epoch, gradz, gradz_act);
+    if (rc) return rc;
+    MM_REQUIRE(ws && nsplit >= 2 && nsplit <= 64, "conv1d_fwd_splitk: workspace / nsplit=%d", nsplit);
+    MM_REQUIRE(taps > 1 && Cin % 64 == 0, "conv1d_fwd_splitk: k > 1 convolutions with Cin %% 64 == 0 only (taps=%d Cin=%d)", taps, Cin);
+    const int chunks = Cin / 64;
+    a.csplit = ceil_div(chunks, nsplit) * 64;
+    MM_REQUIRE(ceil_div(Cin, a.csplit) >= 2, "conv1d_fwd_splitk: nsplit=%d leaves one slice", nsplit);
+    a.partial = ws;                               // ceil(Cin / csplit) <= nsplit slices of B * T * Cout floats
+    return conv1d_dispatch(a, st);
+}
+
 // Generic forward implicit GEMM.  See include/mmeeg_hip.h for the contract.
 int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
                   const float* scale, const float* shift, int act, const float* residual, const float* pe,
                   int pool, float* stats, float* out_f32, void* out_bf16, void* out_pre,
                   float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, const void* gradz, int gradz_act,
                   hipStream_t st) {
+    ConvArgs a;
+    int rc = conv1d_fwd_args(a, x, w, B, T, Cin, Cout, taps, pad, scale, shift, act, residual, pe, pool, stats, out_f32, out_bf16,
+                             out_pre, drop_p, drop_seed, seed_epoch, gradz, gradz_act);
+    return rc ? rc : conv1d_dispatch(a, st);
+}
+
+static int conv1d_fwd_args(ConvArgs& a, const void* x, const void* w, int B, int T, int Cin, int Cout, int taps, int pad,
+                           const float* scale, const float* shift, int act, const float* residual, const float* pe,
+                           int pool, float* stats, float* out_f32, void* out_bf16, void* out_pre,
+                           float drop_p, uint32_t drop_seed, const uint32_t* seed_epoch, const void* gradz, int gradz_act) {
     MM_REQUIRE(x && w, "conv1d_fwd: null operand");
     MM_REQUIRE(B > 0 && T > 0 && Cout > 0 && taps >= 1 && taps <= 9 && pad >= 0 && pad < taps, "conv1d_fwd: bad dims");
     MM_REQUIRE(Cin > 0 && Cin % 16 == 0, "conv1d_fwd: Cin=%d must be a multiple of 16", Cin);
@@ -1276,7 +1389,6 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     MM_REQUIRE(out_f32 || out_bf16 || out_pre, "conv1d_fwd: no output");
     MM_REQUIRE(Cout % 4 == 0, "conv1d_fwd: Cout=%d must be a multiple of 4", Cout);
     MM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1d_fwd: drop_p");
-    ConvArgs a;
     a.x = (const bf16*)x; a.w = (const bf16*)w;
     a.B = B; a.T = T; a.Cin = Cin; a.Cout = Cout; a.taps = taps; a.pad = pad;
     a.e.scale = scale; a.e.shift = shift; a.e.residual = residual; a.e.pe = pe; a.e.stats = stats;
@@ -1290,7 +1402,7 @@ int mm_conv1d_fwd(const void* x, const void* w, int B, int T, int Cin, int Cout,
     a.e.ln_x = nullptr; a.e.ln_stat = nullptr; a.e.ln_gamma = nullptr; a.e.ln_dgb = nullptr;
     a.e.pool_out = nullptr; a.e.pool_rows = 0; a.e.pool_scale = 0.f;
     a.e.lnf_out = nullptr; a.e.lnf_stat = nullptr; a.e.lnf_gamma = nullptr; a.e.lnf_beta = nullptr; a.e.lnf_eps = 0.f;
-    return conv1d_dispatch(a, st);
+    return 0;
 }
 
 // Data-gradient convolution of a conv block (dy (B, T, Cin) bf16 x that block's dgrad weight image -> dx (B, T, Cout)

@@ -125,6 +125,7 @@ def _zeros(shape, like, dtype=_F32):
     return torch.zeros(shape, dtype=dtype, device=like.device)
 
 
+_NO_SPLITK = bool(os.environ.get("MM_NO_SPLITK"))
 _NO_FFN1_FUSE = not os.environ.get("MM_FFN1_FUSE")        # the first FFN Linear inside the out-projection's launch: measured, not
                                                            # faster (2-byte column stores of 2 x 16 MB) - off unless MM_FFN1_FUSE=1
 _NO_QKV_FUSE = bool(os.environ.get("MM_NO_QKV_FUSE"))     # A/B knob: the next block's QKV projection as its own launch
@@ -307,10 +308,32 @@ def igemm(x: torch.Tensor, wf: torch.Tensor, taps: int, pad: int, cout: int, *,
     of = _empty((B, T // pool, cout), _F32, x) if out_f32 else None
     ob = _empty((B, T // pool, cout), _BF, x) if out_bf16 else None
     op = _empty((B, T, cout), _BF, x) if out_pre else None
-    _hip.call("mm_conv1d_fwd", x, wf, B, T, cin, cout, taps, pad, scale, shift, ACT[act], residual, pe,
-              pool, stats, of, ob, op, float(drop_p), int(seed), EP(), gradz, ACT[gradz_act])
+    args = (x, wf, B, T, cin, cout, taps, pad, scale, shift, ACT[act], residual, pe,
+            pool, stats, of, ob, op, float(drop_p), int(seed), EP(), gradz, ACT[gradz_act])
+    nsplit, ws_floats = _splitk_plan(B, T, cin, cout, taps)
+    if nsplit > 1:                # few output tiles, long reduction (config #5's merged conv): channel slices + an epilogue launch
+        _hip.call("mm_conv1d_fwd_splitk", *args, _empty((ws_floats,), _F32, x), nsplit)
+    else:
+        _hip.call("mm_conv1d_fwd", *args)
     res["f32"], res["bf16"], res["pre"] = of, ob, op
     return res
+
+
+_SPLITK_PLANS: Dict[tuple, tuple] = {}
+
+
+def _splitk_plan(B: int, T: int, cin: int, cout: int, taps: int):
+    """(slices, workspace floats) of mm_conv1d_fwd_splitk_plan, cached per shape; MM_NO_SPLITK=1 turns it off (A/B)"""
+    if taps == 1 or _NO_SPLITK:
+        return 1, 0
+    key = (B, T, cin, cout, taps)
+    plan = _SPLITK_PLANS.get(key)
+    if plan is None:
+        import ctypes
+        n, ws = ctypes.c_int(0), ctypes.c_int64(0)
+        _hip.call("mm_conv1d_fwd_splitk_plan", B, T, cin, cout, taps, ctypes.addressof(n), ctypes.addressof(ws))
+        plan = _SPLITK_PLANS[key] = (n.value, ws.value)
+    return plan
 
 
 def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, *, act="none", residual=None,

@@ -95,6 +95,64 @@ def test_conv1d_fwd_epilogue_bn_gelu_pool_stats():
     torch.testing.assert_close(stats[1].cpu(), (z * z).sum(dim=(0, 2)), rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("B,C,T,Cout,k,nsplit", [(3, 1024, 50, 192, 7, 2), (2, 1536, 64, 192, 7, 5), (1, 1088, 70, 64, 3, 8)])
+def test_conv1d_fwd_splitk_equals_the_whole_launch(B, C, T, Cout, k, nsplit):
+    """mm_conv1d_fwd_splitk (input channels reduced in `nsplit` slices by nsplit x the workgroups, slices added in order by
+    a second launch that runs the epilogue) against mm_conv1d_fwd on the same operands: fp32 pre-BatchNorm output and the
+    activation statistics to fp32 re-association level (1e-5 of the output scale), the bf16 pooled GELU output to one bf16
+    step, both against F.conv1d; ragged last row tile, a last slice shorter than the others (17 chunks in 8 slices), run
+    twice -> bit-identical (no atomics).  The plan function picks the config-#5 shape and leaves the others alone."""
+    import ctypes
+    hip = _hip()
+    g = torch.Generator().manual_seed(B + C + T)
+    x = torch.randn(B, C, T, generator=g)
+    w = torch.randn(Cout, C, k, generator=g) / math.sqrt(C * k)
+    bias = torch.randn(Cout, generator=g)
+    xg = torch.empty(B, T, C, dtype=torch.bfloat16, device="cuda")
+    hip.call("mm_pack_nct_bf16", x.cuda(), xg, B, C, T, C)
+    wf, _ = _prep_w(hip, w, C)
+
+    def run(split, pooled):
+        stats = torch.zeros(32, 2, Cout, device="cuda")
+        of = None if pooled else torch.empty(B, T, Cout, device="cuda")
+        ob = torch.empty(B, T // 2, Cout, dtype=torch.bfloat16, device="cuda") if pooled else None
+        args = (xg, wf, B, T, C, Cout, k, k // 2, None, bias.cuda(), 1 if pooled else 0, None, None, 2 if pooled else 1,
+                stats, of, ob, None, 0.0, 0, None, None, 0)
+        if split:
+            ws = torch.full((split * B * T * Cout,), float("nan"), device="cuda")
+            hip.call("mm_conv1d_fwd_splitk", *args, ws, split)
+        else:
+            hip.call("mm_conv1d_fwd", *args)
+        return (ob if pooled else of), _stat(stats)
+    z = F.conv1d(_bf(x), _bf(w), bias, padding=k // 2)
+    for pooled in (False, True):
+        if pooled and T % 2:
+            continue
+        y0, s0 = run(0, pooled)
+        y1, s1 = run(nsplit, pooled)
+        y2, s2 = run(nsplit, pooled)
+        assert torch.equal(y1, y2) and torch.equal(s1, s2)
+        if pooled:
+            want = F.max_pool1d(F.gelu(z), 2).transpose(1, 2)
+            torch.testing.assert_close(y1.float().cpu(), want, rtol=1e-2, atol=1e-2)
+            assert (y1.float() - y0.float()).abs().max().item() <= 2 ** -7 * max(1.0, y0.float().abs().max().item())
+        else:
+            torch.testing.assert_close(y1.cpu(), z.transpose(1, 2), rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-3)
+    plan = {}
+    for shape in ((32, 64, 6272, 192, 7), (32, 1024, 64, 128, 7), (32, 512, 128, 128, 1), (2, 64, 1536, 192, 7)):
+        n, f = ctypes.c_int(0), ctypes.c_int64(0)
+        hip.call("mm_conv1d_fwd_splitk_plan", *shape, ctypes.addressof(n), ctypes.addressof(f))
+        plan[shape] = (n.value, f.value)
+    assert plan[(32, 64, 6272, 192, 7)] == (5, 5 * 32 * 64 * 192)
+    assert plan[(32, 1024, 64, 128, 7)] == (1, 0) and plan[(32, 512, 128, 128, 1)] == (1, 0)
+    assert plan[(2, 64, 1536, 192, 7)][0] == 3
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_conv1d_fwd_splitk", xg, wf, B, T, C, Cout, k, k // 2, None, None, 0, None, None, 1, None,
+                 torch.empty(B, T, Cout, device="cuda"), None, None, 0.0, 0, None, None, 0, None, nsplit)
+
+
 def _attn_ref(qkv, H):
     B, L, E3 = qkv.shape
     E = E3 // 3
