@@ -1159,14 +1159,52 @@ __global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __rest
 }
 
 // every conv weight-gradient workspace of a backward pass in one launch (blockIdx.y = tensor)
-struct ScatterDesc { const float* ws; float* dw; int Cout, Cin, taps, Cinp, nrep, pad_; };
+struct ScatterDesc { const float* ws; float* dw; int Cout, Cin, taps, Cinp, nrep, cout_all; };      // cout_all: 0, or the output channels of the WHOLE workspace when this descriptor covers a slice of them (replica stride)
 constexpr int SM_MAX = 64;
 struct ScatterTable { ScatterDesc d[SM_MAX]; };
+// wide layers (Cin >= 256: config #5's merged convolution has 6 272 input channels, 8.4 M weights): the strided
+// read-modify-write of the plain form below ran at 0.6 TB/s (168 us).  Here a workgroup takes one output channel x 256
+// input channels, reads the workspace rows of every tap coalesced, turns the [tap][c] block into [c][tap] through LDS and
+// adds it to a CONTIGUOUS range of the gradient.  Same replica order as the plain form: same bits.
+__device__ __forceinline__ void scatter_body_tiled(const ScatterDesc& d, int blk, int nblk) {
+    __shared__ float tile[256 * 9];
+    const size_t rstride = (size_t)(d.cout_all ? d.cout_all : d.Cout) * d.taps * d.Cinp;
+    const int cch = (d.Cin + 255) / 256, items = d.Cout * cch, ts = d.taps | 1, tid = threadIdx.x;
+    for (int item = blk; item < items; item += nblk) {
+        const int n = item / cch, c0 = (item - n * cch) * 256;
+        const int cn = min(256, d.Cin - c0);
+        if (tid < cn)
+            for (int tap = 0; tap < d.taps; ++tap) {
+                const float* src = d.ws + ((size_t)n * d.taps + tap) * d.Cinp + c0 + tid;
+                float s = 0.f;
+                int r = 0;
+                for (; r + 8 <= d.nrep; r += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = src[(r + q) * rstride];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s += v[q];
+                }
+                for (; r < d.nrep; ++r) s += src[r * rstride];
+                tile[tid * ts + tap] = s;
+            }
+        __syncthreads();
+        float* dst = d.dw + ((size_t)n * d.Cin + c0) * d.taps;
+        for (int j = tid; j < cn * d.taps; j += 256) {
+            const int cl = j / d.taps;
+            dst[j] += tile[cl * ts + (j - cl * d.taps)];
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ void scatter_body(const ScatterDesc& d, int blk, int nblk) {
+    if (d.taps > 1 && d.taps <= 8 && d.Cin >= 256) return scatter_body_tiled(d, blk, nblk);      // (uniform per descriptor)
     // walk the workspace in ITS order (channel-contiguous: the nrep replica reads coalesce) and
     // scatter one strided write per element, not nrep strided reads
-    const size_t rstride = (size_t)d.Cout * d.taps * d.Cinp;
-    for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < rstride; i += (size_t)nblk * blockDim.x) {
+    const size_t rstride = (size_t)(d.cout_all ? d.cout_all : d.Cout) * d.taps * d.Cinp;
+    const size_t count = (size_t)d.Cout * d.taps * d.Cinp;
+    for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < count; i += (size_t)nblk * blockDim.x) {
         const int c = (int)(i % d.Cinp);
         if (c >= d.Cin) continue;
         const int tap = (int)((i / d.Cinp) % d.taps);
@@ -1773,19 +1811,41 @@ int mm_reduce_replicas(const float* src, float* dst, int K, int nrep, int64_t re
 int mm_flush_many(const void* scatter_desc_host, int nscatter, const void* reduce_desc_host, int nreduce, hipStream_t st) {
     MM_REQUIRE(nscatter >= 0 && nreduce >= 0 && nscatter + nreduce > 0 && (scatter_desc_host || !nscatter) &&
                    (reduce_desc_host || !nreduce), "flush_many: bad args");
-    const ScatterDesc* sd = (const ScatterDesc*)scatter_desc_host;
+    const ScatterDesc* sd_in = (const ScatterDesc*)scatter_desc_host;
     const ReduceDesc* rd = (const ReduceDesc*)reduce_desc_host;
     static_assert(sizeof(FlushTable) <= 4096, "kernel arguments");
+    // every scatter descriptor gets FM_SB workgroups: a big workspace (config #5's merged convolution: 8.4 M weights) is dealt
+    // out as up to 8 descriptors over slices of its output channels, so that it gets 8 x the workgroups
+    constexpr int EXP_MAX = 1024;
+    static thread_local ScatterDesc expanded[EXP_MAX];
+    int nexp = 0;
+    for (int i = 0; i < nscatter; ++i) {
+        const ScatterDesc& d = sd_in[i];
+        MM_REQUIRE(d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.Cinp >= d.Cin && d.nrep >= 1,
+                   "flush_many: scatter descriptor %d", i);
+        const size_t elems = (size_t)d.Cout * d.taps * d.Cinp;
+        int parts = (int)((elems + (1u << 20) - 1) >> 20);
+        if (parts > 8) parts = 8;
+        if (parts > d.Cout) parts = d.Cout;
+        if (parts < 1) parts = 1;
+        MM_REQUIRE(nexp + parts <= EXP_MAX, "flush_many: too many scatter descriptors");
+        for (int q = 0; q < parts; ++q) {
+            const int o0 = (int)((long)d.Cout * q / parts), o1 = (int)((long)d.Cout * (q + 1) / parts);
+            ScatterDesc e = d;
+            e.ws = d.ws + (size_t)o0 * d.taps * d.Cinp;
+            e.dw = d.dw + (size_t)o0 * d.Cin * d.taps;
+            e.Cout = o1 - o0;
+            e.cout_all = d.Cout;
+            expanded[nexp++] = e;
+        }
+    }
+    const ScatterDesc* sd = expanded;
+    nscatter = nexp;
     for (int sb = 0, rb = 0; sb < nscatter || rb < nreduce; sb += FM_MAX, rb += FM_MAX) {
         FlushTable tab;
         tab.ns = nscatter - sb > FM_MAX ? FM_MAX : (nscatter - sb > 0 ? nscatter - sb : 0);
         tab.nr = nreduce - rb > FM_MAX ? FM_MAX : (nreduce - rb > 0 ? nreduce - rb : 0);
-        for (int i = 0; i < tab.ns; ++i) {
-            const ScatterDesc& d = sd[sb + i];
-            MM_REQUIRE(d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.Cinp >= d.Cin && d.nrep >= 1,
-                       "flush_many: scatter descriptor %d", sb + i);
-            tab.s[i] = d;
-        }
+        for (int i = 0; i < tab.ns; ++i) tab.s[i] = sd[sb + i];
         for (int i = 0; i < tab.nr; ++i) {
             const ReduceDesc& d = rd[rb + i];
             MM_REQUIRE(d.src && d.dst && d.K > 0 && d.stride >= d.K && (d.nrep == 1 || (d.nrep == MM_ACC_REPL && ((uintptr_t)d.src & 7) == 0)),
@@ -1825,6 +1885,7 @@ int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t st) {
             MM_REQUIRE(d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.Cinp >= d.Cin && d.nrep >= 1,
                        "scatter_many: descriptor %d", base + i);
             tab.d[i] = d;
+            tab.d[i].cout_all = 0;
         }
         hipLaunchKernelGGL(scatter_many_kernel, dim3(256, n), dim3(256), 0, st, tab);
     }

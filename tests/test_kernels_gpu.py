@@ -1361,10 +1361,11 @@ def test_batched_launches_equal_their_single_forms():
     assert (arena[:4096] == 0).all() and (arena[4096:] == 7.0).all()
     with pytest.raises(hip.HipLibraryError):
         hip.call("mm_prep_many_zero", ctypes.addressof(host), len(shapes), arena, 4095)      # not a multiple of 4 floats
-    # gradient flush: three slot workspaces + five reductions (accumulator workspaces and one compact fp32 vector)
+    # gradient flush: six slot workspaces + five reductions (accumulator workspaces and one compact fp32 vector)
     from multimodal_eeg_fmri_amd.ops import ACC_GRAD, acc_encode
     sdesc, rdesc, ref = [], [], []
-    for cout, cin, k, slots in [(64, 48, 5, 7), (128, 128, 1, 3), (32, 20, 3, 1)]:
+    # (the 300- and 1 000-channel ones take mm_flush_many's LDS-transposing form for wide layers; mm_wgrad_scatter is the plain form)
+    for cout, cin, k, slots in [(64, 48, 5, 7), (128, 128, 1, 3), (32, 20, 3, 1), (24, 300, 7, 3), (40, 1000, 5, 9), (190, 1600, 7, 2)]:      # (the last: > 2 M weights, dealt out as three descriptors)
         cinp = _cpad(cin)
         ws = torch.randn(slots, cout, k, cinp, generator=g).cuda()
         dw_a, dw_b = torch.ones(cout, cin, k, device="cuda"), torch.ones(cout, cin, k, device="cuda")
