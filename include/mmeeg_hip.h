@@ -126,7 +126,10 @@ int mm_prep_many(const void* desc_host, int ndesc, hipStream_t stream);
  * accumulator workspaces, which would otherwise be one more fill node in front of the first kernel */
 int mm_prep_many_zero(const void* desc_host, int ndesc, float* zero, int64_t nzero, hipStream_t stream);
 /* mm_wgrad_scatter for ndesc workspaces in one launch per 64 descriptors; desc_host = HOST array of
- * {const float* ws; float* dw; int32 Cout, Cin, taps, Cinp, nrep, 0} (40 bytes each) */
+ * {const float* ws; float* dw; int32 Cout, Cin, taps, Cinp, nrep, cout_all} (40 bytes each).  A descriptor may take a BLOCK
+ * of a wider workspace (the three branches of EnhancedPowerEncoder's merged convolution, mm_power_merge): taps = the
+ * gradient tensor's taps | first workspace tap << 8 | workspace taps << 16 (upper bits 0 = the whole kernel), ws already
+ * advanced to the block's first output channel, cout_all = the workspace's output channels (0 = Cout). */
 int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t stream);
 /* ndesc independent reductions into parameter gradients in one launch per 64 descriptors; desc_host =
  * HOST array of {const void* src; float* dst; int64 K, nrep, rep_stride} (40 bytes each), copied into the

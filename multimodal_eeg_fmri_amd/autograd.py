@@ -40,19 +40,35 @@ def _reduce_into(dst, src, K, stride, offset=0, nrep=REPL):
         _hip.call("mm_reduce_replicas", ptr, dst, K, 1, stride)
 
 
-def _scatter_into(dw, ws, cout, cin, taps, cinp, nrep):
-    """dw[n][c][tap] += sum_rep ws[rep][n][tap][c]   (deferred to GradBag.flush when a bag is active)"""
+def _scatter_into(dw, ws, cout, cin, taps, cinp, nrep, window=None):
+    """dw[n][c][tap] += sum_rep ws[rep][n][tap][c]   (deferred to GradBag.flush when a bag is active).
+    ``window`` = (first output channel, first tap, workspace taps, workspace output channels): ``dw`` (cout, cin, taps) takes
+    only that block of a wider workspace (the branches of EnhancedPowerEncoder's merged convolution)."""
     bag = _BAG["cur"]
     if bag is not None:
-        bag.defer_scatter(ws, dw, cout, cin, taps, cinp, nrep)
-    else:
+        bag.defer_scatter(ws, dw, cout, cin, taps, cinp, nrep, window)
+    elif window is None:
         _hip.call("mm_wgrad_scatter", ws, dw, cout, cin, taps, cinp, nrep)
+    else:
+        import ctypes
+        import struct
+        raw = struct.pack("<QQiiiiii", *scatter_desc(ws, dw, cout, cin, taps, cinp, nrep, window))
+        host = ctypes.create_string_buffer(raw, len(raw))
+        _hip.call("mm_scatter_many", ctypes.addressof(host), 1)
+
+
+def scatter_desc(ws, dw, cout, cin, taps, cinp, nrep, window=None):
+    """the 40-byte descriptor of mm_scatter_many / mm_flush_many (include/mmeeg_hip.h)"""
+    if window is None:
+        return (ws.data_ptr(), dw.data_ptr(), cout, cin, taps, cinp, nrep, 0)
+    n0, tap0, ws_taps, ws_cout = window
+    return (ws.data_ptr() + 4 * n0 * ws_taps * cinp, dw.data_ptr(), cout, cin, taps | (tap0 << 8) | (ws_taps << 16), cinp, nrep, ws_cout)
 
 
 _SLOTS = {}
 
 
-def _wgrad_slots(dy, x, dw, dbr, B, T, cinp, N, k, pad, cin):
+def _wgrad_slots(dy, x, dw, dbr, B, T, cinp, N, k, pad, cin, parts=None):
     """conv / linear weight gradient without atomics: every row-chunk workgroup stores its partial
     dW[n][tap][c] into its own slot of a workspace; the (deferred, batched) scatter sums the slots
     into the parameter layout."""
@@ -80,7 +96,12 @@ def _wgrad_slots(dy, x, dw, dbr, B, T, cinp, N, k, pad, cin):
     else:
         _hip.call("mm_conv1d_wgrad", dy, x, ws, dbr, B, T, cinp, N, k, pad, cinp, k * cinp, 1, cinp,
                   slots, N * k * cinp, 1)
-    _scatter_into(dw, ws, N, cin, k, cinp, slots)
+    if parts is None:
+        _scatter_into(dw, ws, N, cin, k, cinp, slots)
+    else:            # (gradient tensor, first output channel, output channels, kernel size): centred tap windows of the workspace
+        for t, n0, cn, kk in parts:
+            if t is not None:
+                _scatter_into(t, ws, cn, cin, kk, cinp, slots, window=(n0, (k - kk) // 2, k, N))
 
 
 class deferred:
@@ -143,8 +164,8 @@ class GradBag:
         self.pending.append((src_ptr, dst.data_ptr(), K, nrep, stride))
         self._keep.append((dst, keep))
 
-    def defer_scatter(self, ws: torch.Tensor, dw: torch.Tensor, cout, cin, taps, cinp, nrep):
-        self.scatters.append((ws.data_ptr(), dw.data_ptr(), cout, cin, taps, cinp, nrep))
+    def defer_scatter(self, ws: torch.Tensor, dw: torch.Tensor, cout, cin, taps, cinp, nrep, window=None):
+        self.scatters.append(scatter_desc(ws, dw, cout, cin, taps, cinp, nrep, window))
         self._keep.append((dw, ws))
 
     def defer_wgrad(self, dy, x, ws, dbr, B, T, cinp, N, slots):
@@ -175,7 +196,7 @@ class GradBag:
         if not self.scatters and not self.pending:
             return
         # slot sums (weight gradients) and accumulator reductions (bias / norm-parameter gradients): one launch
-        sraw = b"".join(struct.pack("<QQiiiiii", *d, 0) for d in self.scatters)
+        sraw = b"".join(struct.pack("<QQiiiiii", *d) for d in self.scatters)
         rraw = b"".join(struct.pack("<QQqqq", *d) for d in self.pending)
         shost = ctypes.create_string_buffer(sraw, max(len(sraw), 1))      # descriptors travel as kernel arguments
         rhost = ctypes.create_string_buffer(rraw, max(len(rraw), 1))
@@ -272,12 +293,18 @@ def conv_bn_act_bwd(bag: GradBag, s: dict, dout_bf16=None, dout_f32=None, need_d
     _bn_param_grads(bag, bn, sums, N, nrep=REPL)
     k, pad = conv.kernel_size[0], conv.padding[0]
     cin = conv.in_channels
-    dw = bag.target(conv.weight)
-    if dw is not None:
+    # a convolution merged from several modules (ops._power_merged_train) sends its slot sums straight into THEIR gradients
+    parts = getattr(conv, "parts", None)
+    if parts is not None:
+        parts = [(bag.target(w), n0, w.shape[0], w.shape[2]) for w, n0 in parts]
+        dw = None
+    else:
+        dw = bag.target(conv.weight)
+    if dw is not None or (parts is not None and any(t is not None for t, *_ in parts)):
         cinp_x = xb.shape[2]
         db = bag.target(conv.bias)
         dbr = _zeros((REPL, N), y) if db is not None else None
-        _wgrad_slots(dy, xb, dw, dbr, B, T, cinp_x, N, k, pad, cin)
+        _wgrad_slots(dy, xb, dw, dbr, B, T, cinp_x, N, k, pad, cin, parts=parts)
         if db is not None:
             _reduce_into(db, dbr, N, N)
     if not need_dx:
@@ -545,7 +572,8 @@ def power_encoder_bwd(bag: GradBag, sv: dict, dout: torch.Tensor, need_dx: bool 
     conv, bn, seqs = sv["merged"]
 
     def finish():
-        # ONE launch adds the merged gradients' slices into the six real parameters' sinks (it was twelve sliced add_)
+        # ONE launch adds the merged bias / BatchNorm gradients' slices into the real parameters' sinks (it was twelve sliced
+        # add_); the weight gradients went straight from the slot workspace into the three real tensors (conv_bn_act_bwd)
         tg = lambda ps: [bag.target(p) for p in ps]       # noqa: E731
         none3 = [None] * 3
         ops.power_merge_call(2, (tg([sq[0].weight for sq in seqs]), tg([sq[0].bias for sq in seqs]), tg([sq[1].weight for sq in seqs]),

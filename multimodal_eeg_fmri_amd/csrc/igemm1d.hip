@@ -1159,7 +1159,18 @@ __global__ void wgrad_scatter_kernel(const float* __restrict__ ws, float* __rest
 }
 
 // every conv weight-gradient workspace of a backward pass in one launch (blockIdx.y = tensor)
-struct ScatterDesc { const float* ws; float* dw; int Cout, Cin, taps, Cinp, nrep, cout_all; };      // cout_all: 0, or the output channels of the WHOLE workspace when this descriptor covers a slice of them (replica stride)
+// taps: bits 0-7 the taps of the gradient tensor, bits 8-15 the first workspace tap it takes, bits 16-23 the taps of the
+// workspace rows (0 = the same): a descriptor may take a WINDOW of the workspace's taps (the k = 3 / 5 branches of
+// EnhancedPowerEncoder's merged k = 7 convolution: their gradients are the centre taps of their 64 output channels)
+struct ScatterDesc { const float* ws; float* dw; int Cout, Cin, taps, Cinp, nrep, cout_all; };
+__device__ __host__ inline int scatter_taps(const ScatterDesc& d) { return d.taps & 255; }
+__device__ __host__ inline int scatter_tap0(const ScatterDesc& d) { return (d.taps >> 8) & 255; }
+__device__ __host__ inline int scatter_ws_taps(const ScatterDesc& d) { return (d.taps >> 16) & 255 ? (d.taps >> 16) & 255 : (d.taps & 255); }
+static bool scatter_desc_ok(const ScatterDesc& d) {
+    return d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && scatter_taps(d) > 0 && d.Cinp >= d.Cin && d.nrep >= 1 &&
+           scatter_tap0(d) + scatter_taps(d) <= scatter_ws_taps(d) && (d.cout_all == 0 || d.cout_all >= d.Cout);
+}
+// cout_all: 0, or the output channels of the WHOLE workspace when the descriptor covers a slice of them (replica stride)
 constexpr int SM_MAX = 64;
 struct ScatterTable { ScatterDesc d[SM_MAX]; };
 // wide layers (Cin >= 256: config #5's merged convolution has 6 272 input channels, 8.4 M weights): the strided
@@ -1168,14 +1179,15 @@ struct ScatterTable { ScatterDesc d[SM_MAX]; };
 // adds it to a CONTIGUOUS range of the gradient.  Same replica order as the plain form: same bits.
 __device__ __forceinline__ void scatter_body_tiled(const ScatterDesc& d, int blk, int nblk) {
     __shared__ float tile[256 * 9];
-    const size_t rstride = (size_t)(d.cout_all ? d.cout_all : d.Cout) * d.taps * d.Cinp;
-    const int cch = (d.Cin + 255) / 256, items = d.Cout * cch, ts = d.taps | 1, tid = threadIdx.x;
+    const int taps = scatter_taps(d), tap0 = scatter_tap0(d), tws = scatter_ws_taps(d);
+    const size_t rstride = (size_t)(d.cout_all ? d.cout_all : d.Cout) * tws * d.Cinp;
+    const int cch = (d.Cin + 255) / 256, items = d.Cout * cch, ts = taps | 1, tid = threadIdx.x;
     for (int item = blk; item < items; item += nblk) {
         const int n = item / cch, c0 = (item - n * cch) * 256;
         const int cn = min(256, d.Cin - c0);
         if (tid < cn)
-            for (int tap = 0; tap < d.taps; ++tap) {
-                const float* src = d.ws + ((size_t)n * d.taps + tap) * d.Cinp + c0 + tid;
+            for (int tap = 0; tap < taps; ++tap) {
+                const float* src = d.ws + ((size_t)n * tws + tap0 + tap) * d.Cinp + c0 + tid;
                 float s = 0.f;
                 int r = 0;
                 for (; r + 8 <= d.nrep; r += 8) {
@@ -1189,37 +1201,39 @@ __device__ __forceinline__ void scatter_body_tiled(const ScatterDesc& d, int blk
                 tile[tid * ts + tap] = s;
             }
         __syncthreads();
-        float* dst = d.dw + ((size_t)n * d.Cin + c0) * d.taps;
-        for (int j = tid; j < cn * d.taps; j += 256) {
-            const int cl = j / d.taps;
-            dst[j] += tile[cl * ts + (j - cl * d.taps)];
+        float* dst = d.dw + ((size_t)n * d.Cin + c0) * taps;
+        for (int j = tid; j < cn * taps; j += 256) {
+            const int cl = j / taps;
+            dst[j] += tile[cl * ts + (j - cl * taps)];
         }
         __syncthreads();
     }
 }
 
 __device__ __forceinline__ void scatter_body(const ScatterDesc& d, int blk, int nblk) {
-    if (d.taps > 1 && d.taps <= 8 && d.Cin >= 256) return scatter_body_tiled(d, blk, nblk);      // (uniform per descriptor)
+    const int taps = scatter_taps(d), tap0 = scatter_tap0(d), tws = scatter_ws_taps(d);
+    if (taps > 1 && taps <= 8 && d.Cin >= 256) return scatter_body_tiled(d, blk, nblk);      // (uniform per descriptor)
     // walk the workspace in ITS order (channel-contiguous: the nrep replica reads coalesce) and
     // scatter one strided write per element, not nrep strided reads
-    const size_t rstride = (size_t)(d.cout_all ? d.cout_all : d.Cout) * d.taps * d.Cinp;
-    const size_t count = (size_t)d.Cout * d.taps * d.Cinp;
+    const size_t rstride = (size_t)(d.cout_all ? d.cout_all : d.Cout) * tws * d.Cinp;
+    const size_t count = (size_t)d.Cout * taps * d.Cinp;
     for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < count; i += (size_t)nblk * blockDim.x) {
         const int c = (int)(i % d.Cinp);
         if (c >= d.Cin) continue;
-        const int tap = (int)((i / d.Cinp) % d.taps);
-        const int n = (int)(i / ((size_t)d.Cinp * d.taps));
+        const int tap = (int)((i / d.Cinp) % taps);
+        const int n = (int)(i / ((size_t)d.Cinp * taps));
+        const size_t e = ((size_t)n * tws + tap0 + tap) * d.Cinp + c;      // (= i for a whole-kernel descriptor)
         float s = 0.f;
         int r = 0;
         for (; r + 8 <= d.nrep; r += 8) {                   // eight independent loads at a time, not a latency chain
             float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = d.ws[(r + q) * rstride + i];
+            for (int q = 0; q < 8; ++q) v[q] = d.ws[(r + q) * rstride + e];
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += v[q];
         }
-        for (; r < d.nrep; ++r) s += d.ws[r * rstride + i];
-        d.dw[((size_t)n * d.Cin + c) * d.taps + tap] += s;
+        for (; r < d.nrep; ++r) s += d.ws[r * rstride + e];
+        d.dw[((size_t)n * d.Cin + c) * taps + tap] += s;
     }
 }
 __global__ void scatter_many_kernel(ScatterTable tab) { scatter_body(tab.d[blockIdx.y], blockIdx.x, gridDim.x); }
@@ -1821,9 +1835,9 @@ int mm_flush_many(const void* scatter_desc_host, int nscatter, const void* reduc
     int nexp = 0;
     for (int i = 0; i < nscatter; ++i) {
         const ScatterDesc& d = sd_in[i];
-        MM_REQUIRE(d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.Cinp >= d.Cin && d.nrep >= 1,
-                   "flush_many: scatter descriptor %d", i);
-        const size_t elems = (size_t)d.Cout * d.taps * d.Cinp;
+        MM_REQUIRE(scatter_desc_ok(d), "flush_many: scatter descriptor %d", i);
+        const int tws = scatter_ws_taps(d);
+        const size_t elems = (size_t)d.Cout * scatter_taps(d) * d.Cinp;
         int parts = (int)((elems + (1u << 20) - 1) >> 20);
         if (parts > 8) parts = 8;
         if (parts > d.Cout) parts = d.Cout;
@@ -1832,10 +1846,10 @@ int mm_flush_many(const void* scatter_desc_host, int nscatter, const void* reduc
         for (int q = 0; q < parts; ++q) {
             const int o0 = (int)((long)d.Cout * q / parts), o1 = (int)((long)d.Cout * (q + 1) / parts);
             ScatterDesc e = d;
-            e.ws = d.ws + (size_t)o0 * d.taps * d.Cinp;
-            e.dw = d.dw + (size_t)o0 * d.Cin * d.taps;
+            e.ws = d.ws + (size_t)o0 * tws * d.Cinp;
+            e.dw = d.dw + (size_t)o0 * d.Cin * scatter_taps(d);
             e.Cout = o1 - o0;
-            e.cout_all = d.Cout;
+            e.cout_all = d.cout_all ? d.cout_all : d.Cout;
             expanded[nexp++] = e;
         }
     }
@@ -1882,10 +1896,8 @@ int mm_scatter_many(const void* desc_host, int ndesc, hipStream_t st) {
         const int n = ndesc - base < SM_MAX ? ndesc - base : SM_MAX;
         for (int i = 0; i < n; ++i) {
             const ScatterDesc& d = src[base + i];
-            MM_REQUIRE(d.ws && d.dw && d.Cout > 0 && d.Cin > 0 && d.taps > 0 && d.Cinp >= d.Cin && d.nrep >= 1,
-                       "scatter_many: descriptor %d", base + i);
+            MM_REQUIRE(scatter_desc_ok(d), "scatter_many: descriptor %d", base + i);
             tab.d[i] = d;
-            tab.d[i].cout_all = 0;
         }
         hipLaunchKernelGGL(scatter_many_kernel, dim3(256, n), dim3(256), 0, st, tab);
     }

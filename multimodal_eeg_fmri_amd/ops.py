@@ -1364,7 +1364,8 @@ def _power_merged_train(m):
     w._mm_transient = True        # rebuilt every step: a trainer's recorded weight list must not hold on to this one
     conv = _Merged(weight=w.requires_grad_(any(s[0].weight.requires_grad for s in seqs)),
                    bias=vec[0].requires_grad_(any(s[0].bias.requires_grad for s in seqs)),
-                   kernel_size=(7,), padding=(3,), in_channels=cin, out_channels=192)
+                   kernel_size=(7,), padding=(3,), in_channels=cin, out_channels=192,
+                   parts=[(s[0].weight, 64 * i) for i, s in enumerate(seqs)])        # (real weight, its first merged output channel)
     bn = _Merged(weight=vec[1].requires_grad_(any(s[1].weight.requires_grad for s in seqs)),
                  bias=vec[2].requires_grad_(any(s[1].bias.requires_grad for s in seqs)),
                  running_mean=vec[3], running_var=vec[4],

@@ -1393,6 +1393,29 @@ def test_batched_launches_equal_their_single_forms():
         assert torch.equal(a_, b_)
     with pytest.raises(hip.HipLibraryError):
         hip.call("mm_flush_many", None, 0, None, 0)
+    # descriptors that take a BLOCK of a wider workspace (the k = 3 / 5 / 7 branches of EnhancedPowerEncoder's merged k = 7
+    # convolution: 64 output channels each, centred tap windows), narrow (plain form) and wide (LDS-transposing form)
+    from multimodal_eeg_fmri_amd.autograd import scatter_desc
+    for cin in (40, 300):
+        cinp, slots = _cpad(cin), 2
+        ws = torch.randn(slots, 192, 7, cinp, generator=g).cuda()
+        outs, raw = [], []
+        for i, kk in enumerate((3, 5, 7)):
+            dw = torch.ones(64, cin, kk, device="cuda")
+            raw.append(struct.pack("<QQiiiiii", *scatter_desc(ws, dw, 64, cin, kk, cinp, slots, window=(64 * i, (7 - kk) // 2, 7, 192))))
+            outs.append((dw, i, kk))
+        sb = b"".join(raw)
+        sh = ctypes.create_string_buffer(sb, len(sb))
+        hip.call("mm_flush_many", ctypes.addressof(sh), 3, None, 0)
+        tot = ws[0] + ws[1]
+        for dw, i, kk in outs:
+            lo = (7 - kk) // 2
+            want_w = 1.0 + tot[64 * i:64 * i + 64, lo:lo + kk, :cin].permute(0, 2, 1)
+            assert torch.equal(dw, want_w), (cin, kk)
+    bad = struct.pack("<QQiiiiii", ws.data_ptr(), outs[0][0].data_ptr(), 64, 300, 5 | (3 << 8) | (7 << 16), 304, 2, 192)   # taps 3..7 of 7
+    bh = ctypes.create_string_buffer(bad, len(bad))
+    with pytest.raises(hip.HipLibraryError):
+        hip.call("mm_flush_many", ctypes.addressof(bh), 1, None, 0)
 
 
 @pytest.mark.parametrize("B,C,T", [(3, 64, 1024), (2, 20, 77), (1, 16, 32)])
