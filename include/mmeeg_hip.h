@@ -534,9 +534,13 @@ int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, 
                   int ch_off, int ch_total, hipStream_t stream);
 /* normalize_modality (run_training_lite.py:48-51; applied per sample to the power features at :162):
  * out[b] = bf16((x[b] - mean(x[b])) / (std(x[b]) + eps)), population std (numpy ddof = 0), over all rows x ch_valid elements of
- * sample b; x / out [B][rows][ch_total] channels-last, channels >= ch_valid are written as zeros. */
-int mm_sample_zscore_bf16(const float* x, void* out_bf16, int B, int rows, int ch_valid, int ch_total, float eps,
-                          hipStream_t stream);
+ * sample b; x / out [B][rows][ch_total] channels-last, channels >= ch_valid are written as zeros.
+ * ws (nullable; MM_ZSCORE_WS_DOUBLES doubles per sample, 8-byte aligned): with it, big unpadded samples (ch_valid ==
+ * ch_total, >= 65 536 elements) are dealt out over 32 workgroups each - per-chunk sums in double, added in chunk order by
+ * every workgroup of the second launch (same bits every run); without it one workgroup per sample does it all. */
+#define MM_ZSCORE_WS_DOUBLES 64
+int mm_sample_zscore_bf16(const float* x, void* out_bf16, double* ws, int B, int rows, int ch_valid, int ch_total,
+                          float eps, hipStream_t stream);
 /* Backward of the STFT power front-end and of its z-score (gradient w.r.t. the RAW EEG: saliency / integrated
  * gradients on the config-#5 model, the protocol of bridge_utils.py:158-229 / eeg_xai_analysis.py on an end-to-end
  * path).  mm_sample_zscore_bwd: x = the fp32 spectra the forward z-scored, g_bf16 = gradient w.r.t. the z-scored

@@ -21,5 +21,5 @@ int mm_check_launch(const char* what) {
 
 extern "C" {
 const char* mm_last_error(void) { return g_err; }
-int mm_abi_version(void) { return 4; }
+int mm_abi_version(void) { return 5; }
 }

@@ -1251,6 +1251,51 @@ __global__ __launch_bounds__(1024) void sample_zscore_kernel(const float* __rest
     for (size_t i = tid; i < n; i += 1024) os[i] = (bf16)(((int)(i % ch_total) < ch_valid) ? (xs[i] - mean) * inv : 0.f);
 }
 
+// The same z-score with the sample's elements dealt out over ZS_CHUNKS workgroups (config #5: 33 frames x 6 272 channels per
+// sample - one workgroup per sample was 32 workgroups on 256 CUs, 41 us for 40 MB).  Pass 1: every workgroup leaves the sum
+// and the sum of squares of its chunk in DOUBLE precision (the variance is then E[x^2] - mean^2 without the two-pass form's
+// second sweep; fp64 keeps the cancellation harmless); pass 2: every workgroup adds the sample's partials in chunk order -
+// the same value in all of them, the same bits every run - and writes its chunk.  No-padding layouts only (the fast path above).
+constexpr int ZS_CHUNKS = 32;
+__global__ __launch_bounds__(256) void zscore_partial_kernel(const float* __restrict__ x, double* __restrict__ part, unsigned n4) {
+    __shared__ double red[8];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)b * n4;
+    const unsigned lo = (unsigned)((unsigned long long)n4 * c / ZS_CHUNKS), hi = (unsigned)((unsigned long long)n4 * (c + 1) / ZS_CHUNKS);
+    double s = 0.0, q = 0.0;
+    for (unsigned i = lo + tid; i < hi; i += 256) {
+        const float4 v = x4[i];
+        s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        q += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        double* p = part + ((size_t)b * ZS_CHUNKS + c) * 2;
+        p[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        p[1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+__global__ __launch_bounds__(256) void zscore_apply_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                          bf16* __restrict__ out, unsigned n4, float cnt, float eps) {
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < ZS_CHUNKS; ++k) { s += part[((size_t)b * ZS_CHUNKS + k) * 2]; q += part[((size_t)b * ZS_CHUNKS + k) * 2 + 1]; }
+    const double mean_d = s / (double)cnt;
+    const double var = fmax(q / (double)cnt - mean_d * mean_d, 0.0);
+    const float mean = (float)mean_d, inv = 1.f / ((float)sqrt(var) + eps);
+    const float4* x4 = reinterpret_cast<const float4*>(x) + (size_t)b * n4;
+    bf16* os = out + (size_t)b * n4 * 4;
+    const unsigned lo = (unsigned)((unsigned long long)n4 * c / ZS_CHUNKS), hi = (unsigned)((unsigned long long)n4 * (c + 1) / ZS_CHUNKS);
+    for (unsigned i = lo + tid; i < hi; i += 256) {
+        const float4 v = x4[i];
+        bf16x4 o = {(bf16)((v.x - mean) * inv), (bf16)((v.y - mean) * inv), (bf16)((v.z - mean) * inv), (bf16)((v.w - mean) * inv)};
+        *reinterpret_cast<bf16x4*>(os + 4 * (size_t)i) = o;
+    }
+}
+
 // backward of sample_zscore_kernel: y = (x - mean) / d, d = std + eps (population std over the cnt valid elements):
 //   dx_i = (g_i - mean(g)) / d - y_i * mean(g * y) / std        (padding channels: 0)
 // g = bf16 gradient w.r.t. the z-scored (bf16) tensor, same layout; dx fp32.  Fixed-order block sums.
@@ -1785,9 +1830,18 @@ int mm_stft_power(const float* x, void* out_bf16, float* out_f32, int B, int C, 
     return mm_check_launch("stft_power");
 }
 
-int mm_sample_zscore_bf16(const float* x, void* out_bf16, int B, int rows, int ch_valid, int ch_total, float eps,
+int mm_sample_zscore_bf16(const float* x, void* out_bf16, double* ws, int B, int rows, int ch_valid, int ch_total, float eps,
                           hipStream_t st) {
     MM_REQUIRE(x && out_bf16 && B > 0 && rows > 0 && ch_valid > 0 && ch_valid <= ch_total, "sample_zscore: null/invalid");
+    const size_t n = (size_t)rows * ch_total;
+    if (ws && ch_valid == ch_total && (n & 3) == 0 && n < (1ull << 31) && n >= (1u << 16)) {
+        // big unpadded samples: ZS_CHUNKS workgroups per sample, partial sums in ws (MM_ZSCORE_WS_DOUBLES per sample)
+        MM_REQUIRE(((uintptr_t)ws & 7) == 0, "sample_zscore: workspace alignment");
+        hipLaunchKernelGGL(zscore_partial_kernel, dim3(ZS_CHUNKS, B), dim3(256), 0, st, x, ws, (unsigned)(n >> 2));
+        hipLaunchKernelGGL(zscore_apply_kernel, dim3(ZS_CHUNKS, B), dim3(256), 0, st, x, (const double*)ws, (bf16*)out_bf16,
+                           (unsigned)(n >> 2), (float)rows * (float)ch_valid, eps);
+        return mm_check_launch("sample_zscore(chunked)");
+    }
     hipLaunchKernelGGL(sample_zscore_kernel, dim3(B), dim3(1024), 0, st, x, (bf16*)out_bf16, rows, ch_valid, ch_total, eps);
     return mm_check_launch("sample_zscore");
 }

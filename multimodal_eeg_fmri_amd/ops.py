@@ -1296,7 +1296,7 @@ def stft_front_end(x: torch.Tensor, n_ffts, hop: int, normalize: bool = False, k
         _hip.call("mm_stft_power", xc, None if normalize else out, spec, B, C, T, int(n), int(hop), off, cp)
         off += wdt
     if normalize:
-        _hip.call("mm_sample_zscore_bf16", spec, out, B, frames, total, cp, 1e-8)
+        _hip.call("mm_sample_zscore_bf16", spec, out, _empty((64 * B,), torch.float64, x), B, frames, total, cp, 1e-8)
     return (out, spec) if keep_spec else out
 
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in list(sigs) + ["mm_last_error", "mm_abi_version"] if not hasattr(lib, n)]
     assert not missing, missing
     lib.mm_abi_version.restype = ctypes.c_int
-    assert lib.mm_abi_version() == 4
+    assert lib.mm_abi_version() == 5
 
 
 def test_argument_errors_are_reported_not_crashed():

@@ -1513,3 +1513,31 @@ def test_adamw_clip_kernel_vs_torch_and_its_bookkeeping(n):
         assert st[7].view(torch.int32).item() == 0                      # every workgroup arrived, the counter is at rest
         assert torch.count_nonzero(gd).item() == 0                       # zero_grad
         torch.testing.assert_close(p.cpu(), ref.detach(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_sample_zscore_chunked_form_vs_reference_and_the_one_workgroup_form():
+    """mm_sample_zscore_bf16 (normalize_modality, run_training_lite.py:48-51, on every sample's power features): with a
+    workspace, big unpadded samples (config #5: 33 x 6 272) are dealt out over 32 workgroups each (per-chunk sums in double,
+    E[x^2] - mean^2) - against the fp64 reference to one bf16 step, against the one-workgroup two-pass form (no
+    workspace) likewise, bit-identical between runs; small or padded samples keep the one-workgroup form either way."""
+    hip = _hip()
+    g = torch.Generator().manual_seed(31)
+    for B, rows, chv, cht in ((3, 33, 6272, 6272), (2, 9, 100, 112), (2, 16, 64, 64)):
+        x = (torch.randn(B, rows, cht, generator=g).abs() ** 3 * 40.0 + 5.0)          # heavy-tailed, far from zero mean
+        x[:, :, chv:] = 0.0
+        xd = x[:, :, :chv].double()
+        mean = xd.mean(dim=(1, 2), keepdim=True)
+        std = xd.std(dim=(1, 2), unbiased=False, keepdim=True)
+        want = torch.zeros(B, rows, cht, dtype=torch.float64)
+        want[:, :, :chv] = (xd - mean) / (std + 1e-8)
+        outs = []
+        for ws in (torch.empty(64 * B, dtype=torch.float64, device="cuda"), None,
+                   torch.full((64 * B,), float("nan"), dtype=torch.float64, device="cuda")):
+            out = torch.full((B, rows, cht), 7.0, dtype=torch.bfloat16, device="cuda")
+            hip.call("mm_sample_zscore_bf16", x.cuda(), out, ws, B, rows, chv, cht, 1e-8)
+            outs.append(out.float().cpu())
+        for o in outs:
+            assert ((o.double() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-4).all(), (B, rows, (o.double() - want).abs().max())
+        assert torch.equal(outs[0], outs[2])
+        assert ((outs[0] - outs[1]).abs() <= 2.0 ** -7 * outs[1].abs() + 1e-4).all()
