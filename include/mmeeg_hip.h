@@ -587,9 +587,7 @@ int mm_meanpool_bf16(const void* x, float* out, int R, int S, int N, hipStream_t
 /* ---- optimizer: clip_grad_norm_(max_norm) + AdamW.step() on one flat bucket
  * (run_training_lite.py:487-488; _test_bridge.py:784-786).  state (device, MM_OPT_STATE_FLOATS
  * = 8 + 1024 floats): [0] step count, [1] sum of squared grads of the last step, [2] lr,
- * [3] clip coefficient of the last step, [4] grad norm of the last step, [7] an unsigned word the
- * update kernel's workgroups count their arrival in (zero at rest: the last one does the
- * bookkeeping of [0], [1], [3], [4] and seed_epoch, no separate launch), [8..) per-block
+ * [3] clip coefficient of the last step, [4] grad norm of the last step, [8..) per-block
  * partial sums written by mm_sumsq and added in a fixed order by mm_adamw_clip (no float
  * atomics: ranks holding the same all-reduced gradient stay bit-identical).
  * zero_grad != 0: g is cleared after use (the next step's zero_grad()); seed_epoch (nullable): the

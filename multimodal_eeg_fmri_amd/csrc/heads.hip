@@ -494,8 +494,7 @@ __global__ __launch_bounds__(256) void clip_rows_kernel(const float* __restrict_
 // fused AdamW (decoupled weight decay) + global-norm clip on a flat fp32 bucket.
 // state[0] = step counter (float, incremented on device so the launch can live
 // in a hipGraph), state[2] = learning rate (host-updatable), state[3] = last clip
-// coefficient, state[4] = last gradient norm, state[7] = arrival counter of the update kernel's
-// workgroups (an unsigned word, zero at rest), state[8 .. 8+1024) = per-block partial
+// coefficient, state[4] = last gradient norm, state[8 .. 8+1024) = per-block partial
 // sums of squared gradients.  The partials are summed in a FIXED order (no float
 // atomics), so data-parallel ranks holding the same all-reduced gradient compute
 // bit-identical clip coefficients and their parameters never drift apart.
@@ -525,18 +524,15 @@ __device__ inline float sumsq_total(const float* __restrict__ state) {
     return (tot[0] + tot[1]) + (tot[2] + tot[3]);
 }
 
-// The bookkeeping of the step (step counter, last norm / clip coefficient, the dropout epoch word of the NEXT step) is
-// done by the LAST workgroup to finish: by then every workgroup has read the step counter, the learning rate and the
-// partial sums it needs (they are read before the update loop), so nothing races with the writes.  (It used to be a
-// one-workgroup launch of its own at the serial end of the step: 4 us + a launch gap with nothing beside it.)
+// (The bookkeeping below - step counter, last norm / clip coefficient, the dropout epoch word of the next step - stays a
+// one-workgroup launch of its own.  Folding it into the update kernel's LAST-ARRIVING workgroup was tried: 2 048 arrivals on
+// one counter serialise at the L2 and the update went from 10 to 30 us, profiles/r04_step_kernel_summary.txt history.)
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, float* __restrict__ state, size_t n, float beta1,
-                             float beta2, float eps, float wd, float max_norm, float grad_scale, int zero_grad,
-                             uint32_t* __restrict__ epoch) {
+                             float* __restrict__ v, const float* __restrict__ state, size_t n, float beta1,
+                             float beta2, float eps, float wd, float max_norm, float grad_scale, int zero_grad) {
     const float step = state[0] + 1.f;
     const float lr = state[2];
-    const float ss = sumsq_total(state);
-    const float gn = sqrtf(ss) * grad_scale;
+    const float gn = sqrtf(sumsq_total(state)) * grad_scale;
     const float clip = (max_norm > 0.f) ? fminf(1.f, max_norm / (gn + 1e-6f)) : 1.f;
     const float gs = grad_scale * clip;
     const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
@@ -550,17 +546,17 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
         p[i] = pi; m[i] = mi; v[i] = vi;
         if (zero_grad) g[i] = 0.f;                 // the next step's zero_grad(), for free
     }
-    if (threadIdx.x == 0) {
-        unsigned int* arrivals = reinterpret_cast<unsigned int*>(state + 7);
-        if (atomicAdd(arrivals, 1u) == gridDim.x - 1) {       // every other workgroup read its inputs long before it arrived
-            *arrivals = 0u;
-            if (epoch) epoch[0] += 1;              // dropout epoch word of the NEXT step (hipGraph replays)
-            state[3] = clip;
-            state[4] = gn;
-            state[0] = step;
-            state[1] = ss;
-        }
-    }
+}
+
+__global__ void adamw_finish_kernel(float* __restrict__ state, float max_norm, float grad_scale, uint32_t* epoch) {
+    const float ss = sumsq_total(state);
+    if (threadIdx.x != 0) return;
+    if (epoch) epoch[0] += 1;                      // dropout epoch word of the NEXT step (hipGraph replays)
+    const float gn = sqrtf(ss) * grad_scale;
+    state[3] = (max_norm > 0.f) ? fminf(1.f, max_norm / (gn + 1e-6f)) : 1.f;
+    state[4] = gn;
+    state[0] += 1.f;
+    state[1] = ss;
 }
 
 
@@ -1686,7 +1682,8 @@ int mm_adamw_clip(float* p, float* g, float* m, float* v, float* state, int64_t 
                   hipStream_t st) {
     MM_REQUIRE(p && g && m && v && state && n > 0, "adamw_clip: null");
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_h((size_t)n)), dim3(256), 0, st, p, g, m, v, state, (size_t)n, beta1,
-                       beta2, eps, weight_decay, max_norm, grad_scale, zero_grad, seed_epoch);
+                       beta2, eps, weight_decay, max_norm, grad_scale, zero_grad);
+    hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(256), 0, st, state, max_norm, grad_scale, seed_epoch);
     return mm_check_launch("adamw_clip");
 }
 
