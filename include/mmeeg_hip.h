@@ -466,12 +466,14 @@ int mm_clip_loss_ws_floats(int B, int Bg, int* floats_host, hipStream_t stream);
  *           bias / gamma / beta / running mean / running var concatenated
  *   mode 1  merged running mean / var -> the parts' (after a train-mode forward); batches_tracked[i] += 1 (nullable)
  *   mode 2  gradients: the parts' sinks (w, b, gamma, beta; null = frozen) += their slices of the merged gradients
- *           (W, B, Gamma, Beta; null = absent) */
+ *           (W, B, Gamma, Beta; null = absent)
+ *   mode 3  as mode 0, but W receives the merged weight as mm_conv1d_fwd's bf16 image [192][7][cinp] (what
+ *           mm_prep_conv_weight makes of the fp32 merged weight, which is then never written) */
 typedef struct {
     float* w[3]; float* b[3]; float* gamma[3]; float* beta[3]; float* run_mean[3]; float* run_var[3];
     void* batches_tracked[3];            /* int64 device scalars */
     float* W; float* B; float* Gamma; float* Beta; float* Run_mean; float* Run_var;
-    int cin; int k[3];
+    int cin; int k[3]; int cinp; int reserved;
 } mm_power_merge_t;
 int mm_power_merge(const void* desc_host, int mode, hipStream_t stream);
 

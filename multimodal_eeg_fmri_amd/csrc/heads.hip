@@ -569,12 +569,15 @@ __global__ void adamw_finish_kernel(float* __restrict__ state, float max_norm, f
 //                                 lo_i = (7 - k_i) / 2: the shorter kernels sit around the centre tap);  vectors concatenated
 //   mode 1: merged running mean / var -> the parts';  batches_tracked += 1
 //   mode 2: parts' gradient sinks += their slices of the merged gradients (null part = frozen parameter: skipped)
+//   mode 3: as mode 0, but the merged WEIGHT is written as the forward kernel's bf16 image [192][7][cinp] (what
+//           mm_prep_conv_weight would make of the fp32 merged weight, which is then never materialised: 33 MB written and
+//           read back per step at config #5); W points to that image
 // ---------------------------------------------------------------------------
 struct PowerMergeArgs {
     float* w[3]; float* b[3]; float* gamma[3]; float* beta[3]; float* run_mean[3]; float* run_var[3];
     long long* tracked[3];
     float* W; float* B; float* Gamma; float* Beta; float* Run_mean; float* Run_var;
-    int cin, k[3];
+    int cin, k[3], cinp, reserved;
 };
 
 template <int MODE>
@@ -583,7 +586,7 @@ __global__ void power_merge_kernel(PowerMergeArgs a) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < 192) {                                          // the per-channel vectors
         const int i = (int)gid / 64, j = (int)gid % 64;
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 3) {
             a.B[gid] = a.b[i][j]; a.Gamma[gid] = a.gamma[i][j]; a.Beta[gid] = a.beta[i][j];
             a.Run_mean[gid] = a.run_mean[i][j]; a.Run_var[gid] = a.run_var[i][j];
         } else if (MODE == 1) {
@@ -596,6 +599,20 @@ __global__ void power_merge_kernel(PowerMergeArgs a) {
         }
     }
     if (MODE == 1 || (MODE == 2 && !a.W)) return;
+    if (MODE == 3) {
+        // image element (o, t, c): channel-contiguous stores; the fp32 reads of a branch stride by its kernel size
+        bf16* img = reinterpret_cast<bf16*>(a.W);
+        const size_t per_oi = (size_t)7 * a.cinp, itotal = 192 * per_oi;
+        for (size_t e = gid; e < itotal; e += (size_t)gridDim.x * blockDim.x) {
+            const int o = (int)(e / per_oi);
+            const int r = (int)(e - (size_t)o * per_oi);
+            const int t = r / a.cinp, c = r - t * a.cinp;
+            const int i = o / 64, k = a.k[i], lo = (7 - k) >> 1;
+            const bool in = c < a.cin && t >= lo && t < lo + k;
+            img[e] = (bf16)(in ? a.w[i][((size_t)(o - 64 * i) * a.cin + c) * k + (t - lo)] : 0.f);
+        }
+        return;
+    }
     for (size_t e = gid; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int o = (int)(e / per_o);
         const int r = (int)(e - (size_t)o * per_o);
@@ -1688,21 +1705,23 @@ int mm_adamw_clip(float* p, float* g, float* m, float* v, float* state, int64_t 
 }
 
 int mm_power_merge(const void* desc_host, int mode, hipStream_t st) {
-    MM_REQUIRE(desc_host && mode >= 0 && mode <= 2, "power_merge: null / mode");
+    MM_REQUIRE(desc_host && mode >= 0 && mode <= 3, "power_merge: null / mode");
     const PowerMergeArgs a = *static_cast<const PowerMergeArgs*>(desc_host);
     MM_REQUIRE(a.cin > 0, "power_merge: cin");
     for (int i = 0; i < 3; ++i) MM_REQUIRE(a.k[i] == 3 || a.k[i] == 5 || a.k[i] == 7, "power_merge: kernel sizes must be 3, 5 or 7");
-    if (mode == 0) {
+    if (mode == 0 || mode == 3) {
         for (int i = 0; i < 3; ++i)
             MM_REQUIRE(a.w[i] && a.b[i] && a.gamma[i] && a.beta[i] && a.run_mean[i] && a.run_var[i], "power_merge(0): null part");
         MM_REQUIRE(a.W && a.B && a.Gamma && a.Beta && a.Run_mean && a.Run_var, "power_merge(0): null merged tensor");
+        MM_REQUIRE(mode == 0 || (a.cinp >= a.cin && a.cinp % 16 == 0), "power_merge(3): cinp=%d", a.cinp);
     } else if (mode == 1) {
         for (int i = 0; i < 3; ++i) MM_REQUIRE(a.run_mean[i] && a.run_var[i], "power_merge(1): null part");
         MM_REQUIRE(a.Run_mean && a.Run_var, "power_merge(1): null merged statistics");
     }
     const size_t total = (size_t)192 * a.cin * 7;
     const int grid = mode == 1 ? 1 : grid_h(total, 2048);
-    if (mode == 0) hipLaunchKernelGGL(power_merge_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+    if (mode == 3) hipLaunchKernelGGL(power_merge_kernel<3>, dim3(grid), dim3(256), 0, st, a);
+    else if (mode == 0) hipLaunchKernelGGL(power_merge_kernel<0>, dim3(grid), dim3(256), 0, st, a);
     else if (mode == 1) hipLaunchKernelGGL(power_merge_kernel<1>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(power_merge_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     return mm_check_launch("power_merge");

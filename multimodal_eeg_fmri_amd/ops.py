@@ -257,6 +257,11 @@ class _WeightCache:
         elif zero is not None:
             zero[0][:int(zero[1])].zero_()
 
+    def seed(self, w: torch.Tensor, wf: torch.Tensor, wd, cinp: int, coutp: int):
+        """hand in images that were built elsewhere (mm_power_merge mode 3); ``get(w, ...)`` then returns them as long as
+        ``w`` is unchanged and no data-gradient image is asked for that was not handed in"""
+        self._store[id(w)] = ((w.data_ptr(), w._version, self._gen, tuple(w.shape)), wf, wd, cinp, coutp, weakref.ref(w))
+
     def get(self, w: torch.Tensor, need_dgrad: bool, key=None):
         owner = w if key is None else key          # the nn.Parameter the image belongs to
         if self._rec is not None and not getattr(owner, "_mm_transient", False):
@@ -1334,23 +1339,25 @@ class _Merged:
         self.__dict__.update(kw)
 
 
-def power_merge_call(mode: int, parts, merged, tracked=(None, None, None), cin: int = 0, ks=(3, 5, 7)):
+def power_merge_call(mode: int, parts, merged, tracked=(None, None, None), cin: int = 0, ks=(3, 5, 7), cinp: int = 0):
     """mm_power_merge: ``parts`` = six triples (conv weight, conv bias, BN weight, BN bias, running mean, running var) of
     fp32 tensors or None, ``merged`` = the six merged tensors or None (include/mmeeg_hip.h: mm_power_merge_t)"""
     import ctypes
     import struct
     ptr = lambda t: 0 if t is None else t.data_ptr()      # noqa: E731
     flat = [ptr(t) for trip in parts for t in trip] + [ptr(t) for t in tracked] + [ptr(t) for t in merged]
-    buf = struct.pack("<27Q4i", *flat, int(cin), *[int(k) for k in ks])
+    buf = struct.pack("<27Q6i", *flat, int(cin), *[int(k) for k in ks], int(cinp), 0)
     host = ctypes.create_string_buffer(buf, len(buf))
     _hip.call("mm_power_merge", ctypes.addressof(host), int(mode))
 
 
-def _power_merged_train(m):
+def _power_merged_train(m, need_dgrad: bool = True):
     """the three conv scales as ONE Conv1d(C -> 192, k=7, p=3) + BatchNorm1d(192) whose tensors are
     fresh leaves (requires_grad as the parts'), so the generic conv/BN forward+backward applies;
     autograd.power_encoder_bwd adds their gradients back into the six real parameters.  Built by ONE launch
-    (mm_power_merge mode 0: the pads / cats of the three branches were ~20 tiny torch launches per step)."""
+    (mm_power_merge mode 0: the pads / cats of the three branches were ~20 tiny torch launches per step).
+    ``need_dgrad`` False (no gradient w.r.t. the input: the trainers): the merged weight exists only as the forward
+    kernel's bf16 image (mode 3), handed to the weight cache - its fp32 tensor is a never-read placeholder."""
     seqs = (m.conv_scale1, m.conv_scale2, m.conv_scale3)
     ref = seqs[0][0].weight
     cin = seqs[0][0].in_channels
@@ -1360,7 +1367,13 @@ def _power_merged_train(m):
     vec = [_empty((192,), _F32, ref) for _ in range(5)]
     parts = ([s[0].weight.detach() for s in seqs], [s[0].bias.detach() for s in seqs], [s[1].weight.detach() for s in seqs],
              [s[1].bias.detach() for s in seqs], [s[1].running_mean for s in seqs], [s[1].running_var for s in seqs])
-    power_merge_call(0, parts, [w] + vec, cin=cin, ks=ks)
+    if need_dgrad:
+        power_merge_call(0, parts, [w] + vec, cin=cin, ks=ks)
+    else:
+        cinp = cpad(cin)
+        wf = _empty((192, 7, cinp), _BF, ref)
+        power_merge_call(3, parts, [wf] + vec, cin=cin, ks=ks, cinp=cinp)
+        weights.seed(w, wf, None, cinp, cpad(192))
     w._mm_transient = True        # rebuilt every step: a trainer's recorded weight list must not hold on to this one
     conv = _Merged(weight=w.requires_grad_(any(s[0].weight.requires_grad for s in seqs)),
                    bias=vec[0].requires_grad_(any(s[0].bias.requires_grad for s in seqs)),
@@ -1377,7 +1390,7 @@ def _power_merged_train(m):
 def _power_forward_impl(m, xb: torch.Tensor, training: bool, need_dgrad: bool, save=None):
     """EnhancedPowerEncoder on packed (B, T, Cp) bf16 input, train / frozen-BN forms."""
     save = training if save is None else save
-    conv, bn, seqs = _power_merged_train(m)
+    conv, bn, seqs = _power_merged_train(m, need_dgrad)
     r, s0 = conv_bn_act(xb, conv, bn, training=training, need_dgrad=need_dgrad, save=save)
     if training:                                  # running statistics live in the three real modules: handed back in one launch
         none3 = [None] * 3

@@ -1540,3 +1540,54 @@ def test_sample_zscore_chunked_form_vs_reference_and_the_one_workgroup_form():
             assert ((o.double() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-4).all(), (B, rows, (o.double() - want).abs().max())
         assert torch.equal(outs[0], outs[2])
         assert ((outs[0] - outs[1]).abs() <= 2.0 ** -7 * outs[1].abs() + 1e-4).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin", [20, 304])
+def test_power_merge_modes(cin):
+    """mm_power_merge (EnhancedPowerEncoder's three Conv1d(C -> 64, k = 3 | 5 | 7) + BatchNorm1d(64) branches as ONE k = 7
+    layer, enhanced_models_v4.py:210-234): mode 0 == F.pad + torch.cat of the parts; mode 3's bf16 image == mm_prep_conv_weight
+    of mode 0's weight, bit for bit; mode 1 hands the running statistics back and counts the batch; mode 2 adds the merged
+    bias / BatchNorm / weight gradients' slices into the parts' (a null part is skipped)."""
+    from multimodal_eeg_fmri_amd import ops
+    hip = _hip()
+    g = torch.Generator().manual_seed(cin)
+    ks = (3, 5, 7)
+    dev = "cuda"
+    w = [torch.randn(64, cin, k, generator=g).to(dev) for k in ks]
+    vecs = [[torch.randn(64, generator=g).to(dev) for _ in ks] for _ in range(5)]          # bias, gamma, beta, mean, var
+    parts = (w, *vecs)
+    W = torch.empty(192, cin, 7, device=dev)
+    V = [torch.empty(192, device=dev) for _ in range(5)]
+    ops.power_merge_call(0, parts, [W] + V, cin=cin, ks=ks)
+    want_w = torch.cat([F.pad(t, ((7 - k) // 2,) * 2) for t, k in zip(w, ks)], dim=0)
+    assert torch.equal(W, want_w)
+    for got, trip in zip(V, vecs):
+        assert torch.equal(got, torch.cat(trip))
+    cinp = _cpad(cin)
+    img_ref = torch.empty(192, 7, cinp, dtype=torch.bfloat16, device=dev)
+    hip.call("mm_prep_conv_weight", W, img_ref, None, 192, cin, 7, cinp, 0)
+    img = torch.full((192, 7, cinp), 3.0, dtype=torch.bfloat16, device=dev)
+    V3 = [torch.empty(192, device=dev) for _ in range(5)]
+    ops.power_merge_call(3, parts, [img] + V3, cin=cin, ks=ks, cinp=cinp)
+    assert torch.equal(img.view(torch.int16), img_ref.view(torch.int16))
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(V3, V))
+    # mode 1
+    rm, rv = [torch.zeros(64, device=dev) for _ in ks], [torch.zeros(64, device=dev) for _ in ks]
+    nbt = [torch.full((), 4, dtype=torch.int64, device=dev) for _ in ks]
+    RM, RV = torch.randn(192, generator=g).to(dev), torch.rand(192, generator=g).to(dev)
+    none3 = [None] * 3
+    ops.power_merge_call(1, (none3, none3, none3, none3, rm, rv), [None, None, None, None, RM, RV], tracked=nbt, cin=cin, ks=ks)
+    assert torch.equal(torch.cat(rm), RM) and torch.equal(torch.cat(rv), RV) and all(int(t) == 5 for t in nbt)
+    # mode 2 (the second branch's weight and the third's bias are frozen)
+    dW, dB, dG, dBe = (torch.randn(192, cin, 7, generator=g).to(dev), *(torch.randn(192, generator=g).to(dev) for _ in range(3)))
+    gw = [torch.ones(64, cin, k, device=dev) for k in ks]
+    gb, gg, gbe = ([torch.ones(64, device=dev) for _ in ks] for _ in range(3))
+    gw2, gb2 = [gw[0], None, gw[2]], [gb[0], gb[1], None]
+    ops.power_merge_call(2, (gw2, gb2, gg, gbe, none3, none3), [dW, dB, dG, dBe, None, None], cin=cin, ks=ks)
+    for i, k in enumerate(ks):
+        lo = (7 - k) // 2
+        want_g = 1.0 + dW[64 * i:64 * i + 64, :, lo:lo + k] if i != 1 else torch.ones(64, cin, k, device=dev)
+        assert torch.equal(gw[i], want_g)
+        assert torch.equal(gb[i], 1.0 + dB[64 * i:64 * i + 64] if i != 2 else torch.ones(64, device=dev))
+        assert torch.equal(gg[i], 1.0 + dG[64 * i:64 * i + 64]) and torch.equal(gbe[i], 1.0 + dBe[64 * i:64 * i + 64])
