@@ -1163,20 +1163,46 @@ __global__ __launch_bounds__(256) void stft_power_fft_kernel(const float* __rest
     const float* xr = x + ((size_t)b * C + c) * T;
     float* r = re[wave];
     float* q = im[wave];
-    const int rounds = (frames + 3) / 4;                        // the four waves step together (block barriers below)
-    for (int it = 0; it < rounds; ++it) {
-        const int frame = it * 4 + wave;
-        const bool live = frame < frames;
-        // bit-reversed load of the windowed frame
-        for (int n = lane; n < N; n += 64) {
+    // Every wave owns its frame and its own LDS arrays: after the twiddle tables nothing is shared between waves, so the
+    // stages are ordered by WAVE-level fences only (a wave's LDS operations execute in issue order; the fence keeps the
+    // compiler from moving them).  With a workgroup barrier per stage the four waves advanced in lock-step: ten barriers per
+    // frame round in a kernel that is nothing but latency (45 us for nfft = 128 at config #5).
+    auto wave_sync = []() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int rounds = (frames + 3) / 4;
+    // the samples of the NEXT round's frame are requested before this round's butterflies (a frame's global round trip was
+    // as long as its whole transform)
+    constexpr int PER = (N + 63) / 64;
+    float nxt[PER];
+    auto fetch = [&](int frame) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int n = lane + 64 * u;
             int t = frame * hop + n - H;
             if (t < 0) t = -t;                                  // reflect padding (torch.stft center = True)
             if (t >= T) t = 2 * (T - 1) - t;
-            const int rv = (int)(__brev((unsigned)n) >> (32 - LOG2N));
-            r[rv] = live ? xr[t] * win[n] : 0.f;
-            q[rv] = 0.f;
+            nxt[u] = (n < N && frame < frames) ? xr[t] : 0.f;
         }
-        __syncthreads();
+    };
+    fetch(wave);
+    for (int it = 0; it < rounds; ++it) {
+        const int frame = it * 4 + wave;
+        const bool live = frame < frames;
+        // bit-reversed store of the windowed frame
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int n = lane + 64 * u;
+            if (n < N) {
+                const int rv = (int)(__brev((unsigned)n) >> (32 - LOG2N));
+                r[rv] = nxt[u] * win[n];
+                q[rv] = 0.f;
+            }
+        }
+        if (it + 1 < rounds) fetch(frame + 4);
+        wave_sync();
 #pragma unroll
         for (int sgm = 0; sgm < LOG2N; ++sgm) {
             const int m = 1 << sgm;                             // half size of this stage's butterflies
@@ -1191,7 +1217,7 @@ __global__ __launch_bounds__(256) void stft_power_fft_kernel(const float* __rest
                 r[i0] = br + tr; q[i0] = bi + ti;
                 r[i1] = br - tr; q[i1] = bi - ti;
             }
-            __syncthreads();
+            wave_sync();
         }
         if (live) {
             const size_t o = ((size_t)b * frames + frame) * ch_total + ch_off + (size_t)c * F;
@@ -1201,7 +1227,7 @@ __global__ __launch_bounds__(256) void stft_power_fft_kernel(const float* __rest
                 if (out_f32) out_f32[o + f] = p;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
