@@ -428,7 +428,15 @@ class BridgeTrainer(nn.Module):
         c["pool"] = torch.cuda.graph_pool_handle()
         graphs = []
 
-        def record(fn, mode="global"):
+        # A process group's watchdog thread polls the events of its finished collectives (hipEventQuery) for a while after
+        # they are done; under a GLOBAL-mode capture that call is refused and the watchdog ends the process ("operation
+        # not permitted when stream is capturing" - seen once in the aborted-capture rehearsal, where the communicator
+        # check runs right before the segments are recorded).  Every capture of a distributed job is therefore
+        # thread-local: only this thread's calls are policed.
+        dist_alive = torch.distributed.is_available() and torch.distributed.is_initialized()
+
+        def record(fn, mode=None):
+            mode = mode or ("thread_local" if dist_alive else "global")
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=c["pool"], capture_error_mode=mode), torch.no_grad():
                 fn()
