@@ -14,7 +14,8 @@ for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_IN
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d "$root/gpurun_out/pmck_${tag}_$i" -- \
+  kt=""; [ $i -eq 2 ] && kt="--kernel-trace"          # one pass also keeps the (serialised) kernel durations
+  rocprofv3 $kt --pmc $grp --output-format csv -d "$root/gpurun_out/pmck_${tag}_$i" -- \
       python3 "$root/tools/kbench.py" "$kcase" > "$root/gpurun_out/pmck_${tag}_$i.log" 2>&1 || echo "group $i ($grp) failed"
 done
 python3 - "$root" "$tag" "$kname" <<'PY'
@@ -26,6 +27,12 @@ for f in glob.glob(f"{root}/gpurun_out/pmck_{tag}_*/*/*counter_collection.csv"):
         if kname in r["Kernel_Name"]:
             k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+dur = collections.defaultdict(list)
+for f in glob.glob(f"{root}/gpurun_out/pmck_{tag}_*/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if kname in r["Kernel_Name"]:
+            k = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 lines = []
 for k in sorted(acc):
     lines.append(f"== {k}")
@@ -38,6 +45,11 @@ for k in sorted(acc):
         lines.append(f"  HBM traffic per launch: fetch (x2 gfx950 correction: an UPPER bound for narrow loads) {fe/1e6:.2f} MB "
                      f"[uncorrected {fe/2e6:.2f}] + write {wr/1e6:.2f} MB = {(fe+wr)/1e6:.2f} MB")
     m = {n: sum(v) / len(v) for n, v in c.items()}
+    if k in dur:
+        d = sorted(dur[k])
+        lines.append(f"  duration with the profiler serialising kernels: median {d[len(d) // 2]:.1f} us over {len(d)} launches")
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            lines.append(f"  -> {(fe + wr) / 1e6 / d[len(d) // 2]:.2f} TB/s of ~8 (upper bound, see the fetch correction)")
     if "SQ_WAVE_CYCLES" in m and "SQ_WAIT_ANY" in m:
         lines.append(f"  waiting fraction of wave cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES): {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.3f}")
     if "SQ_ACTIVE_INST_VALU" in m and "SQ_BUSY_CYCLES" in m:

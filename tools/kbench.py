@@ -357,8 +357,28 @@ def l1_case(B=32, D=32, H=32, W=32, p=0.3):
               f"{byts / 1e6:5.1f} MB compulsory -> {byts / t / 1e6:6.2f} TB/s of 8")
 
 
+def step_case(config="c2", steps=4):
+    """the captured training step itself, a few replays: the PMC collector (profiles/run_pmc_kernels.sh <tag> step "")
+    reads counters for EVERY kernel of the step (the profiler serialises them: stand-alone figures in the step's order)"""
+    from multimodal_eeg_fmri_amd.bridge_trainer import BridgeTrainer, synthetic_pairs
+    torch.manual_seed(0)
+    enc = None
+    if config == "c5":
+        from multimodal_eeg_fmri_amd.crossmodal_v4_enhancements import MultiScaleSTFTPowerEncoder
+        enc = MultiScaleSTFTPowerEncoder(64, (64, 128), 32, 128, 2, 4, 0.3)
+    tr = BridgeTrainer(eeg_channels=64, dropout=0.3, eeg_encoder=enc).train()
+    eeg, fmri = synthetic_pairs(32, 64, 1024, (32, 32, 32), seed=1234)
+    for _ in range(steps):
+        out = tr.train_step(eeg, fmri)
+    torch.cuda.synchronize()
+    print(f"step case {config}: {steps} steps, loss {out['loss'].item():.4f}")
+
+
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    if flt in ("step", "step5"):
+        step_case("c5" if flt == "step5" else "c2")
+        return
     if flt in ("l1", "pmcl1"):
         l1_case()
         return
