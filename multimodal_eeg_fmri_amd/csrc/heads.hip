@@ -1503,7 +1503,17 @@ __global__ __launch_bounds__(256) void pooled_head_fwd_kernel(const float* __res
     for (int n = threadIdx.x; n < N; n += 256) {
         const float* wr = W + (size_t)n * D;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < D; k += 16) {                   // four independent float4 loads per round
+        int k = 0;
+        for (; k + 64 <= D; k += 64) {                      // sixteen independent float4 loads per round (see pooled_head_bwd_kernel)
+            float4 w4[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w4[q] = *reinterpret_cast<const float4*>(wr + k + q * 4);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                acc[q & 3] += w4[q].x * xs[k + q * 4] + w4[q].y * xs[k + q * 4 + 1] + w4[q].z * xs[k + q * 4 + 2] +
+                              w4[q].w * xs[k + q * 4 + 3];
+        }
+        for (; k < D; k += 16) {                            // four independent float4 loads per round
             float4 w4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const float4*>(wr + k + q * 4);
@@ -1543,7 +1553,17 @@ __global__ __launch_bounds__(256) void pooled_head_bwd_kernel(const float* __res
     const float invL = 1.f / (float)L;
     for (int k = threadIdx.x; k < D; k += 256) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int n = 0; n < N; n += 4) {                    // coalesced across k; four independent chains
+        int n = 0;
+        // coalesced across k; four chains, SIXTEEN loads in flight per round: this loop is a chain of L2 round trips with one
+        // workgroup per sample on the chip (13 us for N = 128 at four per round, alone in the serial heads section of the step)
+        for (; n + 16 <= N; n += 16) {
+            float w[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = W[(size_t)(n + q) * D + k];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q & 3] += dz[n + q] * w[q];
+        }
+        for (; n < N; n += 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[q] += dz[n + q] * W[(size_t)(n + q) * D + k];
         }
