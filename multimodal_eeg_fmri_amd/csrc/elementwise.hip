@@ -612,7 +612,9 @@ static int bn_act_fwd_common(const float* y, const float* scale, const float* sh
     const size_t total = (size_t)R * (S / pool) * (N / 4);
     MM_REQUIRE(total < (1ull << 31), "bn_act_fwd: %zu vectors (32-bit indices)", total);
     // FIN: every workgroup re-reads the statistics workspace (256 N bytes) in its prologue: few, longer workgroups
-    int grid = grid_for(total, 256, with_fin ? 512 : 4096);
+    // with the finalize in the prologue every workgroup re-reads the statistics workspace, so few and longer ones:
+    // three per CU (256 / 512 / 768 / 1 024 / 2 048: 0.788 / 0.770 / 0.766 / 0.771 / 0.770 ms per step, profiles/r04_fin_fold_and_third_stream_ab.txt)
+    int grid = grid_for(total, 256, with_fin ? 768 : 4096);
     if (ln_out) {
         MM_REQUIRE(N == 128 && pool == 1 && ln_gamma && ln_beta, "bn_act_fwd_ln: N=%d (128) pool=%d (1)", N, pool);
         // every 32-lane group must walk its rows together (cross-lane sums): total is a multiple of 32; a grid that
