@@ -459,7 +459,7 @@ int pool3_launch(int mode, Pool3Args a, float drop_p, hipStream_t st, bool with_
         if (grid > 4096) grid = 4096;
         const bool gelu = a.act == MM_ACT_GELU;
         if (with_fin) {                                  // (mode 0, GELU, N <= 256: checked by the caller) few, longer workgroups:
-            if (grid > 512) grid = 512;                  // each re-reads the statistics workspace in its prologue
+            if (grid > 768) grid = 768;                  // each re-reads the statistics workspace in its prologue: three per CU
             hipLaunchKernelGGL((pool3_bn_act_kernel<0, MM_ACT_GELU, true>), dim3(grid), dim3(256), 0, st, a);
         } else if (mode == 0 && gelu) hipLaunchKernelGGL((pool3_bn_act_kernel<0, MM_ACT_GELU>), dim3(grid), dim3(256), 0, st, a);
         else if (mode == 0) hipLaunchKernelGGL((pool3_bn_act_kernel<0>), dim3(grid), dim3(256), 0, st, a);
