@@ -909,10 +909,7 @@ __global__ void prep_many_kernel(PrepTable tab, int ndesc, float4* __restrict__ 
 // banks.  Partial sums leave the workgroup as fp32 atomics straight into the
 // parameter-gradient tensor (arbitrary element strides sn/sc/stap).
 // ---------------------------------------------------------------------------
-constexpr int WG_MK = 64;          // t rows per LDS tile (the 128 x 128 Linear kernel; the granule of rows_per_wg)
-// ... of the k > 1 convolution kernel (template parameter CW_MK): its row loop is a chain of global round trips (one tile of
-// look-ahead), so long row ranges take 128 rows per trip - half the trips with twice the loads in flight; short sequences
-// (config #5: 33 frames per sample, one tile each) keep 64
+constexpr int WG_MK = 64;          // t rows per LDS tile
 constexpr int WG_LD = 96;          // LDS row stride in elements (192 B)
 
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int row0, int col0, int lane) {
@@ -935,10 +932,10 @@ struct WgradArgs {
     int bgroup;               // samples one workgroup accumulates over (> 1 only when a sample is a single row chunk)
 };
 
-template <int TAPS, int CW_MK>
+template <int TAPS>
 __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int bx, const int by, const int bz) {
-    __shared__ __attribute__((aligned(16))) bf16 Ys[CW_MK * WG_LD];
-    __shared__ __attribute__((aligned(16))) bf16 Xs[(CW_MK + TAPS - 1) * WG_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Ys[WG_MK * WG_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Xs[(WG_MK + TAPS - 1) * WG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
     const int chunksT = (a.T + a.rows_per_wg - 1) / a.rows_per_wg;
@@ -959,8 +956,8 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
 
     // tiles are fetched into registers one work item (sample, row tile) ahead (all loads in flight
     // before any LDS write, and in flight during the previous tile's MFMAs)
-    constexpr int YREG = CW_MK * 8 / 256;                           // 4
-    constexpr int XREG = ((CW_MK + TAPS - 1) * 8 + 255) / 256;      // 5
+    constexpr int YREG = WG_MK * 8 / 256;                           // 2
+    constexpr int XREG = ((WG_MK + TAPS - 1) * 8 + 255) / 256;      // 3
     uint4 yv[YREG], xv[XREG];
     auto fetch = [&](int b, int t0) {
         const bf16* dyb = a.dy + (size_t)b * a.T * a.Cout;
@@ -975,7 +972,7 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
         for (int i = 0; i < XREG; ++i) {
             const int s = tid + i * 256, r = s >> 3, sg = s & 7;
             const int t = t0 - a.pad + r, c = c0 + sg * 8;
-            xv[i] = (s < (CW_MK + TAPS - 1) * 8 && t >= 0 && t < a.T && c < a.Cin)
+            xv[i] = (s < (WG_MK + TAPS - 1) * 8 && t >= 0 && t < a.T && c < a.Cin)
                         ? *reinterpret_cast<const uint4*>(xb + (size_t)t * a.Cin + c) : make_uint4(0, 0, 0, 0);
         }
     };
@@ -991,14 +988,14 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
 #pragma unroll
         for (int i = 0; i < XREG; ++i) {
             const int s = tid + i * 256;
-            if (s < (CW_MK + TAPS - 1) * 8) *reinterpret_cast<uint4*>(Xs + (s >> 3) * WG_LD + (s & 7) * 8) = xv[i];
+            if (s < (WG_MK + TAPS - 1) * 8) *reinterpret_cast<uint4*>(Xs + (s >> 3) * WG_LD + (s & 7) * 8) = xv[i];
         }
         __syncthreads();
-        int nb = b, nt = t0 + CW_MK;                                // next work item
+        int nb = b, nt = t0 + WG_MK;                                // next work item
         if (nt >= tend) { ++nb; nt = tbeg; }
         if (nb < b1) fetch(nb, nt);
 #pragma unroll
-        for (int kk = 0; kk < CW_MK; kk += 16) {
+        for (int kk = 0; kk < WG_MK; kk += 16) {
             const bf16x8 af = tr_frag(Ys, kk, wn * 32, lane);
             if (a.dbias && bz == 0 && wc == 0)
 #pragma unroll
@@ -1030,9 +1027,9 @@ __device__ __forceinline__ void conv1d_wgrad_body(const WgradArgs& a, const int 
     }
 }
 
-template <int TAPS, int CW_MK = 64>
+template <int TAPS>
 __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs a) {
-    conv1d_wgrad_body<TAPS, CW_MK>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv1d_wgrad_body<TAPS>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // several independent Linear (taps = 1) weight gradients in ONE launch: workgroup id -> (problem,
@@ -1275,11 +1272,7 @@ template <int TAPS>
 int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int chunksT = ceil_div(a.T, a.rows_per_wg);
     dim3 grid(ceil_div(a.B, a.bgroup) * chunksT, ceil_div(a.Cout, 64), ceil_div(a.Cin, 64));
-    // 128-row tiles when a workgroup walks at least two of them per sample (C2 step, one box, alternating 64 / 128:
-    // 0.7657 / 0.7630 ms on average - within noise; the kernels themselves are shorter)
-    const bool tall = a.rows_per_wg >= 256 && a.T >= 256;
-    if (tall) hipLaunchKernelGGL((conv1d_wgrad_kernel<TAPS, 128>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv1d_wgrad_kernel<TAPS, 64>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(conv1d_wgrad_kernel<TAPS>, grid, dim3(256), 0, st, a);
     return mm_check_launch("conv1d_wgrad");
 }
 
