@@ -36,6 +36,9 @@
 // 4 dz fragments built member by member, 8 halo of tile i + 1 prefetched into registers during tile i.
 // Measured on one box, alternating: 1 and 8 make the backward 0.7 / 1.5 us SLOWER (and are off), 2 and 4 are what the
 // product does NOT do (they cost 0.3 / 1.3 us).
+#ifndef L1_BWD_WAVES
+#define L1_BWD_WAVES 2          // workgroups per CU (= waves per SIMD) of the backward kernels (A/B builds: 3)
+#endif
 #ifndef L1_ABL
 #define L1_ABL 0
 #endif
@@ -148,7 +151,7 @@ __device__ __forceinline__ const float* tile_ptr(const float* x, const TileCoord
 // ARG (mode 1): also write the window winners (inspection output of the parity tests, mm_conv3d_l1_fwd_winners).
 // FIN (mode 1): the train-mode BatchNorm finalize as the prologue (csrc/common.h: bn_fin_channel).
 template <int MODE, bool FULLT = false, bool ARG = false, bool FIN = false>
-__global__ __launch_bounds__(256, MODE <= 1 ? 3 : 2) void conv3d_l1_kernel(L1Args a) {   // statistics / forward: three waves per SIMD (<= 168 registers), backward two
+__global__ __launch_bounds__(256, MODE <= 1 ? 3 : L1_BWD_WAVES) void conv3d_l1_kernel(L1Args a) {   // statistics / forward: three waves per SIMD (<= 168 registers), backward two
     a.seed = mm_eff_seed(a.seed, a.epoch);
     __shared__ __attribute__((aligned(16))) unsigned short halo[2][HSZ];
     __shared__ float red[4][32];
@@ -786,7 +789,7 @@ int mm_conv3d_l1_bwd(const float* x, const void* wimg, const float* bias, const 
     L1Args a;
     l1_fill(a, x, wimg, bias, out4, B, D, H, W, train, drop_p, seed, seed_epoch);
     a.dout = (const bf16*)dout; a.stats = sums_out; a.dw = a1;
-    const int grid = l1_grid(l1_tiles(B, D, H, W), 2);
+    const int grid = l1_grid(l1_tiles(B, D, H, W), L1_BWD_WAVES);
     if (H % 8 == 0 && W % 32 == 0) hipLaunchKernelGGL((conv3d_l1_kernel<4, true>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3d_l1_kernel<4, false>), dim3(grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(l1_combine_kernel, dim3(ceil_div(32 * 27 * 16, 256)), dim3(256), 0, st, a1, gram,
